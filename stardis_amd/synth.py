@@ -1,0 +1,154 @@
+"""Seeded synthetic inputs for the hot path (SURVEY.md §8d recipe).
+
+No atomic data, TARDIS or line list is available offline, so tests and
+``bench.py`` drive the path with inputs derived from the solar MARCS structure
+(``data/sun_marcs_columns.json`` holds the T / Depth / Pe / Pg columns of
+docs/quickstart/sun.mod, captured by tests/golden/make_golden.py) plus a random
+line list whose strength mixture exercises the three regimes of the reference's
+window rule (opacities_solvers/base.py:561-575): hw = 10 floor, medium windows,
+and lines spanning the whole grid.
+
+numpy only: this module is also imported by the golden-vector generator under
+a different interpreter.
+"""
+import json
+import math
+import os
+
+import numpy as np
+
+from . import constants as K
+
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+
+# name -> (lambda_start [AA], lambda_stop [AA], R or None, step [AA] or None, n_lines, gamma per depth)
+WORKLOADS = {
+    "S-c1": dict(lam0=6560.0, lam1=6570.0, step=0.01, n_lines=2000, gamma_per_depth=True),
+    "S-c2": dict(lam0=6500.0, lam1=6600.0, R=5.0e5, n_lines=2000, gamma_per_depth=True),
+    "S-c3": dict(lam0=3000.0, lam1=10000.0, R=1.0e5, n_lines=150000, gamma_per_depth=True),
+    "S-c4": dict(lam0=3000.0, lam1=10000.0, R=1.0e5, n_lines=1000000, gamma_per_depth=False),
+    "S-big": dict(lam0=3000.0, lam1=10000.0, R=1.0e6, n_lines=1000000, gamma_per_depth=False),
+}
+SEED = 20250926
+N_THETAS = 20  # benchmarks/benchmark_config.yml:19
+
+
+def solar_atmosphere():
+    """Per-depth state, innermost point first (io/model/marcs.py:45,204 flips MARCS order)."""
+    with open(os.path.join(_DATA, "sun_marcs_columns.json")) as fh:
+        col = json.load(fh)
+    t = np.asarray(col["t"], dtype=np.float64)[::-1].copy()
+    depth = np.asarray(col["depth"], dtype=np.float64)[::-1].copy()
+    pe = np.asarray(col["pe"], dtype=np.float64)[::-1].copy()
+    pg = np.asarray(col["pg"], dtype=np.float64)[::-1].copy()
+    r = -depth
+    n_e = pe / (K.K_B_CGS * t)
+    n_h = 0.9 * (pg - pe) / (K.K_B_CGS * t)
+    return dict(
+        temperatures=t,
+        r=r,
+        dist=(r[1:] - r[:-1]).copy(),
+        n_e=n_e,
+        n_h=n_h,
+        microturbulence=1.0e5,  # 1 km/s in cgs
+    )
+
+
+def tracing_grid(lam0, lam1, R=None, step=None, n_override=None):
+    """Wavelengths ascending -> frequencies DESCENDING (stardis/base.py:34)."""
+    if step is not None:
+        lam = np.arange(lam0, lam1, step)
+    else:
+        n = int(math.ceil(math.log(lam1 / lam0) * R)) if n_override is None else int(n_override)
+        lam = lam0 * np.exp(np.arange(n, dtype=np.float64) * (math.log(lam1 / lam0) / n))
+    return K.C_CGS * 1.0e8 / lam
+
+
+def thetas_and_weights(n_thetas=N_THETAS):
+    """Gauss-Legendre nodes mapped as the reference does (radiation_field/base.py:61-63)."""
+    x, w = np.polynomial.legendre.leggauss(n_thetas)
+    return x / 2.0 + 0.5 * math.pi / 2.0, w * math.pi / 2.0
+
+
+def synth_lines(nus, atm, n_lines, seed=SEED, gamma_per_depth=True, mix=(0.90, 0.09, 0.01)):
+    """Random line list sorted by frequency, layout as calc_alan_entries takes it (N_l, N_d)."""
+    rng = np.random.default_rng(seed)
+    t = atm["temperatures"]
+    n_e = atm["n_e"]
+    nu_lo, nu_hi = float(nus.min()), float(nus.max())
+    line_nus = np.sort(nu_lo + (nu_hi - nu_lo) * rng.random(n_lines))
+    masses = np.array([1.008, 12.011, 24.305, 55.845, 47.867 + 15.999]) * K.AMU_CGS
+    mass = masses[rng.integers(0, len(masses), n_lines)]
+    doppler = (
+        line_nus[:, None]
+        / K.C_CGS
+        * np.sqrt(2.0 * K.K_B_CGS * t[None, :] / mass[:, None] + atm["microturbulence"] ** 2)
+    )
+    g_rad = 10.0 ** (7.0 + 2.0 * rng.random(n_lines))
+    g_col = 10.0 ** (-9.0 + 2.0 * rng.random(n_lines))
+    if gamma_per_depth:
+        gammas = g_rad[:, None] + g_col[:, None] * n_e[None, :]
+    else:
+        gammas = g_rad[:, None].copy()
+    e_low = 5.0 * rng.random(n_lines) * K.EV_CGS
+    u = rng.random(n_lines)
+    v = rng.random(n_lines)
+    s = np.where(
+        u < mix[0],
+        -6.0 + 5.0 * v,
+        np.where(u < mix[0] + mix[1], -1.0 + 3.0 * v, 2.0 + 3.0 * v),
+    )
+    boltz = np.exp(-e_low[:, None] / (K.K_B_CGS * t[None, :]) + e_low[:, None] / (K.K_B_CGS * t.max()))
+    alphas = (10.0**s)[:, None] * boltz
+    return dict(
+        line_nus=np.ascontiguousarray(line_nus),
+        doppler_widths=np.ascontiguousarray(doppler),
+        gammas=np.ascontiguousarray(gammas),
+        alphas=np.ascontiguousarray(alphas),
+    )
+
+
+def synth_continuum_state(atm, n_levels=10):
+    """Per-depth densities for H I bf/ff, H- bf (Wishart table), Thomson: an LTE-like
+    hydrogen state good enough to give a solar-looking continuum."""
+    t = atm["temperatures"]
+    n_e = atm["n_e"]
+    n_h = atm["n_h"]
+    kt = K.K_B_CGS * t
+    chi = 13.598434 * K.EV_CGS
+    lam3 = (K.H_CGS**2 / (2.0 * math.pi * K.M_E_CGS * kt)) ** 1.5
+    saha = (1.0 / lam3) * np.exp(-chi / kt) / n_e  # n(HII)/n(HI), g ratio 2*1/2
+    n_h1 = n_h / (1.0 + saha)
+    n_h2 = n_h - n_h1
+    n_hminus = n_h1 * n_e * lam3 * 0.25 * np.exp(0.754 * K.EV_CGS / kt)
+    n = np.arange(1, n_levels + 1, dtype=np.float64)
+    exc = chi * (1.0 - 1.0 / n**2)
+    g = 2.0 * n**2
+    lev = g[:, None] * np.exp(-exc[:, None] / kt[None, :])
+    lev = lev / lev.sum(axis=0, keepdims=True) * n_h1[None, :]
+    with open(os.path.join(_DATA, "hminus_bf_wishart1979.json")) as fh:
+        tab = json.load(fh)
+    return dict(
+        n_h1=n_h1,
+        n_h2=n_h2,
+        n_hminus=n_hminus,
+        n_he1=0.085 * n_h,
+        level_excitation=exc,
+        level_density=np.ascontiguousarray(lev),
+        ionization_energy=chi,
+        hminus_bf_wavelength=np.asarray(tab["wavelength"], dtype=np.float64),
+        hminus_bf_cross_section=np.asarray(tab["cross_section"], dtype=np.float64),
+    )
+
+
+def make_workload(tag, n_lines=None, seed=SEED, n_nu_override=None):
+    cfg = dict(WORKLOADS[tag])
+    atm = solar_atmosphere()
+    nus = tracing_grid(cfg["lam0"], cfg["lam1"], cfg.get("R"), cfg.get("step"), n_nu_override)
+    lines = synth_lines(
+        nus, atm, cfg["n_lines"] if n_lines is None else n_lines, seed, cfg["gamma_per_depth"]
+    )
+    thetas, weights = thetas_and_weights()
+    return dict(
+        tag=tag, nus=nus, atm=atm, lines=lines, cont=synth_continuum_state(atm), thetas=thetas, weights=weights
+    )

@@ -1,0 +1,647 @@
+"""Generate golden input/output vectors by EXECUTING the reference (un-jitted) here.
+
+    /opt/conda/bin/python3.9 tests/golden/make_golden.py
+
+Runs only in the authoring container (needs /root/reference and astropy).  The
+outputs are data: seeded inputs and what the reference's own functions return
+for them.  They are committed as small .npz files; the GPU box never sees the
+reference.  See ref_loader.py for how the reference modules are imported.
+"""
+import json
+import os
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+import pandas as pd
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, REPO)
+
+import ref_loader  # noqa: E402
+
+R = ref_loader.load()
+from astropy import units as u, constants as const  # noqa: E402
+
+NS = types.SimpleNamespace
+REF_DATA = Path("/root/reference/stardis/data")
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+# ----------------------------------------------------------------------------- data capture
+def capture_data():
+    m = R.mk.read_marcs_model(Path("/root/reference/docs/quickstart/sun.mod"), gzipped=False)
+    cols = {c: [float(x) for x in m.data[c].values] for c in ("t", "depth", "pe", "pg")}
+    os.makedirs(os.path.join(REPO, "stardis_amd", "data"), exist_ok=True)
+    with open(os.path.join(REPO, "stardis_amd", "data", "sun_marcs_columns.json"), "w") as fh:
+        json.dump(cols, fh)
+    tab = pd.read_csv(
+        REF_DATA / "h_minus_bf_W1979.dat", header=None, comment="#", names=["wavelength", "cross_section"]
+    )
+    with open(os.path.join(REPO, "stardis_amd", "data", "hminus_bf_wishart1979.json"), "w") as fh:
+        json.dump(
+            dict(
+                wavelength=[float(x) for x in tab.wavelength.values],
+                cross_section=[float(x) for x in tab.cross_section.values],
+            ),
+            fh,
+        )
+    geometry = m.to_geometry()
+    return m, geometry
+
+
+def dump_constants():
+    c = dict(
+        H_CGS=R.bb.H_CGS,
+        C_CGS=R.bb.C_CGS,
+        K_B_CGS=R.bb.K_B_CGS,
+        M_E_CGS=float(const.m_e.cgs.value),
+        M_P_CGS=R.br.H_MASS,
+        AMU_CGS=float(R.br.AMU_CGS),
+        E_ESU=R.br.ELEMENTARY_CHARGE,
+        BOHR_RADIUS=R.br.BOHR_RADIUS,
+        SIGMA_T=float(const.sigma_T.cgs.value),
+        RYDBERG_FREQUENCY=float(R.ob.RYDBERG_FREQUENCY),
+        RYDBERG_ENERGY=R.br.RYDBERG_ENERGY,
+        BF_CONSTANT=float(R.ob.BF_CONSTANT),
+        FF_CONSTANT=float(R.ob.FF_CONSTANT),
+        VACUUM_ELECTRIC_PERMITTIVITY=R.br.VACUUM_ELECTRIC_PERMITTIVITY,
+        C_KMS=R.br.C_KMS,
+        PI=R.vg.PI,
+        SQRT_PI=float(R.vg.SQRT_PI),
+    )
+    with open(os.path.join(HERE, "constants.json"), "w") as fh:
+        json.dump({k: float(v).hex() for k, v in c.items()}, fh, indent=1)
+
+
+# ----------------------------------------------------------------------------- G1 / G2
+def g1_faddeeva(rng):
+    n = 1500
+    pts = []
+    # region I: s > 15 ; II: 5.5 < s <= 15 ; III / IV split by y >= 0.195|x| - 0.176
+    x = rng.uniform(-60, 60, n)
+    y = 10 ** rng.uniform(-6, 2, n)
+    pts.append(x + 1j * y)
+    x = rng.uniform(-15, 15, n)
+    y = 10 ** rng.uniform(-5, 1.2, n)
+    pts.append(x + 1j * y)
+    x = rng.uniform(-5.5, 5.5, n)
+    y = 10 ** rng.uniform(-8, 0.7, n)
+    pts.append(x + 1j * y)
+    x = rng.uniform(-5.5, 5.5, n)
+    y = 10 ** rng.uniform(-12, -1, n)
+    pts.append(x + 1j * y)
+    # points hugging the three region boundaries from both sides
+    x = rng.uniform(-15, 15, 300)
+    for s0 in (15.0, 5.5):
+        for eps in (-1e-9, 1e-9, -1e-3, 1e-3):
+            yy = s0 * (1 + eps) - np.abs(x)
+            ok = yy > 0
+            pts.append(x[ok] + 1j * yy[ok])
+    x = rng.uniform(0.95, 5.4, 300) * rng.choice([-1.0, 1.0], 300)
+    for eps in (-1e-9, 1e-9, -1e-3, 1e-3):
+        yy = (0.195 * np.abs(x) - 0.176) * (1 + eps)
+        ok = (yy > 0) & (np.abs(x) + yy <= 5.5)
+        pts.append(x[ok] + 1j * yy[ok])
+    pts.append(np.array([0j, 1e-300j, 1 + 0j, -1 + 0j, 5.5 + 0j, 15 + 0j, 0.9025641025641 + 0j, 20j, 6j, 1j]))
+    z = np.concatenate(pts)
+    w = R.vg.faddeeva(z)
+    save("g1_faddeeva", z=z, w=w)
+
+
+def g2_voigt(rng):
+    n = 4000
+    dw = 10 ** rng.uniform(8.5, 10.5, n)
+    gamma = 10 ** rng.uniform(5, 11, n)
+    dnu = dw * rng.uniform(-1, 1, n) * 10 ** rng.uniform(-2, 3, n)
+    dnu[:50] = 0.0
+    phi = R.vg.voigt_profile(dnu, dw, gamma)
+    save("g2_voigt", delta_nu=dnu, doppler_width=dw, gamma=gamma, phi=phi.astype(np.float64))
+
+
+# ----------------------------------------------------------------------------- atmosphere helpers
+def atmosphere():
+    from stardis_amd import synth
+
+    return synth.solar_atmosphere()
+
+
+def fake_lines_table(rng, nus, n_lines, with_vald=False, autoion=True):
+    """A TARDIS-looking `lines` table restricted to what calc_alpha_line_at_nu /
+    calculate_broadening read (opacities_solvers/base.py:362-430, broadening.py:706-730)."""
+    lo, hi = nus.min(), nus.max()
+    span = hi - lo
+    nu = rng.uniform(lo - 0.05 * span, hi + 0.05 * span, n_lines)  # some fall outside the grid
+    nu[0] = lo  # exactly on the grid ends: `between` is inclusive
+    nu[1] = hi
+    z = rng.choice([1, 2, 6, 12, 20, 26], n_lines, p=[0.15, 0.05, 0.1, 0.2, 0.2, 0.3])
+    ion = np.where(z == 1, 0, rng.integers(0, 2, n_lines))
+    ion_energy = {1: 13.598, 2: 24.587, 6: 11.26, 12: 7.646, 20: 6.113, 26: 7.902}
+    ion_energy2 = {2: 54.418, 6: 24.383, 12: 15.035, 20: 11.872, 26: 16.199}
+    chi = np.array([(ion_energy[a] if i == 0 else ion_energy2[a]) for a, i in zip(z, ion)]) * 1.602176634e-12
+    e_low = rng.uniform(0.0, 0.6, n_lines) * chi
+    e_up = e_low + R.bb.H_CGS * nu
+    # a few auto-ionising lines (upper level above the ionisation limit) — filtered at :413-421
+    if autoion:
+        z[5:8] = 26
+        chi[5:8] = 7.902 * 1.602176634e-12
+        ion[5:8] = 0
+        e_up[5:8] = chi[5:8] * 1.05
+        e_low[5:8] = e_up[5:8] - R.bb.H_CGS * nu[5:8]
+    df = pd.DataFrame(
+        dict(
+            atomic_number=z,
+            ion_number=ion,
+            level_number_lower=rng.integers(0, 5, n_lines),
+            level_number_upper=rng.integers(5, 10, n_lines),
+            nu=nu,
+            A_ul=10 ** rng.uniform(6, 9, n_lines),
+            ionization_energy=chi,
+            level_energy_lower=e_low,
+            level_energy_upper=e_up,
+        )
+    )
+    if with_vald:
+        df["stark"] = np.where(rng.random(n_lines) < 0.2, 0.0, -rng.uniform(4.5, 6.5, n_lines))
+        w = np.empty(n_lines)
+        pick = rng.random(n_lines)
+        w[pick < 0.3] = -rng.uniform(7.0, 8.0, (pick < 0.3).sum())
+        w[(pick >= 0.3) & (pick < 0.4)] = 0.0
+        w[(pick >= 0.4) & (pick < 0.7)] = rng.uniform(0.5, 3.0, ((pick >= 0.4) & (pick < 0.7)).sum())
+        m = pick >= 0.7
+        w[m] = rng.integers(150, 900, m.sum()) + rng.uniform(0.2, 0.35, m.sum())
+        if autoion:
+            w[5:8] = -7.5  # keep sqrt(negative) out of the Unsoeld branch for auto-ionising lines
+        df["waals"] = w
+    return df
+
+
+def alpha_table(rng, lines, atm):
+    t = atm["temperatures"]
+    n = len(lines)
+    e = rng.uniform(0, 5, n) * 1.602176634e-12
+    u_ = rng.random(n)
+    s = np.where(u_ < 0.85, rng.uniform(-6, -1, n), np.where(u_ < 0.97, rng.uniform(-1, 2, n), rng.uniform(2, 4, n)))
+    boltz = np.exp(-e[:, None] / (R.bb.K_B_CGS * t[None, :]) + e[:, None] / (R.bb.K_B_CGS * t.max()))
+    a = (10.0**s)[:, None] * boltz
+    df = pd.DataFrame(a, columns=np.arange(len(t)))
+    df["nu"] = lines.nu.values
+    return df
+
+
+NUCLIDE_MASSES = pd.Series(
+    np.array([1.008, 4.0026, 12.011, 24.305, 40.078, 55.845]) * 1.6605390666e-24,
+    index=pd.Index([1, 2, 6, 12, 20, 26], name="atomic_number"),
+)
+
+
+def fake_plasma(atm, cont, lines=None, alpha_line=None, vald=False):
+    t = atm["temperatures"]
+    nd = len(t)
+    cols = np.arange(nd)
+    ind = pd.MultiIndex.from_tuples([(1, 0), (1, 1), (2, 0), (2, 1)], names=["atomic_number", "ion_number"])
+    ion_number_density = pd.DataFrame(
+        np.vstack([cont["n_h1"], cont["n_h2"], cont["n_he1"], 1e-6 * cont["n_he1"]]), index=ind, columns=cols
+    )
+    n_lev = cont["level_density"].shape[0]
+    lev_index = pd.MultiIndex.from_tuples(
+        [(1, 0, k) for k in range(n_lev)] + [(2, 0, 0)],
+        names=["atomic_number", "ion_number", "level_number"],
+    )
+    excitation_energy = pd.Series(np.append(cont["level_excitation"], 0.0), index=lev_index)
+    level_number_density = pd.DataFrame(
+        np.vstack([cont["level_density"], cont["n_he1"][None, :]]), index=lev_index, columns=cols
+    )
+    ionization_data = pd.Series(
+        np.array([13.598434, 24.587, 54.418]) * 1.602176634e-12,
+        index=pd.MultiIndex.from_tuples([(1, 1), (2, 1), (2, 2)], names=["atomic_number", "ion_number"]),
+        name="ionization_energy",
+    )
+    pl = NS(
+        ion_number_density=ion_number_density,
+        electron_densities=pd.Series(atm["n_e"], index=cols),
+        levels=lev_index,
+        excitation_energy=excitation_energy,
+        level_number_density=level_number_density,
+        ionization_data=ionization_data,
+        h_minus_density=pd.Series(cont["n_hminus"], index=cols),
+        h2_density=pd.Series(1e-4 * cont["n_h1"] * (5000.0 / t) ** 4, index=cols),
+        h2_plus_density=pd.Series(1e-9 * cont["n_h1"], index=cols),
+    )
+    if lines is not None:
+        if vald:
+            pl.lines_from_linelist = lines
+            pl.alpha_line_from_linelist = alpha_line
+        else:
+            # plasma.lines is indexed; ionization / level energies come from merges (:366-390).
+            # Here the merged columns are already on the frame, so make the merges no-ops by
+            # giving the plasma tables that reproduce those columns.
+            pl.lines_from_linelist = lines
+            pl.alpha_line_from_linelist = alpha_line
+    return pl
+
+
+def fake_model(atm, geometry=None):
+    t = atm["temperatures"]
+    return NS(
+        temperatures=t * u.K,
+        no_of_depth_points=len(t),
+        spherical=False,
+        geometry=NS(dist_to_next_depth_point=atm["dist"], r=atm["r"], reference_r=None, no_of_depth_points=len(t)),
+        composition=NS(nuclide_masses=NUCLIDE_MASSES),
+        microturbulence=1.0 * u.km / u.s,
+    )
+
+
+# ----------------------------------------------------------------------------- G3 broadening
+def g3_broadening(rng, atm, cont):
+    from stardis_amd import synth
+
+    nus = synth.tracing_grid(6560.0, 6570.0, step=0.1)
+    lines = fake_lines_table(rng, nus, 64, with_vald=True, autoion=False)
+    t = atm["temperatures"]
+    n_e = atm["n_e"]
+    n_h1 = cont["n_h1"]
+    col = lambda s: lines[s].values[:, np.newaxis]  # noqa: E731
+    zion = col("ion_number") + 1
+    n_up = R.br.calc_n_effective(zion, col("ionization_energy"), col("level_energy_upper"))
+    n_lo = R.br.calc_n_effective(zion, col("ionization_energy"), col("level_energy_lower"))
+    out = dict(
+        n_eff_upper=n_up.astype(np.float64),
+        n_eff_lower=n_lo.astype(np.float64),
+        linear_stark=R.br.calc_gamma_linear_stark(n_up, n_lo, n_e).astype(np.float64),
+        quadratic_stark=R.br.calc_gamma_quadratic_stark(zion, n_up, n_lo, n_e, t).astype(np.float64),
+        van_der_waals=R.br.calc_gamma_van_der_waals(zion, n_up, n_lo, t, n_h1).astype(np.float64),
+        doppler=R.br.calc_doppler_width(
+            col("nu"), t, NUCLIDE_MASSES.loc[lines.atomic_number].values[:, np.newaxis], 1.0e5
+        ).astype(np.float64),
+    )
+    for tag, flags in {
+        "all": (True, True, True, True),
+        "no_lin": (False, True, True, True),
+        "rad_only": (False, False, False, True),
+        "qs_vdw": (False, True, True, False),
+    }.items():
+        out["gamma_" + tag] = R.br.calc_gamma(
+            col("atomic_number"),
+            zion,
+            col("ionization_energy"),
+            col("level_energy_upper"),
+            col("level_energy_lower"),
+            col("A_ul"),
+            n_e,
+            t,
+            n_h1,
+            *flags,
+        ).astype(np.float64)
+    model = fake_model(atm)
+    plasma = fake_plasma(atm, cont)
+    out["vald_gamma_all"] = R.br.calc_vald_gamma(lines, model, plasma, True, True, True, True)
+    out["vald_gamma_rad_vdw"] = R.br.calc_vald_gamma(lines, model, plasma, False, False, True, True)
+    out["vald_stark"] = R.br.calc_vald_stark_gamma(n_e, col("stark"), t)
+    out["vald_vdw"] = R.br.calc_vald_vdW(
+        lines.waals.values,
+        t,
+        NUCLIDE_MASSES.loc[lines.atomic_number].values[:, np.newaxis],
+        col("level_energy_upper"),
+        col("level_energy_lower"),
+        n_h1,
+        zion,
+        col("ionization_energy"),
+    )
+    # molecules (broadening.py:735-821, non-VALD branch)
+    mol_lines = pd.DataFrame(
+        dict(molecule=rng.choice(["CH", "MgH"], 20), nu=rng.uniform(nus.min(), nus.max(), 20), A_ul=10 ** rng.uniform(5, 8, 20))
+    )
+    plasma.molecule_ion_map = pd.DataFrame(dict(Ion1=[6, 12], Ion2=[1, 1]), index=["CH", "MgH"])
+    mg, md = R.br.calculate_molecule_broadening(mol_lines, model, plasma, ["radiation"])
+    out.update(
+        mol_gammas=np.asarray(mg, dtype=np.float64),
+        mol_doppler=np.asarray(md, dtype=np.float64),
+        mol_nu=mol_lines.nu.values,
+        mol_A_ul=mol_lines.A_ul.values,
+        mol_mass=(
+            NUCLIDE_MASSES.loc[plasma.molecule_ion_map.loc[mol_lines.molecule].Ion1].values
+            + NUCLIDE_MASSES.loc[plasma.molecule_ion_map.loc[mol_lines.molecule].Ion2].values
+        ),
+    )
+    inputs = {("line_" + c): lines[c].values for c in lines.columns}
+    inputs["line_mass"] = NUCLIDE_MASSES.loc[lines.atomic_number].values
+    save("g3_broadening", temperatures=t, n_e=n_e, n_h1=n_h1, microturbulence=np.float64(1.0e5), **inputs, **out)
+
+
+# ----------------------------------------------------------------------------- G4 line opacity
+def g4_alan(rng, atm):
+    from stardis_amd import synth
+
+    cases = {
+        "a": dict(nus=synth.tracing_grid(6560.0, 6570.0, step=0.1), n=40, per_depth=True, seed=11),
+        "b": dict(nus=synth.tracing_grid(6560.0, 6570.0, step=0.01), n=200, per_depth=True, seed=12),
+        "c": dict(nus=synth.tracing_grid(6500.0, 6600.0, R=1.0e4), n=60, per_depth=False, seed=13),
+    }
+    out = {}
+    for tag, c in cases.items():
+        nus = c["nus"]
+        ln = synth.synth_lines(nus, atm, c["n"], seed=c["seed"], gamma_per_depth=c["per_depth"], mix=(0.85, 0.12, 0.03))
+        # edge lines: exactly at the grid ends (c = N_nu and c = 0 under the rule at :556-558)
+        ln["line_nus"][0] = nus.min()
+        ln["line_nus"][-1] = nus.max()
+        # one line exactly on an interior grid frequency
+        ln["line_nus"][c["n"] // 2] = nus[len(nus) // 3]
+        ln["line_nus"] = np.sort(ln["line_nus"])
+        res = R.ob.calc_alan_entries(
+            len(atm["temperatures"]), nus, ln["line_nus"], ln["doppler_widths"], ln["gammas"], ln["alphas"]
+        )
+        out.update(
+            {
+                f"{tag}_nus": nus,
+                f"{tag}_line_nus": ln["line_nus"],
+                f"{tag}_doppler_widths": ln["doppler_widths"],
+                f"{tag}_gammas": ln["gammas"],
+                f"{tag}_alphas": ln["alphas"],
+                f"{tag}_alpha_line_at_nu": res,
+            }
+        )
+        print("  g4", tag, res.shape, float(res.max()))
+    save("g4_alan_entries", **out)
+
+
+# ----------------------------------------------------------------------------- G5 continuum
+def opacity_config(lines=True, vald=False, vald_broadening=False, file_sources=("Hminus_bf", "Hminus_ff", "H2plus_bf")):
+    files = {
+        "Hminus_bf": str(REF_DATA / "h_minus_bf_W1979.dat"),
+        "Hminus_ff": str(REF_DATA / "h_minus_ff_B1987.dat"),
+        "H2plus_bf": str(REF_DATA / "h2_plus_bf_S1994.dat"),
+    }
+    return NS(
+        file={k: files[k] for k in file_sources},
+        bf={"H_I": {}},
+        ff={"H_I": {}},
+        rayleigh=["H", "He", "H2"],
+        disable_electron_scattering=False,
+        line=NS(
+            disable=not lines,
+            broadening=["linear_stark", "quadratic_stark", "van_der_waals", "radiation"],
+            vald_linelist=NS(use_linelist=vald, use_vald_broadening=vald_broadening),
+            include_molecules=False,
+        ),
+    )
+
+
+def g5_continuum(atm, cont):
+    from stardis_amd import synth
+
+    model = fake_model(atm)
+    plasma = fake_plasma(atm, cont)
+    out = {}
+    for tag, nus in {
+        "opt": synth.tracing_grid(6500.0, 6600.0, R=2.0e3),
+        "wide": synth.tracing_grid(1500.0, 24000.0, R=60.0),  # crosses bf edges, table ends, Rayleigh cut-off
+    }.items():
+        q = lambda: nus.copy() * u.Hz  # noqa: E731
+        cfg = opacity_config()
+        out[f"{tag}_nus"] = nus
+        for src, path in cfg.file.items():
+            out[f"{tag}_alpha_file_{src}"] = np.asarray(R.ob.calc_alpha_file(plasma, model, q(), src, path), dtype=np.float64)
+            lam = q().to(u.AA, u.spectral()).value
+            out[f"{tag}_sigma_{src}"] = np.asarray(
+                R.ut.sigma_file(lam, atm["temperatures"], Path(path), src), dtype=np.float64
+            )
+        out[f"{tag}_lambdas"] = q().to(u.AA, u.spectral()).value
+        out[f"{tag}_alpha_bf"] = R.ob.calc_alpha_bf(plasma, model, q(), cfg.bf)
+        out[f"{tag}_alpha_ff"] = R.ob.calc_alpha_ff(plasma, model, q(), cfg.ff)
+        qq = q()
+        out[f"{tag}_alpha_rayleigh"] = R.ob.calc_alpha_rayleigh(plasma, model, qq, cfg.rayleigh)
+        out[f"{tag}_nus_after_rayleigh"] = qq.value  # the reference zeroes nu > 2.3e15 in place (:99)
+        out[f"{tag}_alpha_rayleigh_H_only"] = R.ob.calc_alpha_rayleigh(plasma, model, q(), ["H"])
+        out[f"{tag}_alpha_electron"] = R.ob.calc_alpha_electron(plasma, model, q())
+    state = dict(
+        temperatures=atm["temperatures"],
+        n_e=atm["n_e"],
+        n_h1=cont["n_h1"],
+        n_h2=cont["n_h2"],
+        n_he1=cont["n_he1"],
+        n_hminus=cont["n_hminus"],
+        h2_density=plasma.h2_density.values,
+        h2_plus_density=plasma.h2_plus_density.values,
+        level_excitation=cont["level_excitation"],
+        level_density=cont["level_density"],
+        ionization_energy=np.float64(cont["ionization_energy"]),
+    )
+    save("g5_continuum", **state, **out)
+
+
+# ----------------------------------------------------------------------------- G6 / G7 raytrace
+def g6_weights(rng):
+    tau = np.concatenate(
+        [
+            10 ** rng.uniform(-12, 3, 3000),
+            np.array([0.0, 5e-4, np.nextafter(5e-4, 0), np.nextafter(5e-4, 1), 50.0, np.nextafter(50.0, 0), np.nextafter(50.0, 100), 1e3]),
+        ]
+    ).reshape(4, -1)
+    w0, w1, w2 = R.rt.calc_weights_parallel(tau)
+    save("g6_weights", tau=tau, w0=w0, w1=w1, w2=w2)
+
+
+def run_raytrace(atm, nus, total_alphas, n_thetas, track=True):
+    model = fake_model(atm)
+    th, w = np.polynomial.legendre.leggauss(n_thetas)
+    field = NS(
+        thetas=th / 2 + 0.5 * np.pi / 2,
+        I_nus_weights=w * np.pi / 2,
+        frequencies=nus * u.Hz,
+        source_function=R.bb.blackbody_flux_at_nu,
+        track_individual_intensities=track,
+        F_nu=np.zeros((len(atm["temperatures"]), len(nus))),
+        opacities=NS(total_alphas=total_alphas),
+    )
+    if track:
+        field.I_nus = np.zeros((len(atm["temperatures"]), len(nus), n_thetas))
+    R.rt.raytrace(model, field)
+    return field
+
+
+def g7_raytrace(rng, atm, cont):
+    from stardis_amd import synth
+
+    nus = synth.tracing_grid(6560.0, 6570.0, step=0.05)
+    ln = synth.synth_lines(nus, atm, 60, seed=21, mix=(0.7, 0.2, 0.1))
+    model = fake_model(atm)
+    plasma = fake_plasma(atm, cont)
+    line = R.ob.calc_alan_entries(len(atm["temperatures"]), nus, ln["line_nus"], ln["doppler_widths"], ln["gammas"], ln["alphas"])
+    cfg = opacity_config()
+    total = (
+        R.ob.calc_alpha_file(plasma, model, nus * u.Hz, "Hminus_bf", cfg.file["Hminus_bf"])
+        + R.ob.calc_alpha_bf(plasma, model, nus * u.Hz, cfg.bf)
+        + R.ob.calc_alpha_ff(plasma, model, nus * u.Hz, cfg.ff)
+        + R.ob.calc_alpha_electron(plasma, model, nus * u.Hz)
+        + line
+    )
+    # a transparent column (tau == 0 short-circuit, :203-206) and a transparent last gap (:253-254)
+    total[:, 7] = 0.0
+    total[-1, 11] = 0.0
+    out = dict(nus=nus, total_alphas=total, temperatures=atm["temperatures"], dist=atm["dist"])
+    bb = R.bb.blackbody_flux_at_nu(nus, atm["temperatures"].reshape(-1, 1))
+    out["blackbody"] = np.asarray(bb, dtype=np.float64)
+    with np.errstate(all="ignore"):
+        for n_theta in (1, 4, 20):
+            f = run_raytrace(atm, nus, total, n_theta)
+            out[f"F_nu_{n_theta}"] = f.F_nu
+            out[f"thetas_{n_theta}"] = f.thetas
+            out[f"weights_{n_theta}"] = f.I_nus_weights
+            if n_theta == 4:
+                out["I_nus_4"] = f.I_nus
+        one = R.rt.single_theta_trace_parallel(
+            atm["dist"] / np.cos(0.3), atm["temperatures"].reshape(-1, 1), total, nus, R.bb.blackbody_flux_at_nu
+        )
+    out["I_single_theta_0p3"] = one
+    save("g7_raytrace", **out)
+
+
+# ----------------------------------------------------------------------------- G8 rotation
+def g8_rotation(rng):
+    lam = 6500.0 * np.exp(np.arange(3000) / 2.0e5)
+    flux = 1e6 * (1 - 0.6 * np.exp(-0.5 * ((lam - 6530) / 0.4) ** 2) - 0.3 * np.exp(-0.5 * ((lam - 6560) / 0.1) ** 2))
+    flux *= 1 + 0.01 * rng.standard_normal(len(lam))
+    vpp = R.br.C_KMS / 2.0e5
+    out = dict(wavelength=lam, flux=flux, velocity_per_pix=np.float64(vpp))
+    for v in (0.0, 20.0, 500.0):
+        _, f = R.br.rotation_broadening(vpp * u.km / u.s, lam * u.AA, flux, v_rot=v * u.km / u.s)
+        out[f"flux_v{int(v)}"] = np.asarray(getattr(f, "value", f), dtype=np.float64)
+    _, f = R.br.rotation_broadening(vpp * u.km / u.s, lam * u.AA, flux, v_rot=35.0 * u.km / u.s, limb_darkening=0.3)
+    out["flux_v35_ld0p3"] = np.asarray(f.value, dtype=np.float64)
+    save("g8_rotation", **out)
+
+
+# ----------------------------------------------------------------------------- G9 end to end
+def g9_end_to_end(rng, atm, cont):
+    """calc_alphas + raytrace of the reference on a pandas stand-in for the plasma: pins the
+    host-side logic (line selection, sort, auto-ionisation filter, dict keys/order, totals)."""
+    from stardis_amd import synth
+
+    nus = synth.tracing_grid(6560.0, 6566.0, step=0.02)
+    model = fake_model(atm)
+    for tag, vald, vb in (("tardis", False, False), ("vald", True, True), ("vald_nb", True, False)):
+        lines = fake_lines_table(rng, nus, 90, with_vald=True)
+        alpha_line = alpha_table(rng, lines, atm)
+        plasma = fake_plasma(atm, cont)
+        if vald:
+            plasma.lines_from_linelist = lines
+            plasma.alpha_line_from_linelist = alpha_line
+        else:
+            base_cols = ["atomic_number", "ion_number", "level_number_lower", "level_number_upper", "nu", "A_ul"]
+            # unique keys so the three merges at :371-390 are one-to-one
+            lines = lines.copy()
+            lines["level_number_lower"] = np.arange(len(lines)) * 2
+            lines["level_number_upper"] = np.arange(len(lines)) * 2 + 1
+            alpha_line = alpha_table(rng, lines, atm)
+            plasma.lines = lines[base_cols].copy()
+            plasma.lines.index.name = "line_id"
+            # ionization_data here must be a Series named ionization_energy indexed (Z, ion+1)
+            ion_keys = lines[["atomic_number", "ion_number", "ionization_energy"]].drop_duplicates(
+                ["atomic_number", "ion_number"]
+            )
+            # make ionization energies a function of (Z, ion) only
+            lines["ionization_energy"] = lines.merge(ion_keys, on=["atomic_number", "ion_number"], suffixes=("_old", ""))[
+                "ionization_energy"
+            ].values
+            plasma_ion = pd.Series(
+                ion_keys.ionization_energy.values,
+                index=pd.MultiIndex.from_arrays(
+                    [ion_keys.atomic_number.values, ion_keys.ion_number.values + 1], names=["atomic_number", "ion_number"]
+                ),
+                name="ionization_energy",
+            )
+            h_he = plasma.ionization_data
+            plasma.ionization_data = pd.concat([h_he[~h_he.index.isin(plasma_ion.index)], plasma_ion]).sort_index()
+            lev_idx = pd.MultiIndex.from_arrays(
+                [
+                    np.concatenate([lines.atomic_number.values] * 2),
+                    np.concatenate([lines.ion_number.values] * 2),
+                    np.concatenate([lines.level_number_lower.values, lines.level_number_upper.values]),
+                ],
+                names=["atomic_number", "ion_number", "level_number"],
+            )
+            energy = pd.Series(
+                np.concatenate([lines.level_energy_lower.values, lines.level_energy_upper.values]), index=lev_idx, name="energy"
+            )
+            plasma.atomic_data = NS(levels=NS(energy=energy))
+            plasma.alpha_line = alpha_line
+        cfg = opacity_config(vald=vald, vald_broadening=vb, file_sources=("Hminus_bf",))
+        th, w = np.polynomial.legendre.leggauss(6)
+        field = NS(
+            frequencies=nus.copy() * u.Hz,
+            source_function=R.bb.blackbody_flux_at_nu,
+            opacities=R.op.Opacities(nus, model),
+            F_nu=np.zeros((model.no_of_depth_points, len(nus))),
+            thetas=th / 2 + 0.5 * np.pi / 2,
+            I_nus_weights=w * np.pi / 2,
+            track_individual_intensities=False,
+        )
+        R.ob.calc_alphas(plasma, model, field, cfg)
+        R.rt.raytrace(model, field)
+        out = dict(nus=nus, F_nu=field.F_nu, total_alphas=field.opacities.total_alphas, thetas=field.thetas, weights=field.I_nus_weights)
+        out["dict_keys"] = np.array(list(field.opacities.opacities_dict.keys()))
+        for k, v in field.opacities.opacities_dict.items():
+            out["od_" + k] = np.asarray(v, dtype=np.float64)
+        for c in lines.columns:
+            out["lines_" + c] = lines[c].values
+        out["alpha_line_table"] = alpha_line.drop(columns="nu").to_numpy()
+        out["alpha_line_nu"] = alpha_line.nu.values
+        out["line_mass_by_z_keys"] = NUCLIDE_MASSES.index.values
+        out["line_mass_by_z_vals"] = NUCLIDE_MASSES.values
+        st = dict(
+            temperatures=atm["temperatures"],
+            dist=atm["dist"],
+            n_e=atm["n_e"],
+            n_h1=cont["n_h1"],
+            n_h2=cont["n_h2"],
+            n_he1=cont["n_he1"],
+            n_hminus=cont["n_hminus"],
+            h2_density=plasma.h2_density.values,
+            level_excitation=cont["level_excitation"],
+            level_density=cont["level_density"],
+            ionization_energy=np.float64(cont["ionization_energy"]),
+        )
+        save("g9_end_to_end_" + tag, **st, **out)
+
+
+def main():
+    rng = np.random.default_rng(20250926)
+    capture_data()
+    dump_constants()
+    from stardis_amd import synth
+
+    atm = atmosphere()
+    cont = synth.synth_continuum_state(atm)
+    which = set(sys.argv[1:]) or {"g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"}
+    if "g1" in which:
+        g1_faddeeva(rng)
+    if "g2" in which:
+        g2_voigt(rng)
+    if "g3" in which:
+        g3_broadening(rng, atm, cont)
+    if "g4" in which:
+        g4_alan(rng, atm)
+    if "g5" in which:
+        g5_continuum(atm, cont)
+    if "g6" in which:
+        g6_weights(rng)
+    if "g7" in which:
+        g7_raytrace(rng, atm, cont)
+    if "g8" in which:
+        g8_rotation(rng)
+    if "g9" in which:
+        g9_end_to_end(rng, atm, cont)
+
+
+if __name__ == "__main__":
+    main()
