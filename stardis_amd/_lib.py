@@ -1,0 +1,248 @@
+"""ctypes binding of libstardis_hip.so (include/stardis_hip.h) and the device-array helper.
+
+There is no CPU fallback anywhere in this package: if the HIP library is missing or no
+MI355X is visible, every compute entry point raises.
+"""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libstardis_hip.so")
+
+c_dp = C.POINTER(C.c_double)
+_vp = C.c_void_p
+_i64 = C.c_int64
+_int = C.c_int
+
+
+class Continuum(C.Structure):
+    """struct sdx_continuum (include/stardis_hip.h)"""
+
+    _fields_ = [
+        ("lambdas", _vp),
+        ("n_table", _int),
+        ("table_wavelength", _vp),
+        ("table_sigma", _vp),
+        ("table_density", _vp),
+        ("bf_n_species", _int),
+        ("bf_species_offsets", _vp),
+        ("bf_species_ion_number", _vp),
+        ("bf_cutoff", _vp),
+        ("bf_level_density", _vp),
+        ("ff_n_species", _int),
+        ("ff_species_ion_number", _vp),
+        ("ff_number_density", _vp),
+        ("ray_n_h", _vp),
+        ("ray_n_he", _vp),
+        ("ray_n_h2", _vp),
+        ("rayleigh_enabled", _int),
+        ("electron_density", _vp),
+        ("temperature", _vp),
+    ]
+
+
+# name -> (restype, argtypes); every function declared in include/stardis_hip.h
+PROTOTYPES = {
+    "sdx_version": (C.c_char_p, []),
+    "sdx_last_error_string": (C.c_char_p, []),
+    "sdx_device_count": (_int, []),
+    "sdx_create": (_vp, [_int, _vp]),
+    "sdx_destroy": (None, [_vp]),
+    "sdx_set_stream": (_int, [_vp, _vp]),
+    "sdx_get_stream": (_vp, [_vp]),
+    "sdx_synchronize": (_int, [_vp]),
+    "sdx_malloc": (_vp, [_vp, C.c_size_t]),
+    "sdx_free": (_int, [_vp, _vp]),
+    "sdx_memcpy_h2d": (_int, [_vp, _vp, _vp, C.c_size_t]),
+    "sdx_memcpy_d2h": (_int, [_vp, _vp, _vp, C.c_size_t]),
+    "sdx_memset": (_int, [_vp, _vp, _int, C.c_size_t]),
+    "sdx_reserve_line_workspace": (_int, [_vp, _int, _i64]),
+    "sdx_graph_begin": (_int, [_vp]),
+    "sdx_graph_end": (_int, [_vp, C.POINTER(_vp)]),
+    "sdx_graph_launch": (_int, [_vp, _vp]),
+    "sdx_graph_destroy": (_int, [_vp, _vp]),
+    "sdx_timer_start": (_int, [_vp]),
+    "sdx_timer_stop": (_int, [_vp, c_dp]),
+    "sdx_profile_enable": (_int, [_vp, _int]),
+    "sdx_profile_reset": (_int, [_vp]),
+    "sdx_profile_get": (_int, [_vp, C.c_char_p, C.POINTER(_i64), c_dp]),
+    "sdx_line_opacity_dev": (_int, [_vp, _int, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _int, _vp, _vp, _i64, _int, _vp]),
+    "sdx_line_opacity_f64": (_int, [_vp, _int, _i64, _vp, _i64, _vp, _vp, _vp, _int, _vp, _vp, C.POINTER(_i64)]),
+    "sdx_line_windows_dev": (_int, [_vp, _int, _i64, _vp, _i64, _vp, _vp, _vp, _int, _vp, _vp, _vp]),
+    "sdx_faddeeva_dev": (_int, [_vp, _i64, _vp, _vp]),
+    "sdx_voigt_profile_dev": (_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
+    "sdx_calc_gamma_dev": (_int, [_vp, _i64, _int] + [_vp] * 9 + [_int, _vp]),
+    "sdx_doppler_widths_dev": (_int, [_vp, _i64, _int, _vp, _vp, _vp, C.c_double, _vp]),
+    "sdx_calc_vald_gamma_dev": (_int, [_vp, _i64, _int] + [_vp] * 12 + [_int, _vp]),
+    "sdx_broadening_scalar_dev": (_int, [_vp, _int, _i64] + [_vp] * 6),
+    "sdx_alpha_file_1d_dev": (_int, [_vp, _int, _i64, _vp, _int, _vp, _vp, _vp, _vp, _i64]),
+    "sdx_alpha_file_2d_dev": (_int, [_vp, _int, _i64, _vp, _i64, _vp, _vp, _i64]),
+    "sdx_alpha_bf_dev": (_int, [_vp, _int, _i64, _vp, _int, _vp, _vp, _vp, _vp, _vp, _i64]),
+    "sdx_alpha_ff_dev": (_int, [_vp, _int, _i64, _vp, _vp, _int, _vp, _vp, _vp, _i64]),
+    "sdx_alpha_rayleigh_dev": (_int, [_vp, _int, _i64, _vp, _vp, _vp, _vp, _vp, _i64]),
+    "sdx_alpha_electron_dev": (_int, [_vp, _int, _i64, _vp, _vp, _i64]),
+    "sdx_accumulate_dev": (_int, [_vp, _int, _i64, _vp, _i64, _vp, _i64]),
+    "sdx_blackbody_dev": (_int, [_vp, _int, _i64, _vp, _vp, _vp, _i64]),
+    "sdx_calc_weights_dev": (_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
+    "sdx_raytrace_dev": (_int, [_vp, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp]),
+    "sdx_raytrace_f64": (_int, [_vp, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sdx_total_alphas_dev": (_int, [_vp, _int, _i64, _vp, _i64, _i64, C.POINTER(Continuum), _vp, _i64, _vp, _i64]),
+}
+
+_lib = None
+_lock = threading.RLock()
+_contexts = {}
+
+
+def load():
+    """The shared library, or RuntimeError when it has not been built."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise RuntimeError(
+                        f"{LIB_PATH} is missing: build it with `make -C stardis_amd/csrc` "
+                        "(or __graft_entry__.build()); stardis_amd has no CPU fallback"
+                    )
+                lib = C.CDLL(LIB_PATH)
+                for name, (res, args) in PROTOTYPES.items():
+                    fn = getattr(lib, name)
+                    fn.restype = res
+                    fn.argtypes = args
+                _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc == 0:
+        return
+    msg = load().sdx_last_error_string().decode()
+    if rc == -1:
+        raise ValueError(msg)
+    if rc == -4:
+        raise MemoryError(msg)
+    raise RuntimeError(f"stardis_hip error {rc}: {msg}")
+
+
+class Context:
+    """One sdx_ctx: a device, a stream and the library's scratch."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = load()
+        if self.lib.sdx_device_count() <= device:
+            raise RuntimeError(
+                f"no HIP device {device} visible (sdx_device_count() = {self.lib.sdx_device_count()}); "
+                "the STARDIS hot path of stardis_amd runs on MI355X only"
+            )
+        self.device = device
+        self.handle = self.lib.sdx_create(device, stream)
+        if not self.handle:
+            raise RuntimeError(self.lib.sdx_last_error_string().decode())
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.sdx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        check(self.lib.sdx_synchronize(self.handle))
+
+    # -- arrays -------------------------------------------------------------------------------
+    def empty(self, shape, dtype=np.float64):
+        return DeviceArray(self, shape, dtype)
+
+    def zeros(self, shape, dtype=np.float64):
+        a = DeviceArray(self, shape, dtype)
+        check(self.lib.sdx_memset(self.handle, a.ptr, 0, a.nbytes))
+        return a
+
+    def upload(self, array, dtype=np.float64):
+        host = np.ascontiguousarray(array, dtype=dtype)
+        a = DeviceArray(self, host.shape, dtype)
+        check(self.lib.sdx_memcpy_h2d(self.handle, a.ptr, host.ctypes.data, host.nbytes))
+        return a
+
+    def call(self, name, *args):
+        check(getattr(self.lib, name)(self.handle, *args))
+
+
+class DeviceArray:
+    """A device buffer allocated through the C ABI (sdx_malloc): pointer + shape, nothing more."""
+
+    def __init__(self, ctx, shape, dtype=np.float64):
+        self.ctx = ctx
+        self.shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        self.ptr = ctx.lib.sdx_malloc(ctx.handle, max(self.nbytes, 8))
+        if not self.ptr:
+            raise MemoryError(ctx.lib.sdx_last_error_string().decode())
+
+    def numpy(self):
+        out = np.empty(self.shape, dtype=self.dtype)
+        check(self.ctx.lib.sdx_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr, self.nbytes))
+        return out
+
+    def set(self, array):
+        host = np.ascontiguousarray(array, dtype=self.dtype)
+        assert host.shape == self.shape
+        check(self.ctx.lib.sdx_memcpy_h2d(self.ctx.handle, self.ptr, host.ctypes.data, host.nbytes))
+
+    def zero(self):
+        check(self.ctx.lib.sdx_memset(self.ctx.handle, self.ptr, 0, self.nbytes))
+
+    def free(self):
+        if self.ptr and self.ctx.handle:
+            self.ctx.lib.sdx_free(self.ctx.handle, self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def default_context():
+    """Process-wide context on the device chosen by LOCAL_RANK (one process per GPU) or device 0."""
+    dev = int(os.environ.get("STARDIS_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    ctx = _contexts.get(dev)
+    if ctx is None:
+        with _lock:
+            ctx = _contexts.get(dev)
+            if ctx is None:
+                ctx = Context(dev)
+                _contexts[dev] = ctx
+    return ctx
+
+
+def ptr_of(x):
+    """Device address of a DeviceArray, a torch CUDA tensor or None."""
+    if x is None:
+        return None
+    if isinstance(x, DeviceArray):
+        return x.ptr
+    if hasattr(x, "data_ptr"):
+        if not x.is_cuda or not x.is_contiguous():
+            raise ValueError("torch tensors passed to stardis_amd must be contiguous CUDA tensors")
+        return x.data_ptr()
+    raise TypeError(f"not a device array: {type(x)!r}")
+
+
+def plain(x):
+    """Strip astropy units / pandas wrappers the way numba does at its boundary."""
+    if hasattr(x, "unit") and hasattr(x, "value"):  # astropy Quantity
+        x = x.value
+    elif hasattr(x, "to_numpy"):  # pandas Series / DataFrame
+        x = x.to_numpy()
+    return np.asarray(x)

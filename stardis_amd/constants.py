@@ -27,6 +27,14 @@ C_KMS = 299792.458
 PI = math.pi
 SQRT_PI = math.sqrt(math.pi)  # 1.7724538509055159, voigt.py:12
 EV_CGS = 1.602176634e-12
+C_SI = 299792458.0
+# astropy's metre -> Angstrom scale, 1 / (0.1 * 1e-9): tracing_nus.to(u.AA, u.spectral()) evaluates
+# (c / nu) * this (opacities_solvers/base.py:62); the golden vectors pin it bit-for-bit.
+M_TO_ANGSTROM = 1.0 / (0.1 * 1e-9)
+
+
+def nu_to_angstrom(nus):
+    return (C_SI / nus) * M_TO_ANGSTROM
 
 ALL = {
     k: v

@@ -1,0 +1,668 @@
+// sdx_kernels.h — HIP kernels of the STARDIS hot path for gfx950.  Included once by stardis_hip.hip.
+//
+// Data layout in HBM
+//   inputs   reference layout: line arrays [N_l][N_d] (doppler, alpha, gamma[N_l][N_d|1]), grid nus[N_nu] descending.
+//   pre-pass depth-major SoA  [N_d][N_l]: inv_dw, y, amp (f64) and lo, hi (i32 window bounds); so that a
+//            (depth, line-range) read in the line kernel is contiguous.  32 B per (line, depth).
+//   outputs  [N_d][ld] with the frequency index contiguous: every kernel has lane <-> nu, coalesced.
+#pragma once
+#include "sdx_math.h"
+
+namespace sdx {
+
+constexpr int kBlock = 256;
+
+// ------------------------------------------------------------------------------------------------
+// d_nu = -max(diff(nus))  (opacities_solvers/base.py:524-526): partial maxima, finished by consumers.
+constexpr int kDnuPartials = 256;
+
+__global__ __launch_bounds__(kBlock) void k_dnu_partial(int64_t n_nu, const double* __restrict__ nus,
+                                                        double* __restrict__ partial)
+{
+    double m = -INFINITY;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i + 1 < n_nu; i += (int64_t)gridDim.x * kBlock)
+        m = fmax(m, nus[i + 1] - nus[i]);
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
+    __shared__ double s[kBlock / 64];
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; ++w) m = fmax(m, s[w]);
+        partial[blockIdx.x] = m;
+    }
+}
+
+__device__ __forceinline__ double block_dnu(const double* __restrict__ partial, int n_partial, double* s_red)
+{
+    double m = -INFINITY;
+    for (int i = threadIdx.x; i < n_partial; i += blockDim.x) m = fmax(m, partial[i]);
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = s_red[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = fmax(m, s_red[w]);
+    __syncthreads();
+    return -m;
+}
+
+// index of the first grid frequency strictly below line_nu in the DESCENDING grid
+//   = N_nu - searchsorted(nus[::-1], line_nu)   (base.py:556-558)
+__device__ __forceinline__ int64_t closest_index(const double* __restrict__ nus, int64_t n_nu, double line_nu)
+{
+    int64_t lo = 0, hi = n_nu;  // first i with nus[i] < line_nu
+    while (lo < hi) {
+        const int64_t mid = lo + ((hi - lo) >> 1);
+        if (nus[mid] >= line_nu) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// window rule base.py:561-575, bit-for-bit (each operation rounds once, same order)
+__device__ __forceinline__ void window_rule(int64_t c, int64_t n_nu, double d_nu, double gamma, double dw, double alpha,
+                                            int& lo, int& hi)
+{
+    const double pixels = mul_rn(mul_rn(add_rn(gamma, dw), alpha) / d_nu, 20.0);
+    const double forced = pixels > 10.0 ? pixels : 10.0;  // max(10, x); NaN keeps 10
+    const int64_t hw = forced >= (double)n_nu ? n_nu : (int64_t)forced;  // int() truncates; saturating is equivalent
+    const int64_t l = c - hw, h = c + hw;
+    lo = (int)(l < 0 ? 0 : l);
+    hi = (int)(h > n_nu ? n_nu : h);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pre-pass: one block = 32 lines x up to 64 depths.  Reads the reference layout coalesced into LDS,
+// writes the depth-major SoA coalesced.
+constexpr int kPreLines = 32;
+constexpr int kPreDepths = 64;
+
+struct LineWork {
+    double* inv_dw;  // [N_d][N_l]
+    double* y;
+    double* amp;
+    int* lo;
+    int* hi;
+    unsigned long long* evals;
+};
+
+__global__ __launch_bounds__(kBlock) void k_line_prepass(int n_depth, int64_t n_nu, const double* __restrict__ nus,
+                                                         const double* __restrict__ dnu_partial, int n_partial,
+                                                         int64_t n_lines, const double* __restrict__ line_nus,
+                                                         const double* __restrict__ doppler,
+                                                         const double* __restrict__ gammas, int gamma_cols,
+                                                         const double* __restrict__ alphas, LineWork w,
+                                                         int* __restrict__ out_lo_ref, int* __restrict__ out_hi_ref)
+{
+    constexpr int kStride = kPreDepths + 1;  // odd row stride: conflict-free transposed LDS reads
+    __shared__ double s_dw[kPreLines * kStride], s_g[kPreLines * kStride], s_a[kPreLines * kStride];
+    __shared__ int64_t s_c[kPreLines];
+    __shared__ double s_red[kBlock / 64];
+    __shared__ unsigned long long s_ev[kBlock / 64];
+
+    const double d_nu = block_dnu(dnu_partial, n_partial, s_red);
+    const int64_t l0 = (int64_t)blockIdx.x * kPreLines;
+    const int d0 = blockIdx.y * kPreDepths;
+    const int nl = (int)min((int64_t)kPreLines, n_lines - l0);
+    const int nd = min(kPreDepths, n_depth - d0);
+
+    for (int k = threadIdx.x; k < nl * nd; k += kBlock) {
+        const int ll = k / nd, dd = k - ll * nd;
+        const int64_t l = l0 + ll;
+        const int d = d0 + dd;
+        s_dw[ll * kStride + dd] = doppler[l * n_depth + d];
+        s_a[ll * kStride + dd] = alphas[l * n_depth + d];
+        s_g[ll * kStride + dd] = gamma_cols > 1 ? gammas[l * gamma_cols + d] : gammas[l * gamma_cols];
+    }
+    if (threadIdx.x < nl) s_c[threadIdx.x] = closest_index(nus, n_nu, line_nus[l0 + threadIdx.x]);
+    __syncthreads();
+
+    unsigned long long ev = 0;
+    for (int k = threadIdx.x; k < nl * nd; k += kBlock) {
+        const int dd = k / nl, ll = k - dd * nl;
+        const double dw = s_dw[ll * kStride + dd], g = s_g[ll * kStride + dd], a = s_a[ll * kStride + dd];
+        int lo, hi;
+        window_rule(s_c[ll], n_nu, d_nu, g, dw, a, lo, hi);
+        const int64_t l = l0 + ll;
+        const int d = d0 + dd;
+        if (w.inv_dw) {
+            const size_t o = (size_t)d * n_lines + l;
+            w.inv_dw[o] = 1.0 / dw;
+            w.y[o] = (g / mul_rn(kSqrtPi, kPi)) / dw;  // voigt.py:148
+            w.amp[o] = a / mul_rn(kSqrtPi, dw);        // voigt.py:149 x base.py:627
+            w.lo[o] = lo;
+            w.hi[o] = hi;
+        }
+        if (out_lo_ref) {  // reference layout [N_l][N_d], for sdx_line_windows_dev
+            out_lo_ref[l * n_depth + d] = lo;
+            out_hi_ref[l * n_depth + d] = hi;
+        }
+        if (hi > lo) ev += (unsigned long long)(hi - lo);
+    }
+    if (w.evals) {
+        for (int off = 32; off > 0; off >>= 1) ev += __shfl_xor(ev, off);
+        if ((threadIdx.x & 63) == 0) s_ev[threadIdx.x >> 6] = ev;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int i = 1; i < kBlock / 64; ++i) ev += s_ev[i];
+            if (ev) atomicAdd(w.evals, ev);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Line opacity, gather form: one block owns (depth d, a tile of 256*R grid points); each lane owns R
+// of them and accumulates in registers.  Lines are streamed in chunks of 256: each lane tests one
+// line's window against the tile, survivors are compacted (order-preserving) into LDS together with
+// their depth-column constants, then every lane walks the compacted list.  No atomics; the sum for a
+// grid point runs in ascending line order, so results are bit-stable run to run.
+template <int R>
+__global__ __launch_bounds__(kBlock) void k_line_opacity(int64_t n_nu, const double* __restrict__ nus, int64_t nu_begin,
+                                                         int64_t nu_count, int64_t n_lines,
+                                                         const double* __restrict__ line_nus, LineWork w,
+                                                         double* __restrict__ out, int64_t out_ld, int accumulate)
+{
+    constexpr int kTile = kBlock * R;
+    __shared__ double s_nu[kBlock], s_inv[kBlock], s_y[kBlock], s_amp[kBlock];
+    __shared__ int s_lo[kBlock], s_hi[kBlock];
+    __shared__ int s_wcount[2][kBlock / 64];
+
+    const int d = blockIdx.y;
+    const int64_t t0 = nu_begin + (int64_t)blockIdx.x * kTile;
+    const int64_t t1 = min(t0 + kTile, nu_begin + nu_count);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+    double nu_i[R], acc[R];
+    int idx[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t i = t0 + threadIdx.x + r * kBlock;
+        idx[r] = i < t1 ? (int)i : -1;
+        nu_i[r] = i < t1 ? nus[i] : 0.0;
+        acc[r] = 0.0;
+    }
+    const size_t base = (size_t)d * n_lines;
+    int buf = 0;
+    for (int64_t c0 = 0; c0 < n_lines; c0 += kBlock, buf ^= 1) {
+        const int64_t l = c0 + threadIdx.x;
+        int lo = 0, hi = 0;
+        bool hit = false;
+        if (l < n_lines) {
+            lo = w.lo[base + l];
+            hi = w.hi[base + l];
+            hit = (lo < t1) & (hi > t0) & (hi > lo);
+        }
+        const unsigned long long m = __ballot(hit);
+        if (lane == 0) s_wcount[buf][wave] = __popcll(m);
+        __syncthreads();
+        int off = 0, total = 0;
+#pragma unroll
+        for (int k = 0; k < kBlock / 64; ++k) {
+            const int c = s_wcount[buf][k];
+            off += k < wave ? c : 0;
+            total += c;
+        }
+        if (total == 0) continue;  // uniform; the other s_wcount buffer is used next, so no barrier needed
+        if (hit) {
+            const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
+            s_nu[pos] = line_nus[l];
+            s_inv[pos] = w.inv_dw[base + l];
+            s_y[pos] = w.y[base + l];
+            s_amp[pos] = w.amp[base + l];
+            s_lo[pos] = lo;
+            s_hi[pos] = hi;
+        }
+        __syncthreads();
+        for (int j = 0; j < total; ++j) {
+            const double lnu = s_nu[j], inv = s_inv[j], y = s_y[j], amp = s_amp[j];
+            const int jlo = s_lo[j], jhi = s_hi[j];
+            const RegionI k1 = region1_setup(y);
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (idx[r] >= jlo && idx[r] < jhi) acc[r] += voigt_term(nu_i[r] - lnu, inv, y, amp, k1);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (idx[r] >= 0) {
+            double* p = out + (size_t)d * out_ld + (idx[r] - nu_begin);
+            *p = accumulate ? *p + acc[r] : acc[r];
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// element-wise entry points
+__global__ __launch_bounds__(kBlock) void k_faddeeva(int64_t n, const double* __restrict__ z, double* __restrict__ wout)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const c64 r = faddeeva_full(c64{z[2 * i], z[2 * i + 1]});
+    wout[2 * i] = r.re;
+    wout[2 * i + 1] = r.im;
+}
+
+__global__ __launch_bounds__(kBlock) void k_voigt_profile(int64_t n, const double* __restrict__ dnu,
+                                                          const double* __restrict__ dw, const double* __restrict__ g,
+                                                          double* __restrict__ phi)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) phi[i] = voigt_profile_full(dnu[i], dw[i], g[i]);
+}
+
+__global__ __launch_bounds__(kBlock) void k_blackbody(int n_depth, int64_t n_nu, const double* __restrict__ nus,
+                                                      const double* __restrict__ temps, double* __restrict__ out, int64_t ld)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int d = blockIdx.y;
+    if (i < n_nu) out[(size_t)d * ld + i] = planck(nus[i], temps[d]);
+}
+
+__global__ __launch_bounds__(kBlock) void k_weights(int64_t n, const double* __restrict__ tau, double* __restrict__ w0,
+                                                    double* __restrict__ w1, double* __restrict__ w2)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    double a, b, c;
+    rt_weights(tau[i], a, b, c);
+    w0[i] = a;
+    w1[i] = b;
+    w2[i] = c;
+}
+
+// ------------------------------------------------------------------------------------------------
+// broadening.py scalar formulas (:32-66, :114-137, :193-229, :281-343, :420-473)
+__device__ __forceinline__ double n_effective(int ion, double e_ion, double e_lev)
+{
+    return mul_rn(sqrt(kRydEnergy / sub_rn(e_ion, e_lev)), (double)ion);
+}
+__device__ __forceinline__ double gamma_linear_stark(double nu_, double nl_, double ne)
+{
+    const double a1 = (sub_rn(nu_, nl_) < 1.5) ? 0.642 : 1.0;
+    return mul_rn(mul_rn(mul_rn(0.60, a1), sub_rn(mul_rn(nu_, nu_), mul_rn(nl_, nl_))), pow(ne, 2.0 / 3.0));
+}
+__device__ __forceinline__ double gamma_quadratic_stark(int ion, double nu_, double nl_, double ne, double t)
+{
+    const double eps0 = 1.0 / (4.0 * kPi);
+    const double zi = (double)ion;
+    const double pre = mul_rn(mul_rn(mul_rn(mul_rn(kEesu, kEesu), kBohr), kBohr), kBohr) /
+                       mul_rn(mul_rn(mul_rn(mul_rn(mul_rn(mul_rn(36.0, kH), eps0), zi), zi), zi), zi);
+    const double t1 = mul_rn(nu_, add_rn(mul_rn(mul_rn(5.0, nu_), nu_), 1.0));
+    const double t2 = mul_rn(nl_, add_rn(mul_rn(mul_rn(5.0, nl_), nl_), 1.0));
+    const double c4 = mul_rn(pre, sub_rn(mul_rn(t1, t1), mul_rn(t2, t2)));
+    return mul_rn(mul_rn(mul_rn(mul_rn(1e19, kKB), ne), pow(c4, 2.0 / 3.0)), pow(t, 1.0 / 6.0));
+}
+__device__ __forceinline__ double gamma_van_der_waals(int ion, double nu_, double nl_, double t, double nh)
+{
+    const double u2 = mul_rn(nu_, nu_), l2 = mul_rn(nl_, nl_);
+    const double c6 = mul_rn(6.46e-34, sub_rn(add_rn(mul_rn(5.0, mul_rn(u2, u2)), u2), add_rn(mul_rn(5.0, mul_rn(l2, l2)), l2))) /
+                      (double)(2 * ion * ion);
+    return mul_rn(mul_rn(mul_rn(17.0, pow(mul_rn(mul_rn(8.0, kKB), t) / mul_rn(kPi, kMp), 0.3)), pow(c6, 0.4)), nh);
+}
+__device__ __forceinline__ double doppler_width(double nu, double t, double mass, double xi)
+{
+    return mul_rn(nu / kC, sqrt(add_rn(mul_rn(mul_rn(2.0, kKB), t) / mass, mul_rn(xi, xi))));
+}
+
+__global__ __launch_bounds__(kBlock) void k_calc_gamma(int64_t n_lines, int n_depth, const int* __restrict__ z,
+                                                       const int* __restrict__ ion, const double* __restrict__ e_ion,
+                                                       const double* __restrict__ e_up, const double* __restrict__ e_lo,
+                                                       const double* __restrict__ a_ul, const double* __restrict__ ne,
+                                                       const double* __restrict__ temps, const double* __restrict__ nh,
+                                                       int flags, double* __restrict__ out)
+{
+    const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (k >= n_lines * n_depth) return;
+    const int64_t l = k / n_depth;
+    const int d = (int)(k - l * n_depth);
+    const double nu_ = n_effective(ion[l], e_ion[l], e_up[l]);
+    const double nl_ = n_effective(ion[l], e_ion[l], e_lo[l]);
+    const double g_lin = ((flags & 1) && z[l] == 1) ? gamma_linear_stark(nu_, nl_, ne[d]) : 0.0;
+    const double g_q = (flags & 2) ? gamma_quadratic_stark(ion[l], nu_, nl_, ne[d], temps[d]) : 0.0;
+    const double g_w = (flags & 4) ? gamma_van_der_waals(ion[l], nu_, nl_, temps[d], nh[d]) : 0.0;
+    const double g_r = (flags & 8) ? a_ul[l] : 0.0;
+    out[k] = add_rn(add_rn(add_rn(g_lin, g_q), g_w), g_r);  // broadening.py:649-654
+}
+
+__global__ __launch_bounds__(kBlock) void k_doppler_widths(int64_t n_lines, int n_depth, const double* __restrict__ lnu,
+                                                           const double* __restrict__ mass, const double* __restrict__ temps,
+                                                           double xi, double* __restrict__ out)
+{
+    const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (k >= n_lines * n_depth) return;
+    const int64_t l = k / n_depth;
+    const int d = (int)(k - l * n_depth);
+    out[k] = doppler_width(lnu[l], temps[d], mass[l], xi);
+}
+
+// the reference's element-wise ufuncs (broadening.py:69-71, :140-146, :232-234, :346-360, :476-490)
+enum BroadeningOp { kOpDoppler = 0, kOpNEff = 1, kOpLinearStark = 2, kOpQuadraticStark = 3, kOpVanDerWaals = 4 };
+__global__ __launch_bounds__(kBlock) void k_broadening_scalar(int op, int64_t n, const double* __restrict__ a,
+                                                              const double* __restrict__ b, const double* __restrict__ c,
+                                                              const double* __restrict__ d, const double* __restrict__ e,
+                                                              double* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    double r = 0.0;
+    switch (op) {
+        case kOpDoppler: r = doppler_width(a[i], b[i], c[i], d[i]); break;                              // nu, T, mass, xi
+        case kOpNEff: r = n_effective((int)a[i], b[i], c[i]); break;                                    // ion, E_ion, E_lev
+        case kOpLinearStark: r = gamma_linear_stark(a[i], b[i], c[i]); break;                           // n_up, n_lo, n_e
+        case kOpQuadraticStark: r = gamma_quadratic_stark((int)a[i], b[i], c[i], d[i], e[i]); break;    // ion, n_up, n_lo, n_e, T
+        case kOpVanDerWaals: r = gamma_van_der_waals((int)a[i], b[i], c[i], d[i], e[i]); break;         // ion, n_up, n_lo, T, n_H
+    }
+    out[i] = r;
+}
+
+// broadening.py:880-1006
+__device__ __forceinline__ double vald_stark(double ne, double stark, double t)
+{
+    const double g = mul_rn(mul_rn(ne, pow(10.0, stark)), pow(t / 1e4, 1.0 / 6));
+    return (mul_rn(ne, stark) >= 0) ? 0.0 : g;
+}
+__device__ inline double vald_vdw(double vdw, double t, double mass, double e_up, double e_lo, double nh, int ion, double e_ion)
+{
+    double g = 0.0;
+    if (vdw < 0) g = mul_rn(pow(10.0, vdw), pow(t / 1e4, 0.38));
+    else if (vdw == 0.0) g = 0.0;
+    else if (vdw < 20) {
+        const double nu_ = n_effective(ion, e_ion, e_up);
+        const double nl_ = n_effective(ion, e_ion, e_lo);
+        g = mul_rn(gamma_van_der_waals(ion, nu_, nl_, t, 1.0), vdw);
+    } else {
+        const double vi = trunc(vdw);
+        const double sigma = mul_rn(mul_rn(vi, kBohr), kBohr);
+        const double alpha = sub_rn(vdw, vi);
+        const double inv_mu = add_rn(1.0 / mul_rn(1.008, kAmu), 1.0 / mass);
+        const double vbar = sqrt(mul_rn(mul_rn(mul_rn(8.0, kKB), t) / kPi, inv_mu));
+        g = mul_rn(mul_rn(mul_rn(mul_rn(mul_rn(2.0, pow(4.0 / kPi, alpha / 2)), tgamma(sub_rn(4.0, alpha) / 2)), 1e6), sigma),
+                   pow(vbar / 1e6, sub_rn(1.0, alpha)));
+    }
+    return mul_rn(g, nh);
+}
+
+__global__ __launch_bounds__(kBlock) void k_calc_vald_gamma(int64_t n_lines, int n_depth, const int* __restrict__ z,
+                                                            const int* __restrict__ ion, const double* __restrict__ e_ion,
+                                                            const double* __restrict__ e_up, const double* __restrict__ e_lo,
+                                                            const double* __restrict__ a_ul, const double* __restrict__ stark,
+                                                            const double* __restrict__ waals, const double* __restrict__ mass,
+                                                            const double* __restrict__ ne, const double* __restrict__ temps,
+                                                            const double* __restrict__ nh, int flags, double* __restrict__ out)
+{
+    const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (k >= n_lines * n_depth) return;
+    const int64_t l = k / n_depth;
+    const int d = (int)(k - l * n_depth);
+    double g = 0.0;
+    if (flags & 8) g = add_rn(g, a_ul[l]);
+    if ((flags & 1) && z[l] == 1) {
+        const double nu_ = n_effective(ion[l], e_ion[l], e_up[l]);
+        const double nl_ = n_effective(ion[l], e_ion[l], e_lo[l]);
+        g = add_rn(g, gamma_linear_stark(nu_, nl_, ne[d]));
+    }
+    if (flags & 2) g = add_rn(g, vald_stark(ne[d], stark[l], temps[d]));
+    if (flags & 4) g = add_rn(g, vald_vdw(waals[l], temps[d], mass[l], e_up[l], e_lo[l], nh[d], ion[l], e_ion[l]));
+    out[k] = g / 2;  // broadening.py:1084
+}
+
+// ------------------------------------------------------------------------------------------------
+// continuum sources (opacities_solvers/base.py:40-317).  Each returns the value for one (depth, nu).
+__device__ __forceinline__ double interp1(double x, int n, const double* __restrict__ xp, const double* __restrict__ fp)
+{  // np.interp, xp ascending
+    if (x <= xp[0]) return fp[0];
+    if (x >= xp[n - 1]) return fp[n - 1];
+    int lo = 0, hi = n - 1;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (xp[mid] <= x) lo = mid; else hi = mid;
+    }
+    if (xp[lo] == x) return fp[lo];
+    const double slope = sub_rn(fp[lo + 1], fp[lo]) / sub_rn(xp[lo + 1], xp[lo]);
+    return add_rn(mul_rn(slope, sub_rn(x, xp[lo])), fp[lo]);
+}
+__device__ __forceinline__ double inv_nu3(double nu) { return 1.0 / mul_rn(mul_rn(nu, nu), nu); }  // nu ** -3
+
+// bf (:178-271): per (level, depth) coefficient BF_CONSTANT * Z**4 * n / n5 (:267-268), precomputed once
+__global__ __launch_bounds__(kBlock) void k_bf_coef(int n_depth, int n_species, const int* __restrict__ offs,
+                                                    const int* __restrict__ ions, const double* __restrict__ cutoff,
+                                                    const double* __restrict__ level_density, double* __restrict__ coef)
+{
+    const int n_levels = offs[n_species];
+    const int k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= n_levels * n_depth) return;
+    const int L = k / n_depth;
+    int s = 0;
+    while (s + 1 < n_species && L >= offs[s + 1]) ++s;
+    const int zi = ions[s] + 1;
+    const double zeff = (double)zi;
+    const double r = mul_rn(zeff, sqrt(kRydFreq / cutoff[L]));
+    const double r2 = mul_rn(r, r);
+    const double n5 = mul_rn(mul_rn(r2, r2), r);  // (...) ** 5
+    coef[k] = mul_rn(mul_rn(kBfConst, (double)(zi * zi * zi * zi)), level_density[k]) / n5;
+}
+
+struct ContinuumArgs {
+    // mirrors sdx_continuum (device pointers)
+    const double* lambdas;
+    int n_table;
+    const double* table_wavelength;
+    const double* table_sigma;
+    const double* table_density;
+    int bf_n_species;
+    const int* bf_species_offsets;
+    const int* bf_species_ion_number;
+    const double* bf_cutoff;
+    const double* bf_coef;  // [n_levels][n_depth] from k_bf_coef
+    int ff_n_species;
+    const int* ff_species_ion_number;
+    const double* ff_number_density;
+    const double* ray_n_h;
+    const double* ray_n_he;
+    const double* ray_n_h2;
+    int rayleigh_enabled;
+    const double* electron_density;
+    const double* temperature;
+};
+
+__device__ inline double alpha_bf_point(int n_depth, int d, double nu, int n_species, const int* __restrict__ offs,
+                                        const double* __restrict__ cutoff, const double* __restrict__ coef)
+{
+    double total = 0.0;
+    for (int s = 0; s < n_species; ++s) {
+        double spec = 0.0;  // alpha_spec (:214), levels in plasma order (:221-233)
+        for (int L = offs[s]; L < offs[s + 1]; ++L)
+            spec = add_rn(spec, nu >= cutoff[L] ? coef[(size_t)L * n_depth + d] : 0.0);
+        total = add_rn(total, spec);  // alpha_bf += alpha_spec (:235)
+    }
+    return mul_rn(total, inv_nu3(nu));  // :237
+}
+__device__ inline double alpha_ff_point(int n_depth, int d, double nu, double temp, int n_species,
+                                        const int* __restrict__ ions, const double* __restrict__ number_density)
+{
+    double total = 0.0;
+    for (int s = 0; s < n_species; ++s) {
+        double v = number_density[(size_t)s * n_depth + d] / sqrt(temp);
+        v = mul_rn(v, mul_rn(kFfConst, (double)(ions[s] * ions[s])));
+        total = add_rn(total, v);
+    }
+    return mul_rn(total, inv_nu3(nu));
+}
+__device__ inline double alpha_rayleigh_point(int d, double nu, const double* __restrict__ nh, const double* __restrict__ nhe,
+                                              const double* __restrict__ nh2)
+{
+    double c4 = 0, c6 = 0, c8 = 0;
+    if (nh) { c4 = add_rn(c4, mul_rn(20.24, nh[d])); c6 = add_rn(c6, mul_rn(239.2, nh[d])); c8 = add_rn(c8, mul_rn(2256.0, nh[d])); }
+    if (nhe) { c4 = add_rn(c4, mul_rn(1.913, nhe[d])); c6 = add_rn(c6, mul_rn(4.52, nhe[d])); c8 = add_rn(c8, mul_rn(7.90, nhe[d])); }
+    if (nh2) { c4 = add_rn(c4, mul_rn(28.39, nh2[d])); c6 = add_rn(c6, mul_rn(215.0, nh2[d])); c8 = add_rn(c8, mul_rn(1303.0, nh2[d])); }
+    const double nuc = nu > 2.3e15 ? 0.0 : nu;
+    const double r = nuc / mul_rn(2.0, mul_rn(kC, kRydCm));
+    const double r2 = mul_rn(r, r), r4 = mul_rn(r2, r2);
+    const double r6 = mul_rn(r4, r2), r8 = mul_rn(r4, r4);
+    return mul_rn(add_rn(add_rn(mul_rn(c4, r4), mul_rn(c6, r6)), mul_rn(c8, r8)), kSigmaT);
+}
+
+enum ContSource { kSrcFile1d = 0, kSrcBf = 1, kSrcFf = 2, kSrcRayleigh = 3, kSrcElectron = 4 };
+
+// one source -> out (drop-in calc_alpha_* functions)
+__global__ __launch_bounds__(kBlock) void k_continuum_source(int src, int n_depth, int64_t n_nu,
+                                                             const double* __restrict__ nus, ContinuumArgs a,
+                                                             double* __restrict__ out, int64_t ld)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int d = blockIdx.y;
+    if (i >= n_nu) return;
+    double v = 0.0;
+    switch (src) {
+        case kSrcFile1d: v = mul_rn(interp1(a.lambdas[i], a.n_table, a.table_wavelength, a.table_sigma), a.table_density[d]); break;
+        case kSrcBf: v = alpha_bf_point(n_depth, d, nus[i], a.bf_n_species, a.bf_species_offsets, a.bf_cutoff, a.bf_coef); break;
+        case kSrcFf: v = alpha_ff_point(n_depth, d, nus[i], a.temperature[d], a.ff_n_species, a.ff_species_ion_number, a.ff_number_density); break;
+        case kSrcRayleigh: v = alpha_rayleigh_point(d, nus[i], a.ray_n_h, a.ray_n_he, a.ray_n_h2); break;
+        case kSrcElectron: v = mul_rn(kSigmaT, a.electron_density[d]); break;
+    }
+    out[(size_t)d * ld + i] = v;
+}
+
+__global__ __launch_bounds__(kBlock) void k_rayleigh_clip(int64_t n_nu, double* __restrict__ nus)
+{  // base.py:99: tracing_nus[tracing_nus > 2.3e15] = 0, in the caller's array
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n_nu && nus[i] > 2.3e15) nus[i] = 0.0;
+}
+
+__global__ __launch_bounds__(kBlock) void k_scale_rows(int n_depth, int64_t n_nu, const double* __restrict__ src, int64_t src_ld,
+                                                       const double* __restrict__ density, double* __restrict__ out, int64_t ld)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int d = blockIdx.y;
+    if (i < n_nu) out[(size_t)d * ld + i] = mul_rn(src[(size_t)d * src_ld + i], density[d]);
+}
+
+__global__ __launch_bounds__(kBlock) void k_accumulate(int n_depth, int64_t n_nu, double* __restrict__ total, int64_t tld,
+                                                       const double* __restrict__ src, int64_t sld)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int d = blockIdx.y;
+    if (i < n_nu) total[(size_t)d * tld + i] = add_rn(total[(size_t)d * tld + i], src[(size_t)d * sld + i]);
+}
+
+// fused: total = ((((0 + file) + bf) + ff) + rayleigh) + electron) + line  (calc_alphas order, :655-738,
+// then Opacities.calc_total_alphas insertion order, opacities/base.py:24-28)
+__global__ __launch_bounds__(kBlock) void k_total_alphas(int n_depth, int64_t nu_begin, int64_t nu_count,
+                                                         const double* __restrict__ nus, ContinuumArgs a,
+                                                         const double* __restrict__ line, int64_t line_ld,
+                                                         double* __restrict__ total, int64_t total_ld)
+{
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int d = blockIdx.y;
+    if (j >= nu_count) return;
+    const int64_t i = nu_begin + j;
+    const double nu = nus[i];
+    double t = 0.0;
+    if (a.table_sigma) t = add_rn(t, mul_rn(interp1(a.lambdas[i], a.n_table, a.table_wavelength, a.table_sigma), a.table_density[d]));
+    t = add_rn(t, a.bf_n_species > 0 ? alpha_bf_point(n_depth, d, nu, a.bf_n_species, a.bf_species_offsets, a.bf_cutoff, a.bf_coef) : 0.0);
+    t = add_rn(t, a.ff_n_species > 0 ? alpha_ff_point(n_depth, d, nu, a.temperature[d], a.ff_n_species, a.ff_species_ion_number, a.ff_number_density) : 0.0);
+    if (a.rayleigh_enabled) t = add_rn(t, alpha_rayleigh_point(d, nu, a.ray_n_h, a.ray_n_he, a.ray_n_h2));
+    if (a.electron_density) t = add_rn(t, mul_rn(kSigmaT, a.electron_density[d]));
+    if (line) t = add_rn(t, line[(size_t)d * line_ld + j]);
+    total[(size_t)d * total_ld + j] = t;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Formal solution (radiation_field_solvers/base.py:85-346).  A group of G adjacent lanes of one wave
+// owns one frequency (64/G groups per wave); lane g of the group traces angles g, g+G, ... (at most P of
+// them) through all depth gaps, keeping the rolling state — two mean opacities, three source values, one
+// intensity per angle — in registers.  After every gap the group sums I_theta * w_theta in ascending-theta
+// order with wave shuffles and lane 0 adds it to F_nu[gap+1] (:336-338).  Geometric-mean opacity (:121),
+// tau (:123-129), Planck source (:133) and the weights (:138) are formed with the reference's operations;
+// the mean opacity and source are shared by the angles a lane owns instead of being recomputed per angle.
+template <int P>
+__global__ __launch_bounds__(kBlock) void k_raytrace(int n_depth, int64_t n_nu, int n_theta, int theta_stride, int G,
+                                                     const double* __restrict__ nus, const double* __restrict__ temps,
+                                                     const double* __restrict__ ray_dist, const double* __restrict__ wts,
+                                                     const double* __restrict__ alphas, int64_t ald, double* __restrict__ F,
+                                                     int64_t fld, double* __restrict__ I_nus)
+{
+    // n_theta angles are traced here; ray_dist / I_nus rows have theta_stride entries (a chunk of a longer list)
+    const int lane = threadIdx.x & 63;
+    const int gpw = 64 / G;  // groups per wave
+    const int grp = lane / G, g = lane - grp * G;
+    const int64_t i = ((int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * gpw + grp;
+    const bool valid = grp < gpw && i < n_nu;
+    const int64_t ic = i < n_nu ? i : n_nu - 1;
+    const int lane0 = lane - g;
+    const int n_gap = n_depth - 1;
+    const double nu = nus[ic];
+
+    double la0 = log(alphas[ic]);                                 // log alpha[gap]
+    double la1 = log(alphas[(size_t)ald + ic]);                   // log alpha[gap+1]
+    double mean0 = exp(mul_rn(add_rn(la1, la0), 0.5));            // :121
+    double s0 = planck(nu, temps[0]), s1 = planck(nu, temps[1]);  // :133
+    double inten[P], wt[P];
+    int th[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+        inten[k] = 0.0;  // I[0] = 0 (:134-136)
+        th[k] = g + k * G;
+        wt[k] = th[k] < n_theta ? wts[th[k]] : 0.0;
+        if (valid && I_nus && th[k] < n_theta) I_nus[(size_t)i * theta_stride + th[k]] = 0.0;
+    }
+
+    for (int gap = 0; gap < n_gap; ++gap) {
+        const bool last = gap == n_gap - 1;
+        double mean1 = 0.0, s2 = 0.0, la2 = 0.0;
+        if (!last) {
+            la2 = log(alphas[(size_t)(gap + 2) * ald + ic]);
+            mean1 = exp(mul_rn(add_rn(la2, la1), 0.5));
+            s2 = planck(nu, temps[gap + 2]);
+        }
+        double fsum = 0.0;
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            if (th[k] < n_theta) {
+                const double tau0 = mul_rn(mean0, ray_dist[(size_t)gap * theta_stride + th[k]]);
+                double inew;
+                if (tau0 == 0.0) {
+                    inew = inten[k];  // :203-206, :253-254
+                } else {
+                    double w0, w1, w2;
+                    rt_weights(tau0, w0, w1, w2);
+                    if (!last) {  // :208-249
+                        const double tau1 = mul_rn(mean1, ray_dist[(size_t)(gap + 1) * theta_stride + th[k]]);
+                        const double sum01 = add_rn(tau0, tau1);
+                        const double second =
+                            mul_rn(w1, sub_rn(mul_rn(sub_rn(s1, s2), tau0 / tau1), mul_rn(sub_rn(s1, s0), tau1 / tau0))) / sum01;
+                        const double third = mul_rn(w2, add_rn(sub_rn(s2, s1) / tau1, sub_rn(s0, s1) / tau0)) / sum01;
+                        inew = add_rn(add_rn(add_rn(mul_rn(sub_rn(1.0, w0), inten[k]), mul_rn(w0, s1)), second), third);
+                    } else {  // :256-266
+                        const double third = mul_rn(w2, sub_rn(s0, s1)) / mul_rn(tau0, tau0);
+                        inew = add_rn(add_rn(mul_rn(sub_rn(1.0, w0), inten[k]), mul_rn(w0, s1)), third);
+                    }
+                }
+                inten[k] = inew;
+                if (valid && I_nus) I_nus[((size_t)(gap + 1) * n_nu + i) * theta_stride + th[k]] = inew;
+            }
+        }
+        if (F) {
+            if (G == 1) {
+#pragma unroll
+                for (int k = 0; k < P; ++k)
+                    if (th[k] < n_theta) fsum = add_rn(fsum, mul_rn(inten[k], wt[k]));
+            } else {
+                // ascending theta = gg + k*G: k outer, group lanes inner
+#pragma unroll
+                for (int k = 0; k < P; ++k) {
+                    const double mine = mul_rn(inten[k], wt[k]);
+                    for (int gg = 0; gg < G; ++gg) {
+                        const double v = __shfl(mine, lane0 + gg);
+                        if (gg + k * G < n_theta) fsum = add_rn(fsum, v);
+                    }
+                }
+            }
+            if (valid && g == 0) {
+                double* p = F + (size_t)(gap + 1) * fld + i;
+                *p = add_rn(*p, fsum);
+            }
+        }
+        la0 = la1; la1 = la2; mean0 = mean1; s0 = s1; s1 = s2;
+    }
+}
+
+}  // namespace sdx

@@ -1,0 +1,895 @@
+// stardis_hip.hip — C ABI (include/stardis_hip.h) over the gfx950 kernels in sdx_kernels.h.
+// Build: stardis_amd/csrc/Makefile  (hipcc --offload-arch=gfx950 -O3 -ffp-contract=off)
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/stardis_hip.h"
+#include "sdx_kernels.h"
+
+using namespace sdx;
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const std::string& msg)
+{
+    g_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(e_ == hipErrorOutOfMemory ? SDX_ERR_OOM : SDX_ERR_HIP,                     \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                        \
+    } while (0)
+
+#define REQUIRE(cond, msg)                                  \
+    do {                                                    \
+        if (!(cond)) return fail(SDX_ERR_ARG, msg);         \
+    } while (0)
+
+struct ProfileRecord {
+    const char* name;
+    hipEvent_t start, stop;
+};
+
+}  // namespace
+
+struct sdx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    // line-opacity scratch (depth-major pre-pass arrays)
+    void* line_ws = nullptr;
+    size_t line_ws_bytes = 0;
+    // small scratch: d_nu partials, evaluation counter, bf coefficients
+    void* small_ws = nullptr;
+    size_t small_ws_bytes = 0;
+    // timing
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    bool profile = false;
+    std::vector<ProfileRecord> records;
+    std::vector<hipEvent_t> event_pool;
+};
+
+namespace {
+
+constexpr size_t kSmallHeader = 4096;  // [0,2048): d_nu partials; [2048,2056): evaluation counter
+
+int ensure(sdx_ctx* ctx, void** buf, size_t* have, size_t need)
+{
+    if (*have >= need) return SDX_OK;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    hipStreamIsCapturing(ctx->stream, &st);
+    if (st != hipStreamCaptureStatusNone)
+        return fail(SDX_ERR_ARG, "workspace must be reserved before stream capture (sdx_reserve_line_workspace / warm-up call)");
+    if (*buf) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(hipFree(*buf));
+        *buf = nullptr;
+        *have = 0;
+    }
+    HIP_TRY(hipMalloc(buf, need));
+    *have = need;
+    return SDX_OK;
+}
+
+size_t line_ws_need(int n_depth, int64_t n_lines) { return (size_t)n_depth * (size_t)n_lines * 32 + 256; }
+
+LineWork carve(sdx_ctx* ctx, int n_depth, int64_t n_lines)
+{
+    const size_t n = (size_t)n_depth * (size_t)n_lines;
+    char* p = (char*)ctx->line_ws;
+    LineWork w;
+    w.inv_dw = (double*)p;
+    w.y = w.inv_dw + n;
+    w.amp = w.y + n;
+    w.lo = (int*)(w.amp + n);
+    w.hi = w.lo + n;
+    w.evals = (unsigned long long*)((char*)ctx->small_ws + 2048);
+    return w;
+}
+
+hipEvent_t take_event(sdx_ctx* ctx)
+{
+    if (!ctx->event_pool.empty()) {
+        hipEvent_t e = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    hipEventCreate(&e);
+    return e;
+}
+
+struct LaunchScope {
+    sdx_ctx* ctx;
+    ProfileRecord rec{};
+    bool on;
+    LaunchScope(sdx_ctx* c, const char* name) : ctx(c), on(c->profile)
+    {
+        if (on) {
+            rec.name = name;
+            rec.start = take_event(ctx);
+            rec.stop = take_event(ctx);
+            hipEventRecord(rec.start, ctx->stream);
+        }
+    }
+    ~LaunchScope()
+    {
+        if (on) {
+            hipEventRecord(rec.stop, ctx->stream);
+            ctx->records.push_back(rec);
+        }
+    }
+};
+
+int check_launch(const char* what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(SDX_ERR_HIP, std::string(what) + " launch: " + hipGetErrorString(e));
+    return SDX_OK;
+}
+
+inline dim3 grid2(int64_t n, int rows) { return dim3((unsigned)((n + kBlock - 1) / kBlock), (unsigned)rows); }
+inline unsigned blocks1(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
+
+// d_nu partial maxima into small_ws
+int launch_dnu(sdx_ctx* ctx, int64_t n_nu, const double* nus, int* n_partial)
+{
+    int rc = ensure(ctx, &ctx->small_ws, &ctx->small_ws_bytes, kSmallHeader);
+    if (rc) return rc;
+    const int nb = (int)std::min<int64_t>(kDnuPartials, std::max<int64_t>(1, (n_nu + kBlock * 8 - 1) / (kBlock * 8)));
+    {
+        LaunchScope ls(ctx, "k_dnu_partial");
+        hipLaunchKernelGGL(k_dnu_partial, dim3(nb), dim3(kBlock), 0, ctx->stream, n_nu, nus, (double*)ctx->small_ws);
+    }
+    *n_partial = nb;
+    return check_launch("k_dnu_partial");
+}
+
+ContinuumArgs to_args(const sdx_continuum* c, const double* bf_coef)
+{
+    ContinuumArgs a{};
+    a.lambdas = c->lambdas;
+    a.n_table = c->n_table;
+    a.table_wavelength = c->table_wavelength;
+    a.table_sigma = c->table_sigma;
+    a.table_density = c->table_density;
+    a.bf_n_species = c->bf_cutoff ? c->bf_n_species : 0;
+    a.bf_species_offsets = c->bf_species_offsets;
+    a.bf_species_ion_number = c->bf_species_ion_number;
+    a.bf_cutoff = c->bf_cutoff;
+    a.bf_coef = bf_coef;
+    a.ff_n_species = c->ff_number_density ? c->ff_n_species : 0;
+    a.ff_species_ion_number = c->ff_species_ion_number;
+    a.ff_number_density = c->ff_number_density;
+    a.ray_n_h = c->ray_n_h;
+    a.ray_n_he = c->ray_n_he;
+    a.ray_n_h2 = c->ray_n_h2;
+    a.rayleigh_enabled = c->rayleigh_enabled;
+    a.electron_density = c->electron_density;
+    a.temperature = c->temperature;
+    return a;
+}
+
+// bf coefficients [n_levels][n_depth] into small_ws after the header; n_levels must be known on the host
+int launch_bf_coef(sdx_ctx* ctx, int n_depth, int n_species, int n_levels, const int32_t* offs, const int32_t* ions,
+                   const double* cutoff, const double* level_density, double** coef_out)
+{
+    const size_t need = kSmallHeader + (size_t)n_levels * n_depth * sizeof(double);
+    int rc = ensure(ctx, &ctx->small_ws, &ctx->small_ws_bytes, need);
+    if (rc) return rc;
+    double* coef = (double*)((char*)ctx->small_ws + kSmallHeader);
+    {
+        LaunchScope ls(ctx, "k_bf_coef");
+        hipLaunchKernelGGL(k_bf_coef, dim3(blocks1((int64_t)n_levels * n_depth)), dim3(kBlock), 0, ctx->stream, n_depth,
+                           n_species, offs, ions, cutoff, level_density, coef);
+    }
+    *coef_out = coef;
+    return check_launch("k_bf_coef");
+}
+
+}  // namespace
+
+// ================================================================================================ runtime
+extern "C" {
+
+const char* sdx_version(void) { return "stardis_hip 0.1 (gfx950, fp64)"; }
+const char* sdx_last_error_string(void) { return g_error.c_str(); }
+
+int sdx_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+sdx_ctx* sdx_create(int device, void* stream)
+{
+    if (hipSetDevice(device) != hipSuccess) {
+        fail(SDX_ERR_HIP, "hipSetDevice failed: no usable HIP device " + std::to_string(device));
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    sdx_ctx* ctx = new sdx_ctx();
+    ctx->device = device;
+    if (stream) {
+        ctx->stream = (hipStream_t)stream;
+    } else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+            fail(SDX_ERR_HIP, "hipStreamCreate failed");
+            delete ctx;
+            return nullptr;
+        }
+        ctx->own_stream = true;
+    }
+    hipEventCreate(&ctx->t0);
+    hipEventCreate(&ctx->t1);
+    return ctx;
+}
+
+void sdx_destroy(sdx_ctx* ctx)
+{
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    for (auto& r : ctx->records) {
+        hipEventDestroy(r.start);
+        hipEventDestroy(r.stop);
+    }
+    for (auto e : ctx->event_pool) hipEventDestroy(e);
+    if (ctx->t0) hipEventDestroy(ctx->t0);
+    if (ctx->t1) hipEventDestroy(ctx->t1);
+    if (ctx->line_ws) hipFree(ctx->line_ws);
+    if (ctx->small_ws) hipFree(ctx->small_ws);
+    if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int sdx_set_stream(sdx_ctx* ctx, void* stream)
+{
+    REQUIRE(ctx, "null context");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream) {
+        hipStreamDestroy(ctx->stream);
+        ctx->own_stream = false;
+    }
+    if (stream) {
+        ctx->stream = (hipStream_t)stream;
+    } else {
+        HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ctx->own_stream = true;
+    }
+    return SDX_OK;
+}
+
+void* sdx_get_stream(sdx_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int sdx_synchronize(sdx_ctx* ctx)
+{
+    REQUIRE(ctx, "null context");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SDX_OK;
+}
+
+void* sdx_malloc(sdx_ctx* ctx, size_t bytes)
+{
+    if (!ctx) return nullptr;
+    hipSetDevice(ctx->device);
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes ? bytes : 8);
+    if (e != hipSuccess) {
+        fail(SDX_ERR_OOM, std::string("hipMalloc: ") + hipGetErrorString(e));
+        return nullptr;
+    }
+    return p;
+}
+
+int sdx_free(sdx_ctx* ctx, void* ptr)
+{
+    REQUIRE(ctx, "null context");
+    if (!ptr) return SDX_OK;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipFree(ptr));
+    return SDX_OK;
+}
+
+int sdx_memcpy_h2d(sdx_ctx* ctx, void* dst, const void* src, size_t bytes)
+{
+    REQUIRE(ctx && (bytes == 0 || (dst && src)), "sdx_memcpy_h2d: null pointer");
+    if (bytes == 0) return SDX_OK;
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));  // pageable source: safe to reuse on return
+    return SDX_OK;
+}
+
+int sdx_memcpy_d2h(sdx_ctx* ctx, void* dst, const void* src, size_t bytes)
+{
+    REQUIRE(ctx && (bytes == 0 || (dst && src)), "sdx_memcpy_d2h: null pointer");
+    if (bytes == 0) return SDX_OK;
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SDX_OK;
+}
+
+int sdx_memset(sdx_ctx* ctx, void* dst, int value, size_t bytes)
+{
+    REQUIRE(ctx && (bytes == 0 || dst), "sdx_memset: null pointer");
+    if (bytes == 0) return SDX_OK;
+    HIP_TRY(hipMemsetAsync(dst, value, bytes, ctx->stream));
+    return SDX_OK;
+}
+
+int sdx_reserve_line_workspace(sdx_ctx* ctx, int n_depth, int64_t n_lines)
+{
+    REQUIRE(ctx && n_depth > 0 && n_lines >= 0, "sdx_reserve_line_workspace: bad sizes");
+    int rc = ensure(ctx, &ctx->small_ws, &ctx->small_ws_bytes, kSmallHeader);
+    if (rc) return rc;
+    return ensure(ctx, &ctx->line_ws, &ctx->line_ws_bytes, line_ws_need(n_depth, n_lines));
+}
+
+int sdx_graph_begin(sdx_ctx* ctx)
+{
+    REQUIRE(ctx, "null context");
+    HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    return SDX_OK;
+}
+
+int sdx_graph_end(sdx_ctx* ctx, void** graph_exec_out)
+{
+    REQUIRE(ctx && graph_exec_out, "sdx_graph_end: null pointer");
+    hipGraph_t graph = nullptr;
+    HIP_TRY(hipStreamEndCapture(ctx->stream, &graph));
+    hipGraphExec_t exec = nullptr;
+    hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    hipGraphDestroy(graph);
+    if (e != hipSuccess) return fail(SDX_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+    *graph_exec_out = (void*)exec;
+    return SDX_OK;
+}
+
+int sdx_graph_launch(sdx_ctx* ctx, void* graph_exec)
+{
+    REQUIRE(ctx && graph_exec, "sdx_graph_launch: null pointer");
+    HIP_TRY(hipGraphLaunch((hipGraphExec_t)graph_exec, ctx->stream));
+    return SDX_OK;
+}
+
+int sdx_graph_destroy(sdx_ctx* ctx, void* graph_exec)
+{
+    REQUIRE(ctx, "null context");
+    if (graph_exec) HIP_TRY(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+    return SDX_OK;
+}
+
+int sdx_timer_start(sdx_ctx* ctx)
+{
+    REQUIRE(ctx, "null context");
+    HIP_TRY(hipEventRecord(ctx->t0, ctx->stream));
+    return SDX_OK;
+}
+
+int sdx_timer_stop(sdx_ctx* ctx, double* elapsed_ms)
+{
+    REQUIRE(ctx && elapsed_ms, "sdx_timer_stop: null pointer");
+    HIP_TRY(hipEventRecord(ctx->t1, ctx->stream));
+    HIP_TRY(hipEventSynchronize(ctx->t1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, ctx->t0, ctx->t1));
+    *elapsed_ms = ms;
+    return SDX_OK;
+}
+
+int sdx_profile_enable(sdx_ctx* ctx, int on)
+{
+    REQUIRE(ctx, "null context");
+    ctx->profile = on != 0;
+    return SDX_OK;
+}
+
+int sdx_profile_reset(sdx_ctx* ctx)
+{
+    REQUIRE(ctx, "null context");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (auto& r : ctx->records) {
+        ctx->event_pool.push_back(r.start);
+        ctx->event_pool.push_back(r.stop);
+    }
+    ctx->records.clear();
+    return SDX_OK;
+}
+
+int sdx_profile_get(sdx_ctx* ctx, const char* kernel, int64_t* launches, double* total_ms)
+{
+    REQUIRE(ctx && kernel && launches && total_ms, "sdx_profile_get: null pointer");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    int64_t n = 0;
+    double tot = 0.0;
+    for (auto& r : ctx->records) {
+        if (std::strcmp(r.name, kernel) != 0) continue;
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, r.start, r.stop));
+        tot += ms;
+        ++n;
+    }
+    *launches = n;
+    *total_ms = tot;
+    return SDX_OK;
+}
+
+// ================================================================================================ line opacity
+static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t n_lines, const double* line_nus,
+                        const double* doppler, const double* gammas, int gamma_cols, const double* alphas, bool fill_work,
+                        int32_t* lo_ref, int32_t* hi_ref, LineWork* w_out)
+{
+    int n_partial = 0;
+    int rc = launch_dnu(ctx, n_nu, nus, &n_partial);
+    if (rc) return rc;
+    LineWork w{};
+    if (fill_work) {
+        rc = ensure(ctx, &ctx->line_ws, &ctx->line_ws_bytes, line_ws_need(n_depth, n_lines));
+        if (rc) return rc;
+        w = carve(ctx, n_depth, n_lines);
+        HIP_TRY(hipMemsetAsync(w.evals, 0, sizeof(unsigned long long), ctx->stream));
+    }
+    const dim3 grid((unsigned)((n_lines + kPreLines - 1) / kPreLines), (unsigned)((n_depth + kPreDepths - 1) / kPreDepths));
+    {
+        LaunchScope ls(ctx, "k_line_prepass");
+        hipLaunchKernelGGL(k_line_prepass, grid, dim3(kBlock), 0, ctx->stream, n_depth, n_nu, nus,
+                           (const double*)ctx->small_ws, n_partial, n_lines, line_nus, doppler, gammas, gamma_cols, alphas,
+                           w, (int*)lo_ref, (int*)hi_ref);
+    }
+    if (w_out) *w_out = w;
+    return check_launch("k_line_prepass");
+}
+
+static int check_line_args(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t n_lines,
+                           const double* line_nus, const double* doppler, const double* gammas, int gamma_cols,
+                           const double* alphas)
+{
+    REQUIRE(ctx, "null context");
+    REQUIRE(n_depth > 0 && n_nu >= 0 && n_lines >= 0, "line opacity: negative or zero sizes");
+    REQUIRE(n_nu < (int64_t)2147483647, "line opacity: n_nu must fit int32");
+    REQUIRE(gamma_cols == n_depth || gamma_cols == 1, "line opacity: gammas must have n_depth or 1 columns");
+    REQUIRE(n_nu == 0 || nus, "line opacity: null frequency grid");
+    REQUIRE(n_lines == 0 || (line_nus && doppler && gammas && alphas), "line opacity: null line arrays");
+    return SDX_OK;
+}
+
+int sdx_line_opacity_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin, int64_t nu_count,
+                         int64_t n_lines, const double* line_nus, const double* doppler, const double* gammas,
+                         int gamma_cols, const double* alphas, double* out, int64_t out_ld, int accumulate,
+                         int64_t* n_evaluations_dev)
+{
+    int rc = check_line_args(ctx, n_depth, n_nu, nus, n_lines, line_nus, doppler, gammas, gamma_cols, alphas);
+    if (rc) return rc;
+    REQUIRE(nu_begin >= 0 && nu_count >= 0 && nu_begin + nu_count <= n_nu, "line opacity: shard outside the grid");
+    REQUIRE(nu_count == 0 || (out && out_ld >= nu_count), "line opacity: bad output buffer");
+    if (nu_count == 0) return SDX_OK;
+    if (n_lines == 0) {
+        if (!accumulate) HIP_TRY(hipMemset2DAsync(out, out_ld * sizeof(double), 0, nu_count * sizeof(double), n_depth, ctx->stream));
+        if (n_evaluations_dev) HIP_TRY(hipMemsetAsync(n_evaluations_dev, 0, sizeof(int64_t), ctx->stream));
+        return SDX_OK;
+    }
+    LineWork w;
+    rc = line_prepass(ctx, n_depth, n_nu, nus, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, true, nullptr, nullptr, &w);
+    if (rc) return rc;
+    {
+        LaunchScope ls(ctx, "k_line_opacity");
+        constexpr int R = 2;
+        const dim3 grid((unsigned)((nu_count + kBlock * R - 1) / (kBlock * R)), (unsigned)n_depth);
+        hipLaunchKernelGGL(k_line_opacity<R>, grid, dim3(kBlock), 0, ctx->stream, n_nu, nus, nu_begin, nu_count, n_lines,
+                           line_nus, w, out, out_ld, accumulate);
+    }
+    rc = check_launch("k_line_opacity");
+    if (rc) return rc;
+    if (n_evaluations_dev)
+        HIP_TRY(hipMemcpyAsync(n_evaluations_dev, w.evals, sizeof(int64_t), hipMemcpyDeviceToDevice, ctx->stream));
+    return SDX_OK;
+}
+
+int sdx_line_windows_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t n_lines, const double* line_nus,
+                         const double* doppler, const double* gammas, int gamma_cols, const double* alphas, int32_t* lower,
+                         int32_t* upper)
+{
+    int rc = check_line_args(ctx, n_depth, n_nu, nus, n_lines, line_nus, doppler, gammas, gamma_cols, alphas);
+    if (rc) return rc;
+    REQUIRE(n_lines == 0 || (lower && upper), "line windows: null output");
+    if (n_lines == 0) return SDX_OK;
+    return line_prepass(ctx, n_depth, n_nu, nus, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, false, lower, upper,
+                        nullptr);
+}
+
+// host-pointer variant: what a numpy caller (the reference's calc_alpha_line_at_nu, base.py:432-439) binds
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf()
+    {
+        if (p) hipFree(p);
+    }
+    int alloc(size_t bytes)
+    {
+        hipError_t e = hipMalloc(&p, bytes ? bytes : 8);
+        return e == hipSuccess ? SDX_OK : fail(SDX_ERR_OOM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    }
+    int upload(sdx_ctx* ctx, const void* src, size_t bytes)
+    {
+        int rc = alloc(bytes);
+        if (rc) return rc;
+        if (bytes) HIP_TRY(hipMemcpyAsync(p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        return SDX_OK;
+    }
+};
+
+static int host_grid_check(int64_t n_nu, const double* nus)
+{
+    for (int64_t i = 0; i + 1 < n_nu; ++i)
+        if (!(nus[i + 1] < nus[i])) return fail(SDX_ERR_ARG, "tracing frequencies must be strictly descending (stardis/base.py:34)");
+    return SDX_OK;
+}
+
+int sdx_line_opacity_f64(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t n_lines, const double* line_nus,
+                         const double* doppler, const double* gammas, int gamma_cols, const double* alphas, double* out,
+                         int64_t* n_evaluations)
+{
+    int rc = check_line_args(ctx, n_depth, n_nu, nus, n_lines, line_nus, doppler, gammas, gamma_cols, alphas);
+    if (rc) return rc;
+    REQUIRE(n_nu == 0 || out, "line opacity: null output");
+    if ((rc = host_grid_check(n_nu, nus))) return rc;
+    for (int64_t k = 0; k < n_lines * n_depth; ++k)
+        if (doppler[k] == 0.0) return fail(SDX_ERR_ARG, "doppler_width == 0 (ZeroDivisionError in the reference, voigt.py:148)");
+    HIP_TRY(hipSetDevice(ctx->device));
+    DevBuf d_nus, d_ln, d_dw, d_g, d_a, d_out, d_ev;
+    const size_t ld = (size_t)n_lines * n_depth * sizeof(double);
+    if ((rc = d_nus.upload(ctx, nus, n_nu * sizeof(double)))) return rc;
+    if ((rc = d_ln.upload(ctx, line_nus, n_lines * sizeof(double)))) return rc;
+    if ((rc = d_dw.upload(ctx, doppler, ld))) return rc;
+    if ((rc = d_g.upload(ctx, gammas, (size_t)n_lines * gamma_cols * sizeof(double)))) return rc;
+    if ((rc = d_a.upload(ctx, alphas, ld))) return rc;
+    if ((rc = d_out.alloc((size_t)n_depth * n_nu * sizeof(double)))) return rc;
+    if ((rc = d_ev.alloc(sizeof(int64_t)))) return rc;
+    rc = sdx_line_opacity_dev(ctx, n_depth, n_nu, (const double*)d_nus.p, 0, n_nu, n_lines, (const double*)d_ln.p,
+                              (const double*)d_dw.p, (const double*)d_g.p, gamma_cols, (const double*)d_a.p, (double*)d_out.p,
+                              n_nu, 0, (int64_t*)d_ev.p);
+    if (rc) return rc;
+    if (n_nu) HIP_TRY(hipMemcpyAsync(out, d_out.p, (size_t)n_depth * n_nu * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    int64_t ev = 0;
+    HIP_TRY(hipMemcpyAsync(&ev, d_ev.p, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (n_evaluations) *n_evaluations = ev;
+    return SDX_OK;
+}
+
+int sdx_faddeeva_dev(sdx_ctx* ctx, int64_t n, const double* z, double* w)
+{
+    REQUIRE(ctx && n >= 0 && (n == 0 || (z && w)), "faddeeva: bad arguments");
+    if (n == 0) return SDX_OK;
+    {
+        LaunchScope ls(ctx, "k_faddeeva");
+        hipLaunchKernelGGL(k_faddeeva, dim3(blocks1(n)), dim3(kBlock), 0, ctx->stream, n, z, w);
+    }
+    return check_launch("k_faddeeva");
+}
+
+int sdx_voigt_profile_dev(sdx_ctx* ctx, int64_t n, const double* dnu, const double* dw, const double* gamma, double* phi)
+{
+    REQUIRE(ctx && n >= 0 && (n == 0 || (dnu && dw && gamma && phi)), "voigt_profile: bad arguments");
+    if (n == 0) return SDX_OK;
+    {
+        LaunchScope ls(ctx, "k_voigt_profile");
+        hipLaunchKernelGGL(k_voigt_profile, dim3(blocks1(n)), dim3(kBlock), 0, ctx->stream, n, dnu, dw, gamma, phi);
+    }
+    return check_launch("k_voigt_profile");
+}
+
+// ================================================================================================ broadening
+int sdx_calc_gamma_dev(sdx_ctx* ctx, int64_t n_lines, int n_depth, const int32_t* z, const int32_t* ion, const double* e_ion,
+                       const double* e_up, const double* e_lo, const double* a_ul, const double* ne, const double* temps,
+                       const double* nh, int flags, double* gammas)
+{
+    REQUIRE(ctx && n_lines >= 0 && n_depth > 0, "calc_gamma: bad sizes");
+    if (n_lines == 0) return SDX_OK;
+    REQUIRE(z && ion && e_ion && e_up && e_lo && a_ul && ne && temps && nh && gammas, "calc_gamma: null pointer");
+    {
+        LaunchScope ls(ctx, "k_calc_gamma");
+        hipLaunchKernelGGL(k_calc_gamma, dim3(blocks1(n_lines * n_depth)), dim3(kBlock), 0, ctx->stream, n_lines, n_depth,
+                           (const int*)z, (const int*)ion, e_ion, e_up, e_lo, a_ul, ne, temps, nh, flags, gammas);
+    }
+    return check_launch("k_calc_gamma");
+}
+
+int sdx_doppler_widths_dev(sdx_ctx* ctx, int64_t n_lines, int n_depth, const double* line_nus, const double* mass,
+                           const double* temps, double microturbulence, double* out)
+{
+    REQUIRE(ctx && n_lines >= 0 && n_depth > 0, "doppler_widths: bad sizes");
+    if (n_lines == 0) return SDX_OK;
+    REQUIRE(line_nus && mass && temps && out, "doppler_widths: null pointer");
+    {
+        LaunchScope ls(ctx, "k_doppler_widths");
+        hipLaunchKernelGGL(k_doppler_widths, dim3(blocks1(n_lines * n_depth)), dim3(kBlock), 0, ctx->stream, n_lines, n_depth,
+                           line_nus, mass, temps, microturbulence, out);
+    }
+    return check_launch("k_doppler_widths");
+}
+
+int sdx_calc_vald_gamma_dev(sdx_ctx* ctx, int64_t n_lines, int n_depth, const int32_t* z, const int32_t* ion,
+                            const double* e_ion, const double* e_up, const double* e_lo, const double* a_ul,
+                            const double* stark, const double* waals, const double* mass, const double* ne,
+                            const double* temps, const double* nh, int flags, double* gammas)
+{
+    REQUIRE(ctx && n_lines >= 0 && n_depth > 0, "calc_vald_gamma: bad sizes");
+    if (n_lines == 0) return SDX_OK;
+    REQUIRE(z && ion && e_ion && e_up && e_lo && a_ul && stark && waals && mass && ne && temps && nh && gammas,
+            "calc_vald_gamma: null pointer");
+    {
+        LaunchScope ls(ctx, "k_calc_vald_gamma");
+        hipLaunchKernelGGL(k_calc_vald_gamma, dim3(blocks1(n_lines * n_depth)), dim3(kBlock), 0, ctx->stream, n_lines,
+                           n_depth, (const int*)z, (const int*)ion, e_ion, e_up, e_lo, a_ul, stark, waals, mass, ne, temps, nh,
+                           flags, gammas);
+    }
+    return check_launch("k_calc_vald_gamma");
+}
+
+int sdx_broadening_scalar_dev(sdx_ctx* ctx, int op, int64_t n, const double* a, const double* b, const double* c,
+                              const double* d, const double* e, double* out)
+{
+    REQUIRE(ctx && op >= 0 && op <= 4 && n >= 0, "broadening_scalar: bad arguments");
+    if (n == 0) return SDX_OK;
+    REQUIRE(a && b && c && out && (op == kOpNEff || op == kOpLinearStark || d) && (op < kOpQuadraticStark || e),
+            "broadening_scalar: null pointer");
+    {
+        LaunchScope ls(ctx, "k_broadening_scalar");
+        hipLaunchKernelGGL(k_broadening_scalar, dim3(blocks1(n)), dim3(kBlock), 0, ctx->stream, op, n, a, b, c, d, e, out);
+    }
+    return check_launch("k_broadening_scalar");
+}
+
+// ================================================================================================ continuum
+static int launch_source(sdx_ctx* ctx, const char* name, int src, int n_depth, int64_t n_nu, const double* nus,
+                         const ContinuumArgs& a, double* out, int64_t ld)
+{
+    REQUIRE(n_depth > 0 && n_nu >= 0 && (n_nu == 0 || (out && ld >= n_nu)), "continuum: bad output");
+    if (n_nu == 0) return SDX_OK;
+    {
+        LaunchScope ls(ctx, name);
+        hipLaunchKernelGGL(k_continuum_source, grid2(n_nu, n_depth), dim3(kBlock), 0, ctx->stream, src, n_depth, n_nu, nus, a,
+                           out, ld);
+    }
+    return check_launch(name);
+}
+
+int sdx_alpha_file_1d_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* lambdas, int n_table, const double* tab_x,
+                          const double* tab_y, const double* density, double* out, int64_t ld)
+{
+    REQUIRE(ctx && lambdas && tab_x && tab_y && density && n_table > 0, "alpha_file_1d: bad arguments");
+    ContinuumArgs a{};
+    a.lambdas = lambdas;
+    a.n_table = n_table;
+    a.table_wavelength = tab_x;
+    a.table_sigma = tab_y;
+    a.table_density = density;
+    return launch_source(ctx, "k_alpha_file_1d", kSrcFile1d, n_depth, n_nu, nullptr, a, out, ld);
+}
+
+int sdx_alpha_file_2d_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* sigma, int64_t sigma_ld,
+                          const double* density, double* out, int64_t ld)
+{
+    REQUIRE(ctx && n_depth > 0 && n_nu >= 0 && sigma && density && out && sigma_ld >= n_nu && ld >= n_nu,
+            "alpha_file_2d: bad arguments");
+    if (n_nu == 0) return SDX_OK;
+    {
+        LaunchScope ls(ctx, "k_scale_rows");
+        hipLaunchKernelGGL(k_scale_rows, grid2(n_nu, n_depth), dim3(kBlock), 0, ctx->stream, n_depth, n_nu, sigma, sigma_ld,
+                           density, out, ld);
+    }
+    return check_launch("k_scale_rows");
+}
+
+int sdx_alpha_bf_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int n_species, const int32_t* offs,
+                     const int32_t* ions, const double* cutoff, const double* level_density, double* out, int64_t ld)
+{
+    REQUIRE(ctx && nus && n_species >= 0, "alpha_bf: bad arguments");
+    ContinuumArgs a{};
+    if (n_species > 0) {
+        REQUIRE(offs && ions && cutoff && level_density, "alpha_bf: null pointer");
+        int32_t n_levels = 0;  // offsets live on the device; the last one is the level count
+        HIP_TRY(hipMemcpyAsync(&n_levels, offs + n_species, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        double* coef = nullptr;
+        if (n_levels > 0) {
+            int rc = launch_bf_coef(ctx, n_depth, n_species, n_levels, offs, ions, cutoff, level_density, &coef);
+            if (rc) return rc;
+        }
+        a.bf_n_species = n_species;
+        a.bf_species_offsets = (const int*)offs;
+        a.bf_species_ion_number = (const int*)ions;
+        a.bf_cutoff = cutoff;
+        a.bf_coef = coef;
+    }
+    return launch_source(ctx, "k_alpha_bf", kSrcBf, n_depth, n_nu, nus, a, out, ld);
+}
+
+int sdx_alpha_ff_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, const double* temps, int n_species,
+                     const int32_t* ions, const double* number_density, double* out, int64_t ld)
+{
+    REQUIRE(ctx && nus && temps && n_species >= 0 && (n_species == 0 || (ions && number_density)), "alpha_ff: bad arguments");
+    ContinuumArgs a{};
+    a.ff_n_species = n_species;
+    a.ff_species_ion_number = (const int*)ions;
+    a.ff_number_density = number_density;
+    a.temperature = temps;
+    return launch_source(ctx, "k_alpha_ff", kSrcFf, n_depth, n_nu, nus, a, out, ld);
+}
+
+int sdx_alpha_rayleigh_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, double* nus, const double* n_h, const double* n_he,
+                           const double* n_h2, double* out, int64_t ld)
+{
+    REQUIRE(ctx && nus, "alpha_rayleigh: bad arguments");
+    if (n_nu == 0) return SDX_OK;
+    {
+        LaunchScope ls(ctx, "k_rayleigh_clip");
+        hipLaunchKernelGGL(k_rayleigh_clip, dim3(blocks1(n_nu)), dim3(kBlock), 0, ctx->stream, n_nu, nus);
+    }
+    int rc = check_launch("k_rayleigh_clip");
+    if (rc) return rc;
+    ContinuumArgs a{};
+    a.ray_n_h = n_h;
+    a.ray_n_he = n_he;
+    a.ray_n_h2 = n_h2;
+    return launch_source(ctx, "k_alpha_rayleigh", kSrcRayleigh, n_depth, n_nu, nus, a, out, ld);
+}
+
+int sdx_alpha_electron_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* ne, double* out, int64_t ld)
+{
+    REQUIRE(ctx && ne, "alpha_electron: bad arguments");
+    ContinuumArgs a{};
+    a.electron_density = ne;
+    return launch_source(ctx, "k_alpha_electron", kSrcElectron, n_depth, n_nu, nullptr, a, out, ld);
+}
+
+int sdx_accumulate_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, double* total, int64_t tld, const double* src, int64_t sld)
+{
+    REQUIRE(ctx && n_depth > 0 && n_nu >= 0 && (n_nu == 0 || (total && src && tld >= n_nu && sld >= n_nu)),
+            "accumulate: bad arguments");
+    if (n_nu == 0) return SDX_OK;
+    {
+        LaunchScope ls(ctx, "k_accumulate");
+        hipLaunchKernelGGL(k_accumulate, grid2(n_nu, n_depth), dim3(kBlock), 0, ctx->stream, n_depth, n_nu, total, tld, src, sld);
+    }
+    return check_launch("k_accumulate");
+}
+
+int sdx_total_alphas_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin, int64_t nu_count,
+                         const sdx_continuum* cont, const double* alpha_line, int64_t line_ld, double* total, int64_t total_ld)
+{
+    REQUIRE(ctx && cont && nus && n_depth > 0, "total_alphas: bad arguments");
+    REQUIRE(nu_begin >= 0 && nu_count >= 0 && nu_begin + nu_count <= n_nu, "total_alphas: shard outside the grid");
+    REQUIRE(nu_count == 0 || (total && total_ld >= nu_count && (!alpha_line || line_ld >= nu_count)), "total_alphas: bad buffers");
+    if (nu_count == 0) return SDX_OK;
+    double* coef = nullptr;
+    if (cont->bf_cutoff && cont->bf_n_species > 0) {
+        int32_t n_levels = 0;
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        hipStreamIsCapturing(ctx->stream, &st);
+        REQUIRE(st == hipStreamCaptureStatusNone || ctx->small_ws_bytes > kSmallHeader,
+                "total_alphas: run once outside stream capture first (bound-free scratch)");
+        if (st == hipStreamCaptureStatusNone) {
+            HIP_TRY(hipMemcpyAsync(&n_levels, cont->bf_species_offsets + cont->bf_n_species, sizeof(int32_t), hipMemcpyDeviceToHost,
+                                   ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+        } else {
+            n_levels = (int32_t)((ctx->small_ws_bytes - kSmallHeader) / sizeof(double) / n_depth);
+        }
+        if (n_levels > 0) {
+            int rc = launch_bf_coef(ctx, n_depth, cont->bf_n_species, n_levels, cont->bf_species_offsets,
+                                    cont->bf_species_ion_number, cont->bf_cutoff, cont->bf_level_density, &coef);
+            if (rc) return rc;
+        }
+    }
+    const ContinuumArgs a = to_args(cont, coef);
+    {
+        LaunchScope ls(ctx, "k_total_alphas");
+        hipLaunchKernelGGL(k_total_alphas, grid2(nu_count, n_depth), dim3(kBlock), 0, ctx->stream, n_depth, nu_begin, nu_count,
+                           nus, a, alpha_line, line_ld, total, total_ld);
+    }
+    return check_launch("k_total_alphas");
+}
+
+// ================================================================================================ formal solution
+int sdx_blackbody_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, const double* temps, double* out, int64_t ld)
+{
+    REQUIRE(ctx && n_depth > 0 && n_nu >= 0 && (n_nu == 0 || (nus && temps && out && ld >= n_nu)), "blackbody: bad arguments");
+    if (n_nu == 0) return SDX_OK;
+    {
+        LaunchScope ls(ctx, "k_blackbody");
+        hipLaunchKernelGGL(k_blackbody, grid2(n_nu, n_depth), dim3(kBlock), 0, ctx->stream, n_depth, n_nu, nus, temps, out, ld);
+    }
+    return check_launch("k_blackbody");
+}
+
+int sdx_calc_weights_dev(sdx_ctx* ctx, int64_t n, const double* tau, double* w0, double* w1, double* w2)
+{
+    REQUIRE(ctx && n >= 0 && (n == 0 || (tau && w0 && w1 && w2)), "calc_weights: bad arguments");
+    if (n == 0) return SDX_OK;
+    {
+        LaunchScope ls(ctx, "k_weights");
+        hipLaunchKernelGGL(k_weights, dim3(blocks1(n)), dim3(kBlock), 0, ctx->stream, n, tau, w0, w1, w2);
+    }
+    return check_launch("k_weights");
+}
+
+int sdx_raytrace_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, const double* nus, const double* temps,
+                     const double* ray_dist, const double* wts, const double* alphas, int64_t ald, double* F, int64_t fld,
+                     double* I_nus)
+{
+    REQUIRE(ctx && n_depth >= 2 && n_nu >= 0 && n_theta > 0, "raytrace: need n_depth >= 2, n_theta > 0");
+    if (n_nu == 0) return SDX_OK;
+    REQUIRE(nus && temps && ray_dist && wts && alphas && ald >= n_nu, "raytrace: null pointer");
+    REQUIRE((F && fld >= n_nu) || I_nus, "raytrace: no output requested");
+    // angles per lane P and lanes per frequency G: fill the chip when the grid is small, share the
+    // per-(gap, nu) work (log/exp/Planck) across more angles when it is large
+    constexpr int kMaxChunk = 64;
+    for (int th0 = 0; th0 < n_theta; th0 += kMaxChunk) {
+        const int nth = std::min(kMaxChunk, n_theta - th0);
+        const bool small = n_nu * (int64_t)nth < (int64_t)1 << 20;
+        int P = small ? 1 : 4;
+        int G = (nth + P - 1) / P;
+        const int gpw = 64 / G;
+        const unsigned blocks = (unsigned)((n_nu + (int64_t)gpw * (kBlock / 64) - 1) / ((int64_t)gpw * (kBlock / 64)));
+        const double* rd = ray_dist + th0;
+        const double* w = wts + th0;
+        double* inus = I_nus ? I_nus + th0 : nullptr;
+        {
+            LaunchScope ls(ctx, "k_raytrace");
+            if (P == 1)
+                hipLaunchKernelGGL(k_raytrace<1>, dim3(blocks), dim3(kBlock), 0, ctx->stream, n_depth, n_nu, nth, n_theta, G, nus,
+                                   temps, rd, w, alphas, ald, F, fld, inus);
+            else
+                hipLaunchKernelGGL(k_raytrace<4>, dim3(blocks), dim3(kBlock), 0, ctx->stream, n_depth, n_nu, nth, n_theta, G, nus,
+                                   temps, rd, w, alphas, ald, F, fld, inus);
+        }
+        int rc = check_launch("k_raytrace");
+        if (rc) return rc;
+    }
+    return SDX_OK;
+}
+
+int sdx_raytrace_f64(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, const double* nus, const double* temps,
+                     const double* ray_dist, const double* wts, const double* alphas, double* F, double* I_nus)
+{
+    REQUIRE(ctx && n_depth >= 2 && n_nu >= 0 && n_theta > 0, "raytrace: need n_depth >= 2, n_theta > 0");
+    REQUIRE(n_nu == 0 || (nus && temps && ray_dist && wts && alphas && F), "raytrace: null pointer");
+    if (n_nu == 0) return SDX_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc;
+    DevBuf d_nus, d_t, d_rd, d_w, d_a, d_f, d_i;
+    const size_t plane = (size_t)n_depth * n_nu * sizeof(double);
+    if ((rc = d_nus.upload(ctx, nus, n_nu * sizeof(double)))) return rc;
+    if ((rc = d_t.upload(ctx, temps, n_depth * sizeof(double)))) return rc;
+    if ((rc = d_rd.upload(ctx, ray_dist, (size_t)(n_depth - 1) * n_theta * sizeof(double)))) return rc;
+    if ((rc = d_w.upload(ctx, wts, n_theta * sizeof(double)))) return rc;
+    if ((rc = d_a.upload(ctx, alphas, plane))) return rc;
+    if ((rc = d_f.upload(ctx, F, plane))) return rc;  // F_nu is accumulated into (base.py:336)
+    if (I_nus && (rc = d_i.alloc(plane * n_theta))) return rc;
+    rc = sdx_raytrace_dev(ctx, n_depth, n_nu, n_theta, (const double*)d_nus.p, (const double*)d_t.p, (const double*)d_rd.p,
+                          (const double*)d_w.p, (const double*)d_a.p, n_nu, (double*)d_f.p, n_nu, (double*)d_i.p);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(F, d_f.p, plane, hipMemcpyDeviceToHost, ctx->stream));
+    if (I_nus) HIP_TRY(hipMemcpyAsync(I_nus, d_i.p, plane * n_theta, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SDX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,165 @@
+"""Device-resident spectral synthesis: line opacity + continuum + formal solution for data already in HBM.
+
+This is the path bench.py times and the one a frequency-sharded multi-GPU run uses: inputs are
+uploaded once, every step is a handful of kernel launches on one stream (optionally replayed as a
+hipGraph), and the only host traffic is the final flux.  Numerically it is the same sequence as
+calc_alphas + raytrace in stardis_amd.radiation_field (and hence the reference's
+radiation_field/base.py:104-115): total = ((((file + bf) + ff) + rayleigh) + electron) + line.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from . import constants as K
+from ._lib import Continuum, default_context, ptr_of
+
+
+def shard_bounds(n_nu, world_size, rank):
+    """Contiguous block of the GLOBAL frequency index owned by `rank`."""
+    per = -(-n_nu // world_size)
+    begin = min(rank * per, n_nu)
+    return begin, min(per, n_nu - begin)
+
+
+class SpectralSynthesizer:
+    def __init__(self, nus, temperatures, dist, thetas, theta_weights, lines, continuum=None, ctx=None, shard=None,
+                 flux_out=None, track_evaluations=True):
+        """nus: global grid (descending).  lines: dict(line_nus, doppler_widths, gammas, alphas) in the
+        reference layout (N_l, N_d).  continuum: dict as produced by synth.synth_continuum_state or None.
+        shard: (begin, count) of the global frequency index computed here (default: everything).
+        flux_out: optional contiguous CUDA tensor (N_d, count) to receive F_nu (e.g. for an RCCL gather)."""
+        self.ctx = ctx or default_context()
+        c = self.ctx
+        nus = np.ascontiguousarray(nus, dtype=np.float64)
+        if np.any(np.diff(nus) >= 0):
+            raise ValueError("tracing frequencies must be strictly descending (stardis/base.py:34)")
+        if np.any(np.asarray(lines["doppler_widths"]) == 0):
+            raise ZeroDivisionError("float division by zero")  # voigt.py:148
+        self.n_nu = nus.size
+        self.begin, self.count = shard if shard is not None else (0, self.n_nu)
+        t = np.ascontiguousarray(temperatures, dtype=np.float64).reshape(-1)
+        self.n_depth = t.size
+        thetas = np.asarray(thetas, dtype=np.float64)
+        self.n_theta = thetas.size
+        ray = np.asarray(dist, dtype=np.float64).reshape(-1, 1) / np.cos(thetas)  # radiation_field_solvers/base.py:302-305
+
+        self.d_nus = c.upload(nus)
+        self.d_t = c.upload(t)
+        self.d_ray = c.upload(ray)
+        self.d_w = c.upload(np.asarray(theta_weights, dtype=np.float64))
+        ln = np.ascontiguousarray(lines["line_nus"], dtype=np.float64)
+        self.n_lines = ln.size
+        g = np.ascontiguousarray(lines["gammas"], dtype=np.float64).reshape(self.n_lines, -1)
+        self.gamma_cols = g.shape[1] if self.n_lines else 1
+        self.d_ln = c.upload(ln)
+        self.d_dw = c.upload(np.ascontiguousarray(lines["doppler_widths"], dtype=np.float64))
+        self.d_g = c.upload(g)
+        self.d_a = c.upload(np.ascontiguousarray(lines["alphas"], dtype=np.float64))
+
+        self._keep = []
+        self.cont = self._build_continuum(continuum, nus, t)
+
+        self.d_line = c.empty((self.n_depth, self.count))
+        self.d_total = c.empty((self.n_depth, self.count))
+        self._flux_tensor = flux_out
+        self.d_F = None if flux_out is not None else c.empty((self.n_depth, self.count))
+        self.d_evals = c.zeros((1,), np.int64) if track_evaluations else None
+        self.graph = None
+        c.call("sdx_reserve_line_workspace", self.n_depth, self.n_lines)
+
+    # -- set-up ---------------------------------------------------------------------------------
+    def _build_continuum(self, cont, nus, t):
+        c = self.ctx
+        s = Continuum()
+        up = lambda a, dt=np.float64: self._hold(c.upload(np.ascontiguousarray(a, dtype=dt), dt))  # noqa: E731
+        s.temperature = self.d_t.ptr
+        if cont is None:
+            return s
+        lam = K.nu_to_angstrom(nus)  # tracing_nus.to(u.AA, u.spectral()) (opacities_solvers/base.py:62)
+        s.lambdas = up(lam)
+        s.n_table = len(cont["hminus_bf_wavelength"])
+        s.table_wavelength = up(cont["hminus_bf_wavelength"])
+        s.table_sigma = up(cont["hminus_bf_cross_section"])
+        s.table_density = up(cont["n_hminus"])
+        cutoff = (cont["ionization_energy"] - np.asarray(cont["level_excitation"])) / K.H_CGS
+        s.bf_n_species = 1
+        s.bf_species_offsets = up([0, len(cutoff)], np.int32)
+        s.bf_species_ion_number = up([0], np.int32)
+        s.bf_cutoff = up(cutoff)
+        s.bf_level_density = up(cont["level_density"])
+        s.ff_n_species = 1
+        s.ff_species_ion_number = up([1], np.int32)  # get_number_density("H_I_ff") returns ion_number + 1
+        s.ff_number_density = up(np.asarray(cont["n_e"]) * np.asarray(cont["n_h2"]))  # util.py:160-164
+        s.rayleigh_enabled = 0
+        s.electron_density = up(cont["n_e"])
+        return s
+
+    def _hold(self, dev):
+        self._keep.append(dev)
+        return dev.ptr
+
+    @property
+    def flux_ptr(self):
+        return ptr_of(self._flux_tensor) if self._flux_tensor is not None else self.d_F.ptr
+
+    # -- one step: everything from resident inputs to F_nu -----------------------------------------
+    def enqueue(self):
+        c = self.ctx
+        nd, cnt = self.n_depth, self.count
+        c.call("sdx_line_opacity_dev", nd, self.n_nu, self.d_nus.ptr, self.begin, cnt, self.n_lines, self.d_ln.ptr,
+               self.d_dw.ptr, self.d_g.ptr, self.gamma_cols, self.d_a.ptr, self.d_line.ptr, cnt, 0, ptr_of(self.d_evals))
+        c.call("sdx_total_alphas_dev", nd, self.n_nu, self.d_nus.ptr, self.begin, cnt, C.byref(self.cont), self.d_line.ptr, cnt,
+               self.d_total.ptr, cnt)
+        c.call("sdx_memset", self.flux_ptr, 0, nd * cnt * 8)
+        nus_shard = self.d_nus.ptr + 8 * self.begin
+        c.call("sdx_raytrace_dev", nd, cnt, self.n_theta, nus_shard, self.d_t.ptr, self.d_ray.ptr, self.d_w.ptr,
+               self.d_total.ptr, cnt, self.flux_ptr, cnt, None)
+
+    def capture(self):
+        """Record one step into a hipGraph (after one eager step has sized the scratch)."""
+        c = self.ctx
+        self.enqueue()
+        c.synchronize()
+        c.call("sdx_graph_begin")
+        try:
+            self.enqueue()
+        finally:
+            handle = C.c_void_p()
+            _lib.check(c.lib.sdx_graph_end(c.handle, C.byref(handle)))
+        self.graph = handle
+        return self
+
+    def step(self):
+        if self.graph is not None:
+            self.ctx.call("sdx_graph_launch", self.graph)
+        else:
+            self.enqueue()
+
+    def synchronize(self):
+        self.ctx.synchronize()
+
+    # -- results ----------------------------------------------------------------------------------
+    def F_nu(self):
+        if self._flux_tensor is not None:
+            self.ctx.synchronize()
+            return self._flux_tensor.cpu().numpy()
+        return self.d_F.numpy()
+
+    def total_alphas(self):
+        return self.d_total.numpy()
+
+    def alpha_line(self):
+        return self.d_line.numpy()
+
+    def evaluations(self):
+        return int(self.d_evals.numpy()[0]) if self.d_evals is not None else None
+
+    def algorithmic_bytes(self):
+        """line list, grid read once; total_alphas and F_nu written once (this shard's columns)."""
+        return 8 * self.n_lines * (1 + 2 * self.n_depth + self.gamma_cols) + 8 * self.n_nu + 16 * self.n_depth * self.count
+
+    def close(self):
+        if self.graph is not None:
+            self.ctx.call("sdx_graph_destroy", self.graph)
+            self.graph = None

@@ -1,0 +1,60 @@
+"""Frequency sharding across the GPUs of one node: one process per GPU, one collective.
+
+The hot path shards along the frequency axis with no data-path exchange (every output column depends
+only on its own frequency).  Each rank runs the fused synthesis on a contiguous block of
+the GLOBAL frequency index — the window rule keeps using the global grid, so results are identical to
+a single-GPU run — and the emergent flux F_nu[-1] is gathered with ONE all-gather (RCCL over xGMI when
+the backend is "nccl"; gloo works for CPU tests).  Shards are padded to equal length for the
+collective and trimmed afterwards.
+"""
+import os
+
+import numpy as np
+
+from .engine import shard_bounds  # noqa: F401  (re-exported)
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torch.distributed.run sets them).
+    Returns (rank, world_size, local_rank).  Single-process runs return (0, 1, 0) without touching torch."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        if not dist.is_initialized():
+            if backend is None:
+                backend = "nccl" if torch.cuda.is_available() else "gloo"
+            if backend == "nccl":
+                torch.cuda.set_device(local)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def padded_count(n_nu, world_size):
+    return -(-n_nu // world_size)
+
+
+def gather_flux(local_flux, n_nu, world_size):
+    """All-gather per-rank emergent-flux shards (1-D tensors of this rank's `count` columns, on the
+    device the backend wants) into the full (n_nu,) spectrum on every rank."""
+    import torch
+    import torch.distributed as dist
+
+    per = padded_count(n_nu, world_size)
+    send = torch.zeros(per, dtype=local_flux.dtype, device=local_flux.device)
+    send[: local_flux.numel()] = local_flux
+    if world_size == 1:
+        return send[:n_nu].clone()
+    recv = torch.empty(per * world_size, dtype=local_flux.dtype, device=local_flux.device)
+    dist.all_gather_into_tensor(recv, send)
+    return recv[:n_nu]
+
+
+def assemble_shards(shards, n_nu, world_size):
+    """Host-side twin of gather_flux for tests: concatenate per-rank arrays in rank order."""
+    out = np.concatenate([np.asarray(s) for s in shards], axis=-1)
+    assert out.shape[-1] == n_nu
+    return out

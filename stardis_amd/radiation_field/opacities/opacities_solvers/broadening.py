@@ -1,0 +1,120 @@
+"""Line broadening on the GPU, call-compatible with
+stardis/radiation_field/opacities/opacities_solvers/broadening.py.
+
+Every formula runs in a HIP kernel (stardis_amd/csrc/sdx_kernels.h); this module only unpacks the
+DataFrame / model / plasma objects into flat arrays the way calculate_broadening (:659-732),
+calculate_molecule_broadening (:735-821) and calc_vald_gamma (:1009-1085) do."""
+import logging
+
+import numpy as np
+
+from stardis_amd import constants as K
+from stardis_amd import ops
+from stardis_amd._lib import plain
+
+logger = logging.getLogger(__name__)
+
+_OP_DOPPLER, _OP_NEFF, _OP_LINEAR_STARK, _OP_QUADRATIC_STARK, _OP_VDW = range(5)
+
+
+# -- element-wise ufunc counterparts ---------------------------------------------------------------
+def calc_doppler_width(nu_line, temperature, atomic_mass, microturbulence=0.0):
+    return ops.broadening_scalar(_OP_DOPPLER, nu_line, temperature, atomic_mass, microturbulence)
+
+
+def calc_n_effective(ion_number, ionization_energy, level_energy):
+    return ops.broadening_scalar(_OP_NEFF, ion_number, ionization_energy, level_energy)
+
+
+def calc_gamma_linear_stark(n_eff_upper, n_eff_lower, electron_density):
+    return ops.broadening_scalar(_OP_LINEAR_STARK, n_eff_upper, n_eff_lower, electron_density)
+
+
+def calc_gamma_quadratic_stark(ion_number, n_eff_upper, n_eff_lower, electron_density, temperature):
+    return ops.broadening_scalar(_OP_QUADRATIC_STARK, ion_number, n_eff_upper, n_eff_lower, electron_density, temperature)
+
+
+def calc_gamma_van_der_waals(ion_number, n_eff_upper, n_eff_lower, temperature, h_density):
+    return ops.broadening_scalar(_OP_VDW, ion_number, n_eff_upper, n_eff_lower, temperature, h_density)
+
+
+def calc_gamma(atomic_number, ion_number, ionization_energy, upper_level_energy, lower_level_energy, A_ul,
+               electron_density, temperature, h_density, linear_stark=True, quadratic_stark=True, van_der_waals=True,
+               radiation=True):
+    """Total gamma (N_l, N_d); ion_number is already `ion_number + 1` as at :708-709."""
+    return ops.calc_gamma(atomic_number, ion_number, ionization_energy, upper_level_energy, lower_level_energy, A_ul,
+                          electron_density, temperature, h_density, linear_stark, quadratic_stark, van_der_waals, radiation)
+
+
+# -- object-level entry points ---------------------------------------------------------------------
+def _switches(cfg):
+    return ("linear_stark" in cfg, "quadratic_stark" in cfg, "van_der_waals" in cfg, "radiation" in cfg)
+
+
+def _depth_state(stellar_model, stellar_plasma):
+    return (
+        plain(stellar_plasma.electron_densities),
+        plain(stellar_model.temperatures),
+        plain(stellar_plasma.ion_number_density.loc[1, 0]),
+    )
+
+
+def _microturbulence_cgs(stellar_model):
+    xi = stellar_model.microturbulence
+    return float(xi.cgs.value) if hasattr(xi, "cgs") else float(xi)
+
+
+def calc_vald_gamma(lines, stellar_model, stellar_plasma, linear_stark, quadratic_stark, van_der_waals, radiation):
+    n_e, temps, n_h = _depth_state(stellar_model, stellar_plasma)
+    masses = stellar_model.composition.nuclide_masses.loc[lines.atomic_number].values
+    return ops.calc_vald_gamma_arrays(
+        lines.atomic_number.values, lines.ion_number.values + 1, lines.ionization_energy.values,
+        lines.level_energy_upper.values, lines.level_energy_lower.values, lines.A_ul.values, lines.stark.values,
+        lines.waals.values, masses, n_e, temps, n_h, linear_stark, quadratic_stark, van_der_waals, radiation,
+    )
+
+
+def calculate_broadening(lines, stellar_model, stellar_plasma, broadening_line_opacity_config, use_vald_broadening=False):
+    """-> (gammas (N_l, N_d), doppler_widths (N_l, N_d))"""
+    lin, quad, vdw, rad = _switches(broadening_line_opacity_config)
+    n_e, temps, n_h = _depth_state(stellar_model, stellar_plasma)
+    if use_vald_broadening:
+        logger.info("Using VALD broadening parameters.")
+        gammas = calc_vald_gamma(lines, stellar_model, stellar_plasma, lin, quad, vdw, rad)
+    else:
+        logger.info("Calculating broadening parameters.")
+        gammas = ops.calc_gamma(
+            lines.atomic_number.values, lines.ion_number.values + 1, lines.ionization_energy.values,
+            lines.level_energy_upper.values, lines.level_energy_lower.values, lines.A_ul.values, n_e, temps, n_h,
+            lin, quad, vdw, rad,
+        )
+    masses = stellar_model.composition.nuclide_masses.loc[lines.atomic_number].values
+    doppler_widths = ops.doppler_widths(lines.nu.values, masses, temps, _microturbulence_cgs(stellar_model))
+    return gammas, doppler_widths
+
+
+def calculate_molecule_broadening(lines, stellar_model, stellar_plasma, broadening_line_opacity_config, use_vald_broadening=False):
+    """Molecular lines: gamma = A_ul as an (N_l, 1) column when "radiation" is configured (:800-801), Doppler
+    width with the summed mass of the two constituent nuclides (:808-819)."""
+    if use_vald_broadening:
+        raise NotImplementedError("VALD broadening for molecules is not reachable in the reference either (:444-474)")
+    n_depth = stellar_model.no_of_depth_points if hasattr(stellar_model, "no_of_depth_points") else len(plain(stellar_model.temperatures))
+    if "radiation" in broadening_line_opacity_config:
+        gammas = np.asarray(lines.A_ul.values, dtype=float)[:, np.newaxis]
+    else:
+        gammas = np.zeros((len(lines), n_depth), dtype=float)
+    ions = stellar_plasma.molecule_ion_map.loc[lines.molecule]
+    masses = stellar_model.composition.nuclide_masses
+    molecule_masses = masses.loc[ions.Ion1].values + masses.loc[ions.Ion2].values
+    doppler_widths = ops.doppler_widths(
+        lines.nu.values, molecule_masses, plain(stellar_model.temperatures), _microturbulence_cgs(stellar_model)
+    )
+    return gammas, doppler_widths
+
+
+def rotation_broadening(velocity_per_pix, wavelength, flux, v_rot=0.0, limb_darkening=0.6):
+    """Rotational broadening (:824-877).  Velocities in km/s (astropy quantities are accepted and stripped
+    after conversion when astropy is available).  Returns (wavelength, broadened flux values)."""
+    from stardis_amd.postprocess import rotation_broadening as impl
+
+    return impl(velocity_per_pix, wavelength, flux, v_rot, limb_darkening)

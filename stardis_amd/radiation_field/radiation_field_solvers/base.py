@@ -1,0 +1,77 @@
+"""LTE formal solution on MI355X, call-compatible with
+stardis/radiation_field/radiation_field_solvers/base.py (van Noort 2002 eq. 14 short characteristics).
+
+The per-angle, per-frequency depth recurrence runs in one HIP kernel (k_raytrace in
+stardis_amd/csrc/sdx_kernels.h); this module builds the ray-length table and moves arrays."""
+import numpy as np
+
+from stardis_amd import ops
+from stardis_amd._lib import default_context, plain
+
+
+def calc_weights_parallel(delta_tau):
+    """w0, w1, w2 of eq. 14 for an array of optical depths.  Reference :6-47."""
+    return ops.calc_weights_parallel(delta_tau)
+
+
+calc_weights = calc_weights_parallel  # the reference keeps an unused numpy twin (:50-82) with the same contract
+
+
+def _check_source_function(source_function):
+    name = getattr(source_function, "__name__", "")
+    if source_function is not None and name != "blackbody_flux_at_nu":
+        raise NotImplementedError(
+            "the GPU formal solver evaluates the Planck source function in-kernel; "
+            f"source_function={name!r} is not supported (the reference only ever passes blackbody_flux_at_nu)"
+        )
+
+
+def single_theta_trace_parallel(ray_dist_to_next_depth_point, temps, alphas, tracing_nus, source_function=None,
+                                inward_rays=False):
+    """Specific intensity (N_d, N_nu) along one ray direction.  Reference :85-268 (outward pass)."""
+    if inward_rays:
+        raise NotImplementedError("spherical inward sweep (:141-198) is not built yet (SURVEY §8 f4)")
+    _check_source_function(source_function)
+    rd = np.asarray(plain(ray_dist_to_next_depth_point), dtype=np.float64).reshape(-1, 1)
+    _, I = ops.raytrace_arrays(tracing_nus, temps, rd, np.ones(1), alphas, track=True)
+    return I[:, :, 0]
+
+
+def calculate_spherical_ray(thetas, depth_points_radii):
+    """Chord length of each ray through each shell (N_d-1, N_theta).  Reference :349-381.  Geometry set-up,
+    a (N_d x N_theta) table built once on the host."""
+    thetas = np.asarray(thetas, dtype=np.float64)
+    r = np.asarray(plain(depth_points_radii), dtype=np.float64)
+    out = np.zeros((len(r) - 1, len(thetas)))
+    for k, theta in enumerate(thetas):
+        b = r[-1] * np.sin(theta)
+        with np.errstate(invalid="ignore"):
+            z = np.sqrt(r**2 - b**2)
+        dz = np.diff(z)
+        ok = ~np.isnan(dz)
+        out[ok, k] = dz[ok]
+    return out
+
+
+def raytrace(stellar_model, stellar_radiation_field):
+    """Trace every angle and accumulate the Gauss-Legendre flux sum into stellar_radiation_field.F_nu
+    (in place, like the reference :324-338).  Fills I_nus when track_individual_intensities is set."""
+    field = stellar_radiation_field
+    if stellar_model.spherical:
+        raise NotImplementedError("spherical geometry (:296-300, :340-344) is not built yet (SURVEY §8 f4)")
+    _check_source_function(getattr(field, "source_function", None))
+    thetas = np.asarray(field.thetas, dtype=np.float64)
+    dist = np.asarray(plain(stellar_model.geometry.dist_to_next_depth_point), dtype=np.float64)
+    ray_distances = dist.reshape(-1, 1) / np.cos(thetas)  # :302-305
+    ctx = default_context()
+    opac = field.opacities
+    alphas = opac.total_alphas_device(ctx) if hasattr(opac, "total_alphas_device") else opac.total_alphas
+    track = bool(getattr(field, "track_individual_intensities", False))
+    F, I = ops.raytrace_arrays(
+        field.frequencies, plain(stellar_model.temperatures), ray_distances, field.I_nus_weights, alphas, F_nu=field.F_nu,
+        track=track, ctx=ctx,
+    )
+    field.F_nu[...] = F
+    if track:
+        field.I_nus[...] = I
+    return field.F_nu

@@ -129,6 +129,7 @@ def synth_continuum_state(atm, n_levels=10):
     with open(os.path.join(_DATA, "hminus_bf_wishart1979.json")) as fh:
         tab = json.load(fh)
     return dict(
+        n_e=n_e,
         n_h1=n_h1,
         n_h2=n_h2,
         n_hminus=n_hminus,

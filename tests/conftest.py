@@ -1,0 +1,46 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return load_golden
+
+
+def rel_err(a, b):
+    """max |a-b| / |b| where b != 0, absolute where b == 0; NaNs must coincide."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert np.array_equal(np.isnan(a), np.isnan(b)), "NaN pattern differs"
+    ok = ~np.isnan(b)
+    a, b = a[ok], b[ok]
+    if a.size == 0:
+        return 0.0
+    d = np.abs(a - b)
+    scale = np.where(b == 0, 1.0, np.abs(b))
+    return float(np.max(d / scale))
+
+
+@pytest.fixture(scope="session")
+def ctx():
+    from stardis_amd._lib import default_context
+
+    return default_context()
