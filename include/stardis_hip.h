@@ -165,10 +165,12 @@ int sdx_blackbody_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus
 int sdx_calc_weights_dev(sdx_ctx* ctx, int64_t n, const double* delta_tau, double* w0, double* w1, double* w2);
 /* raytrace :271-346, plane-parallel branch.  ray_dist is [n_depth-1][n_theta] = dist[:,None]/cos(thetas)
  * (:302-305).  nus/total_alphas/F_nu hold the n_nu columns being traced (a shard passes its own
- * slice).  F_nu is ACCUMULATED into (:336).  I_nus [n_depth][n_nu][n_theta] optional (:333-334). */
+ * slice).  accumulate = 1: F_nu is ACCUMULATED into, the reference's behaviour (:336); 0: F_nu is overwritten
+ * (row 0 becomes 0).  I_nus [n_depth][n_nu][n_theta] optional (:333-334). */
 int sdx_raytrace_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, const double* nus,
                      const double* temperature, const double* ray_dist, const double* theta_weights,
-                     const double* total_alphas, int64_t alpha_ld, double* F_nu, int64_t F_ld, double* I_nus);
+                     const double* total_alphas, int64_t alpha_ld, double* F_nu, int64_t F_ld, double* I_nus,
+                     int accumulate);
 int sdx_raytrace_f64(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, const double* nus,
                      const double* temperature, const double* ray_dist, const double* theta_weights,
                      const double* total_alphas, double* F_nu, double* I_nus);
@@ -186,6 +188,7 @@ typedef struct sdx_continuum {
     const double* table_density;    /* [n_depth] */
     /* bf */
     int bf_n_species;
+    int bf_n_levels;                /* = bf_species_offsets[bf_n_species], known to the host */
     const int32_t* bf_species_offsets;
     const int32_t* bf_species_ion_number;
     const double* bf_cutoff;
@@ -207,6 +210,16 @@ typedef struct sdx_continuum {
 int sdx_total_alphas_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin,
                          int64_t nu_count, const sdx_continuum* cont, const double* alpha_line, int64_t line_ld,
                          double* total_alphas, int64_t total_ld);
+
+/* Everything in one call for resident data: pre-pass + line opacity + total (above) + raytrace (F_nu
+ * overwritten).  alpha_line_out is optional; total_alphas and F_nu are [n_depth][ld].  This is the step
+ * bench.py times; it skips the intermediate line-opacity plane when the line list was split over blocks. */
+int sdx_synthesize_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin, int64_t nu_count,
+                       int64_t n_lines, const double* line_nus, const double* doppler_widths, const double* gammas,
+                       int gamma_cols, const double* alphas, const sdx_continuum* cont, int n_theta,
+                       const double* temperature, const double* ray_dist, const double* theta_weights,
+                       double* alpha_line_out, double* total_alphas, double* F_nu, int64_t ld,
+                       int64_t* n_evaluations_dev);
 
 #ifdef __cplusplus
 }

@@ -28,6 +28,7 @@ class Continuum(C.Structure):
         ("table_sigma", _vp),
         ("table_density", _vp),
         ("bf_n_species", _int),
+        ("bf_n_levels", _int),
         ("bf_species_offsets", _vp),
         ("bf_species_ion_number", _vp),
         ("bf_cutoff", _vp),
@@ -87,9 +88,11 @@ PROTOTYPES = {
     "sdx_accumulate_dev": (_int, [_vp, _int, _i64, _vp, _i64, _vp, _i64]),
     "sdx_blackbody_dev": (_int, [_vp, _int, _i64, _vp, _vp, _vp, _i64]),
     "sdx_calc_weights_dev": (_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
-    "sdx_raytrace_dev": (_int, [_vp, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp]),
+    "sdx_raytrace_dev": (_int, [_vp, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _int]),
     "sdx_raytrace_f64": (_int, [_vp, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sdx_total_alphas_dev": (_int, [_vp, _int, _i64, _vp, _i64, _i64, C.POINTER(Continuum), _vp, _i64, _vp, _i64]),
+    "sdx_synthesize_dev": (_int, [_vp, _int, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _int, _vp, C.POINTER(Continuum), _int,
+                                  _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
 }
 
 _lib = None

@@ -45,6 +45,19 @@ __device__ __forceinline__ double block_dnu(const double* __restrict__ partial, 
     return -m;
 }
 
+__device__ __forceinline__ double block_dnu_scan(const double* __restrict__ nus, int64_t n_nu, double* s_red)
+{
+    double m = -INFINITY;
+    for (int64_t i = threadIdx.x; i + 1 < n_nu; i += blockDim.x) m = fmax(m, nus[i + 1] - nus[i]);
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = s_red[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = fmax(m, s_red[w]);
+    __syncthreads();
+    return -m;
+}
+
 // index of the first grid frequency strictly below line_nu in the DESCENDING grid
 //   = N_nu - searchsorted(nus[::-1], line_nu)   (base.py:556-558)
 __device__ __forceinline__ int64_t closest_index(const double* __restrict__ nus, int64_t n_nu, double line_nu)
@@ -58,8 +71,8 @@ __device__ __forceinline__ int64_t closest_index(const double* __restrict__ nus,
 }
 
 // window rule base.py:561-575, bit-for-bit (each operation rounds once, same order)
-__device__ __forceinline__ void window_rule(int64_t c, int64_t n_nu, double d_nu, double gamma, double dw, double alpha,
-                                            int& lo, int& hi)
+__device__ __forceinline__ int64_t window_rule(int64_t c, int64_t n_nu, double d_nu, double gamma, double dw, double alpha,
+                                               int& lo, int& hi)
 {
     const double pixels = mul_rn(mul_rn(add_rn(gamma, dw), alpha) / d_nu, 20.0);
     const double forced = pixels > 10.0 ? pixels : 10.0;  // max(10, x); NaN keeps 10
@@ -67,6 +80,7 @@ __device__ __forceinline__ void window_rule(int64_t c, int64_t n_nu, double d_nu
     const int64_t l = c - hw, h = c + hw;
     lo = (int)(l < 0 ? 0 : l);
     hi = (int)(h > n_nu ? n_nu : h);
+    return hw;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -75,12 +89,17 @@ __device__ __forceinline__ void window_rule(int64_t c, int64_t n_nu, double d_nu
 constexpr int kPreLines = 32;
 constexpr int kPreDepths = 64;
 
+constexpr int kNarrowHalfWidth = 64;  // windows with half-width <= this go to k_line_narrow
+
 struct LineWork {
     double* inv_dw;  // [N_d][N_l]
     double* y;
     double* amp;
-    int* lo;
+    int* lo;         // window of WIDE (line, depth) items, 0/0 for narrow ones
     int* hi;
+    int* nlo;        // window of NARROW items (half-width <= kNarrowHalfWidth), 0/0 for wide ones
+    int* nhi;
+    int* cnt_ge;     // [N_nu + 2]: number of lines whose centre index is >= p (lines are a prefix: centres descend)
     unsigned long long* evals;
 };
 
@@ -90,15 +109,39 @@ __global__ __launch_bounds__(kBlock) void k_line_prepass(int n_depth, int64_t n_
                                                          const double* __restrict__ doppler,
                                                          const double* __restrict__ gammas, int gamma_cols,
                                                          const double* __restrict__ alphas, LineWork w,
-                                                         int* __restrict__ out_lo_ref, int* __restrict__ out_hi_ref)
+                                                         int* __restrict__ out_lo_ref, int* __restrict__ out_hi_ref,
+                                                         int n_line_blocks)
 {
+    if ((int)blockIdx.x >= n_line_blocks) {
+        // trailing blocks: cnt_ge[p] = #{l : centre_l >= p} = #{l : line_nu_l <= nus[p-1]}  (centre_l = #{i : nus[i] >= line_nu_l})
+        if (blockIdx.y == 0 && w.cnt_ge) {
+            const int64_t pidx = (int64_t)(blockIdx.x - n_line_blocks) * kBlock + threadIdx.x;
+            if (pidx <= n_nu + 1) {
+                int64_t cnt;
+                if (pidx == 0) cnt = n_lines;
+                else if (pidx == n_nu + 1) cnt = 0;
+                else {
+                    const double v = nus[pidx - 1];
+                    int64_t lo = 0, hi = n_lines;  // first l with line_nus[l] > v
+                    while (lo < hi) {
+                        const int64_t mid = lo + ((hi - lo) >> 1);
+                        if (line_nus[mid] <= v) lo = mid + 1; else hi = mid;
+                    }
+                    cnt = lo;
+                }
+                w.cnt_ge[pidx] = (int)cnt;
+            }
+        }
+        return;
+    }
     constexpr int kStride = kPreDepths + 1;  // odd row stride: conflict-free transposed LDS reads
     __shared__ double s_dw[kPreLines * kStride], s_g[kPreLines * kStride], s_a[kPreLines * kStride];
     __shared__ int64_t s_c[kPreLines];
     __shared__ double s_red[kBlock / 64];
     __shared__ unsigned long long s_ev[kBlock / 64];
 
-    const double d_nu = block_dnu(dnu_partial, n_partial, s_red);
+    // d_nu (:524-526): from the partial maxima of k_dnu_partial, or — small grids — scanned here directly
+    const double d_nu = dnu_partial ? block_dnu(dnu_partial, n_partial, s_red) : block_dnu_scan(nus, n_nu, s_red);
     const int64_t l0 = (int64_t)blockIdx.x * kPreLines;
     const int d0 = blockIdx.y * kPreDepths;
     const int nl = (int)min((int64_t)kPreLines, n_lines - l0);
@@ -120,16 +163,19 @@ __global__ __launch_bounds__(kBlock) void k_line_prepass(int n_depth, int64_t n_
         const int dd = k / nl, ll = k - dd * nl;
         const double dw = s_dw[ll * kStride + dd], g = s_g[ll * kStride + dd], a = s_a[ll * kStride + dd];
         int lo, hi;
-        window_rule(s_c[ll], n_nu, d_nu, g, dw, a, lo, hi);
+        const int64_t hw = window_rule(s_c[ll], n_nu, d_nu, g, dw, a, lo, hi);
         const int64_t l = l0 + ll;
         const int d = d0 + dd;
         if (w.inv_dw) {
             const size_t o = (size_t)d * n_lines + l;
+            const bool narrow = hw <= kNarrowHalfWidth;
             w.inv_dw[o] = 1.0 / dw;
             w.y[o] = (g / mul_rn(kSqrtPi, kPi)) / dw;  // voigt.py:148
             w.amp[o] = a / mul_rn(kSqrtPi, dw);        // voigt.py:149 x base.py:627
-            w.lo[o] = lo;
-            w.hi[o] = hi;
+            w.lo[o] = narrow ? 0 : lo;
+            w.hi[o] = narrow ? 0 : hi;
+            w.nlo[o] = narrow ? lo : 0;
+            w.nhi[o] = narrow ? hi : 0;
         }
         if (out_lo_ref) {  // reference layout [N_l][N_d], for sdx_line_windows_dev
             out_lo_ref[l * n_depth + d] = lo;
@@ -149,23 +195,27 @@ __global__ __launch_bounds__(kBlock) void k_line_prepass(int n_depth, int64_t n_
 }
 
 // ------------------------------------------------------------------------------------------------
-// Line opacity, gather form: one block owns (depth d, a tile of 256*R grid points); each lane owns R
-// of them and accumulates in registers.  Lines are streamed in chunks of 256: each lane tests one
-// line's window against the tile, survivors are compacted (order-preserving) into LDS together with
-// their depth-column constants, then every lane walks the compacted list.  No atomics; the sum for a
-// grid point runs in ascending line order, so results are bit-stable run to run.
+// Line opacity, gather form: one block owns (depth d, a tile of 256*R grid points, one of S line subsets);
+// each lane owns R grid points and accumulates in registers.  The block streams its subset of the line list
+// in chunks of 256 (chunk c belongs to subset c mod S): each lane tests one line's window against the tile,
+// survivors are compacted (order-preserving) into LDS together with their depth-column constants, then every
+// lane walks the compacted list.  Splitting the line list over S blocks shortens the serial chain of the
+// deepest (hottest) layers, whose windows are widest; the S partial sums are added in subset order by the
+// consumer (k_reduce_partials / k_total_alphas).  No atomics: results are bit-stable run to run.
 template <int R>
 __global__ __launch_bounds__(kBlock) void k_line_opacity(int64_t n_nu, const double* __restrict__ nus, int64_t nu_begin,
                                                          int64_t nu_count, int64_t n_lines,
                                                          const double* __restrict__ line_nus, LineWork w,
-                                                         double* __restrict__ out, int64_t out_ld, int accumulate)
+                                                         double* __restrict__ partial, int64_t pld, int n_depth)
 {
     constexpr int kTile = kBlock * R;
     __shared__ double s_nu[kBlock], s_inv[kBlock], s_y[kBlock], s_amp[kBlock];
+    __shared__ double s_yk[kBlock], s_c2[kBlock], s_c3[kBlock], s_c4[kBlock];
     __shared__ int s_lo[kBlock], s_hi[kBlock];
     __shared__ int s_wcount[2][kBlock / 64];
 
     const int d = blockIdx.y;
+    const int split = blockIdx.z, n_split = gridDim.z;
     const int64_t t0 = nu_begin + (int64_t)blockIdx.x * kTile;
     const int64_t t1 = min(t0 + kTile, nu_begin + nu_count);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -181,7 +231,7 @@ __global__ __launch_bounds__(kBlock) void k_line_opacity(int64_t n_nu, const dou
     }
     const size_t base = (size_t)d * n_lines;
     int buf = 0;
-    for (int64_t c0 = 0; c0 < n_lines; c0 += kBlock, buf ^= 1) {
+    for (int64_t c0 = (int64_t)split * kBlock; c0 < n_lines; c0 += (int64_t)n_split * kBlock, buf ^= 1) {
         const int64_t l = c0 + threadIdx.x;
         int lo = 0, hi = 0;
         bool hit = false;
@@ -203,10 +253,16 @@ __global__ __launch_bounds__(kBlock) void k_line_opacity(int64_t n_nu, const dou
         if (total == 0) continue;  // uniform; the other s_wcount buffer is used next, so no barrier needed
         if (hit) {
             const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
+            const double y = w.y[base + l];
+            const RegionI k1 = region1_setup(y);
             s_nu[pos] = line_nus[l];
             s_inv[pos] = w.inv_dw[base + l];
-            s_y[pos] = w.y[base + l];
+            s_y[pos] = y;
             s_amp[pos] = w.amp[base + l];
+            s_yk[pos] = k1.yk;
+            s_c2[pos] = k1.c2;
+            s_c3[pos] = k1.c3;
+            s_c4[pos] = k1.c4;
             s_lo[pos] = lo;
             s_hi[pos] = hi;
         }
@@ -214,7 +270,7 @@ __global__ __launch_bounds__(kBlock) void k_line_opacity(int64_t n_nu, const dou
         for (int j = 0; j < total; ++j) {
             const double lnu = s_nu[j], inv = s_inv[j], y = s_y[j], amp = s_amp[j];
             const int jlo = s_lo[j], jhi = s_hi[j];
-            const RegionI k1 = region1_setup(y);
+            const RegionI k1 = {s_yk[j], s_c2[j], s_c3[j], s_c4[j]};
 #pragma unroll
             for (int r = 0; r < R; ++r)
                 if (idx[r] >= jlo && idx[r] < jhi) acc[r] += voigt_term(nu_i[r] - lnu, inv, y, amp, k1);
@@ -223,10 +279,58 @@ __global__ __launch_bounds__(kBlock) void k_line_opacity(int64_t n_nu, const dou
     }
 #pragma unroll
     for (int r = 0; r < R; ++r)
-        if (idx[r] >= 0) {
-            double* p = out + (size_t)d * out_ld + (idx[r] - nu_begin);
-            *p = accumulate ? *p + acc[r] : acc[r];
+        if (idx[r] >= 0) partial[((size_t)split * n_depth + d) * pld + (idx[r] - nu_begin)] = acc[r];
+}
+
+// Narrow windows (half-width <= kNarrowHalfWidth, e.g. the reference's 10-pixel floor for weak lines, :565-567):
+// a 256*R-point tile would be almost empty for them, so lanes are tiled 4 frequencies x 16 depths per wave and
+// each lane owns ONE (depth, frequency) point.  The candidate lines of a wave are the contiguous index range
+// whose centre lies within kNarrowHalfWidth of its 4 frequencies, read from cnt_ge; each lane walks that range
+// in ascending line order, tests its own window and accumulates in a register.  Deterministic, no atomics.
+__global__ __launch_bounds__(kBlock) void k_line_narrow(int n_depth, int64_t n_nu, const double* __restrict__ nus,
+                                                        int64_t nu_begin, int64_t nu_count, int64_t n_lines,
+                                                        const double* __restrict__ line_nus, LineWork w,
+                                                        double* __restrict__ plane, int64_t pld)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nl = lane & 3, dl = lane >> 2;
+    const int64_t i0 = nu_begin + ((int64_t)blockIdx.x * (kBlock / 64) + wave) * 4;
+    const int64_t i = i0 + nl;
+    const int d = blockIdx.y * 16 + dl;
+    const bool valid = d < n_depth && i < nu_begin + nu_count;
+    const int dc = d < n_depth ? d : n_depth - 1;
+    const int ii = (int)i;
+    // lines with centre c in [i0 - H + 1, i0 + 3 + H]
+    const int64_t pa = max(i0 - kNarrowHalfWidth + 1, (int64_t)0);
+    const int64_t pb = min(i0 + 3 + kNarrowHalfWidth, n_nu);
+    const int la = __builtin_amdgcn_readfirstlane(w.cnt_ge[pb + 1]);
+    const int lb = __builtin_amdgcn_readfirstlane(w.cnt_ge[pa]);
+    const double nu_i = valid ? nus[i] : 0.0;
+    const size_t base = (size_t)dc * n_lines;
+    double acc = 0.0;
+    for (int l = la; l < lb; ++l) {
+        const int lo = w.nlo[base + l], hi = w.nhi[base + l];
+        if (valid && ii >= lo && ii < hi) {
+            const double y = w.y[base + l];
+            const RegionI k1 = region1_setup(y);
+            acc += voigt_term(nu_i - line_nus[l], w.inv_dw[base + l], y, w.amp[base + l], k1);
         }
+    }
+    if (valid) plane[(size_t)d * pld + (i - nu_begin)] = acc;
+}
+
+// out (+)= sum over the S line subsets, in subset order
+__global__ __launch_bounds__(kBlock) void k_reduce_partials(int n_depth, int64_t nu_count, int n_split,
+                                                            const double* __restrict__ partial, int64_t pld,
+                                                            double* __restrict__ out, int64_t out_ld, int accumulate)
+{
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int d = blockIdx.y;
+    if (j >= nu_count) return;
+    double v = partial[(size_t)d * pld + j];
+    for (int s = 1; s < n_split; ++s) v = add_rn(v, partial[((size_t)s * n_depth + d) * pld + j]);
+    double* p = out + (size_t)d * out_ld + j;
+    *p = accumulate ? add_rn(*p, v) : v;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -451,7 +555,8 @@ struct ContinuumArgs {
     const int* bf_species_offsets;
     const int* bf_species_ion_number;
     const double* bf_cutoff;
-    const double* bf_coef;  // [n_levels][n_depth] from k_bf_coef
+    const double* bf_coef;           // [n_levels][n_depth] from k_bf_coef (stand-alone bf source)
+    const double* bf_level_density;  // [n_levels][n_depth] (fused total: coefficients formed in LDS)
     int ff_n_species;
     const int* ff_species_ion_number;
     const double* ff_number_density;
@@ -544,24 +649,53 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(int n_depth, int64_t n_nu
 }
 
 // fused: total = ((((0 + file) + bf) + ff) + rayleigh) + electron) + line  (calc_alphas order, :655-738,
-// then Opacities.calc_total_alphas insertion order, opacities/base.py:24-28)
+// then Opacities.calc_total_alphas insertion order, opacities/base.py:24-28).  `line` holds n_split partial
+// planes [n_split][n_depth][line_ld] summed here in subset order; line_out (optional) receives that sum.
+// The bound-free per-level coefficients of this block's depth are formed in LDS first (k_bf_coef's formula).
 __global__ __launch_bounds__(kBlock) void k_total_alphas(int n_depth, int64_t nu_begin, int64_t nu_count,
                                                          const double* __restrict__ nus, ContinuumArgs a,
-                                                         const double* __restrict__ line, int64_t line_ld,
+                                                         const double* __restrict__ line, int64_t line_ld, int n_split,
+                                                         double* __restrict__ line_out, int64_t line_out_ld,
                                                          double* __restrict__ total, int64_t total_ld)
 {
+    extern __shared__ double s_coef[];  // [n_levels] for depth d
     const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int d = blockIdx.y;
+    const int n_levels = a.bf_n_species > 0 ? a.bf_species_offsets[a.bf_n_species] : 0;
+    for (int L = threadIdx.x; L < n_levels; L += kBlock) {
+        int sp = 0;
+        while (sp + 1 < a.bf_n_species && L >= a.bf_species_offsets[sp + 1]) ++sp;
+        const int zi = a.bf_species_ion_number[sp] + 1;
+        const double r = mul_rn((double)zi, sqrt(kRydFreq / a.bf_cutoff[L]));
+        const double r2 = mul_rn(r, r);
+        const double n5 = mul_rn(mul_rn(r2, r2), r);
+        s_coef[L] = mul_rn(mul_rn(kBfConst, (double)(zi * zi * zi * zi)), a.bf_level_density[(size_t)L * n_depth + d]) / n5;
+    }
+    __syncthreads();
     if (j >= nu_count) return;
     const int64_t i = nu_begin + j;
     const double nu = nus[i];
     double t = 0.0;
     if (a.table_sigma) t = add_rn(t, mul_rn(interp1(a.lambdas[i], a.n_table, a.table_wavelength, a.table_sigma), a.table_density[d]));
-    t = add_rn(t, a.bf_n_species > 0 ? alpha_bf_point(n_depth, d, nu, a.bf_n_species, a.bf_species_offsets, a.bf_cutoff, a.bf_coef) : 0.0);
+    {
+        double bf = 0.0;
+        for (int sp = 0; sp < a.bf_n_species; ++sp) {
+            double spec = 0.0;
+            for (int L = a.bf_species_offsets[sp]; L < a.bf_species_offsets[sp + 1]; ++L)
+                spec = add_rn(spec, nu >= a.bf_cutoff[L] ? s_coef[L] : 0.0);
+            bf = add_rn(bf, spec);
+        }
+        t = add_rn(t, a.bf_n_species > 0 ? mul_rn(bf, inv_nu3(nu)) : 0.0);
+    }
     t = add_rn(t, a.ff_n_species > 0 ? alpha_ff_point(n_depth, d, nu, a.temperature[d], a.ff_n_species, a.ff_species_ion_number, a.ff_number_density) : 0.0);
     if (a.rayleigh_enabled) t = add_rn(t, alpha_rayleigh_point(d, nu, a.ray_n_h, a.ray_n_he, a.ray_n_h2));
     if (a.electron_density) t = add_rn(t, mul_rn(kSigmaT, a.electron_density[d]));
-    if (line) t = add_rn(t, line[(size_t)d * line_ld + j]);
+    if (line) {
+        double v = line[(size_t)d * line_ld + j];
+        for (int s = 1; s < n_split; ++s) v = add_rn(v, line[((size_t)s * n_depth + d) * line_ld + j]);
+        if (line_out) line_out[(size_t)d * line_out_ld + j] = v;
+        t = add_rn(t, v);
+    }
     total[(size_t)d * total_ld + j] = t;
 }
 
@@ -574,11 +708,11 @@ __global__ __launch_bounds__(kBlock) void k_total_alphas(int n_depth, int64_t nu
 // tau (:123-129), Planck source (:133) and the weights (:138) are formed with the reference's operations;
 // the mean opacity and source are shared by the angles a lane owns instead of being recomputed per angle.
 template <int P>
-__global__ __launch_bounds__(kBlock) void k_raytrace(int n_depth, int64_t n_nu, int n_theta, int theta_stride, int G,
+__global__ __launch_bounds__(kBlock) void k_raytrace_basic(int n_depth, int64_t n_nu, int n_theta, int theta_stride, int G,
                                                      const double* __restrict__ nus, const double* __restrict__ temps,
                                                      const double* __restrict__ ray_dist, const double* __restrict__ wts,
                                                      const double* __restrict__ alphas, int64_t ald, double* __restrict__ F,
-                                                     int64_t fld, double* __restrict__ I_nus)
+                                                     int64_t fld, double* __restrict__ I_nus, int accumulate)
 {
     // n_theta angles are traced here; ray_dist / I_nus rows have theta_stride entries (a chunk of a longer list)
     const int lane = threadIdx.x & 63;
@@ -658,10 +792,134 @@ __global__ __launch_bounds__(kBlock) void k_raytrace(int n_depth, int64_t n_nu, 
             }
             if (valid && g == 0) {
                 double* p = F + (size_t)(gap + 1) * fld + i;
-                *p = add_rn(*p, fsum);
+                *p = accumulate ? add_rn(*p, fsum) : fsum;
+                if (gap == 0 && !accumulate) F[i] = 0.0;
             }
         }
         la0 = la1; la1 = la2; mean0 = mean1; s0 = s1; s1 = s2;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Formal solution, LDS-staged (the default).  Same lane <-> (frequency, angle) mapping as k_raytrace_basic,
+// but the per-frequency depth column is prepared ONCE per group and kept in LDS:
+//   phase 1  the G lanes of a group split the N_d depth points: log(alpha), Planck source S (:133) -> LDS,
+//            then the N_d-1 geometric-mean opacities exp((log a[g+1] + log a[g]) * 0.5) (:121) -> LDS;
+//   phase 2  every lane walks the gaps for its own angle(s): tau = mean * ray_dist (:123-129), weights
+//            (:22-45), second-order recurrence (:200-266).  1/tau of a gap is carried to the next gap and
+//            the divisions of :208-242 become multiplications by the two reciprocals 1/tau[gap+1] and
+//            1/(tau[gap]+tau[gap+1]) (IEEE divisions, so tau = 0 still yields the reference's inf/NaN);
+//   flux     I_theta * w_theta goes to LDS; every kBatch gaps the wave sums each (gap, frequency) over
+//            theta in ascending order (the reference's order, :324-338) and writes F_nu.
+template <int P>
+__global__ __launch_bounds__(kBlock) void k_raytrace(int n_depth, int64_t n_nu, int n_theta, int theta_stride, int G,
+                                                     const double* __restrict__ nus, const double* __restrict__ temps,
+                                                     const double* __restrict__ ray_dist, const double* __restrict__ wts,
+                                                     const double* __restrict__ alphas, int64_t ald, double* __restrict__ F,
+                                                     int64_t fld, double* __restrict__ I_nus, int accumulate)
+{
+    constexpr int kBatch = P == 1 ? 8 : (P == 2 ? 4 : 2);
+    extern __shared__ double smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gpw = 64 / G;
+    const int grp = lane / G, g = lane - grp * G;
+    const int TH = P * G;  // theta slots per group, ascending theta = k*G + g
+    const int64_t i0 = ((int64_t)blockIdx.x * (kBlock / 64) + wave) * gpw;  // first frequency of this wave
+    const int64_t i = i0 + grp;
+    const bool active = grp < gpw;
+    const bool valid = active && i < n_nu;
+    const int64_t ic = i < n_nu ? i : n_nu - 1;
+    const int n_gap = n_depth - 1;
+    const int col = n_depth;  // LDS row stride per group
+    const int scratch = max(gpw * col, kBatch * gpw * TH);
+    double* sS = smem + (size_t)wave * (2 * gpw * col + scratch);  // source function  [gpw][col]
+    double* sM = sS + gpw * col;                                   // mean opacity    [gpw][col]
+    double* sX = sM + gpw * col;                                   // log(alpha) in phase 1, flux terms in phase 2
+    const double nu = nus[ic];
+
+    if (active) {
+        for (int d = g; d < n_depth; d += G) {
+            sX[grp * col + d] = log(alphas[(size_t)d * ald + ic]);
+            sS[grp * col + d] = planck(nu, temps[d]);
+        }
+    }
+    __syncthreads();
+    if (active)
+        for (int gp = g; gp < n_gap; gp += G) sM[grp * col + gp] = exp(mul_rn(add_rn(sX[grp * col + gp + 1], sX[grp * col + gp]), 0.5));
+    __syncthreads();
+
+    const int gi = active ? grp : 0;  // idle lanes shadow group 0 and never store
+    double inten[P], wt[P], tau0[P], r0[P];
+    int th[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+        th[k] = g + k * G;
+        const bool on = th[k] < n_theta;
+        inten[k] = 0.0;  // I[0] = 0 (:134-136)
+        wt[k] = on ? wts[th[k]] : 0.0;
+        tau0[k] = on ? mul_rn(sM[gi * col], ray_dist[th[k]]) : 1.0;
+        r0[k] = 1.0 / tau0[k];
+        if (valid && I_nus && on) I_nus[(size_t)i * theta_stride + th[k]] = 0.0;
+    }
+    if (valid && g == 0 && F && !accumulate) F[i] = 0.0;
+
+    for (int gap0 = 0; gap0 < n_gap; gap0 += kBatch) {
+        const int nb = min(kBatch, n_gap - gap0);
+        for (int b = 0; b < nb; ++b) {
+            const int gap = gap0 + b;
+            const bool last = gap == n_gap - 1;
+            const double s0 = sS[gi * col + gap], s1 = sS[gi * col + gap + 1];
+            const double s2 = last ? 0.0 : sS[gi * col + gap + 2];
+            const double mean1 = last ? 0.0 : sM[gi * col + gap + 1];
+#pragma unroll
+            for (int k = 0; k < P; ++k) {
+                double contrib = 0.0;
+                if (th[k] < n_theta) {
+                    const double t0 = tau0[k];
+                    double t1 = 0.0, r1 = 0.0, inew;
+                    if (!last) {
+                        t1 = mul_rn(mean1, ray_dist[(size_t)(gap + 1) * theta_stride + th[k]]);
+                        r1 = 1.0 / t1;
+                    }
+                    if (t0 == 0.0) {
+                        inew = inten[k];  // :203-206, :253-254
+                    } else {
+                        double w0, w1, w2;
+                        rt_weights(t0, w0, w1, w2);
+                        const double head = fma(w0, s1, (1.0 - w0) * inten[k]);
+                        if (!last) {  // :208-249
+                            const double rs = 1.0 / (t0 + t1);
+                            const double second = w1 * ((s1 - s2) * (t0 * r1) - (s1 - s0) * (t1 * r0[k])) * rs;
+                            const double third = w2 * ((s2 - s1) * r1 + (s0 - s1) * r0[k]) * rs;
+                            inew = (head + second) + third;
+                        } else {  // :256-266
+                            inew = head + w2 * (s0 - s1) * (r0[k] * r0[k]);
+                        }
+                    }
+                    inten[k] = inew;
+                    tau0[k] = t1;
+                    r0[k] = r1;
+                    contrib = inew * wt[k];
+                    if (valid && I_nus) I_nus[((size_t)(gap + 1) * n_nu + i) * theta_stride + th[k]] = inew;
+                }
+                if (active) sX[(b * gpw + grp) * TH + k * G + g] = contrib;
+            }
+        }
+        __syncthreads();
+        if (F) {
+            for (int p = lane; p < nb * gpw; p += 64) {
+                const int b = p / gpw, gq = p - b * gpw;
+                const double* c = sX + (size_t)(b * gpw + gq) * TH;
+                double sum = 0.0;
+                for (int t = 0; t < n_theta; ++t) sum = add_rn(sum, c[t]);
+                const int64_t iq = i0 + gq;
+                if (iq < n_nu) {
+                    double* dst = F + (size_t)(gap0 + b + 1) * fld + iq;
+                    *dst = accumulate ? add_rn(*dst, sum) : sum;
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 

@@ -53,6 +53,12 @@ struct sdx_ctx {
     // small scratch: d_nu partials, evaluation counter, bf coefficients
     void* small_ws = nullptr;
     size_t small_ws_bytes = 0;
+    // partial line-opacity planes [n_split + 1][n_depth][nu_count] (last plane: narrow windows)
+    void* part_ws = nullptr;
+    size_t part_ws_bytes = 0;
+    // cnt_ge[N_nu + 2] (lines per centre index, for the narrow-window kernel)
+    void* cnt_ws = nullptr;
+    size_t cnt_ws_bytes = 0;
     // timing
     hipEvent_t t0 = nullptr, t1 = nullptr;
     bool profile = false;
@@ -82,7 +88,7 @@ int ensure(sdx_ctx* ctx, void** buf, size_t* have, size_t need)
     return SDX_OK;
 }
 
-size_t line_ws_need(int n_depth, int64_t n_lines) { return (size_t)n_depth * (size_t)n_lines * 32 + 256; }
+size_t line_ws_need(int n_depth, int64_t n_lines) { return (size_t)n_depth * (size_t)n_lines * 40 + 256; }
 
 LineWork carve(sdx_ctx* ctx, int n_depth, int64_t n_lines)
 {
@@ -94,6 +100,9 @@ LineWork carve(sdx_ctx* ctx, int n_depth, int64_t n_lines)
     w.amp = w.y + n;
     w.lo = (int*)(w.amp + n);
     w.hi = w.lo + n;
+    w.nlo = w.hi + n;
+    w.nhi = w.nlo + n;
+    w.cnt_ge = (int*)ctx->cnt_ws;
     w.evals = (unsigned long long*)((char*)ctx->small_ws + 2048);
     return w;
 }
@@ -254,6 +263,8 @@ void sdx_destroy(sdx_ctx* ctx)
     if (ctx->t1) hipEventDestroy(ctx->t1);
     if (ctx->line_ws) hipFree(ctx->line_ws);
     if (ctx->small_ws) hipFree(ctx->small_ws);
+    if (ctx->part_ws) hipFree(ctx->part_ws);
+    if (ctx->cnt_ws) hipFree(ctx->cnt_ws);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -435,21 +446,28 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
                         int32_t* lo_ref, int32_t* hi_ref, LineWork* w_out)
 {
     int n_partial = 0;
-    int rc = launch_dnu(ctx, n_nu, nus, &n_partial);
+    int rc = ensure(ctx, &ctx->small_ws, &ctx->small_ws_bytes, kSmallHeader);
     if (rc) return rc;
+    const bool scan_in_block = n_nu <= 16384;  // every pre-pass block re-scans a small grid instead of a separate launch
+    if (!scan_in_block && (rc = launch_dnu(ctx, n_nu, nus, &n_partial))) return rc;
     LineWork w{};
+    const int n_line_blocks = (int)((n_lines + kPreLines - 1) / kPreLines);
+    int n_pixel_blocks = 0;
     if (fill_work) {
         rc = ensure(ctx, &ctx->line_ws, &ctx->line_ws_bytes, line_ws_need(n_depth, n_lines));
         if (rc) return rc;
+        rc = ensure(ctx, &ctx->cnt_ws, &ctx->cnt_ws_bytes, (size_t)(n_nu + 2) * sizeof(int));
+        if (rc) return rc;
         w = carve(ctx, n_depth, n_lines);
         HIP_TRY(hipMemsetAsync(w.evals, 0, sizeof(unsigned long long), ctx->stream));
+        n_pixel_blocks = (int)((n_nu + 2 + kBlock - 1) / kBlock);
     }
-    const dim3 grid((unsigned)((n_lines + kPreLines - 1) / kPreLines), (unsigned)((n_depth + kPreDepths - 1) / kPreDepths));
+    const dim3 grid((unsigned)(n_line_blocks + n_pixel_blocks), (unsigned)((n_depth + kPreDepths - 1) / kPreDepths));
     {
         LaunchScope ls(ctx, "k_line_prepass");
         hipLaunchKernelGGL(k_line_prepass, grid, dim3(kBlock), 0, ctx->stream, n_depth, n_nu, nus,
-                           (const double*)ctx->small_ws, n_partial, n_lines, line_nus, doppler, gammas, gamma_cols, alphas,
-                           w, (int*)lo_ref, (int*)hi_ref);
+                           scan_in_block ? (const double*)nullptr : (const double*)ctx->small_ws, n_partial, n_lines, line_nus,
+                           doppler, gammas, gamma_cols, alphas, w, (int*)lo_ref, (int*)hi_ref, n_line_blocks);
     }
     if (w_out) *w_out = w;
     return check_launch("k_line_prepass");
@@ -468,6 +486,53 @@ static int check_line_args(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double
     return SDX_OK;
 }
 
+// number of line subsets: enough blocks to fill the chip when the (tile, depth) grid alone is small
+static int choose_splits(int n_depth, int64_t nu_count, int64_t n_lines, int R)
+{
+    const int64_t tiles = (nu_count + kBlock * R - 1) / (kBlock * R);
+    const int64_t chunks = (n_lines + kBlock - 1) / kBlock;
+    const int64_t want = (4096 + tiles * n_depth - 1) / (tiles * n_depth);
+    return (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(want, chunks), 16));
+}
+
+// pre-pass + gather kernel; leaves n_split partial planes in *partial_out ([n_split][n_depth][*pld_out])
+static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin, int64_t nu_count,
+                         int64_t n_lines, const double* line_nus, const double* doppler, const double* gammas, int gamma_cols,
+                         const double* alphas, double* direct_out, int64_t direct_ld, const double** partial_out,
+                         int64_t* pld_out, int* n_split_out, LineWork* w_out)
+{
+    constexpr int R = 2;
+    LineWork w;
+    int rc = line_prepass(ctx, n_depth, n_nu, nus, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, true, nullptr, nullptr, &w);
+    if (rc) return rc;
+    const int n_split = choose_splits(n_depth, nu_count, n_lines, R);
+    (void)direct_out;
+    (void)direct_ld;
+    rc = ensure(ctx, &ctx->part_ws, &ctx->part_ws_bytes, (size_t)(n_split + 1) * n_depth * nu_count * sizeof(double));
+    if (rc) return rc;
+    double* part = (double*)ctx->part_ws;
+    const int64_t pld = nu_count;
+    {
+        LaunchScope ls(ctx, "k_line_opacity");
+        const dim3 grid((unsigned)((nu_count + kBlock * R - 1) / (kBlock * R)), (unsigned)n_depth, (unsigned)n_split);
+        hipLaunchKernelGGL(k_line_opacity<R>, grid, dim3(kBlock), 0, ctx->stream, n_nu, nus, nu_begin, nu_count, n_lines,
+                           line_nus, w, part, pld, n_depth);
+    }
+    rc = check_launch("k_line_opacity");
+    if (rc) return rc;
+    {
+        LaunchScope ls(ctx, "k_line_narrow");
+        const dim3 grid((unsigned)((nu_count + 15) / 16), (unsigned)((n_depth + 15) / 16));
+        hipLaunchKernelGGL(k_line_narrow, grid, dim3(kBlock), 0, ctx->stream, n_depth, n_nu, nus, nu_begin, nu_count, n_lines,
+                           line_nus, w, part + (size_t)n_split * n_depth * pld, pld);
+    }
+    *partial_out = part;
+    *pld_out = pld;
+    *n_split_out = n_split + 1;  // planes to sum: the wide subsets, then the narrow-window plane
+    if (w_out) *w_out = w;
+    return check_launch("k_line_narrow");
+}
+
 int sdx_line_opacity_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin, int64_t nu_count,
                          int64_t n_lines, const double* line_nus, const double* doppler, const double* gammas,
                          int gamma_cols, const double* alphas, double* out, int64_t out_ld, int accumulate,
@@ -483,17 +548,19 @@ int sdx_line_opacity_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
         if (n_evaluations_dev) HIP_TRY(hipMemsetAsync(n_evaluations_dev, 0, sizeof(int64_t), ctx->stream));
         return SDX_OK;
     }
+    const double* part;
+    int64_t pld;
+    int n_split;
     LineWork w;
-    rc = line_prepass(ctx, n_depth, n_nu, nus, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, true, nullptr, nullptr, &w);
+    rc = line_partials(ctx, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, doppler, gammas, gamma_cols, alphas,
+                       accumulate ? nullptr : out, out_ld, &part, &pld, &n_split, &w);
     if (rc) return rc;
     {
-        LaunchScope ls(ctx, "k_line_opacity");
-        constexpr int R = 2;
-        const dim3 grid((unsigned)((nu_count + kBlock * R - 1) / (kBlock * R)), (unsigned)n_depth);
-        hipLaunchKernelGGL(k_line_opacity<R>, grid, dim3(kBlock), 0, ctx->stream, n_nu, nus, nu_begin, nu_count, n_lines,
-                           line_nus, w, out, out_ld, accumulate);
+        LaunchScope ls(ctx, "k_reduce_partials");
+        hipLaunchKernelGGL(k_reduce_partials, grid2(nu_count, n_depth), dim3(kBlock), 0, ctx->stream, n_depth, nu_count, n_split,
+                           part, pld, out, out_ld, accumulate);
     }
-    rc = check_launch("k_line_opacity");
+    rc = check_launch("k_reduce_partials");
     if (rc) return rc;
     if (n_evaluations_dev)
         HIP_TRY(hipMemcpyAsync(n_evaluations_dev, w.evals, sizeof(int64_t), hipMemcpyDeviceToDevice, ctx->stream));
@@ -771,6 +838,25 @@ int sdx_accumulate_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, double* total, i
     return check_launch("k_accumulate");
 }
 
+static int launch_total(sdx_ctx* ctx, int n_depth, const double* nus, int64_t nu_begin, int64_t nu_count,
+                        const sdx_continuum* cont, const double* line, int64_t line_ld, int n_split, double* line_out,
+                        int64_t line_out_ld, double* total, int64_t total_ld)
+{
+    ContinuumArgs a = to_args(cont, nullptr);
+    a.bf_level_density = cont->bf_level_density;
+    size_t shmem = 8;
+    if (a.bf_n_species > 0) {
+        REQUIRE(cont->bf_n_levels > 0 && cont->bf_n_levels <= 4096, "total_alphas: bf_n_levels must be set (1..4096)");
+        shmem = (size_t)cont->bf_n_levels * sizeof(double);
+    }
+    {
+        LaunchScope ls(ctx, "k_total_alphas");
+        hipLaunchKernelGGL(k_total_alphas, grid2(nu_count, n_depth), dim3(kBlock), shmem, ctx->stream, n_depth, nu_begin, nu_count,
+                           nus, a, line, line_ld, n_split, line_out, line_out_ld, total, total_ld);
+    }
+    return check_launch("k_total_alphas");
+}
+
 int sdx_total_alphas_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin, int64_t nu_count,
                          const sdx_continuum* cont, const double* alpha_line, int64_t line_ld, double* total, int64_t total_ld)
 {
@@ -778,33 +864,7 @@ int sdx_total_alphas_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
     REQUIRE(nu_begin >= 0 && nu_count >= 0 && nu_begin + nu_count <= n_nu, "total_alphas: shard outside the grid");
     REQUIRE(nu_count == 0 || (total && total_ld >= nu_count && (!alpha_line || line_ld >= nu_count)), "total_alphas: bad buffers");
     if (nu_count == 0) return SDX_OK;
-    double* coef = nullptr;
-    if (cont->bf_cutoff && cont->bf_n_species > 0) {
-        int32_t n_levels = 0;
-        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-        hipStreamIsCapturing(ctx->stream, &st);
-        REQUIRE(st == hipStreamCaptureStatusNone || ctx->small_ws_bytes > kSmallHeader,
-                "total_alphas: run once outside stream capture first (bound-free scratch)");
-        if (st == hipStreamCaptureStatusNone) {
-            HIP_TRY(hipMemcpyAsync(&n_levels, cont->bf_species_offsets + cont->bf_n_species, sizeof(int32_t), hipMemcpyDeviceToHost,
-                                   ctx->stream));
-            HIP_TRY(hipStreamSynchronize(ctx->stream));
-        } else {
-            n_levels = (int32_t)((ctx->small_ws_bytes - kSmallHeader) / sizeof(double) / n_depth);
-        }
-        if (n_levels > 0) {
-            int rc = launch_bf_coef(ctx, n_depth, cont->bf_n_species, n_levels, cont->bf_species_offsets,
-                                    cont->bf_species_ion_number, cont->bf_cutoff, cont->bf_level_density, &coef);
-            if (rc) return rc;
-        }
-    }
-    const ContinuumArgs a = to_args(cont, coef);
-    {
-        LaunchScope ls(ctx, "k_total_alphas");
-        hipLaunchKernelGGL(k_total_alphas, grid2(nu_count, n_depth), dim3(kBlock), 0, ctx->stream, n_depth, nu_begin, nu_count,
-                           nus, a, alpha_line, line_ld, total, total_ld);
-    }
-    return check_launch("k_total_alphas");
+    return launch_total(ctx, n_depth, nus, nu_begin, nu_count, cont, alpha_line, line_ld, 1, nullptr, 0, total, total_ld);
 }
 
 // ================================================================================================ formal solution
@@ -832,33 +892,41 @@ int sdx_calc_weights_dev(sdx_ctx* ctx, int64_t n, const double* tau, double* w0,
 
 int sdx_raytrace_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, const double* nus, const double* temps,
                      const double* ray_dist, const double* wts, const double* alphas, int64_t ald, double* F, int64_t fld,
-                     double* I_nus)
+                     double* I_nus, int accumulate)
 {
     REQUIRE(ctx && n_depth >= 2 && n_nu >= 0 && n_theta > 0, "raytrace: need n_depth >= 2, n_theta > 0");
     if (n_nu == 0) return SDX_OK;
     REQUIRE(nus && temps && ray_dist && wts && alphas && ald >= n_nu, "raytrace: null pointer");
     REQUIRE((F && fld >= n_nu) || I_nus, "raytrace: no output requested");
-    // angles per lane P and lanes per frequency G: fill the chip when the grid is small, share the
-    // per-(gap, nu) work (log/exp/Planck) across more angles when it is large
+    // Angles per lane P and lanes per frequency G = ceil(n_theta / P): one angle per lane fills the chip when the
+    // grid is small; more angles per lane share the staged column when it is large.
     constexpr int kMaxChunk = 64;
     for (int th0 = 0; th0 < n_theta; th0 += kMaxChunk) {
         const int nth = std::min(kMaxChunk, n_theta - th0);
-        const bool small = n_nu * (int64_t)nth < (int64_t)1 << 20;
-        int P = small ? 1 : 4;
-        int G = (nth + P - 1) / P;
+        const int64_t work = n_nu * (int64_t)nth;
+        const int P = work < ((int64_t)1 << 19) ? 1 : (work < ((int64_t)1 << 21) ? 2 : 4);
+        const int G = (nth + P - 1) / P;
         const int gpw = 64 / G;
+        const int kbatch = P == 1 ? 8 : (P == 2 ? 4 : 2);
         const unsigned blocks = (unsigned)((n_nu + (int64_t)gpw * (kBlock / 64) - 1) / ((int64_t)gpw * (kBlock / 64)));
+        const size_t shmem = (size_t)(kBlock / 64) * (2 * (size_t)gpw * n_depth + std::max((size_t)gpw * n_depth, (size_t)kbatch * gpw * P * G)) * sizeof(double);
         const double* rd = ray_dist + th0;
         const double* w = wts + th0;
         double* inus = I_nus ? I_nus + th0 : nullptr;
+        const int acc = (accumulate || th0 > 0) ? 1 : 0;
         {
             LaunchScope ls(ctx, "k_raytrace");
-            if (P == 1)
-                hipLaunchKernelGGL(k_raytrace<1>, dim3(blocks), dim3(kBlock), 0, ctx->stream, n_depth, n_nu, nth, n_theta, G, nus,
-                                   temps, rd, w, alphas, ald, F, fld, inus);
-            else
-                hipLaunchKernelGGL(k_raytrace<4>, dim3(blocks), dim3(kBlock), 0, ctx->stream, n_depth, n_nu, nth, n_theta, G, nus,
-                                   temps, rd, w, alphas, ald, F, fld, inus);
+#define SDX_RT_ARGS n_depth, n_nu, nth, n_theta, G, nus, temps, rd, w, alphas, ald, F, fld, inus, acc
+            if (shmem <= 64 * 1024) {
+                if (P == 1) hipLaunchKernelGGL(k_raytrace<1>, dim3(blocks), dim3(kBlock), shmem, ctx->stream, SDX_RT_ARGS);
+                else if (P == 2) hipLaunchKernelGGL(k_raytrace<2>, dim3(blocks), dim3(kBlock), shmem, ctx->stream, SDX_RT_ARGS);
+                else hipLaunchKernelGGL(k_raytrace<4>, dim3(blocks), dim3(kBlock), shmem, ctx->stream, SDX_RT_ARGS);
+            } else {  // very deep models: the column does not fit LDS, recompute per lane instead
+                if (P == 1) hipLaunchKernelGGL(k_raytrace_basic<1>, dim3(blocks), dim3(kBlock), 0, ctx->stream, SDX_RT_ARGS);
+                else if (P == 2) hipLaunchKernelGGL(k_raytrace_basic<2>, dim3(blocks), dim3(kBlock), 0, ctx->stream, SDX_RT_ARGS);
+                else hipLaunchKernelGGL(k_raytrace_basic<4>, dim3(blocks), dim3(kBlock), 0, ctx->stream, SDX_RT_ARGS);
+            }
+#undef SDX_RT_ARGS
         }
         int rc = check_launch("k_raytrace");
         if (rc) return rc;
@@ -884,12 +952,45 @@ int sdx_raytrace_f64(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, const
     if ((rc = d_f.upload(ctx, F, plane))) return rc;  // F_nu is accumulated into (base.py:336)
     if (I_nus && (rc = d_i.alloc(plane * n_theta))) return rc;
     rc = sdx_raytrace_dev(ctx, n_depth, n_nu, n_theta, (const double*)d_nus.p, (const double*)d_t.p, (const double*)d_rd.p,
-                          (const double*)d_w.p, (const double*)d_a.p, n_nu, (double*)d_f.p, n_nu, (double*)d_i.p);
+                          (const double*)d_w.p, (const double*)d_a.p, n_nu, (double*)d_f.p, n_nu, (double*)d_i.p, 1);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(F, d_f.p, plane, hipMemcpyDeviceToHost, ctx->stream));
     if (I_nus) HIP_TRY(hipMemcpyAsync(I_nus, d_i.p, plane * n_theta, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return SDX_OK;
+}
+
+// ================================================================================================ fused synthesis
+int sdx_synthesize_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin, int64_t nu_count,
+                       int64_t n_lines, const double* line_nus, const double* doppler, const double* gammas, int gamma_cols,
+                       const double* alphas, const sdx_continuum* cont, int n_theta, const double* temps,
+                       const double* ray_dist, const double* wts, double* alpha_line_out, double* total_alphas, double* F_nu,
+                       int64_t ld, int64_t* n_evaluations_dev)
+{
+    int rc = check_line_args(ctx, n_depth, n_nu, nus, n_lines, line_nus, doppler, gammas, gamma_cols, alphas);
+    if (rc) return rc;
+    REQUIRE(cont && temps && ray_dist && wts && n_theta > 0 && n_depth >= 2, "synthesize: bad arguments");
+    REQUIRE(nu_begin >= 0 && nu_count >= 0 && nu_begin + nu_count <= n_nu, "synthesize: shard outside the grid");
+    REQUIRE(nu_count == 0 || (total_alphas && F_nu && ld >= nu_count), "synthesize: bad output buffers");
+    if (nu_count == 0) return SDX_OK;
+    const double* part = nullptr;
+    int64_t pld = 0;
+    int n_split = 1;
+    if (n_lines > 0) {
+        LineWork w;
+        rc = line_partials(ctx, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, doppler, gammas, gamma_cols, alphas,
+                           nullptr, 0, &part, &pld, &n_split, &w);
+        if (rc) return rc;
+        if (n_evaluations_dev)
+            HIP_TRY(hipMemcpyAsync(n_evaluations_dev, w.evals, sizeof(int64_t), hipMemcpyDeviceToDevice, ctx->stream));
+    } else if (alpha_line_out) {
+        HIP_TRY(hipMemset2DAsync(alpha_line_out, ld * sizeof(double), 0, nu_count * sizeof(double), n_depth, ctx->stream));
+    }
+    rc = launch_total(ctx, n_depth, nus, nu_begin, nu_count, cont, part, pld, n_split, n_lines > 0 ? alpha_line_out : nullptr, ld,
+                      total_alphas, ld);
+    if (rc) return rc;
+    return sdx_raytrace_dev(ctx, n_depth, nu_count, n_theta, nus + nu_begin, temps, ray_dist, wts, total_alphas, ld, F_nu, ld,
+                            nullptr, 0);
 }
 
 }  // extern "C"

@@ -24,7 +24,7 @@ def shard_bounds(n_nu, world_size, rank):
 
 class SpectralSynthesizer:
     def __init__(self, nus, temperatures, dist, thetas, theta_weights, lines, continuum=None, ctx=None, shard=None,
-                 flux_out=None, track_evaluations=True):
+                 flux_out=None, track_evaluations=True, keep_line=True):
         """nus: global grid (descending).  lines: dict(line_nus, doppler_widths, gammas, alphas) in the
         reference layout (N_l, N_d).  continuum: dict as produced by synth.synth_continuum_state or None.
         shard: (begin, count) of the global frequency index computed here (default: everything).
@@ -50,8 +50,9 @@ class SpectralSynthesizer:
         self.d_w = c.upload(np.asarray(theta_weights, dtype=np.float64))
         ln = np.ascontiguousarray(lines["line_nus"], dtype=np.float64)
         self.n_lines = ln.size
-        g = np.ascontiguousarray(lines["gammas"], dtype=np.float64).reshape(self.n_lines, -1)
-        self.gamma_cols = g.shape[1] if self.n_lines else 1
+        g = np.ascontiguousarray(lines["gammas"], dtype=np.float64)
+        g = g.reshape(self.n_lines, -1) if self.n_lines else np.zeros((0, 1))
+        self.gamma_cols = g.shape[1]
         self.d_ln = c.upload(ln)
         self.d_dw = c.upload(np.ascontiguousarray(lines["doppler_widths"], dtype=np.float64))
         self.d_g = c.upload(g)
@@ -65,6 +66,7 @@ class SpectralSynthesizer:
         self._flux_tensor = flux_out
         self.d_F = None if flux_out is not None else c.empty((self.n_depth, self.count))
         self.d_evals = c.zeros((1,), np.int64) if track_evaluations else None
+        self.keep_line = keep_line  # also write the summed line opacity plane (alpha_line())
         self.graph = None
         c.call("sdx_reserve_line_workspace", self.n_depth, self.n_lines)
 
@@ -84,6 +86,7 @@ class SpectralSynthesizer:
         s.table_density = up(cont["n_hminus"])
         cutoff = (cont["ionization_energy"] - np.asarray(cont["level_excitation"])) / K.H_CGS
         s.bf_n_species = 1
+        s.bf_n_levels = len(cutoff)
         s.bf_species_offsets = up([0, len(cutoff)], np.int32)
         s.bf_species_ion_number = up([0], np.int32)
         s.bf_cutoff = up(cutoff)
@@ -105,16 +108,24 @@ class SpectralSynthesizer:
 
     # -- one step: everything from resident inputs to F_nu -----------------------------------------
     def enqueue(self):
+        """One fused step on the context's stream: sdx_synthesize_dev (pre-pass, line gather, total, raytrace)."""
+        c = self.ctx
+        c.call("sdx_synthesize_dev", self.n_depth, self.n_nu, self.d_nus.ptr, self.begin, self.count, self.n_lines,
+               self.d_ln.ptr, self.d_dw.ptr, self.d_g.ptr, self.gamma_cols, self.d_a.ptr, C.byref(self.cont), self.n_theta,
+               self.d_t.ptr, self.d_ray.ptr, self.d_w.ptr, self.d_line.ptr if self.keep_line else None, self.d_total.ptr,
+               self.flux_ptr, self.count, ptr_of(self.d_evals))
+
+    def enqueue_unfused(self):
+        """The same step through the individual entry points (what calc_alphas + raytrace issue)."""
         c = self.ctx
         nd, cnt = self.n_depth, self.count
         c.call("sdx_line_opacity_dev", nd, self.n_nu, self.d_nus.ptr, self.begin, cnt, self.n_lines, self.d_ln.ptr,
                self.d_dw.ptr, self.d_g.ptr, self.gamma_cols, self.d_a.ptr, self.d_line.ptr, cnt, 0, ptr_of(self.d_evals))
         c.call("sdx_total_alphas_dev", nd, self.n_nu, self.d_nus.ptr, self.begin, cnt, C.byref(self.cont), self.d_line.ptr, cnt,
                self.d_total.ptr, cnt)
-        c.call("sdx_memset", self.flux_ptr, 0, nd * cnt * 8)
         nus_shard = self.d_nus.ptr + 8 * self.begin
         c.call("sdx_raytrace_dev", nd, cnt, self.n_theta, nus_shard, self.d_t.ptr, self.d_ray.ptr, self.d_w.ptr,
-               self.d_total.ptr, cnt, self.flux_ptr, cnt, None)
+               self.d_total.ptr, cnt, self.flux_ptr, cnt, None, 0)
 
     def capture(self):
         """Record one step into a hipGraph (after one eager step has sized the scratch)."""

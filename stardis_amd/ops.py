@@ -279,5 +279,5 @@ def raytrace_arrays(tracing_nus, temperatures, ray_distances, theta_weights, tot
     d_F = ctx.zeros((t.size, nus.size)) if F_nu is None else ctx.upload(_host(F_nu))
     d_I = ctx.empty((t.size, nus.size, n_theta)) if track else None
     ctx.call("sdx_raytrace_dev", t.size, nus.size, n_theta, d[0].ptr, d[1].ptr, d[2].ptr, d[3].ptr, ptr_of(d_alpha), nus.size,
-             d_F.ptr, nus.size, ptr_of(d_I))
+             d_F.ptr, nus.size, ptr_of(d_I), 1)
     return d_F.numpy(), (d_I.numpy() if track else None)
