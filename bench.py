@@ -116,6 +116,7 @@ def main():
     syn.step()
     ctx.synchronize()
     evals = syn.evaluations()
+    syn.count_evaluations = False  # known now; the counter costs a memset + a copy per step
     if not args.no_graph:
         syn.capture()
 
@@ -154,7 +155,7 @@ def main():
     kern = {}
     import ctypes as C
 
-    for name in ("k_dnu_partial", "k_line_prepass", "k_line_opacity", "k_line_narrow", "k_reduce_partials", "k_total_alphas", "k_raytrace"):
+    for name in ("k_dnu_partial", "k_line_prepass", "k_line_wide", "k_line_narrow", "k_reduce_partials", "k_total_alphas", "k_raytrace"):
         n, ms = C.c_int64(), C.c_double()
         _lib.check(ctx.lib.sdx_profile_get(ctx.handle, name.encode(), C.byref(n), C.byref(ms)))
         if n.value:
@@ -170,7 +171,7 @@ def main():
         dom = max(kern, key=kern.get)
         alg_bytes = {
             # SURVEY §8d per-stage figures, for the columns this rank produced
-            "k_line_opacity": 8 * (n_l * (1 + 2 * nd + g_cols) + nus.size + nd * count),
+            "k_line_wide": 8 * (n_l * (1 + 2 * nd + g_cols) + nus.size + nd * count),
             "k_raytrace": 16 * nd * count,
         }.get(dom, syn.algorithmic_bytes())
         achieved = alg_bytes / (kern[dom] * 1e-3) / 1e9
@@ -209,7 +210,7 @@ def main():
                 "algorithmic_bytes_per_launch": int(alg_bytes),
                 "avg_kernel_ms": kern,
                 "note": "path is fp64-VALU bound (Faddeeva evaluations), not HBM bound: see DESIGN.md; evaluations/s below",
-                "voigt_evaluations_per_s": (evals / world) / (kern.get("k_line_opacity", float("nan")) * 1e-3),
+                "voigt_evaluations_per_s": (evals / world) / ((kern.get("k_line_wide", 0.0) + kern.get("k_line_narrow", 0.0)) * 1e-3),
             },
         }
         if world == 1 and not args.no_cpu_baseline:

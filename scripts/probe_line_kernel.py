@@ -25,10 +25,10 @@ for name, m in classes.items():
     for _ in range(10): run()
     ctx.synchronize()
     res = {}
-    for k in ("k_line_prepass", "k_line_opacity", "k_line_narrow", "k_reduce_partials"):
+    for k in ("k_line_prepass", "k_line_wide", "k_line_narrow", "k_reduce_partials"):
         cnt, ms = C.c_int64(), C.c_double()
         _lib.check(ctx.lib.sdx_profile_get(ctx.handle, k.encode(), C.byref(cnt), C.byref(ms)))
         res[k] = ms.value / max(cnt.value, 1) * 1e3
     ctx.call("sdx_profile_enable", 0); ctx.call("sdx_profile_reset")
     e = int(ev.numpy()[0])
-    print(f"{name:14s} lines={n:5d} evals={e:10d} prepass={res['k_line_prepass']:7.1f}us wide={res['k_line_opacity']:7.1f}us narrow={res['k_line_narrow']:7.1f}us reduce={res['k_reduce_partials']:6.1f}us  -> {e/ max(res['k_line_opacity']+res['k_line_narrow'],1e-9)/1e3:8.1f} Gevals/s")
+    print(f"{name:14s} lines={n:5d} evals={e:10d} prepass={res['k_line_prepass']:7.1f}us wide={res['k_line_wide']:7.1f}us narrow={res['k_line_narrow']:7.1f}us reduce={res['k_reduce_partials']:6.1f}us  -> {e/ max(res['k_line_wide']+res['k_line_narrow'],1e-9)/1e3:8.1f} Gevals/s")

@@ -195,44 +195,42 @@ __global__ __launch_bounds__(kBlock) void k_line_prepass(int n_depth, int64_t n_
 }
 
 // ------------------------------------------------------------------------------------------------
-// Line opacity, gather form: one block owns (depth d, a tile of 256*R grid points, one of S line subsets);
-// each lane owns R grid points and accumulates in registers.  The block streams its subset of the line list
-// in chunks of 256 (chunk c belongs to subset c mod S): each lane tests one line's window against the tile,
-// survivors are compacted (order-preserving) into LDS together with their depth-column constants, then every
-// lane walks the compacted list.  Splitting the line list over S blocks shortens the serial chain of the
-// deepest (hottest) layers, whose windows are widest; the S partial sums are added in subset order by the
-// consumer (k_reduce_partials / k_total_alphas).  No atomics: results are bit-stable run to run.
+// Line opacity, wide windows, gather form.  One single-wave block owns (depth d, a tile of 64*R grid points, one
+// of S line subsets); lane k owns grid points t0 + k + 64 r (r < R) and accumulates in registers.  The block
+// streams its subset of the line list in chunks of 64 (chunk c belongs to subset c mod S): each lane tests one
+// line's window against the tile, survivors are compacted (order-preserving, wave ballot) into LDS together with
+// their depth-column constants, then every lane walks the compacted list.  Splitting the line list over S blocks
+// shortens the serial chain of the deepest (hottest) layers, whose windows are widest; the S partial planes are
+// added in subset order by the consumer (k_reduce_partials / k_total_alphas).  No atomics: bit-stable results.
 template <int R>
-__global__ __launch_bounds__(kBlock) void k_line_opacity(int64_t n_nu, const double* __restrict__ nus, int64_t nu_begin,
-                                                         int64_t nu_count, int64_t n_lines,
-                                                         const double* __restrict__ line_nus, LineWork w,
-                                                         double* __restrict__ partial, int64_t pld, int n_depth)
+__global__ __launch_bounds__(64, 4) void k_line_wide(int64_t n_nu, const double* __restrict__ nus, int64_t nu_begin,
+                                                  int64_t nu_count, int64_t n_lines, const double* __restrict__ line_nus,
+                                                  LineWork w, double* __restrict__ partial, int64_t pld, int n_depth)
 {
-    constexpr int kTile = kBlock * R;
-    __shared__ double s_nu[kBlock], s_inv[kBlock], s_y[kBlock], s_amp[kBlock];
-    __shared__ double s_yk[kBlock], s_c2[kBlock], s_c3[kBlock], s_c4[kBlock];
-    __shared__ int s_lo[kBlock], s_hi[kBlock];
-    __shared__ int s_wcount[2][kBlock / 64];
+    constexpr int kTile = 64 * R;
+    __shared__ double s_nu[64], s_inv[64], s_y[64], s_amp[64], s_yk[64], s_c2[64], s_c3[64], s_c4[64];
+    __shared__ int s_lo[64], s_hi[64];
 
-    const int d = blockIdx.y;
-    const int split = blockIdx.z, n_split = gridDim.z;
+    // grid = (tiles, subsets, depths): depth is the slowest index so the innermost (hottest, widest-window)
+    // layers are dispatched first and the light outer layers fill the tail
+    const int d = blockIdx.z;
+    const int split = blockIdx.y, n_split = gridDim.y;
     const int64_t t0 = nu_begin + (int64_t)blockIdx.x * kTile;
     const int64_t t1 = min(t0 + kTile, nu_begin + nu_count);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x;
 
     double nu_i[R], acc[R];
     int idx[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const int64_t i = t0 + threadIdx.x + r * kBlock;
+        const int64_t i = t0 + lane + r * 64;
         idx[r] = i < t1 ? (int)i : -1;
         nu_i[r] = i < t1 ? nus[i] : 0.0;
         acc[r] = 0.0;
     }
     const size_t base = (size_t)d * n_lines;
-    int buf = 0;
-    for (int64_t c0 = (int64_t)split * kBlock; c0 < n_lines; c0 += (int64_t)n_split * kBlock, buf ^= 1) {
-        const int64_t l = c0 + threadIdx.x;
+    for (int64_t c0 = (int64_t)split * 64; c0 < n_lines; c0 += (int64_t)n_split * 64) {
+        const int64_t l = c0 + lane;
         int lo = 0, hi = 0;
         bool hit = false;
         if (l < n_lines) {
@@ -241,18 +239,10 @@ __global__ __launch_bounds__(kBlock) void k_line_opacity(int64_t n_nu, const dou
             hit = (lo < t1) & (hi > t0) & (hi > lo);
         }
         const unsigned long long m = __ballot(hit);
-        if (lane == 0) s_wcount[buf][wave] = __popcll(m);
-        __syncthreads();
-        int off = 0, total = 0;
-#pragma unroll
-        for (int k = 0; k < kBlock / 64; ++k) {
-            const int c = s_wcount[buf][k];
-            off += k < wave ? c : 0;
-            total += c;
-        }
-        if (total == 0) continue;  // uniform; the other s_wcount buffer is used next, so no barrier needed
+        if (m == 0) continue;
+        const int total = __popcll(m);
         if (hit) {
-            const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
+            const int pos = __popcll(m & ((1ull << lane) - 1ull));
             const double y = w.y[base + l];
             const RegionI k1 = region1_setup(y);
             s_nu[pos] = line_nus[l];
@@ -266,7 +256,7 @@ __global__ __launch_bounds__(kBlock) void k_line_opacity(int64_t n_nu, const dou
             s_lo[pos] = lo;
             s_hi[pos] = hi;
         }
-        __syncthreads();
+        __syncthreads();  // one wave: orders the LDS writes above before the reads below
         for (int j = 0; j < total; ++j) {
             const double lnu = s_nu[j], inv = s_inv[j], y = s_y[j], amp = s_amp[j];
             const int jlo = s_lo[j], jhi = s_hi[j];

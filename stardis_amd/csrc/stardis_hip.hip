@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -443,7 +444,7 @@ int sdx_profile_get(sdx_ctx* ctx, const char* kernel, int64_t* launches, double*
 // ================================================================================================ line opacity
 static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t n_lines, const double* line_nus,
                         const double* doppler, const double* gammas, int gamma_cols, const double* alphas, bool fill_work,
-                        int32_t* lo_ref, int32_t* hi_ref, LineWork* w_out)
+                        int32_t* lo_ref, int32_t* hi_ref, LineWork* w_out, bool count_evals = true)
 {
     int n_partial = 0;
     int rc = ensure(ctx, &ctx->small_ws, &ctx->small_ws_bytes, kSmallHeader);
@@ -459,7 +460,8 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
         rc = ensure(ctx, &ctx->cnt_ws, &ctx->cnt_ws_bytes, (size_t)(n_nu + 2) * sizeof(int));
         if (rc) return rc;
         w = carve(ctx, n_depth, n_lines);
-        HIP_TRY(hipMemsetAsync(w.evals, 0, sizeof(unsigned long long), ctx->stream));
+        if (count_evals) HIP_TRY(hipMemsetAsync(w.evals, 0, sizeof(unsigned long long), ctx->stream));
+        else w.evals = nullptr;
         n_pixel_blocks = (int)((n_nu + 2 + kBlock - 1) / kBlock);
     }
     const dim3 grid((unsigned)(n_line_blocks + n_pixel_blocks), (unsigned)((n_depth + kPreDepths - 1) / kPreDepths));
@@ -486,24 +488,27 @@ static int check_line_args(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double
     return SDX_OK;
 }
 
-// number of line subsets: enough blocks to fill the chip when the (tile, depth) grid alone is small
+// number of line subsets: enough single-wave blocks to fill the chip when the (tile, depth) grid alone is small
 static int choose_splits(int n_depth, int64_t nu_count, int64_t n_lines, int R)
 {
-    const int64_t tiles = (nu_count + kBlock * R - 1) / (kBlock * R);
-    const int64_t chunks = (n_lines + kBlock - 1) / kBlock;
-    const int64_t want = (4096 + tiles * n_depth - 1) / (tiles * n_depth);
-    return (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(want, chunks), 16));
+    const int64_t tiles = (nu_count + 64 * R - 1) / (64 * R);
+    const int64_t chunks = (n_lines + 63) / 64;
+    int64_t target = 8192;
+    if (const char* e = std::getenv("SDX_WIDE_BLOCKS")) target = std::max(1, std::atoi(e));  // tuning knob
+    const int64_t want = (target + tiles * n_depth - 1) / (tiles * n_depth);
+    return (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(want, chunks), 32));
 }
 
 // pre-pass + gather kernel; leaves n_split partial planes in *partial_out ([n_split][n_depth][*pld_out])
 static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin, int64_t nu_count,
                          int64_t n_lines, const double* line_nus, const double* doppler, const double* gammas, int gamma_cols,
                          const double* alphas, double* direct_out, int64_t direct_ld, const double** partial_out,
-                         int64_t* pld_out, int* n_split_out, LineWork* w_out)
+                         int64_t* pld_out, int* n_split_out, LineWork* w_out, bool count_evals)
 {
-    constexpr int R = 2;
+    constexpr int R = 4;
     LineWork w;
-    int rc = line_prepass(ctx, n_depth, n_nu, nus, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, true, nullptr, nullptr, &w);
+    int rc = line_prepass(ctx, n_depth, n_nu, nus, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, true, nullptr, nullptr, &w,
+                          count_evals);
     if (rc) return rc;
     const int n_split = choose_splits(n_depth, nu_count, n_lines, R);
     (void)direct_out;
@@ -513,12 +518,12 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
     double* part = (double*)ctx->part_ws;
     const int64_t pld = nu_count;
     {
-        LaunchScope ls(ctx, "k_line_opacity");
-        const dim3 grid((unsigned)((nu_count + kBlock * R - 1) / (kBlock * R)), (unsigned)n_depth, (unsigned)n_split);
-        hipLaunchKernelGGL(k_line_opacity<R>, grid, dim3(kBlock), 0, ctx->stream, n_nu, nus, nu_begin, nu_count, n_lines,
-                           line_nus, w, part, pld, n_depth);
+        LaunchScope ls(ctx, "k_line_wide");
+        const dim3 grid((unsigned)((nu_count + 64 * R - 1) / (64 * R)), (unsigned)n_split, (unsigned)n_depth);
+        hipLaunchKernelGGL(k_line_wide<R>, grid, dim3(64), 0, ctx->stream, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w,
+                           part, pld, n_depth);
     }
-    rc = check_launch("k_line_opacity");
+    rc = check_launch("k_line_wide");
     if (rc) return rc;
     {
         LaunchScope ls(ctx, "k_line_narrow");
@@ -553,7 +558,7 @@ int sdx_line_opacity_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
     int n_split;
     LineWork w;
     rc = line_partials(ctx, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, doppler, gammas, gamma_cols, alphas,
-                       accumulate ? nullptr : out, out_ld, &part, &pld, &n_split, &w);
+                       accumulate ? nullptr : out, out_ld, &part, &pld, &n_split, &w, n_evaluations_dev != nullptr);
     if (rc) return rc;
     {
         LaunchScope ls(ctx, "k_reduce_partials");
@@ -904,7 +909,11 @@ int sdx_raytrace_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, const
     for (int th0 = 0; th0 < n_theta; th0 += kMaxChunk) {
         const int nth = std::min(kMaxChunk, n_theta - th0);
         const int64_t work = n_nu * (int64_t)nth;
-        const int P = work < ((int64_t)1 << 19) ? 1 : (work < ((int64_t)1 << 21) ? 2 : 4);
+        int P = work < ((int64_t)1 << 19) ? 1 : (work < ((int64_t)1 << 21) ? 2 : 4);
+        if (const char* e = std::getenv("SDX_RT_P")) {  // tuning knob: angles per lane (1, 2 or 4)
+            const int v = std::atoi(e);
+            if (v == 1 || v == 2 || v == 4) P = v;
+        }
         const int G = (nth + P - 1) / P;
         const int gpw = 64 / G;
         const int kbatch = P == 1 ? 8 : (P == 2 ? 4 : 2);
@@ -979,7 +988,7 @@ int sdx_synthesize_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nu
     if (n_lines > 0) {
         LineWork w;
         rc = line_partials(ctx, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, doppler, gammas, gamma_cols, alphas,
-                           nullptr, 0, &part, &pld, &n_split, &w);
+                           nullptr, 0, &part, &pld, &n_split, &w, n_evaluations_dev != nullptr);
         if (rc) return rc;
         if (n_evaluations_dev)
             HIP_TRY(hipMemcpyAsync(n_evaluations_dev, w.evals, sizeof(int64_t), hipMemcpyDeviceToDevice, ctx->stream));

@@ -67,6 +67,7 @@ class SpectralSynthesizer:
         self.d_F = None if flux_out is not None else c.empty((self.n_depth, self.count))
         self.d_evals = c.zeros((1,), np.int64) if track_evaluations else None
         self.keep_line = keep_line  # also write the summed line opacity plane (alpha_line())
+        self.count_evaluations = track_evaluations  # sum(hi - lo) per step costs a memset + copy: switch off when timing
         self.graph = None
         c.call("sdx_reserve_line_workspace", self.n_depth, self.n_lines)
 
@@ -113,7 +114,7 @@ class SpectralSynthesizer:
         c.call("sdx_synthesize_dev", self.n_depth, self.n_nu, self.d_nus.ptr, self.begin, self.count, self.n_lines,
                self.d_ln.ptr, self.d_dw.ptr, self.d_g.ptr, self.gamma_cols, self.d_a.ptr, C.byref(self.cont), self.n_theta,
                self.d_t.ptr, self.d_ray.ptr, self.d_w.ptr, self.d_line.ptr if self.keep_line else None, self.d_total.ptr,
-               self.flux_ptr, self.count, ptr_of(self.d_evals))
+               self.flux_ptr, self.count, ptr_of(self.d_evals) if self.count_evaluations else None)
 
     def enqueue_unfused(self):
         """The same step through the individual entry points (what calc_alphas + raytrace issue)."""
