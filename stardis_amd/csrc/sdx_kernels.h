@@ -86,7 +86,7 @@ __device__ __forceinline__ int64_t window_rule(int64_t c, int64_t n_nu, double d
 // ------------------------------------------------------------------------------------------------
 // Pre-pass: one block = 32 lines x up to 64 depths.  Reads the reference layout coalesced into LDS,
 // writes the depth-major SoA coalesced.
-constexpr int kPreLines = 32;
+constexpr int kPreLines = 16;
 constexpr int kPreDepths = 64;
 
 constexpr int kNarrowHalfWidth = 64;  // windows with half-width <= this go to k_line_narrow
@@ -140,12 +140,14 @@ __global__ __launch_bounds__(kBlock) void k_line_prepass(int n_depth, int64_t n_
     __shared__ double s_red[kBlock / 64];
     __shared__ unsigned long long s_ev[kBlock / 64];
 
-    // d_nu (:524-526): from the partial maxima of k_dnu_partial, or — small grids — scanned here directly
-    const double d_nu = dnu_partial ? block_dnu(dnu_partial, n_partial, s_red) : block_dnu_scan(nus, n_nu, s_red);
     const int64_t l0 = (int64_t)blockIdx.x * kPreLines;
     const int d0 = blockIdx.y * kPreDepths;
     const int nl = (int)min((int64_t)kPreLines, n_lines - l0);
     const int nd = min(kPreDepths, n_depth - d0);
+    // line centres first (a chain of dependent loads) so they overlap the grid scan of the other threads
+    if (threadIdx.x < nl) s_c[threadIdx.x] = closest_index(nus, n_nu, line_nus[l0 + threadIdx.x]);
+    // d_nu (:524-526): from the partial maxima of k_dnu_partial, or — small grids — scanned here directly
+    const double d_nu = dnu_partial ? block_dnu(dnu_partial, n_partial, s_red) : block_dnu_scan(nus, n_nu, s_red);
 
     for (int k = threadIdx.x; k < nl * nd; k += kBlock) {
         const int ll = k / nd, dd = k - ll * nd;
@@ -155,7 +157,6 @@ __global__ __launch_bounds__(kBlock) void k_line_prepass(int n_depth, int64_t n_
         s_a[ll * kStride + dd] = alphas[l * n_depth + d];
         s_g[ll * kStride + dd] = gamma_cols > 1 ? gammas[l * gamma_cols + d] : gammas[l * gamma_cols];
     }
-    if (threadIdx.x < nl) s_c[threadIdx.x] = closest_index(nus, n_nu, line_nus[l0 + threadIdx.x]);
     __syncthreads();
 
     unsigned long long ev = 0;
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(64, 4) void k_line_wide(int64_t n_nu, const double*
 {
     constexpr int kTile = 64 * R;
     __shared__ double s_nu[64], s_inv[64], s_y[64], s_amp[64], s_yk[64], s_c2[64], s_c3[64], s_c4[64];
-    __shared__ int s_lo[64], s_hi[64];
+    __shared__ int s_lo[64], s_hi[64], s_fast[64];
 
     // grid = (tiles, subsets, depths): depth is the slowest index so the innermost (hottest, widest-window)
     // layers are dispatched first and the light outer layers fill the tail
@@ -229,6 +230,7 @@ __global__ __launch_bounds__(64, 4) void k_line_wide(int64_t n_nu, const double*
         acc[r] = 0.0;
     }
     const size_t base = (size_t)d * n_lines;
+    const double nu_first = nus[t0], nu_last = nus[t1 - 1];  // tile edges (descending grid)
     for (int64_t c0 = (int64_t)split * 64; c0 < n_lines; c0 += (int64_t)n_split * 64) {
         const int64_t l = c0 + lane;
         int lo = 0, hi = 0;
@@ -244,9 +246,18 @@ __global__ __launch_bounds__(64, 4) void k_line_wide(int64_t n_nu, const double*
         if (hit) {
             const int pos = __popcll(m & ((1ull << lane) - 1ull));
             const double y = w.y[base + l];
+            const double inv = w.inv_dw[base + l];
+            const double lnu = line_nus[l];
             const RegionI k1 = region1_setup(y);
-            s_nu[pos] = line_nus[l];
-            s_inv[pos] = w.inv_dw[base + l];
+            // Whole tile inside the window and every point of it in Faddeeva region I (|x| + y > 15, voigt.py:39)?
+            // The smallest |x| of the tile is at the edge nearer to the line; the 1e-3 margin dwarfs rounding, so
+            // every lane's own test would take the same branch: the per-lane tests can be skipped.
+            const double e_first = nu_first - lnu, e_last = nu_last - lnu;
+            const bool beside = e_last > 0.0 || e_first < 0.0;
+            const double nearest = fmin(fabs(e_first), fabs(e_last));
+            s_fast[pos] = (lo <= t0) & (hi >= t1) & beside & (nearest * inv + y > 15.001);
+            s_nu[pos] = lnu;
+            s_inv[pos] = inv;
             s_y[pos] = y;
             s_amp[pos] = w.amp[base + l];
             s_yk[pos] = k1.yk;
@@ -258,12 +269,22 @@ __global__ __launch_bounds__(64, 4) void k_line_wide(int64_t n_nu, const double*
         }
         __syncthreads();  // one wave: orders the LDS writes above before the reads below
         for (int j = 0; j < total; ++j) {
-            const double lnu = s_nu[j], inv = s_inv[j], y = s_y[j], amp = s_amp[j];
-            const int jlo = s_lo[j], jhi = s_hi[j];
+            const double lnu = s_nu[j], inv = s_inv[j], amp = s_amp[j];
             const RegionI k1 = {s_yk[j], s_c2[j], s_c3[j], s_c4[j]};
+            if (__builtin_amdgcn_readfirstlane(s_fast[j])) {
+                // same operations, in the same order, as voigt_term's region-I branch: bit-identical results
 #pragma unroll
-            for (int r = 0; r < R; ++r)
-                if (idx[r] >= jlo && idx[r] < jhi) acc[r] += voigt_term(nu_i[r] - lnu, inv, y, amp, k1);
+                for (int r = 0; r < R; ++r) {
+                    const double x = (nu_i[r] - lnu) * inv;
+                    acc[r] += amp * region1_re(x * x, k1);
+                }
+            } else {
+                const double y = s_y[j];
+                const int jlo = s_lo[j], jhi = s_hi[j];
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    if (idx[r] >= jlo && idx[r] < jhi) acc[r] += voigt_term(nu_i[r] - lnu, inv, y, amp, k1);
+            }
         }
         __syncthreads();
     }
@@ -791,16 +812,26 @@ __global__ __launch_bounds__(kBlock) void k_raytrace_basic(int n_depth, int64_t 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Formal solution, LDS-staged (the default).  Same lane <-> (frequency, angle) mapping as k_raytrace_basic,
-// but the per-frequency depth column is prepared ONCE per group and kept in LDS:
-//   phase 1  the G lanes of a group split the N_d depth points: log(alpha), Planck source S (:133) -> LDS,
-//            then the N_d-1 geometric-mean opacities exp((log a[g+1] + log a[g]) * 0.5) (:121) -> LDS;
-//   phase 2  every lane walks the gaps for its own angle(s): tau = mean * ray_dist (:123-129), weights
-//            (:22-45), second-order recurrence (:200-266).  1/tau of a gap is carried to the next gap and
-//            the divisions of :208-242 become multiplications by the two reciprocals 1/tau[gap+1] and
-//            1/(tau[gap]+tau[gap+1]) (IEEE divisions, so tau = 0 still yields the reference's inf/NaN);
-//   flux     I_theta * w_theta goes to LDS; every kBatch gaps the wave sums each (gap, frequency) over
-//            theta in ascending order (the reference's order, :324-338) and writes F_nu.
+// Formal solution, LDS-staged (the default).  Same lane <-> (frequency, angle) mapping as k_raytrace_basic:
+// a group of G adjacent lanes owns one frequency, lane g traces angle(s) g, g+G, ...  What is shared is
+// prepared once and kept in LDS:
+//   block    the ray-length table ray_dist[gap][theta] (:302-305) and its reciprocals;
+//   group    phase 1: the G lanes split the N_d depth points: log(alpha) and the Planck source S (:133) -> LDS,
+//            then per gap the geometric-mean opacity exp((log a[g+1] + log a[g]) * 0.5) (:121) and its reciprocal;
+//   lane     phase 2: walks the gaps for its own angle(s): tau = mean * ray_dist (:123-129, the reference's
+//            product), weights (:22-45), second-order recurrence (:200-266).  The divisions of :208-242 are
+//            re-expressed with the slopes a = (S[g+2]-S[g+1])/tau[g+1], b = (S[g]-S[g+1])/tau[g]:
+//                second = w1 (b tau[g+1] - a tau[g]) / (tau[g] + tau[g+1]),   third = w2 (a + b) / (tau[g] + tau[g+1])
+//            with 1/tau formed as (1/mean)(1/ray_dist) — shared across angles / frequencies — and one reciprocal
+//            per step for the sum.  tau = 0 gives the same inf/NaN pattern as the reference's unguarded divisions.
+//   flux     I_theta * w_theta goes to LDS; every kBatch gaps the wave sums each (gap, frequency) over theta in
+//            ascending order (the reference's order, :324-338) and writes F_nu.
+__device__ __forceinline__ double recip_guarded(double d)
+{
+    // Newton-refined hardware reciprocal for ordinary magnitudes, IEEE division otherwise (0, inf, NaN, subnormal)
+    return (d > 1e-290 && d < 1e290) ? recip(d) : 1.0 / d;
+}
+
 template <int P>
 __global__ __launch_bounds__(kBlock) void k_raytrace(int n_depth, int64_t n_nu, int n_theta, int theta_stride, int G,
                                                      const double* __restrict__ nus, const double* __restrict__ temps,
@@ -822,11 +853,21 @@ __global__ __launch_bounds__(kBlock) void k_raytrace(int n_depth, int64_t n_nu, 
     const int n_gap = n_depth - 1;
     const int col = n_depth;  // LDS row stride per group
     const int scratch = max(gpw * col, kBatch * gpw * TH);
-    double* sS = smem + (size_t)wave * (2 * gpw * col + scratch);  // source function  [gpw][col]
-    double* sM = sS + gpw * col;                                   // mean opacity    [gpw][col]
-    double* sX = sM + gpw * col;                                   // log(alpha) in phase 1, flux terms in phase 2
+    double* sRD = smem;                       // ray_dist       [n_gap][n_theta]
+    double* sIRD = sRD + n_gap * n_theta;     // 1 / ray_dist
+    double* wbase = sIRD + n_gap * n_theta + (size_t)wave * (3 * gpw * col + scratch);
+    double* sS = wbase;                       // source function      [gpw][col]
+    double* sM = sS + gpw * col;              // mean opacity         [gpw][col]
+    double* sIM = sM + gpw * col;             // 1 / mean opacity     [gpw][col]
+    double* sX = sIM + gpw * col;             // log(alpha) in phase 1, flux terms in phase 2
     const double nu = nus[ic];
 
+    for (int k = threadIdx.x; k < n_gap * n_theta; k += kBlock) {
+        const int gp = k / n_theta, t = k - gp * n_theta;
+        const double rd = ray_dist[(size_t)gp * theta_stride + t];
+        sRD[k] = rd;
+        sIRD[k] = 1.0 / rd;
+    }
     if (active) {
         for (int d = g; d < n_depth; d += G) {
             sX[grp * col + d] = log(alphas[(size_t)d * ald + ic]);
@@ -835,71 +876,72 @@ __global__ __launch_bounds__(kBlock) void k_raytrace(int n_depth, int64_t n_nu, 
     }
     __syncthreads();
     if (active)
-        for (int gp = g; gp < n_gap; gp += G) sM[grp * col + gp] = exp(mul_rn(add_rn(sX[grp * col + gp + 1], sX[grp * col + gp]), 0.5));
+        for (int gp = g; gp < n_gap; gp += G) {
+            const double m = exp(mul_rn(add_rn(sX[grp * col + gp + 1], sX[grp * col + gp]), 0.5));
+            sM[grp * col + gp] = m;
+            sIM[grp * col + gp] = 1.0 / m;
+        }
     __syncthreads();
 
-    const int gi = active ? grp : 0;  // idle lanes shadow group 0 and never store
+    const int gi = (active ? grp : 0) * col;  // idle lanes shadow group 0 and never store
     double inten[P], wt[P], tau0[P], r0[P];
     int th[P];
 #pragma unroll
     for (int k = 0; k < P; ++k) {
-        th[k] = g + k * G;
-        const bool on = th[k] < n_theta;
+        th[k] = min(g + k * G, n_theta - 1);
+        const bool on = g + k * G < n_theta;
         inten[k] = 0.0;  // I[0] = 0 (:134-136)
         wt[k] = on ? wts[th[k]] : 0.0;
-        tau0[k] = on ? mul_rn(sM[gi * col], ray_dist[th[k]]) : 1.0;
-        r0[k] = 1.0 / tau0[k];
+        tau0[k] = mul_rn(sM[gi], sRD[th[k]]);
+        r0[k] = sIM[gi] * sIRD[th[k]];
         if (valid && I_nus && on) I_nus[(size_t)i * theta_stride + th[k]] = 0.0;
     }
     if (valid && g == 0 && F && !accumulate) F[i] = 0.0;
+    double s0 = sS[gi], s1 = sS[gi + 1];
 
     for (int gap0 = 0; gap0 < n_gap; gap0 += kBatch) {
         const int nb = min(kBatch, n_gap - gap0);
+#pragma unroll 2
         for (int b = 0; b < nb; ++b) {
             const int gap = gap0 + b;
             const bool last = gap == n_gap - 1;
-            const double s0 = sS[gi * col + gap], s1 = sS[gi * col + gap + 1];
-            const double s2 = last ? 0.0 : sS[gi * col + gap + 2];
-            const double mean1 = last ? 0.0 : sM[gi * col + gap + 1];
+            const int nx = last ? gap : gap + 1;  // clamp LDS reads of the step that has no successor
+            const double s2 = sS[gi + nx + 1];
+            const double mean1 = sM[gi + nx], imean1 = sIM[gi + nx];
+            const double d10 = s0 - s1, d21 = s2 - s1;
 #pragma unroll
             for (int k = 0; k < P; ++k) {
-                double contrib = 0.0;
-                if (th[k] < n_theta) {
-                    const double t0 = tau0[k];
-                    double t1 = 0.0, r1 = 0.0, inew;
-                    if (!last) {
-                        t1 = mul_rn(mean1, ray_dist[(size_t)(gap + 1) * theta_stride + th[k]]);
-                        r1 = 1.0 / t1;
+                const double t0 = tau0[k];
+                const double t1 = mul_rn(mean1, sRD[nx * n_theta + th[k]]);
+                const double r1 = imean1 * sIRD[nx * n_theta + th[k]];
+                double inew = inten[k];  // tau == 0: no change (:203-206, :253-254)
+                if (t0 != 0.0) {
+                    double w0, w1, w2;
+                    rt_weights(t0, w0, w1, w2);
+                    const double head = fma(w0, s1, (1.0 - w0) * inten[k]);
+                    const double bb = d10 * r0[k];
+                    if (!last) {  // :208-249
+                        const double rs = recip_guarded(t0 + t1);
+                        const double aa = d21 * r1;
+                        inew = (head + w1 * (bb * t1 - aa * t0) * rs) + w2 * (aa + bb) * rs;
+                    } else {  // :256-266
+                        inew = head + w2 * bb * r0[k];
                     }
-                    if (t0 == 0.0) {
-                        inew = inten[k];  // :203-206, :253-254
-                    } else {
-                        double w0, w1, w2;
-                        rt_weights(t0, w0, w1, w2);
-                        const double head = fma(w0, s1, (1.0 - w0) * inten[k]);
-                        if (!last) {  // :208-249
-                            const double rs = 1.0 / (t0 + t1);
-                            const double second = w1 * ((s1 - s2) * (t0 * r1) - (s1 - s0) * (t1 * r0[k])) * rs;
-                            const double third = w2 * ((s2 - s1) * r1 + (s0 - s1) * r0[k]) * rs;
-                            inew = (head + second) + third;
-                        } else {  // :256-266
-                            inew = head + w2 * (s0 - s1) * (r0[k] * r0[k]);
-                        }
-                    }
-                    inten[k] = inew;
-                    tau0[k] = t1;
-                    r0[k] = r1;
-                    contrib = inew * wt[k];
-                    if (valid && I_nus) I_nus[((size_t)(gap + 1) * n_nu + i) * theta_stride + th[k]] = inew;
                 }
-                if (active) sX[(b * gpw + grp) * TH + k * G + g] = contrib;
+                inten[k] = inew;
+                tau0[k] = t1;
+                r0[k] = r1;
+                if (valid && I_nus && g + k * G < n_theta) I_nus[((size_t)(gap + 1) * n_nu + i) * theta_stride + th[k]] = inew;
+                if (active) sX[(b * gpw + grp) * TH + k * G + g] = inew * wt[k];
             }
+            s0 = s1;
+            s1 = s2;
         }
         __syncthreads();
         if (F) {
             for (int p = lane; p < nb * gpw; p += 64) {
                 const int b = p / gpw, gq = p - b * gpw;
-                const double* c = sX + (size_t)(b * gpw + gq) * TH;
+                const double* c = sX + (b * gpw + gq) * TH;
                 double sum = 0.0;
                 for (int t = 0; t < n_theta; ++t) sum = add_rn(sum, c[t]);
                 const int64_t iq = i0 + gq;

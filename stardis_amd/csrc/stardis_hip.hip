@@ -918,7 +918,9 @@ int sdx_raytrace_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, const
         const int gpw = 64 / G;
         const int kbatch = P == 1 ? 8 : (P == 2 ? 4 : 2);
         const unsigned blocks = (unsigned)((n_nu + (int64_t)gpw * (kBlock / 64) - 1) / ((int64_t)gpw * (kBlock / 64)));
-        const size_t shmem = (size_t)(kBlock / 64) * (2 * (size_t)gpw * n_depth + std::max((size_t)gpw * n_depth, (size_t)kbatch * gpw * P * G)) * sizeof(double);
+        const size_t shmem = ((size_t)2 * (n_depth - 1) * nth +
+                              (size_t)(kBlock / 64) * (3 * (size_t)gpw * n_depth + std::max((size_t)gpw * n_depth, (size_t)kbatch * gpw * P * G))) *
+                             sizeof(double);
         const double* rd = ray_dist + th0;
         const double* w = wts + th0;
         double* inus = I_nus ? I_nus + th0 : nullptr;
