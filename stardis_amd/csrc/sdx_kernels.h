@@ -97,9 +97,15 @@ struct LineWork {
     double* amp;
     int* lo;         // window of WIDE (line, depth) items, 0/0 for narrow ones
     int* hi;
-    int* nlo;        // window of NARROW items (half-width <= kNarrowHalfWidth), 0/0 for wide ones
+    // NARROW items (half-width <= kNarrowHalfWidth), LINE-major [N_l][N_d] so that lane <-> depth reads coalesce
+    int* nlo;        // window, 0/0 for wide items
     int* nhi;
+    double* n_inv;
+    double* n_y;
+    double* n_amp;
     int* cnt_ge;     // [N_nu + 2]: number of lines whose centre index is >= p (lines are a prefix: centres descend)
+    int* centre;     // [N_l] centre index of each line
+    int* nhw_max;    // [N_l] largest NARROW half-width of the line over all depths (0: no narrow item)
     unsigned long long* evals;
 };
 
@@ -168,21 +174,62 @@ __global__ __launch_bounds__(kBlock) void k_line_prepass(int n_depth, int64_t n_
         const int64_t l = l0 + ll;
         const int d = d0 + dd;
         if (w.inv_dw) {
-            const size_t o = (size_t)d * n_lines + l;
+            const size_t o = (size_t)d * n_lines + l;  // depth-major (wide kernel)
             const bool narrow = hw <= kNarrowHalfWidth;
-            w.inv_dw[o] = 1.0 / dw;
-            w.y[o] = (g / mul_rn(kSqrtPi, kPi)) / dw;  // voigt.py:148
-            w.amp[o] = a / mul_rn(kSqrtPi, dw);        // voigt.py:149 x base.py:627
+            const double inv = 1.0 / dw;
+            const double yy = (g / mul_rn(kSqrtPi, kPi)) / dw;  // voigt.py:148
+            const double amp = a / mul_rn(kSqrtPi, dw);         // voigt.py:149 x base.py:627
             w.lo[o] = narrow ? 0 : lo;
             w.hi[o] = narrow ? 0 : hi;
-            w.nlo[o] = narrow ? lo : 0;
-            w.nhi[o] = narrow ? hi : 0;
-        }
-        if (out_lo_ref) {  // reference layout [N_l][N_d], for sdx_line_windows_dev
-            out_lo_ref[l * n_depth + d] = lo;
-            out_hi_ref[l * n_depth + d] = hi;
+            if (!narrow) {
+                w.inv_dw[o] = inv;
+                w.y[o] = yy;
+                w.amp[o] = amp;
+            }
         }
         if (hi > lo) ev += (unsigned long long)(hi - lo);
+    }
+    // per-line summary for the narrow kernel's candidate test: centre index and the largest narrow half-width
+    if (w.nhw_max) {
+        __shared__ int s_hwmax[kPreLines];
+        if (threadIdx.x < kPreLines) s_hwmax[threadIdx.x] = 0;
+        __syncthreads();
+        for (int k = threadIdx.x; k < nl * nd; k += kBlock) {
+            const int ll = k / nd, dd = k - ll * nd;
+            int lo, hi;
+            const int64_t hw = window_rule(s_c[ll], n_nu, d_nu, s_g[ll * kStride + dd], s_dw[ll * kStride + dd], s_a[ll * kStride + dd], lo, hi);
+            if (hw <= kNarrowHalfWidth) atomicMax(&s_hwmax[ll], (int)hw);
+        }
+        __syncthreads();
+        if (threadIdx.x < nl) {
+            if (gridDim.y == 1) w.nhw_max[l0 + threadIdx.x] = s_hwmax[threadIdx.x];
+            else atomicMax(&w.nhw_max[l0 + threadIdx.x], s_hwmax[threadIdx.x]);  // deep models: zeroed by the host first
+            if (blockIdx.y == 0) w.centre[l0 + threadIdx.x] = (int)s_c[threadIdx.x];
+        }
+    }
+    // line-major outputs: same items visited with depth fastest so the stores coalesce
+    if (w.nlo || out_lo_ref) {
+        for (int k = threadIdx.x; k < nl * nd; k += kBlock) {
+            const int ll = k / nd, dd = k - ll * nd;
+            const double dw = s_dw[ll * kStride + dd], g = s_g[ll * kStride + dd], a = s_a[ll * kStride + dd];
+            int lo, hi;
+            const int64_t hw = window_rule(s_c[ll], n_nu, d_nu, g, dw, a, lo, hi);
+            const size_t o = (size_t)(l0 + ll) * n_depth + (d0 + dd);
+            if (out_lo_ref) {  // sdx_line_windows_dev
+                out_lo_ref[o] = lo;
+                out_hi_ref[o] = hi;
+            }
+            if (w.nlo) {
+                const bool narrow = hw <= kNarrowHalfWidth;
+                w.nlo[o] = narrow ? lo : 0;
+                w.nhi[o] = narrow ? hi : 0;
+                if (narrow) {
+                    w.n_inv[o] = 1.0 / dw;
+                    w.n_y[o] = (g / mul_rn(kSqrtPi, kPi)) / dw;
+                    w.n_amp[o] = a / mul_rn(kSqrtPi, dw);
+                }
+            }
+        }
     }
     if (w.evals) {
         for (int off = 32; off > 0; off >>= 1) ev += __shfl_xor(ev, off);
@@ -231,15 +278,22 @@ __global__ __launch_bounds__(64, 4) void k_line_wide(int64_t n_nu, const double*
     }
     const size_t base = (size_t)d * n_lines;
     const double nu_first = nus[t0], nu_last = nus[t1 - 1];  // tile edges (descending grid)
-    for (int64_t c0 = (int64_t)split * 64; c0 < n_lines; c0 += (int64_t)n_split * 64) {
+    const int64_t cstep = (int64_t)n_split * 64;
+    int lo_next = 0, hi_next = 0;
+    if ((int64_t)split * 64 + lane < n_lines) {
+        lo_next = w.lo[base + (int64_t)split * 64 + lane];
+        hi_next = w.hi[base + (int64_t)split * 64 + lane];
+    }
+    for (int64_t c0 = (int64_t)split * 64; c0 < n_lines; c0 += cstep) {
         const int64_t l = c0 + lane;
-        int lo = 0, hi = 0;
-        bool hit = false;
-        if (l < n_lines) {
-            lo = w.lo[base + l];
-            hi = w.hi[base + l];
-            hit = (lo < t1) & (hi > t0) & (hi > lo);
+        const int lo = lo_next, hi = hi_next;
+        lo_next = 0;
+        hi_next = 0;
+        if (l + cstep < n_lines) {  // prefetch the next chunk's windows behind this chunk's arithmetic
+            lo_next = w.lo[base + l + cstep];
+            hi_next = w.hi[base + l + cstep];
         }
+        const bool hit = (l < n_lines) & (lo < t1) & (hi > t0) & (hi > lo);
         const unsigned long long m = __ballot(hit);
         if (m == 0) continue;
         const int total = __popcll(m);
@@ -294,37 +348,52 @@ __global__ __launch_bounds__(64, 4) void k_line_wide(int64_t n_nu, const double*
 }
 
 // Narrow windows (half-width <= kNarrowHalfWidth, e.g. the reference's 10-pixel floor for weak lines, :565-567):
-// a 256*R-point tile would be almost empty for them, so lanes are tiled 4 frequencies x 16 depths per wave and
-// each lane owns ONE (depth, frequency) point.  The candidate lines of a wave are the contiguous index range
-// whose centre lies within kNarrowHalfWidth of its 4 frequencies, read from cnt_ge; each lane walks that range
-// in ascending line order, tests its own window and accumulates in a register.  Deterministic, no atomics.
+// a 256-point tile would be almost empty for them.  Here a wave owns ONE frequency and its lanes are the depth
+// points (lane <-> depth, line-major parameter arrays so the loads coalesce): a weak line covers either all
+// depths of that frequency or none, and all lanes share x = (nu_i - nu_l)/doppler up to the slowly varying Doppler
+// width, so the Faddeeva region rarely diverges inside a wave.  The candidate lines of a frequency are the
+// contiguous index range whose centre lies within kNarrowHalfWidth of it, read from cnt_ge; each lane walks that
+// range in ascending line order, tests its own window and accumulates in a register.  Deterministic, no atomics.
 __global__ __launch_bounds__(kBlock) void k_line_narrow(int n_depth, int64_t n_nu, const double* __restrict__ nus,
                                                         int64_t nu_begin, int64_t nu_count, int64_t n_lines,
                                                         const double* __restrict__ line_nus, LineWork w,
                                                         double* __restrict__ plane, int64_t pld)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nl = lane & 3, dl = lane >> 2;
-    const int64_t i0 = nu_begin + ((int64_t)blockIdx.x * (kBlock / 64) + wave) * 4;
-    const int64_t i = i0 + nl;
-    const int d = blockIdx.y * 16 + dl;
-    const bool valid = d < n_depth && i < nu_begin + nu_count;
-    const int dc = d < n_depth ? d : n_depth - 1;
+    const int64_t i = nu_begin + (int64_t)blockIdx.x * (kBlock / 64) + wave;  // wave-uniform
+    if (i >= nu_begin + nu_count) return;
+    const int d = blockIdx.y * 64 + lane;
+    const bool valid = d < n_depth;
+    const int dc = valid ? d : n_depth - 1;
     const int ii = (int)i;
-    // lines with centre c in [i0 - H + 1, i0 + 3 + H]
-    const int64_t pa = max(i0 - kNarrowHalfWidth + 1, (int64_t)0);
-    const int64_t pb = min(i0 + 3 + kNarrowHalfWidth, n_nu);
+    // lines with centre c in [i - H + 1, i + H]
+    const int64_t pa = max(i - kNarrowHalfWidth + 1, (int64_t)0);
+    const int64_t pb = min(i + kNarrowHalfWidth, n_nu);
     const int la = __builtin_amdgcn_readfirstlane(w.cnt_ge[pb + 1]);
     const int lb = __builtin_amdgcn_readfirstlane(w.cnt_ge[pa]);
-    const double nu_i = valid ? nus[i] : 0.0;
-    const size_t base = (size_t)dc * n_lines;
+    const double nu_i = nus[i];
     double acc = 0.0;
-    for (int l = la; l < lb; ++l) {
-        const int lo = w.nlo[base + l], hi = w.nhi[base + l];
-        if (valid && ii >= lo && ii < hi) {
-            const double y = w.y[base + l];
-            const RegionI k1 = region1_setup(y);
-            acc += voigt_term(nu_i - line_nus[l], w.inv_dw[base + l], y, w.amp[base + l], k1);
+    for (int base = la; base < lb; base += 64) {
+        // lanes test 64 candidate lines at once against this frequency (per-line bound), then the wave visits
+        // only the relevant ones, in ascending line order
+        const int lc = base + lane;
+        bool rel = false;
+        if (lc < lb) {
+            const int hwm = w.nhw_max[lc], c = w.centre[lc];
+            rel = hwm > 0 && ii >= c - hwm && ii < c + hwm;
+        }
+        unsigned long long m = __ballot(rel);
+        while (m) {
+            const int j = __builtin_ctzll(m);
+            m &= m - 1;
+            const int l = base + j;
+            const size_t o = (size_t)l * n_depth + dc;
+            const int lo = w.nlo[o], hi = w.nhi[o];
+            if (valid && ii >= lo && ii < hi) {
+                const double y = w.n_y[o];
+                const RegionI k1 = region1_setup(y);
+                acc += voigt_term(nu_i - line_nus[l], w.n_inv[o], y, w.n_amp[o], k1);
+            }
         }
     }
     if (valid) plane[(size_t)d * pld + (i - nu_begin)] = acc;

@@ -60,8 +60,12 @@ struct sdx_ctx {
     // cnt_ge[N_nu + 2] (lines per centre index, for the narrow-window kernel)
     void* cnt_ws = nullptr;
     size_t cnt_ws_bytes = 0;
+    size_t cnt_ge_len = 0;
     // timing
     hipEvent_t t0 = nullptr, t1 = nullptr;
+    // side stream + fork/join events: independent kernels of one step (wide / narrow line opacity) overlap
+    hipStream_t side = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
     bool profile = false;
     std::vector<ProfileRecord> records;
     std::vector<hipEvent_t> event_pool;
@@ -89,7 +93,7 @@ int ensure(sdx_ctx* ctx, void** buf, size_t* have, size_t need)
     return SDX_OK;
 }
 
-size_t line_ws_need(int n_depth, int64_t n_lines) { return (size_t)n_depth * (size_t)n_lines * 40 + 256; }
+size_t line_ws_need(int n_depth, int64_t n_lines) { return (size_t)n_depth * (size_t)n_lines * 64 + 256; }
 
 LineWork carve(sdx_ctx* ctx, int n_depth, int64_t n_lines)
 {
@@ -99,11 +103,16 @@ LineWork carve(sdx_ctx* ctx, int n_depth, int64_t n_lines)
     w.inv_dw = (double*)p;
     w.y = w.inv_dw + n;
     w.amp = w.y + n;
-    w.lo = (int*)(w.amp + n);
+    w.n_inv = w.amp + n;
+    w.n_y = w.n_inv + n;
+    w.n_amp = w.n_y + n;
+    w.lo = (int*)(w.n_amp + n);
     w.hi = w.lo + n;
     w.nlo = w.hi + n;
     w.nhi = w.nlo + n;
     w.cnt_ge = (int*)ctx->cnt_ws;
+    w.centre = w.cnt_ge + ctx->cnt_ge_len;
+    w.nhw_max = w.centre + n_lines;
     w.evals = (unsigned long long*)((char*)ctx->small_ws + 2048);
     return w;
 }
@@ -247,6 +256,9 @@ sdx_ctx* sdx_create(int device, void* stream)
     }
     hipEventCreate(&ctx->t0);
     hipEventCreate(&ctx->t1);
+    hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking);
+    hipEventCreateWithFlags(&ctx->fork, hipEventDisableTiming);
+    hipEventCreateWithFlags(&ctx->join, hipEventDisableTiming);
     return ctx;
 }
 
@@ -260,6 +272,12 @@ void sdx_destroy(sdx_ctx* ctx)
         hipEventDestroy(r.stop);
     }
     for (auto e : ctx->event_pool) hipEventDestroy(e);
+    if (ctx->side) {
+        hipStreamSynchronize(ctx->side);
+        hipStreamDestroy(ctx->side);
+    }
+    if (ctx->fork) hipEventDestroy(ctx->fork);
+    if (ctx->join) hipEventDestroy(ctx->join);
     if (ctx->t0) hipEventDestroy(ctx->t0);
     if (ctx->t1) hipEventDestroy(ctx->t1);
     if (ctx->line_ws) hipFree(ctx->line_ws);
@@ -457,9 +475,11 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
     if (fill_work) {
         rc = ensure(ctx, &ctx->line_ws, &ctx->line_ws_bytes, line_ws_need(n_depth, n_lines));
         if (rc) return rc;
-        rc = ensure(ctx, &ctx->cnt_ws, &ctx->cnt_ws_bytes, (size_t)(n_nu + 2) * sizeof(int));
+        ctx->cnt_ge_len = (size_t)(n_nu + 2 + 63) / 64 * 64;
+        rc = ensure(ctx, &ctx->cnt_ws, &ctx->cnt_ws_bytes, (ctx->cnt_ge_len + 2 * (size_t)n_lines) * sizeof(int));
         if (rc) return rc;
         w = carve(ctx, n_depth, n_lines);
+        if (n_depth > kPreDepths) HIP_TRY(hipMemsetAsync(w.nhw_max, 0, (size_t)n_lines * sizeof(int), ctx->stream));
         if (count_evals) HIP_TRY(hipMemsetAsync(w.evals, 0, sizeof(unsigned long long), ctx->stream));
         else w.evals = nullptr;
         n_pixel_blocks = (int)((n_nu + 2 + kBlock - 1) / kBlock);
@@ -517,6 +537,24 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
     if (rc) return rc;
     double* part = (double*)ctx->part_ws;
     const int64_t pld = nu_count;
+    // The wide and narrow kernels only share the pre-pass: fork the narrow one onto the side stream so the two
+    // fill each other's idle issue slots (serial when per-kernel profiling is on, to keep the timings separable).
+    const bool overlap = !ctx->profile && ctx->side != nullptr;
+    hipStream_t narrow_stream = ctx->stream;
+    if (overlap) {
+        HIP_TRY(hipEventRecord(ctx->fork, ctx->stream));
+        HIP_TRY(hipStreamWaitEvent(ctx->side, ctx->fork, 0));
+        narrow_stream = ctx->side;
+    }
+    {
+        LaunchScope ls(ctx, "k_line_narrow");
+        const dim3 grid((unsigned)((nu_count + kBlock / 64 - 1) / (kBlock / 64)), (unsigned)((n_depth + 63) / 64));
+        hipLaunchKernelGGL(k_line_narrow, grid, dim3(kBlock), 0, narrow_stream, n_depth, n_nu, nus, nu_begin, nu_count, n_lines,
+                           line_nus, w, part + (size_t)n_split * n_depth * pld, pld);
+    }
+    rc = check_launch("k_line_narrow");
+    if (rc) return rc;
+    if (overlap) HIP_TRY(hipEventRecord(ctx->join, ctx->side));
     {
         LaunchScope ls(ctx, "k_line_wide");
         const dim3 grid((unsigned)((nu_count + 64 * R - 1) / (64 * R)), (unsigned)n_split, (unsigned)n_depth);
@@ -525,17 +563,12 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
     }
     rc = check_launch("k_line_wide");
     if (rc) return rc;
-    {
-        LaunchScope ls(ctx, "k_line_narrow");
-        const dim3 grid((unsigned)((nu_count + 15) / 16), (unsigned)((n_depth + 15) / 16));
-        hipLaunchKernelGGL(k_line_narrow, grid, dim3(kBlock), 0, ctx->stream, n_depth, n_nu, nus, nu_begin, nu_count, n_lines,
-                           line_nus, w, part + (size_t)n_split * n_depth * pld, pld);
-    }
+    if (overlap) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->join, 0));
     *partial_out = part;
     *pld_out = pld;
     *n_split_out = n_split + 1;  // planes to sum: the wide subsets, then the narrow-window plane
     if (w_out) *w_out = w;
-    return check_launch("k_line_narrow");
+    return SDX_OK;
 }
 
 int sdx_line_opacity_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin, int64_t nu_count,
