@@ -211,6 +211,13 @@ int sdx_total_alphas_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
                          int64_t nu_count, const sdx_continuum* cont, const double* alpha_line, int64_t line_ld,
                          double* total_alphas, int64_t total_ld);
 
+/* ---- post-processing ---------------------------------------------------------------------------
+ * scipy.ndimage.convolve1d(in, weights) with mode='reflect', origin 0, odd kernel length: the operation
+ * rotation_broadening applies to the spectrum (opacities_solvers/broadening.py:869-871).  symmetric != 0 selects
+ * scipy's pairwise order for symmetric kernels (the caller applies scipy's DBL_EPSILON symmetry test). */
+int sdx_convolve1d_reflect_dev(sdx_ctx* ctx, int64_t n, const double* in, int m, const double* weights, int symmetric,
+                               double* out);
+
 /* Everything in one call for resident data: pre-pass + line opacity + total (above) + raytrace (F_nu
  * overwritten).  alpha_line_out is optional; total_alphas and F_nu are [n_depth][ld].  This is the step
  * bench.py times; it skips the intermediate line-opacity plane when the line list was split over blocks. */

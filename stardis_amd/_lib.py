@@ -91,6 +91,7 @@ PROTOTYPES = {
     "sdx_raytrace_dev": (_int, [_vp, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _int]),
     "sdx_raytrace_f64": (_int, [_vp, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sdx_total_alphas_dev": (_int, [_vp, _int, _i64, _vp, _i64, _i64, C.POINTER(Continuum), _vp, _i64, _vp, _i64]),
+    "sdx_convolve1d_reflect_dev": (_int, [_vp, _i64, _vp, _int, _vp, _int, _vp]),
     "sdx_synthesize_dev": (_int, [_vp, _int, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _int, _vp, C.POINTER(Continuum), _int,
                                   _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
 }

@@ -1024,4 +1024,34 @@ __global__ __launch_bounds__(kBlock) void k_raytrace(int n_depth, int64_t n_nu, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// scipy.ndimage.convolve1d(in, w) with the default mode='reflect' (d c b a | a b c d | d c b a), odd kernel, origin 0:
+// what rotation_broadening applies to the spectrum (broadening.py:869-871).  scipy's summation order is kept:
+// for a symmetric kernel  out = in[0] w[c], then pairs (in[-j] + in[+j]) w[c-j] from the OUTERMOST inwards;
+// otherwise the last tap first, then the ascending-offset sum with the reversed kernel.
+__device__ __forceinline__ int64_t reflect_index(int64_t i, int64_t n)
+{
+    const int64_t p = 2 * n;
+    i %= p;
+    if (i < 0) i += p;
+    return i >= n ? p - 1 - i : i;
+}
+__global__ __launch_bounds__(kBlock) void k_convolve1d_reflect(int64_t n, const double* __restrict__ in, int m,
+                                                               const double* __restrict__ w, int symmetric,
+                                                               double* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int h = m / 2;
+    double acc;
+    if (symmetric) {
+        acc = mul_rn(in[i], w[h]);
+        for (int j = h; j >= 1; --j) acc = add_rn(acc, mul_rn(add_rn(in[reflect_index(i - j, n)], in[reflect_index(i + j, n)]), w[h - j]));
+    } else {
+        acc = mul_rn(in[reflect_index(i + h, n)], w[0]);  // scipy starts from the last tap, then ascends
+        for (int jj = -h; jj < h; ++jj) acc = add_rn(acc, mul_rn(in[reflect_index(i + jj, n)], w[h - jj]));
+    }
+    out[i] = acc;
+}
+
 }  // namespace sdx

@@ -242,9 +242,11 @@ __device__ __forceinline__ double voigt_term(double delta_nu, double inv_dw, dou
 __device__ __forceinline__ void rt_weights(double tau, double& w0, double& w1, double& w2)
 {
     if (tau < 5e-4) {
-        w0 = mul_rn(tau, sub_rn(1.0, tau / 2));
-        w1 = mul_rn(mul_rn(tau, tau), sub_rn(0.5, tau / 3));
-        w2 = mul_rn(mul_rn(mul_rn(tau, tau), tau), sub_rn(1.0 / 3, tau / 4));
+        // tau/2 and tau/4 are exact scalings; tau/3 is a multiplication by the rounded 1/3 (|tau/3| < 2e-4 next to
+        // 0.5: the last-place difference from a true division is below 1e-20 relative in w1)
+        w0 = mul_rn(tau, sub_rn(1.0, mul_rn(tau, 0.5)));
+        w1 = mul_rn(mul_rn(tau, tau), sub_rn(0.5, mul_rn(tau, 1.0 / 3)));
+        w2 = mul_rn(mul_rn(mul_rn(tau, tau), tau), sub_rn(1.0 / 3, mul_rn(tau, 0.25)));
     } else if (tau < 50) {
         const double e = exp(-tau);
         w0 = sub_rn(1.0, e);

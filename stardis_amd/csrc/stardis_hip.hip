@@ -1004,6 +1004,19 @@ int sdx_raytrace_f64(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, const
     return SDX_OK;
 }
 
+// ================================================================================================ post-processing
+int sdx_convolve1d_reflect_dev(sdx_ctx* ctx, int64_t n, const double* in, int m, const double* weights, int symmetric, double* out)
+{
+    REQUIRE(ctx && n >= 0 && m > 0 && (m & 1), "convolve1d: need an odd kernel length");
+    if (n == 0) return SDX_OK;
+    REQUIRE(in && weights && out && in != out, "convolve1d: null or aliased pointer");
+    {
+        LaunchScope ls(ctx, "k_convolve1d_reflect");
+        hipLaunchKernelGGL(k_convolve1d_reflect, dim3(blocks1(n)), dim3(kBlock), 0, ctx->stream, n, in, m, weights, symmetric, out);
+    }
+    return check_launch("k_convolve1d_reflect");
+}
+
 // ================================================================================================ fused synthesis
 int sdx_synthesize_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin, int64_t nu_count,
                        int64_t n_lines, const double* line_nus, const double* doppler, const double* gammas, int gamma_cols,

@@ -210,3 +210,27 @@ def test_raytrace_many_angles_chunks(ctx):
     F, _ = ops.raytrace_arrays(nus, g["temperatures"], rd, w, a)
     ref, _ = oracle.raytrace(nus, g["temperatures"], g["dist"], th, w, a)
     assert rel_err(F, ref) < FLUX_RTOL
+
+
+# ------------------------------------------------------------------------------------------------ post-processing
+def test_rotation_broadening_golden(ctx):
+    """reference rotation_broadening (broadening.py:824-877) incl. scipy's reflect boundary and summation order"""
+    from stardis_amd.radiation_field.opacities.opacities_solvers.broadening import rotation_broadening
+
+    g = load_golden("g8_rotation")
+    vpp, lam, flux = float(g["velocity_per_pix"]), g["wavelength"], g["flux"]
+    w0, f0 = rotation_broadening(vpp, lam, flux, 0.0)
+    assert f0 is flux and w0 is lam  # identity below 1e-5 km/s (:866-867)
+    for v, ld, key in ((20.0, 0.6, "flux_v20"), (500.0, 0.6, "flux_v500"), (35.0, 0.3, "flux_v35_ld0p3")):
+        _, out = rotation_broadening(vpp, lam, flux, v, ld)
+        assert np.array_equal(out, g[key]), key
+        assert rel_err(out, oracle.rotation_broadening(flux, vpp, v, ld)) < 1e-15
+    # non-symmetric kernel takes the general path: compare with scipy directly
+    from scipy.ndimage import convolve1d
+
+    from stardis_amd.postprocess import convolve1d_reflect
+
+    k = np.array([0.1, 0.5, 0.2, 0.15, 0.05])
+    assert np.array_equal(convolve1d_reflect(flux, k), convolve1d(flux, k))
+    short = flux[:3]
+    assert np.array_equal(convolve1d_reflect(short, np.ones(9) / 9), convolve1d(short, np.ones(9) / 9))  # kernel longer than the data

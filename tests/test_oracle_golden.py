@@ -155,6 +155,8 @@ def test_rotation_broadening_golden():
     g = load_golden("g8_rotation")
     vpp = float(g["velocity_per_pix"])
     assert np.array_equal(oracle.rotation_broadening(g["flux"], vpp, 0.0), g["flux_v0"])
-    assert rel_err(oracle.rotation_broadening(g["flux"], vpp, 20.0), g["flux_v20"]) < 1e-14
-    assert rel_err(oracle.rotation_broadening(g["flux"], vpp, 500.0), g["flux_v500"]) < 1e-14
-    assert rel_err(oracle.rotation_broadening(g["flux"], vpp, 35.0, 0.3), g["flux_v35_ld0p3"]) < 1e-14
+    # scipy's symmetric-kernel summation order restated: bit-exact (the kernel itself may differ in the last place
+    # where libm pow and numpy's differ, hence the 1e-15 allowance)
+    assert rel_err(oracle.rotation_broadening(g["flux"], vpp, 20.0), g["flux_v20"]) < 1e-15
+    assert rel_err(oracle.rotation_broadening(g["flux"], vpp, 500.0), g["flux_v500"]) < 1e-15
+    assert rel_err(oracle.rotation_broadening(g["flux"], vpp, 35.0, 0.3), g["flux_v35_ld0p3"]) < 1e-15
