@@ -171,6 +171,13 @@ int sdx_raytrace_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, const
                      const double* temperature, const double* ray_dist, const double* theta_weights,
                      const double* total_alphas, int64_t alpha_ld, double* F_nu, int64_t F_ld, double* I_nus,
                      int accumulate);
+/* raytrace :271-346, spherical branch: ray_dist from calculate_spherical_ray (:349-381, zeros where a ray misses a
+ * shell), the inward sweep of single_theta_trace_parallel (:141-198) before the outward one, and finally
+ * F_nu *= photospheric_correction = (r[-1] / reference_r)**2 (:340-344). */
+int sdx_raytrace_spherical_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, const double* nus,
+                               const double* temperature, const double* ray_dist, const double* theta_weights,
+                               const double* total_alphas, int64_t alpha_ld, double* F_nu, int64_t F_ld, double* I_nus,
+                               int accumulate, double photospheric_correction);
 int sdx_raytrace_f64(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, const double* nus,
                      const double* temperature, const double* ray_dist, const double* theta_weights,
                      const double* total_alphas, double* F_nu, double* I_nus);

@@ -141,35 +141,54 @@ def calc_weights_parallel(delta_tau):
     return w0, w1, w2
 
 
-def single_theta_trace_parallel(ray_dist, temps, alphas, tracing_nus):
-    """radiation_field_solvers/base.py:85-268 (outward pass)"""
+def single_theta_trace_parallel(ray_dist, temps, alphas, tracing_nus, inward_rays=False):
+    """radiation_field_solvers/base.py:85-268"""
     rd, prd = _d(ray_dist)
     t, pt = _d(np.asarray(temps).reshape(-1))
     a, pa = _d(alphas)
     nus, pn = _d(tracing_nus)
     out = np.empty((t.size, nus.size))
-    rc = lib().orc_single_theta_trace(C.c_int(t.size), C.c_int64(nus.size), prd, pt, pa, pn, out.ctypes.data_as(_dp))
+    rc = lib().orc_single_theta_trace(C.c_int(t.size), C.c_int64(nus.size), prd, pt, pa, pn, out.ctypes.data_as(_dp), C.c_int(int(inward_rays)))
     if rc:
         raise MemoryError
     return out
 
 
-def raytrace(tracing_nus, temps, dist, thetas, weights, total_alphas, F_nu=None, track=False):
-    """radiation_field_solvers/base.py:271-346 (plane-parallel); returns (F_nu, I_nus or None)"""
+def calculate_spherical_ray(thetas, radii):
+    """radiation_field_solvers/base.py:349-381"""
+    thetas = np.asarray(thetas, dtype=np.float64)
+    r = np.asarray(radii, dtype=np.float64)
+    out = np.zeros((len(r) - 1, len(thetas)))
+    for k, theta in enumerate(thetas):
+        b = r[-1] * np.sin(theta)
+        with np.errstate(invalid="ignore"):
+            dz = np.diff(np.sqrt(r**2 - b**2))
+        out[~np.isnan(dz), k] = dz[~np.isnan(dz)]
+    return out
+
+
+def raytrace(tracing_nus, temps, dist, thetas, weights, total_alphas, F_nu=None, track=False, spherical_r=None, reference_r=None):
+    """radiation_field_solvers/base.py:271-346; plane-parallel from `dist`, or spherical when spherical_r (radii) and
+    reference_r are given (:296-300, :340-344).  Returns (F_nu, I_nus or None)"""
     nus, pn = _d(tracing_nus)
     t, pt = _d(np.asarray(temps).reshape(-1))
     th = np.asarray(thetas, dtype=np.float64)
-    rdist, prd = _d(np.asarray(dist, dtype=np.float64).reshape(-1, 1) / np.cos(th))
+    if spherical_r is not None:
+        rdist, prd = _d(calculate_spherical_ray(th, spherical_r))
+    else:
+        rdist, prd = _d(np.asarray(dist, dtype=np.float64).reshape(-1, 1) / np.cos(th))
     w, pw = _d(weights)
     a, pa = _d(total_alphas)
     F = np.zeros((t.size, nus.size)) if F_nu is None else F_nu
     I_nus = np.zeros((t.size, nus.size, th.size)) if track else None
     rc = lib().orc_raytrace(
         C.c_int(t.size), C.c_int64(nus.size), C.c_int(th.size), pn, pt, prd, pw, pa, F.ctypes.data_as(_dp),
-        I_nus.ctypes.data_as(_dp) if track else None,
+        I_nus.ctypes.data_as(_dp) if track else None, C.c_int(1 if spherical_r is not None else 0),
     )
     if rc:
         raise MemoryError
+    if spherical_r is not None:
+        F *= (np.asarray(spherical_r, dtype=np.float64)[-1] / reference_r) ** 2  # :340-344
     return F, I_nus
 
 

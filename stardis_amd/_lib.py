@@ -89,6 +89,7 @@ PROTOTYPES = {
     "sdx_blackbody_dev": (_int, [_vp, _int, _i64, _vp, _vp, _vp, _i64]),
     "sdx_calc_weights_dev": (_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "sdx_raytrace_dev": (_int, [_vp, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _int]),
+    "sdx_raytrace_spherical_dev": (_int, [_vp, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _int, C.c_double]),
     "sdx_raytrace_f64": (_int, [_vp, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sdx_total_alphas_dev": (_int, [_vp, _int, _i64, _vp, _i64, _i64, C.POINTER(Continuum), _vp, _i64, _vp, _i64]),
     "sdx_convolve1d_reflect_dev": (_int, [_vp, _i64, _vp, _int, _vp, _int, _vp]),

@@ -720,6 +720,13 @@ __global__ __launch_bounds__(kBlock) void k_scale_rows(int n_depth, int64_t n_nu
     if (i < n_nu) out[(size_t)d * ld + i] = mul_rn(src[(size_t)d * src_ld + i], density[d]);
 }
 
+__global__ __launch_bounds__(kBlock) void k_scale(int n_depth, int64_t n_nu, double* __restrict__ a, int64_t ld, double factor)
+{  // F_nu *= (r[-1] / reference_r)**2, radiation_field_solvers/base.py:340-344
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int d = blockIdx.y;
+    if (i < n_nu) a[(size_t)d * ld + i] = mul_rn(a[(size_t)d * ld + i], factor);
+}
+
 __global__ __launch_bounds__(kBlock) void k_accumulate(int n_depth, int64_t n_nu, double* __restrict__ total, int64_t tld,
                                                        const double* __restrict__ src, int64_t sld)
 {
@@ -901,17 +908,30 @@ __device__ __forceinline__ double recip_guarded(double d)
     return (d > 1e-290 && d < 1e290) ? recip(d) : 1.0 / d;
 }
 
+// One short-characteristic step (:208-249 outward, :150-198 inward): from a point with intensity `inten` and source
+// s0 across a gap of optical depth t0 (reciprocal r0) to the point with source s1; (t1, r1, s2) are the gap and point
+// beyond, which enter the second-order terms.
+__device__ __forceinline__ double rt_step(double inten, double t0, double r0, double t1, double r1, double s0, double s1, double s2)
+{
+    double w0, w1, w2;
+    rt_weights(t0, w0, w1, w2);
+    const double head = fma(w0, s1, (1.0 - w0) * inten);
+    const double bb = (s0 - s1) * r0, aa = (s2 - s1) * r1;
+    const double rs = recip_guarded(t0 + t1);
+    return (head + w1 * (bb * t1 - aa * t0) * rs) + w2 * (aa + bb) * rs;
+}
+
 template <int P>
 __global__ __launch_bounds__(kBlock) void k_raytrace(int n_depth, int64_t n_nu, int n_theta, int theta_stride, int G,
                                                      const double* __restrict__ nus, const double* __restrict__ temps,
                                                      const double* __restrict__ ray_dist, const double* __restrict__ wts,
                                                      const double* __restrict__ alphas, int64_t ald, double* __restrict__ F,
-                                                     int64_t fld, double* __restrict__ I_nus, int accumulate)
+                                                     int64_t fld, double* __restrict__ I_nus, int accumulate, int inward, int gpw)
 {
     constexpr int kBatch = P == 1 ? 8 : (P == 2 ? 4 : 2);
     extern __shared__ double smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int gpw = 64 / G;
+    // gpw = groups (frequencies) per wave, <= 64 / G; the host lowers it when the LDS columns would not fit
     const int grp = lane / G, g = lane - grp * G;
     const int TH = P * G;  // theta slots per group, ascending theta = k*G + g
     const int64_t i0 = ((int64_t)blockIdx.x * (kBlock / 64) + wave) * gpw;  // first frequency of this wave
@@ -955,17 +975,54 @@ __global__ __launch_bounds__(kBlock) void k_raytrace(int n_depth, int64_t n_nu, 
     const int gi = (active ? grp : 0) * col;  // idle lanes shadow group 0 and never store
     double inten[P], wt[P], tau0[P], r0[P];
     int th[P];
+    bool on[P];
 #pragma unroll
     for (int k = 0; k < P; ++k) {
         th[k] = min(g + k * G, n_theta - 1);
-        const bool on = g + k * G < n_theta;
-        inten[k] = 0.0;  // I[0] = 0 (:134-136)
-        wt[k] = on ? wts[th[k]] : 0.0;
+        on[k] = g + k * G < n_theta;
+        inten[k] = 0.0;  // np.zeros (:134)
+        wt[k] = on[k] ? wts[th[k]] : 0.0;
+    }
+    if (inward) {
+        // spherical geometry: sweep from the surface to the innermost point first (:141-198).  Only I[0] of this
+        // sweep survives (the outward pass overwrites the other rows); gap 0 wraps to the LAST gap / depth exactly
+        // as the reference's negative index does.
+        for (int gap = n_gap - 1; gap >= 0; --gap) {
+            const int gm = gap > 0 ? gap - 1 : n_gap - 1;
+            const int dm = gap > 0 ? gap - 1 : n_depth - 1;
+            const double s0 = sS[gi + gap + 1], s1 = sS[gi + gap], s2 = sS[gi + dm];
+            const double mg = sM[gi + gap], img = sIM[gi + gap], mm = sM[gi + gm], imm = sIM[gi + gm];
+#pragma unroll
+            for (int k = 0; k < P; ++k) {
+                const double tg = mul_rn(mg, sRD[gap * n_theta + th[k]]), tm = mul_rn(mm, sRD[gm * n_theta + th[k]]);
+                if (tg != 0.0 && tm != 0.0)
+                    inten[k] = rt_step(inten[k], tg, img * sIRD[gap * n_theta + th[k]], tm, imm * sIRD[gm * n_theta + th[k]], s0, s1, s2);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            if (valid && I_nus && on[k]) I_nus[(size_t)i * theta_stride + th[k]] = inten[k];
+            if (active) sX[grp * TH + k * G + g] = inten[k] * wt[k];
+        }
+        __syncthreads();
+        if (F && lane < gpw && i0 + lane < n_nu) {
+            double sum = 0.0;
+            for (int t = 0; t < n_theta; ++t) sum = add_rn(sum, sX[lane * TH + t]);
+            double* dst = F + i0 + lane;
+            *dst = accumulate ? add_rn(*dst, sum) : sum;
+        }
+        __syncthreads();
+    } else {
+#pragma unroll
+        for (int k = 0; k < P; ++k)
+            if (valid && I_nus && on[k]) I_nus[(size_t)i * theta_stride + th[k]] = 0.0;
+        if (valid && g == 0 && F && !accumulate) F[i] = 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
         tau0[k] = mul_rn(sM[gi], sRD[th[k]]);
         r0[k] = sIM[gi] * sIRD[th[k]];
-        if (valid && I_nus && on) I_nus[(size_t)i * theta_stride + th[k]] = 0.0;
     }
-    if (valid && g == 0 && F && !accumulate) F[i] = 0.0;
     double s0 = sS[gi], s1 = sS[gi + 1];
 
     for (int gap0 = 0; gap0 < n_gap; gap0 += kBatch) {
@@ -1000,7 +1057,7 @@ __global__ __launch_bounds__(kBlock) void k_raytrace(int n_depth, int64_t n_nu, 
                 inten[k] = inew;
                 tau0[k] = t1;
                 r0[k] = r1;
-                if (valid && I_nus && g + k * G < n_theta) I_nus[((size_t)(gap + 1) * n_nu + i) * theta_stride + th[k]] = inew;
+                if (valid && I_nus && on[k]) I_nus[((size_t)(gap + 1) * n_nu + i) * theta_stride + th[k]] = inew;
                 if (active) sX[(b * gpw + grp) * TH + k * G + g] = inew * wt[k];
             }
             s0 = s1;

@@ -928,9 +928,33 @@ int sdx_calc_weights_dev(sdx_ctx* ctx, int64_t n, const double* tau, double* w0,
     return check_launch("k_weights");
 }
 
+static int raytrace_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, const double* nus, const double* temps,
+                         const double* ray_dist, const double* wts, const double* alphas, int64_t ald, double* F, int64_t fld,
+                         double* I_nus, int accumulate, int inward);
+
 int sdx_raytrace_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, const double* nus, const double* temps,
                      const double* ray_dist, const double* wts, const double* alphas, int64_t ald, double* F, int64_t fld,
                      double* I_nus, int accumulate)
+{
+    return raytrace_impl(ctx, n_depth, n_nu, n_theta, nus, temps, ray_dist, wts, alphas, ald, F, fld, I_nus, accumulate, 0);
+}
+
+int sdx_raytrace_spherical_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, const double* nus, const double* temps,
+                               const double* ray_dist, const double* wts, const double* alphas, int64_t ald, double* F,
+                               int64_t fld, double* I_nus, int accumulate, double photospheric_correction)
+{
+    int rc = raytrace_impl(ctx, n_depth, n_nu, n_theta, nus, temps, ray_dist, wts, alphas, ald, F, fld, I_nus, accumulate, 1);
+    if (rc || !F || n_nu == 0) return rc;
+    {
+        LaunchScope ls(ctx, "k_scale");
+        hipLaunchKernelGGL(k_scale, grid2(n_nu, n_depth), dim3(kBlock), 0, ctx->stream, n_depth, n_nu, F, fld, photospheric_correction);
+    }
+    return check_launch("k_scale");
+}
+
+static int raytrace_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, const double* nus, const double* temps,
+                         const double* ray_dist, const double* wts, const double* alphas, int64_t ald, double* F, int64_t fld,
+                         double* I_nus, int accumulate, int inward)
 {
     REQUIRE(ctx && n_depth >= 2 && n_nu >= 0 && n_theta > 0, "raytrace: need n_depth >= 2, n_theta > 0");
     if (n_nu == 0) return SDX_OK;
@@ -948,12 +972,17 @@ int sdx_raytrace_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, const
             if (v == 1 || v == 2 || v == 4) P = v;
         }
         const int G = (nth + P - 1) / P;
-        const int gpw = 64 / G;
         const int kbatch = P == 1 ? 8 : (P == 2 ? 4 : 2);
+        auto lds_bytes = [&](int groups) {
+            return ((size_t)2 * (n_depth - 1) * nth +
+                    (size_t)(kBlock / 64) * (3 * (size_t)groups * n_depth + std::max((size_t)groups * n_depth, (size_t)kbatch * groups * P * G))) *
+                   sizeof(double);
+        };
+        int gpw = 64 / G;  // frequencies per wave; lowered (idle lanes) until the staged columns fit 64 KB of LDS
+        while (gpw > 1 && lds_bytes(gpw) > 64 * 1024) --gpw;
+        const size_t shmem = lds_bytes(gpw);
         const unsigned blocks = (unsigned)((n_nu + (int64_t)gpw * (kBlock / 64) - 1) / ((int64_t)gpw * (kBlock / 64)));
-        const size_t shmem = ((size_t)2 * (n_depth - 1) * nth +
-                              (size_t)(kBlock / 64) * (3 * (size_t)gpw * n_depth + std::max((size_t)gpw * n_depth, (size_t)kbatch * gpw * P * G))) *
-                             sizeof(double);
+        const unsigned blocks_basic = (unsigned)((n_nu + (int64_t)(64 / G) * (kBlock / 64) - 1) / ((int64_t)(64 / G) * (kBlock / 64)));
         const double* rd = ray_dist + th0;
         const double* w = wts + th0;
         double* inus = I_nus ? I_nus + th0 : nullptr;
@@ -962,13 +991,14 @@ int sdx_raytrace_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, const
             LaunchScope ls(ctx, "k_raytrace");
 #define SDX_RT_ARGS n_depth, n_nu, nth, n_theta, G, nus, temps, rd, w, alphas, ald, F, fld, inus, acc
             if (shmem <= 64 * 1024) {
-                if (P == 1) hipLaunchKernelGGL(k_raytrace<1>, dim3(blocks), dim3(kBlock), shmem, ctx->stream, SDX_RT_ARGS);
-                else if (P == 2) hipLaunchKernelGGL(k_raytrace<2>, dim3(blocks), dim3(kBlock), shmem, ctx->stream, SDX_RT_ARGS);
-                else hipLaunchKernelGGL(k_raytrace<4>, dim3(blocks), dim3(kBlock), shmem, ctx->stream, SDX_RT_ARGS);
+                if (P == 1) hipLaunchKernelGGL(k_raytrace<1>, dim3(blocks), dim3(kBlock), shmem, ctx->stream, SDX_RT_ARGS, inward, gpw);
+                else if (P == 2) hipLaunchKernelGGL(k_raytrace<2>, dim3(blocks), dim3(kBlock), shmem, ctx->stream, SDX_RT_ARGS, inward, gpw);
+                else hipLaunchKernelGGL(k_raytrace<4>, dim3(blocks), dim3(kBlock), shmem, ctx->stream, SDX_RT_ARGS, inward, gpw);
             } else {  // very deep models: the column does not fit LDS, recompute per lane instead
-                if (P == 1) hipLaunchKernelGGL(k_raytrace_basic<1>, dim3(blocks), dim3(kBlock), 0, ctx->stream, SDX_RT_ARGS);
-                else if (P == 2) hipLaunchKernelGGL(k_raytrace_basic<2>, dim3(blocks), dim3(kBlock), 0, ctx->stream, SDX_RT_ARGS);
-                else hipLaunchKernelGGL(k_raytrace_basic<4>, dim3(blocks), dim3(kBlock), 0, ctx->stream, SDX_RT_ARGS);
+                REQUIRE(!inward, "raytrace: spherical geometry needs (3*n_depth*64/n_theta + 2*n_depth*n_theta) doubles of LDS per wave; model too deep");
+                if (P == 1) hipLaunchKernelGGL(k_raytrace_basic<1>, dim3(blocks_basic), dim3(kBlock), 0, ctx->stream, SDX_RT_ARGS);
+                else if (P == 2) hipLaunchKernelGGL(k_raytrace_basic<2>, dim3(blocks_basic), dim3(kBlock), 0, ctx->stream, SDX_RT_ARGS);
+                else hipLaunchKernelGGL(k_raytrace_basic<4>, dim3(blocks_basic), dim3(kBlock), 0, ctx->stream, SDX_RT_ARGS);
             }
 #undef SDX_RT_ARGS
         }

@@ -263,11 +263,13 @@ def calc_weights_parallel(delta_tau, ctx=None):
     return tuple(x.numpy() for x in w)
 
 
-def raytrace_arrays(tracing_nus, temperatures, ray_distances, theta_weights, total_alphas, F_nu=None, track=False, ctx=None):
-    """radiation_field_solvers/base.py:271-346 (plane-parallel) on arrays.
+def raytrace_arrays(tracing_nus, temperatures, ray_distances, theta_weights, total_alphas, F_nu=None, track=False, ctx=None,
+                    inward_rays=False, photospheric_correction=1.0, want_flux=True):
+    """radiation_field_solvers/base.py:271-346 on arrays.
 
-    ray_distances is the (N_d-1, N_theta) table of :302-305.  total_alphas may be a host array or a
-    device array.  Returns (F_nu host array — accumulated into when given —, I_nus or None)."""
+    ray_distances is the (N_d-1, N_theta) table of :302-305 (plane-parallel) or of calculate_spherical_ray
+    (:296-300; pass inward_rays=True and the photospheric correction of :340-344).  total_alphas may be a host
+    array or a device array.  Returns (F_nu host array — accumulated into when given —, I_nus or None)."""
     ctx = ctx or default_context()
     nus = _host(tracing_nus).reshape(-1)
     t = _host(temperatures).reshape(-1)
@@ -276,8 +278,14 @@ def raytrace_arrays(tracing_nus, temperatures, ray_distances, theta_weights, tot
     n_theta = w.size
     d_alpha = _dev(ctx, total_alphas)
     d = [ctx.upload(nus), ctx.upload(t), ctx.upload(rd), ctx.upload(w)]
-    d_F = ctx.zeros((t.size, nus.size)) if F_nu is None else ctx.upload(_host(F_nu))
+    d_F = None
+    if want_flux:
+        d_F = ctx.zeros((t.size, nus.size)) if F_nu is None else ctx.upload(_host(F_nu))
     d_I = ctx.empty((t.size, nus.size, n_theta)) if track else None
-    ctx.call("sdx_raytrace_dev", t.size, nus.size, n_theta, d[0].ptr, d[1].ptr, d[2].ptr, d[3].ptr, ptr_of(d_alpha), nus.size,
-             d_F.ptr, nus.size, ptr_of(d_I), 1)
-    return d_F.numpy(), (d_I.numpy() if track else None)
+    args = (t.size, nus.size, n_theta, d[0].ptr, d[1].ptr, d[2].ptr, d[3].ptr, ptr_of(d_alpha), nus.size, ptr_of(d_F), nus.size,
+            ptr_of(d_I), 1)
+    if inward_rays:
+        ctx.call("sdx_raytrace_spherical_dev", *args, float(photospheric_correction))
+    else:
+        ctx.call("sdx_raytrace_dev", *args)
+    return (d_F.numpy() if want_flux else None), (d_I.numpy() if track else None)

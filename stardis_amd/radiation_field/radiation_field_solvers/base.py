@@ -28,12 +28,11 @@ def _check_source_function(source_function):
 
 def single_theta_trace_parallel(ray_dist_to_next_depth_point, temps, alphas, tracing_nus, source_function=None,
                                 inward_rays=False):
-    """Specific intensity (N_d, N_nu) along one ray direction.  Reference :85-268 (outward pass)."""
-    if inward_rays:
-        raise NotImplementedError("spherical inward sweep (:141-198) is not built yet (SURVEY §8 f4)")
+    """Specific intensity (N_d, N_nu) along one ray direction.  Reference :85-268; inward_rays adds the
+    surface-to-centre sweep of spherical geometry (:141-198) before the outward pass."""
     _check_source_function(source_function)
     rd = np.asarray(plain(ray_dist_to_next_depth_point), dtype=np.float64).reshape(-1, 1)
-    _, I = ops.raytrace_arrays(tracing_nus, temps, rd, np.ones(1), alphas, track=True)
+    _, I = ops.raytrace_arrays(tracing_nus, temps, rd, np.ones(1), alphas, track=True, inward_rays=bool(inward_rays), want_flux=False)
     return I[:, :, 0]
 
 
@@ -57,19 +56,23 @@ def raytrace(stellar_model, stellar_radiation_field):
     """Trace every angle and accumulate the Gauss-Legendre flux sum into stellar_radiation_field.F_nu
     (in place, like the reference :324-338).  Fills I_nus when track_individual_intensities is set."""
     field = stellar_radiation_field
-    if stellar_model.spherical:
-        raise NotImplementedError("spherical geometry (:296-300, :340-344) is not built yet (SURVEY §8 f4)")
     _check_source_function(getattr(field, "source_function", None))
     thetas = np.asarray(field.thetas, dtype=np.float64)
-    dist = np.asarray(plain(stellar_model.geometry.dist_to_next_depth_point), dtype=np.float64)
-    ray_distances = dist.reshape(-1, 1) / np.cos(thetas)  # :302-305
+    correction = 1.0
+    if stellar_model.spherical:  # :296-300, :340-344
+        radii = np.asarray(plain(stellar_model.geometry.r), dtype=np.float64)
+        ray_distances = calculate_spherical_ray(thetas, radii)
+        correction = (radii[-1] / float(plain(stellar_model.geometry.reference_r))) ** 2
+    else:
+        dist = np.asarray(plain(stellar_model.geometry.dist_to_next_depth_point), dtype=np.float64)
+        ray_distances = dist.reshape(-1, 1) / np.cos(thetas)  # :302-305
     ctx = default_context()
     opac = field.opacities
     alphas = opac.total_alphas_device(ctx) if hasattr(opac, "total_alphas_device") else opac.total_alphas
     track = bool(getattr(field, "track_individual_intensities", False))
     F, I = ops.raytrace_arrays(
         field.frequencies, plain(stellar_model.temperatures), ray_distances, field.I_nus_weights, alphas, F_nu=field.F_nu,
-        track=track, ctx=ctx,
+        track=track, ctx=ctx, inward_rays=bool(stellar_model.spherical), photospheric_correction=correction,
     )
     field.F_nu[...] = F
     if track:

@@ -614,6 +614,49 @@ def g9_end_to_end(rng, atm, cont):
         save("g9_end_to_end_" + tag, **st, **out)
 
 
+# ----------------------------------------------------------------------------- G10 spherical geometry
+def g10_spherical(atm):
+    """raytrace with stellar_model.spherical = True (radiation_field_solvers/base.py:296-300, :141-198, :340-344)
+    on an extended atmosphere (inner radius 56 % of the outer one, so many rays miss the deep shells)."""
+    g7 = np.load(os.path.join(HERE, "g7_raytrace.npz"))
+    nus = g7["nus"][::4].copy()
+    total = np.ascontiguousarray(g7["total_alphas"][:, ::4])
+    total[:, 1] = 0.0  # a transparent column
+    r = atm["r"] + 1.2e8
+    reference_r = 1.5e8
+    n_theta = 8
+    th, w = np.polynomial.legendre.leggauss(n_theta)
+    thetas = th / 2 + 0.5 * np.pi / 2
+    model = NS(
+        temperatures=atm["temperatures"] * u.K,
+        no_of_depth_points=len(r),
+        spherical=True,
+        geometry=NS(r=r, reference_r=reference_r, dist_to_next_depth_point=atm["dist"]),
+    )
+    field = NS(
+        thetas=thetas,
+        I_nus_weights=w * np.pi / 2,
+        frequencies=nus * u.Hz,
+        source_function=R.bb.blackbody_flux_at_nu,
+        track_individual_intensities=True,
+        F_nu=np.zeros((len(r), len(nus))),
+        I_nus=np.zeros((len(r), len(nus), n_theta)),
+        opacities=NS(total_alphas=total),
+    )
+    rays = R.rt.calculate_spherical_ray(thetas, r)
+    with np.errstate(all="ignore"):
+        R.rt.raytrace(model, field)
+        one = R.rt.single_theta_trace_parallel(
+            rays[:, 5].copy(), atm["temperatures"].reshape(-1, 1), total, nus, R.bb.blackbody_flux_at_nu, inward_rays=True
+        )
+    save(
+        "g10_spherical",
+        nus=nus, total_alphas=total, temperatures=atm["temperatures"], r=r, reference_r=np.float64(reference_r),
+        thetas=thetas, weights=field.I_nus_weights, ray_distances=rays, F_nu=field.F_nu, I_nus=field.I_nus,
+        I_single_inward_theta5=one,
+    )
+
+
 def main():
     rng = np.random.default_rng(20250926)
     capture_data()
@@ -622,7 +665,7 @@ def main():
 
     atm = atmosphere()
     cont = synth.synth_continuum_state(atm)
-    which = set(sys.argv[1:]) or {"g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"}
+    which = set(sys.argv[1:]) or {"g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"}
     if "g1" in which:
         g1_faddeeva(rng)
     if "g2" in which:
@@ -641,6 +684,8 @@ def main():
         g8_rotation(rng)
     if "g9" in which:
         g9_end_to_end(rng, atm, cont)
+    if "g10" in which:
+        g10_spherical(atm)
 
 
 if __name__ == "__main__":

@@ -234,3 +234,36 @@ def test_rotation_broadening_golden(ctx):
     assert np.array_equal(convolve1d_reflect(flux, k), convolve1d(flux, k))
     short = flux[:3]
     assert np.array_equal(convolve1d_reflect(short, np.ones(9) / 9), convolve1d(short, np.ones(9) / 9))  # kernel longer than the data
+
+
+# ------------------------------------------------------------------------------------------------ spherical geometry
+def test_spherical_raytrace_golden(ctx):
+    """raytrace with spherical=True: chord lengths (:349-381), inward sweep with the reference's index wrap at gap 0
+    (:141-198), outward pass, photospheric correction (:340-344).  Flux to the path tolerance; individual
+    intensities of grazing rays are ill-conditioned in the reference itself (optical depths just above the 5e-4
+    switch of :28,:38 amplify one ulp of exp to ~1e-8, see tests/test_oracle_golden.py), hence 1e-7 there."""
+    import types
+
+    from stardis_amd.radiation_field.radiation_field_solvers.base import calculate_spherical_ray, raytrace, single_theta_trace_parallel
+    from stardis_amd.radiation_field.source_functions.blackbody import blackbody_flux_at_nu
+
+    g = load_golden("g10_spherical")
+    assert np.array_equal(calculate_spherical_ray(g["thetas"], g["r"]), g["ray_distances"])
+    NS = types.SimpleNamespace
+    nd, nn, nt = g["temperatures"].size, g["nus"].size, g["thetas"].size
+    model = NS(spherical=True, temperatures=g["temperatures"], no_of_depth_points=nd,
+               geometry=NS(r=g["r"], reference_r=float(g["reference_r"]), dist_to_next_depth_point=np.diff(g["r"])))
+    field = NS(thetas=g["thetas"], I_nus_weights=g["weights"], frequencies=g["nus"], source_function=blackbody_flux_at_nu,
+               track_individual_intensities=True, F_nu=np.zeros((nd, nn)), I_nus=np.zeros((nd, nn, nt)),
+               opacities=NS(total_alphas=g["total_alphas"]))
+    F = raytrace(model, field)
+    assert rel_err(F, g["F_nu"]) < FLUX_RTOL
+    assert rel_err(field.I_nus, g["I_nus"]) < 1e-7
+    with np.errstate(all="ignore"):
+        F_o, I_o = oracle.raytrace(g["nus"], g["temperatures"], None, g["thetas"], g["weights"], g["total_alphas"], track=True,
+                                   spherical_r=g["r"], reference_r=float(g["reference_r"]))
+    assert rel_err(F, F_o) < FLUX_RTOL
+    assert rel_err(field.I_nus, I_o) < 1e-7
+    one = single_theta_trace_parallel(g["ray_distances"][:, 5].copy(), g["temperatures"].reshape(-1, 1), g["total_alphas"], g["nus"],
+                                      blackbody_flux_at_nu, inward_rays=True)
+    assert rel_err(one, g["I_single_inward_theta5"]) < 1e-7

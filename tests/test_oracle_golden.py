@@ -160,3 +160,18 @@ def test_rotation_broadening_golden():
     assert rel_err(oracle.rotation_broadening(g["flux"], vpp, 20.0), g["flux_v20"]) < 1e-15
     assert rel_err(oracle.rotation_broadening(g["flux"], vpp, 500.0), g["flux_v500"]) < 1e-15
     assert rel_err(oracle.rotation_broadening(g["flux"], vpp, 35.0, 0.3), g["flux_v35_ld0p3"]) < 1e-15
+
+
+def test_spherical_raytrace_golden():
+    """Spherical branch incl. the inward sweep's index wrap at gap 0.  Fluxes to the path tolerance; single-ray
+    intensities only to 1e-7: grazing rays have optical depths just above the 5e-4 switch where the reference's
+    w1, w2 lose up to six digits to one ulp of exp (numpy's vs libm's)."""
+    g = load_golden("g10_spherical")
+    assert np.array_equal(oracle.calculate_spherical_ray(g["thetas"], g["r"]), g["ray_distances"])
+    with np.errstate(all="ignore"):
+        F, I = oracle.raytrace(g["nus"], g["temperatures"], None, g["thetas"], g["weights"], g["total_alphas"], track=True,
+                               spherical_r=g["r"], reference_r=float(g["reference_r"]))
+        one = oracle.single_theta_trace_parallel(g["ray_distances"][:, 5].copy(), g["temperatures"], g["total_alphas"], g["nus"], inward_rays=True)
+    assert rel_err(F, g["F_nu"]) < 5e-11
+    assert rel_err(I, g["I_nus"]) < 1e-7
+    assert rel_err(one, g["I_single_inward_theta5"]) < 1e-7
