@@ -94,7 +94,10 @@ def main():
     from stardis_amd import _lib, parallel
     from stardis_amd.engine import SpectralSynthesizer, shard_bounds
 
-    rank, world, local = parallel.init_from_env("nccl")
+    # test hooks: SDX_BENCH_BACKEND=gloo and SDX_BENCH_SINGLE_DEVICE=1 let the N > 1 path run on a 1-GPU box
+    rank, world, local = parallel.init_from_env(os.environ.get("SDX_BENCH_BACKEND", "nccl"))
+    if os.environ.get("SDX_BENCH_SINGLE_DEVICE") == "1":
+        local = 0
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local)
@@ -120,11 +123,11 @@ def main():
     if not args.no_graph:
         syn.capture()
 
+    gather = parallel.FluxGatherer(nus.size, world, flux.device)
+
     def step():
         syn.step()
-        if world > 1:
-            return parallel.gather_flux(flux[-1], nus.size, world)
-        return flux[-1]
+        return gather(flux[-1])
 
     def fence():
         torch.cuda.synchronize()
@@ -141,7 +144,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

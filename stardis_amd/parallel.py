@@ -37,20 +37,43 @@ def padded_count(n_nu, world_size):
     return -(-n_nu // world_size)
 
 
-def gather_flux(local_flux, n_nu, world_size):
-    """All-gather per-rank emergent-flux shards (1-D tensors of this rank's `count` columns, on the
-    device the backend wants) into the full (n_nu,) spectrum on every rank."""
-    import torch
-    import torch.distributed as dist
+class FluxGatherer:
+    """Reusable buffers for the per-step all-gather of emergent-flux shards (no allocation inside the timed loop)."""
 
-    per = padded_count(n_nu, world_size)
-    send = torch.zeros(per, dtype=local_flux.dtype, device=local_flux.device)
-    send[: local_flux.numel()] = local_flux
-    if world_size == 1:
-        return send[:n_nu].clone()
-    recv = torch.empty(per * world_size, dtype=local_flux.dtype, device=local_flux.device)
-    dist.all_gather_into_tensor(recv, send)
-    return recv[:n_nu]
+    def __init__(self, n_nu, world_size, device, dtype=None):
+        import torch
+
+        self.n_nu, self.world = n_nu, world_size
+        self.per = padded_count(n_nu, world_size)
+        dtype = dtype or torch.float64
+        self.send = torch.zeros(self.per, dtype=dtype, device=device)
+        self.recv = torch.empty(self.per * world_size, dtype=dtype, device=device)
+        self.host = None
+
+    def __call__(self, local_flux):
+        import torch
+        import torch.distributed as dist
+
+        if self.world == 1:
+            return local_flux
+        src = local_flux
+        if local_flux.numel() != self.per:  # last, shorter shard: pad
+            self.send[: local_flux.numel()] = local_flux
+            src = self.send
+        if dist.get_backend() == "gloo" and src.is_cuda:  # CPU-side collective (tests / no RCCL): stage through the host
+            if self.host is None:
+                self.host = torch.empty(self.per * self.world, dtype=src.dtype)
+            dist.all_gather_into_tensor(self.host, src.cpu())
+            self.recv.copy_(self.host)
+        else:
+            dist.all_gather_into_tensor(self.recv, src)
+        return self.recv[: self.n_nu]
+
+
+def gather_flux(local_flux, n_nu, world_size):
+    """All-gather per-rank emergent-flux shards (1-D tensors of this rank's `count` columns, on the device the
+    backend wants) into the full (n_nu,) spectrum on every rank."""
+    return FluxGatherer(n_nu, world_size, local_flux.device, local_flux.dtype)(local_flux).clone()
 
 
 def assemble_shards(shards, n_nu, world_size):
