@@ -158,7 +158,7 @@ def main():
     kern = {}
     import ctypes as C
 
-    for name in ("k_dnu_partial", "k_line_prepass", "k_line_wide", "k_line_narrow", "k_reduce_partials", "k_total_alphas", "k_raytrace"):
+    for name in ("k_dnu_partial", "k_prepass_continuum", "k_line_prepass", "k_line_all", "k_line_wide", "k_line_narrow", "k_reduce_partials", "k_total_alphas", "k_raytrace"):
         n, ms = C.c_int64(), C.c_double()
         _lib.check(ctx.lib.sdx_profile_get(ctx.handle, name.encode(), C.byref(n), C.byref(ms)))
         if n.value:
@@ -193,6 +193,7 @@ def main():
         dom = max(kern, key=kern.get)
         alg_bytes = {
             # SURVEY §8d per-stage figures, for the columns this rank produced
+            "k_line_all": 8 * (n_l * (1 + 2 * nd + g_cols) + nus.size + nd * count),
             "k_line_wide": 8 * (n_l * (1 + 2 * nd + g_cols) + nus.size + nd * count),
             "k_raytrace": 16 * nd * count,
         }.get(dom, syn.algorithmic_bytes())
@@ -228,11 +229,11 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": None,
+                "traffic": profiled_traffic(dom) if (world == 1 and args.workload == "S-c2") else None,
                 "algorithmic_bytes_per_launch": int(alg_bytes),
                 "avg_kernel_ms": kern,
                 "note": "path is fp64-VALU bound (Faddeeva evaluations), not HBM bound: see DESIGN.md; evaluations/s below",
-                "voigt_evaluations_per_s": (evals / world) / ((kern.get("k_line_wide", 0.0) + kern.get("k_line_narrow", 0.0)) * 1e-3),
+                "voigt_evaluations_per_s": (evals / world) / ((kern.get("k_line_all", 0.0) + kern.get("k_line_wide", 0.0) + kern.get("k_line_narrow", 0.0)) * 1e-3),
             },
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -250,6 +251,24 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def profiled_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/, S-c2, separate FETCH_SIZE
+    and WRITE_SIZE runs).  Raw counters: these kernels issue 8-byte-per-lane accesses, for which the gfx950
+    16-byte-stream correction does not apply (profiles/README.md).  None when the files are absent."""
+    import csv
+
+    total = 0.0
+    for name in ("FETCH_SIZE", "WRITE_SIZE"):
+        path = os.path.join(ROOT, "profiles", f"r01_S-c2_pmc_{name}.csv")
+        if not os.path.exists(path):
+            return None
+        vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if kernel in r["Kernel_Name"] and r["Counter_Name"] == name]
+        if not vals:
+            return None
+        total += sum(vals) / len(vals) * 1024.0
+    return total
 
 
 def synth_desc(tag):

@@ -109,7 +109,7 @@ struct LineWork {
     unsigned long long* evals;
 };
 
-__global__ __launch_bounds__(kBlock) void k_line_prepass(int n_depth, int64_t n_nu, const double* __restrict__ nus,
+__device__ __forceinline__ void prepass_block(const int bx, const int by, const int gy, int n_depth, int64_t n_nu, const double* __restrict__ nus,
                                                          const double* __restrict__ dnu_partial, int n_partial,
                                                          int64_t n_lines, const double* __restrict__ line_nus,
                                                          const double* __restrict__ doppler,
@@ -118,10 +118,10 @@ __global__ __launch_bounds__(kBlock) void k_line_prepass(int n_depth, int64_t n_
                                                          int* __restrict__ out_lo_ref, int* __restrict__ out_hi_ref,
                                                          int n_line_blocks)
 {
-    if ((int)blockIdx.x >= n_line_blocks) {
+    if (bx >= n_line_blocks) {
         // trailing blocks: cnt_ge[p] = #{l : centre_l >= p} = #{l : line_nu_l <= nus[p-1]}  (centre_l = #{i : nus[i] >= line_nu_l})
-        if (blockIdx.y == 0 && w.cnt_ge) {
-            const int64_t pidx = (int64_t)(blockIdx.x - n_line_blocks) * kBlock + threadIdx.x;
+        if (by == 0 && w.cnt_ge) {
+            const int64_t pidx = (int64_t)(bx - n_line_blocks) * kBlock + threadIdx.x;
             if (pidx <= n_nu + 1) {
                 int64_t cnt;
                 if (pidx == 0) cnt = n_lines;
@@ -146,8 +146,8 @@ __global__ __launch_bounds__(kBlock) void k_line_prepass(int n_depth, int64_t n_
     __shared__ double s_red[kBlock / 64];
     __shared__ unsigned long long s_ev[kBlock / 64];
 
-    const int64_t l0 = (int64_t)blockIdx.x * kPreLines;
-    const int d0 = blockIdx.y * kPreDepths;
+    const int64_t l0 = (int64_t)bx * kPreLines;
+    const int d0 = by * kPreDepths;
     const int nl = (int)min((int64_t)kPreLines, n_lines - l0);
     const int nd = min(kPreDepths, n_depth - d0);
     // line centres first (a chain of dependent loads) so they overlap the grid scan of the other threads
@@ -202,9 +202,9 @@ __global__ __launch_bounds__(kBlock) void k_line_prepass(int n_depth, int64_t n_
         }
         __syncthreads();
         if (threadIdx.x < nl) {
-            if (gridDim.y == 1) w.nhw_max[l0 + threadIdx.x] = s_hwmax[threadIdx.x];
+            if (gy == 1) w.nhw_max[l0 + threadIdx.x] = s_hwmax[threadIdx.x];
             else atomicMax(&w.nhw_max[l0 + threadIdx.x], s_hwmax[threadIdx.x]);  // deep models: zeroed by the host first
-            if (blockIdx.y == 0) w.centre[l0 + threadIdx.x] = (int)s_c[threadIdx.x];
+            if (by == 0) w.centre[l0 + threadIdx.x] = (int)s_c[threadIdx.x];
         }
     }
     // line-major outputs: same items visited with depth fastest so the stores coalesce
@@ -242,6 +242,19 @@ __global__ __launch_bounds__(kBlock) void k_line_prepass(int n_depth, int64_t n_
     }
 }
 
+__global__ __launch_bounds__(kBlock) void k_line_prepass(int n_depth, int64_t n_nu, const double* __restrict__ nus,
+                                                         const double* __restrict__ dnu_partial, int n_partial,
+                                                         int64_t n_lines, const double* __restrict__ line_nus,
+                                                         const double* __restrict__ doppler,
+                                                         const double* __restrict__ gammas, int gamma_cols,
+                                                         const double* __restrict__ alphas, LineWork w,
+                                                         int* __restrict__ out_lo_ref, int* __restrict__ out_hi_ref,
+                                                         int n_line_blocks)
+{
+    prepass_block(blockIdx.x, blockIdx.y, gridDim.y, n_depth, n_nu, nus, dnu_partial, n_partial, n_lines, line_nus, doppler, gammas,
+                  gamma_cols, alphas, w, out_lo_ref, out_hi_ref, n_line_blocks);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Line opacity, wide windows, gather form.  One single-wave block owns (depth d, a tile of 64*R grid points, one
 // of S line subsets); lane k owns grid points t0 + k + 64 r (r < R) and accumulates in registers.  The block
@@ -251,7 +264,7 @@ __global__ __launch_bounds__(kBlock) void k_line_prepass(int n_depth, int64_t n_
 // shortens the serial chain of the deepest (hottest) layers, whose windows are widest; the S partial planes are
 // added in subset order by the consumer (k_reduce_partials / k_total_alphas).  No atomics: bit-stable results.
 template <int R>
-__global__ __launch_bounds__(64, 4) void k_line_wide(int64_t n_nu, const double* __restrict__ nus, int64_t nu_begin,
+__device__ __forceinline__ void line_wide_block(const int tile_idx, const int split, const int n_split, const int d, int64_t n_nu, const double* __restrict__ nus, int64_t nu_begin,
                                                   int64_t nu_count, int64_t n_lines, const double* __restrict__ line_nus,
                                                   LineWork w, double* __restrict__ partial, int64_t pld, int n_depth)
 {
@@ -261,9 +274,7 @@ __global__ __launch_bounds__(64, 4) void k_line_wide(int64_t n_nu, const double*
 
     // grid = (tiles, subsets, depths): depth is the slowest index so the innermost (hottest, widest-window)
     // layers are dispatched first and the light outer layers fill the tail
-    const int d = blockIdx.z;
-    const int split = blockIdx.y, n_split = gridDim.y;
-    const int64_t t0 = nu_begin + (int64_t)blockIdx.x * kTile;
+    const int64_t t0 = nu_begin + (int64_t)tile_idx * kTile;
     const int64_t t1 = min(t0 + kTile, nu_begin + nu_count);
     const int lane = threadIdx.x;
 
@@ -347,6 +358,17 @@ __global__ __launch_bounds__(64, 4) void k_line_wide(int64_t n_nu, const double*
         if (idx[r] >= 0) partial[((size_t)split * n_depth + d) * pld + (idx[r] - nu_begin)] = acc[r];
 }
 
+template <int R>
+__global__ __launch_bounds__(64, 4) void k_line_wide(int64_t n_nu, const double* __restrict__ nus, int64_t nu_begin,
+                                                     int64_t nu_count, int64_t n_lines, const double* __restrict__ line_nus,
+                                                     LineWork w, double* __restrict__ partial, int64_t pld, int n_depth)
+{
+    // grid = (tiles, subsets, depths): depth is the slowest index so the innermost (hottest, widest-window)
+    // layers are dispatched first and the light outer layers fill the tail
+    line_wide_block<R>(blockIdx.x, blockIdx.y, gridDim.y, blockIdx.z, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, partial, pld,
+                       n_depth);
+}
+
 // Narrow windows (half-width <= kNarrowHalfWidth, e.g. the reference's 10-pixel floor for weak lines, :565-567):
 // a 256-point tile would be almost empty for them.  Here a wave owns ONE frequency and its lanes are the depth
 // points (lane <-> depth, line-major parameter arrays so the loads coalesce): a weak line covers either all
@@ -354,15 +376,14 @@ __global__ __launch_bounds__(64, 4) void k_line_wide(int64_t n_nu, const double*
 // width, so the Faddeeva region rarely diverges inside a wave.  The candidate lines of a frequency are the
 // contiguous index range whose centre lies within kNarrowHalfWidth of it, read from cnt_ge; each lane walks that
 // range in ascending line order, tests its own window and accumulates in a register.  Deterministic, no atomics.
-__global__ __launch_bounds__(kBlock) void k_line_narrow(int n_depth, int64_t n_nu, const double* __restrict__ nus,
+__device__ __forceinline__ void line_narrow_wave(const int64_t i, const int depth_chunk, int n_depth, int64_t n_nu, const double* __restrict__ nus,
                                                         int64_t nu_begin, int64_t nu_count, int64_t n_lines,
                                                         const double* __restrict__ line_nus, LineWork w,
                                                         double* __restrict__ plane, int64_t pld)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t i = nu_begin + (int64_t)blockIdx.x * (kBlock / 64) + wave;  // wave-uniform
+    const int lane = threadIdx.x & 63;
     if (i >= nu_begin + nu_count) return;
-    const int d = blockIdx.y * 64 + lane;
+    const int d = depth_chunk * 64 + lane;
     const bool valid = d < n_depth;
     const int dc = valid ? d : n_depth - 1;
     const int ii = (int)i;
@@ -397,6 +418,34 @@ __global__ __launch_bounds__(kBlock) void k_line_narrow(int n_depth, int64_t n_n
         }
     }
     if (valid) plane[(size_t)d * pld + (i - nu_begin)] = acc;
+}
+
+__global__ __launch_bounds__(64) void k_line_narrow(int n_depth, int64_t n_nu, const double* __restrict__ nus, int64_t nu_begin,
+                                                    int64_t nu_count, int64_t n_lines, const double* __restrict__ line_nus,
+                                                    LineWork w, double* __restrict__ plane, int64_t pld)
+{
+    line_narrow_wave(nu_begin + blockIdx.x, blockIdx.y, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, plane, pld);
+}
+
+// Both line kernels in ONE launch: blocks [0, n_wide) take the wide role (depth slowest, hottest layers first), the
+// rest the narrow role.  The two only share the pre-pass, and each leaves issue slots idle on its own; a
+// cross-stream fork/join would cost two ~12 us inter-queue edges per step, one grid costs nothing.
+template <int R>
+__global__ __launch_bounds__(64, 4) void k_line_all(int n_wide, int tiles, int n_split, int n_depth, int64_t n_nu,
+                                                    const double* __restrict__ nus, int64_t nu_begin, int64_t nu_count,
+                                                    int64_t n_lines, const double* __restrict__ line_nus, LineWork w,
+                                                    double* __restrict__ partial, int64_t pld)
+{
+    const int b = blockIdx.x;
+    if (b < n_wide) {
+        const int tile = b % tiles, rest = b / tiles;
+        line_wide_block<R>(tile, rest % n_split, n_split, rest / n_split, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, partial,
+                           pld, n_depth);
+    } else {
+        const int64_t c = b - n_wide;
+        line_narrow_wave(nu_begin + c % nu_count, (int)(c / nu_count), n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w,
+                         partial + (size_t)n_split * n_depth * pld, pld);
+    }
 }
 
 // out (+)= sum over the S line subsets, in subset order
@@ -739,15 +788,14 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(int n_depth, int64_t n_nu
 // then Opacities.calc_total_alphas insertion order, opacities/base.py:24-28).  `line` holds n_split partial
 // planes [n_split][n_depth][line_ld] summed here in subset order; line_out (optional) receives that sum.
 // The bound-free per-level coefficients of this block's depth are formed in LDS first (k_bf_coef's formula).
-__global__ __launch_bounds__(kBlock) void k_total_alphas(int n_depth, int64_t nu_begin, int64_t nu_count,
+__device__ __forceinline__ void total_alphas_block(const int bx, const int d, int n_depth, int64_t nu_begin, int64_t nu_count,
                                                          const double* __restrict__ nus, ContinuumArgs a,
                                                          const double* __restrict__ line, int64_t line_ld, int n_split,
                                                          double* __restrict__ line_out, int64_t line_out_ld,
                                                          double* __restrict__ total, int64_t total_ld)
 {
     extern __shared__ double s_coef[];  // [n_levels] for depth d
-    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    const int d = blockIdx.y;
+    const int64_t j = (int64_t)bx * kBlock + threadIdx.x;
     const int n_levels = a.bf_n_species > 0 ? a.bf_species_offsets[a.bf_n_species] : 0;
     for (int L = threadIdx.x; L < n_levels; L += kBlock) {
         int sp = 0;
@@ -784,6 +832,40 @@ __global__ __launch_bounds__(kBlock) void k_total_alphas(int n_depth, int64_t nu
         t = add_rn(t, v);
     }
     total[(size_t)d * total_ld + j] = t;
+}
+
+__global__ __launch_bounds__(kBlock) void k_total_alphas(int n_depth, int64_t nu_begin, int64_t nu_count,
+                                                         const double* __restrict__ nus, ContinuumArgs a,
+                                                         const double* __restrict__ line, int64_t line_ld, int n_split,
+                                                         double* __restrict__ line_out, int64_t line_out_ld,
+                                                         double* __restrict__ total, int64_t total_ld)
+{
+    total_alphas_block(blockIdx.x, blockIdx.y, n_depth, nu_begin, nu_count, nus, a, line, line_ld, n_split, line_out, line_out_ld, total,
+                       total_ld);
+}
+
+// Pre-pass and continuum in ONE launch: the pre-pass is a few latency-bound blocks (binary searches, a grid scan);
+// the continuum plane depends on nothing and fills the rest of the chip meanwhile.
+__global__ __launch_bounds__(kBlock) void k_prepass_continuum(int n_pre_x, int n_pre_y, int cont_tiles, int n_depth, int64_t n_nu,
+                                                              const double* __restrict__ nus,
+                                                              const double* __restrict__ dnu_partial, int n_partial,
+                                                              int64_t n_lines, const double* __restrict__ line_nus,
+                                                              const double* __restrict__ doppler,
+                                                              const double* __restrict__ gammas, int gamma_cols,
+                                                              const double* __restrict__ alphas, LineWork w, int n_line_blocks,
+                                                              int64_t nu_begin, int64_t nu_count, ContinuumArgs ca,
+                                                              double* __restrict__ cont_plane, int64_t cont_ld)
+{
+    const int b = blockIdx.x;
+    const int n_pre = n_pre_x * n_pre_y;
+    if (b < n_pre) {
+        prepass_block(b % n_pre_x, b / n_pre_x, n_pre_y, n_depth, n_nu, nus, dnu_partial, n_partial, n_lines, line_nus, doppler, gammas,
+                      gamma_cols, alphas, w, nullptr, nullptr, n_line_blocks);
+    } else {
+        const int c = b - n_pre;
+        total_alphas_block(c % cont_tiles, c / cont_tiles, n_depth, nu_begin, nu_count, nus, ca, nullptr, 0, 1, nullptr, 0, cont_plane,
+                           cont_ld);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -908,6 +990,19 @@ __device__ __forceinline__ double recip_guarded(double d)
     return (d > 1e-290 && d < 1e290) ? recip(d) : 1.0 / d;
 }
 
+// Optional fusion of Opacities.calc_total_alphas into the raytrace's column staging: total = continuum + line,
+// line = sum of the partial planes in subset order (the same additions k_total_alphas performs).
+struct FusedTotal {
+    const double* cont;    // [n_depth][cld] continuum in calc_alphas order, or nullptr: read `alphas` instead
+    int64_t cld;
+    const double* planes;  // [n_planes][n_depth][pld] partial line-opacity planes, or nullptr (no lines)
+    int n_planes;
+    int64_t pld;
+    double* total_out;     // [n_depth][out_ld]
+    double* line_out;      // optional
+    int64_t out_ld;
+};
+
 // One short-characteristic step (:208-249 outward, :150-198 inward): from a point with intensity `inten` and source
 // s0 across a gap of optical depth t0 (reciprocal r0) to the point with source s1; (t1, r1, s2) are the gap and point
 // beyond, which enter the second-order terms.
@@ -926,7 +1021,7 @@ __global__ __launch_bounds__(kBlock) void k_raytrace(int n_depth, int64_t n_nu, 
                                                      const double* __restrict__ nus, const double* __restrict__ temps,
                                                      const double* __restrict__ ray_dist, const double* __restrict__ wts,
                                                      const double* __restrict__ alphas, int64_t ald, double* __restrict__ F,
-                                                     int64_t fld, double* __restrict__ I_nus, int accumulate, int inward, int gpw)
+                                                     int64_t fld, double* __restrict__ I_nus, int accumulate, int inward, int gpw, FusedTotal ft)
 {
     constexpr int kBatch = P == 1 ? 8 : (P == 2 ? 4 : 2);
     extern __shared__ double smem[];
@@ -959,7 +1054,20 @@ __global__ __launch_bounds__(kBlock) void k_raytrace(int n_depth, int64_t n_nu, 
     }
     if (active) {
         for (int d = g; d < n_depth; d += G) {
-            sX[grp * col + d] = log(alphas[(size_t)d * ald + ic]);
+            double a;
+            if (ft.cont) {
+                a = ft.cont[(size_t)d * ft.cld + ic];
+                if (ft.planes) {
+                    double line = ft.planes[(size_t)d * ft.pld + ic];
+                    for (int sp = 1; sp < ft.n_planes; ++sp) line = add_rn(line, ft.planes[((size_t)sp * n_depth + d) * ft.pld + ic]);
+                    a = add_rn(a, line);
+                    if (valid && ft.line_out) ft.line_out[(size_t)d * ft.out_ld + i] = line;
+                }
+                if (valid) ft.total_out[(size_t)d * ft.out_ld + i] = a;
+            } else {
+                a = alphas[(size_t)d * ald + ic];
+            }
+            sX[grp * col + d] = log(a);
             sS[grp * col + d] = planck(nu, temps[d]);
         }
     }

@@ -65,7 +65,9 @@ struct sdx_ctx {
     hipEvent_t t0 = nullptr, t1 = nullptr;
     // side stream + fork/join events: independent kernels of one step (wide / narrow line opacity) overlap
     hipStream_t side = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr, fork0 = nullptr;
+    void* cont_ws = nullptr;  // continuum plane [n_depth][nu_count] of the fused step
+    size_t cont_ws_bytes = 0;
     bool profile = false;
     std::vector<ProfileRecord> records;
     std::vector<hipEvent_t> event_pool;
@@ -259,6 +261,7 @@ sdx_ctx* sdx_create(int device, void* stream)
     hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking);
     hipEventCreateWithFlags(&ctx->fork, hipEventDisableTiming);
     hipEventCreateWithFlags(&ctx->join, hipEventDisableTiming);
+    hipEventCreateWithFlags(&ctx->fork0, hipEventDisableTiming);
     return ctx;
 }
 
@@ -278,6 +281,8 @@ void sdx_destroy(sdx_ctx* ctx)
     }
     if (ctx->fork) hipEventDestroy(ctx->fork);
     if (ctx->join) hipEventDestroy(ctx->join);
+    if (ctx->fork0) hipEventDestroy(ctx->fork0);
+    if (ctx->cont_ws) hipFree(ctx->cont_ws);
     if (ctx->t0) hipEventDestroy(ctx->t0);
     if (ctx->t1) hipEventDestroy(ctx->t1);
     if (ctx->line_ws) hipFree(ctx->line_ws);
@@ -460,9 +465,16 @@ int sdx_profile_get(sdx_ctx* ctx, const char* kernel, int64_t* launches, double*
 }
 
 // ================================================================================================ line opacity
+struct ContinuumJob {  // continuum plane computed by the trailing blocks of the pre-pass launch
+    const sdx_continuum* cont;
+    int64_t nu_begin, nu_count;
+    double* plane;
+};
+
 static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t n_lines, const double* line_nus,
                         const double* doppler, const double* gammas, int gamma_cols, const double* alphas, bool fill_work,
-                        int32_t* lo_ref, int32_t* hi_ref, LineWork* w_out, bool count_evals = true)
+                        int32_t* lo_ref, int32_t* hi_ref, LineWork* w_out, bool count_evals = true,
+                        const ContinuumJob* job = nullptr)
 {
     int n_partial = 0;
     int rc = ensure(ctx, &ctx->small_ws, &ctx->small_ws_bytes, kSmallHeader);
@@ -485,11 +497,28 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
         n_pixel_blocks = (int)((n_nu + 2 + kBlock - 1) / kBlock);
     }
     const dim3 grid((unsigned)(n_line_blocks + n_pixel_blocks), (unsigned)((n_depth + kPreDepths - 1) / kPreDepths));
-    {
-        LaunchScope ls(ctx, "k_line_prepass");
-        hipLaunchKernelGGL(k_line_prepass, grid, dim3(kBlock), 0, ctx->stream, n_depth, n_nu, nus,
-                           scan_in_block ? (const double*)nullptr : (const double*)ctx->small_ws, n_partial, n_lines, line_nus,
-                           doppler, gammas, gamma_cols, alphas, w, (int*)lo_ref, (int*)hi_ref, n_line_blocks);
+    if (job) {
+        ContinuumArgs ca = to_args(job->cont, nullptr);
+        ca.bf_level_density = job->cont->bf_level_density;
+        size_t shmem = 8;
+        if (ca.bf_n_species > 0) {
+            REQUIRE(job->cont->bf_n_levels > 0 && job->cont->bf_n_levels <= 4096, "synthesize: bf_n_levels must be set (1..4096)");
+            shmem = (size_t)job->cont->bf_n_levels * sizeof(double);
+        }
+        const int cont_tiles = (int)((job->nu_count + kBlock - 1) / kBlock);
+        const unsigned total_blocks = grid.x * grid.y + (unsigned)cont_tiles * (unsigned)n_depth;
+        LaunchScope ls(ctx, "k_prepass_continuum");
+        hipLaunchKernelGGL(k_prepass_continuum, dim3(total_blocks), dim3(kBlock), shmem, ctx->stream, (int)grid.x, (int)grid.y, cont_tiles,
+                           n_depth, n_nu, nus, scan_in_block ? (const double*)nullptr : (const double*)ctx->small_ws, n_partial, n_lines,
+                           line_nus, doppler, gammas, gamma_cols, alphas, w, n_line_blocks, job->nu_begin, job->nu_count, ca, job->plane,
+                           job->nu_count);
+    } else {
+        {
+            LaunchScope ls(ctx, "k_line_prepass");
+            hipLaunchKernelGGL(k_line_prepass, grid, dim3(kBlock), 0, ctx->stream, n_depth, n_nu, nus,
+                               scan_in_block ? (const double*)nullptr : (const double*)ctx->small_ws, n_partial, n_lines, line_nus,
+                               doppler, gammas, gamma_cols, alphas, w, (int*)lo_ref, (int*)hi_ref, n_line_blocks);
+        }
     }
     if (w_out) *w_out = w;
     return check_launch("k_line_prepass");
@@ -519,56 +548,49 @@ static int choose_splits(int n_depth, int64_t nu_count, int64_t n_lines, int R)
     return (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(want, chunks), 32));
 }
 
-// pre-pass + gather kernel; leaves n_split partial planes in *partial_out ([n_split][n_depth][*pld_out])
+// pre-pass + the two gather kernels; leaves *n_planes_out partial planes in *partial_out ([planes][n_depth][*pld_out]):
+// the wide subsets in subset order, then the narrow-window plane.  With `job` the continuum plane of the fused step is
+// computed by the same launch as the pre-pass.
 static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin, int64_t nu_count,
                          int64_t n_lines, const double* line_nus, const double* doppler, const double* gammas, int gamma_cols,
-                         const double* alphas, double* direct_out, int64_t direct_ld, const double** partial_out,
-                         int64_t* pld_out, int* n_split_out, LineWork* w_out, bool count_evals)
+                         const double* alphas, const double** partial_out, int64_t* pld_out, int* n_planes_out, LineWork* w_out,
+                         bool count_evals, const ContinuumJob* job = nullptr)
 {
     constexpr int R = 4;
     LineWork w;
     int rc = line_prepass(ctx, n_depth, n_nu, nus, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, true, nullptr, nullptr, &w,
-                          count_evals);
+                          count_evals, job);
     if (rc) return rc;
     const int n_split = choose_splits(n_depth, nu_count, n_lines, R);
-    (void)direct_out;
-    (void)direct_ld;
     rc = ensure(ctx, &ctx->part_ws, &ctx->part_ws_bytes, (size_t)(n_split + 1) * n_depth * nu_count * sizeof(double));
     if (rc) return rc;
     double* part = (double*)ctx->part_ws;
     const int64_t pld = nu_count;
-    // The wide and narrow kernels only share the pre-pass: fork the narrow one onto the side stream so the two
-    // fill each other's idle issue slots (serial when per-kernel profiling is on, to keep the timings separable).
-    const bool overlap = !ctx->profile && ctx->side != nullptr;
-    hipStream_t narrow_stream = ctx->stream;
-    if (overlap) {
-        HIP_TRY(hipEventRecord(ctx->fork, ctx->stream));
-        HIP_TRY(hipStreamWaitEvent(ctx->side, ctx->fork, 0));
-        narrow_stream = ctx->side;
-    }
-    {
+    const int tiles = (int)((nu_count + 64 * R - 1) / (64 * R));
+    const int64_t n_wide = (int64_t)tiles * n_split * n_depth;
+    const int64_t n_narrow = nu_count * ((n_depth + 63) / 64);
+    static const bool split_launches = std::getenv("SDX_SPLIT_LAUNCHES") != nullptr;  // analysis knob: time the two roles apart
+    if (!split_launches && n_wide + n_narrow < ((int64_t)1 << 31)) {
+        LaunchScope ls(ctx, "k_line_all");
+        hipLaunchKernelGGL(k_line_all<R>, dim3((unsigned)(n_wide + n_narrow)), dim3(64), 0, ctx->stream, (int)n_wide, tiles, n_split,
+                           n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, part, pld);
+    } else {
+        {
+            LaunchScope ls(ctx, "k_line_wide");
+            hipLaunchKernelGGL(k_line_wide<R>, dim3((unsigned)tiles, (unsigned)n_split, (unsigned)n_depth), dim3(64), 0, ctx->stream, n_nu,
+                               nus, nu_begin, nu_count, n_lines, line_nus, w, part, pld, n_depth);
+        }
+        rc = check_launch("k_line_wide");
+        if (rc) return rc;
         LaunchScope ls(ctx, "k_line_narrow");
-        const dim3 grid((unsigned)((nu_count + kBlock / 64 - 1) / (kBlock / 64)), (unsigned)((n_depth + 63) / 64));
-        hipLaunchKernelGGL(k_line_narrow, grid, dim3(kBlock), 0, narrow_stream, n_depth, n_nu, nus, nu_begin, nu_count, n_lines,
-                           line_nus, w, part + (size_t)n_split * n_depth * pld, pld);
+        hipLaunchKernelGGL(k_line_narrow, dim3((unsigned)nu_count, (unsigned)((n_depth + 63) / 64)), dim3(64), 0, ctx->stream, n_depth,
+                           n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, part + (size_t)n_split * n_depth * pld, pld);
     }
-    rc = check_launch("k_line_narrow");
-    if (rc) return rc;
-    if (overlap) HIP_TRY(hipEventRecord(ctx->join, ctx->side));
-    {
-        LaunchScope ls(ctx, "k_line_wide");
-        const dim3 grid((unsigned)((nu_count + 64 * R - 1) / (64 * R)), (unsigned)n_split, (unsigned)n_depth);
-        hipLaunchKernelGGL(k_line_wide<R>, grid, dim3(64), 0, ctx->stream, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w,
-                           part, pld, n_depth);
-    }
-    rc = check_launch("k_line_wide");
-    if (rc) return rc;
-    if (overlap) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->join, 0));
     *partial_out = part;
     *pld_out = pld;
-    *n_split_out = n_split + 1;  // planes to sum: the wide subsets, then the narrow-window plane
+    *n_planes_out = n_split + 1;
     if (w_out) *w_out = w;
-    return SDX_OK;
+    return check_launch("line kernels");
 }
 
 int sdx_line_opacity_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin, int64_t nu_count,
@@ -590,8 +612,8 @@ int sdx_line_opacity_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
     int64_t pld;
     int n_split;
     LineWork w;
-    rc = line_partials(ctx, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, doppler, gammas, gamma_cols, alphas,
-                       accumulate ? nullptr : out, out_ld, &part, &pld, &n_split, &w, n_evaluations_dev != nullptr);
+    rc = line_partials(ctx, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, &part, &pld,
+                       &n_split, &w, n_evaluations_dev != nullptr);
     if (rc) return rc;
     {
         LaunchScope ls(ctx, "k_reduce_partials");
@@ -878,8 +900,9 @@ int sdx_accumulate_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, double* total, i
 
 static int launch_total(sdx_ctx* ctx, int n_depth, const double* nus, int64_t nu_begin, int64_t nu_count,
                         const sdx_continuum* cont, const double* line, int64_t line_ld, int n_split, double* line_out,
-                        int64_t line_out_ld, double* total, int64_t total_ld)
+                        int64_t line_out_ld, double* total, int64_t total_ld, hipStream_t stream = nullptr)
 {
+    if (!stream) stream = ctx->stream;
     ContinuumArgs a = to_args(cont, nullptr);
     a.bf_level_density = cont->bf_level_density;
     size_t shmem = 8;
@@ -889,7 +912,7 @@ static int launch_total(sdx_ctx* ctx, int n_depth, const double* nus, int64_t nu
     }
     {
         LaunchScope ls(ctx, "k_total_alphas");
-        hipLaunchKernelGGL(k_total_alphas, grid2(nu_count, n_depth), dim3(kBlock), shmem, ctx->stream, n_depth, nu_begin, nu_count,
+        hipLaunchKernelGGL(k_total_alphas, grid2(nu_count, n_depth), dim3(kBlock), shmem, stream, n_depth, nu_begin, nu_count,
                            nus, a, line, line_ld, n_split, line_out, line_out_ld, total, total_ld);
     }
     return check_launch("k_total_alphas");
@@ -930,7 +953,7 @@ int sdx_calc_weights_dev(sdx_ctx* ctx, int64_t n, const double* tau, double* w0,
 
 static int raytrace_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, const double* nus, const double* temps,
                          const double* ray_dist, const double* wts, const double* alphas, int64_t ald, double* F, int64_t fld,
-                         double* I_nus, int accumulate, int inward);
+                         double* I_nus, int accumulate, int inward, const FusedTotal* fused = nullptr);
 
 int sdx_raytrace_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, const double* nus, const double* temps,
                      const double* ray_dist, const double* wts, const double* alphas, int64_t ald, double* F, int64_t fld,
@@ -954,11 +977,14 @@ int sdx_raytrace_spherical_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_th
 
 static int raytrace_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, const double* nus, const double* temps,
                          const double* ray_dist, const double* wts, const double* alphas, int64_t ald, double* F, int64_t fld,
-                         double* I_nus, int accumulate, int inward)
+                         double* I_nus, int accumulate, int inward, const FusedTotal* fused)
 {
+    FusedTotal ft{};
+    if (fused) ft = *fused;
     REQUIRE(ctx && n_depth >= 2 && n_nu >= 0 && n_theta > 0, "raytrace: need n_depth >= 2, n_theta > 0");
     if (n_nu == 0) return SDX_OK;
-    REQUIRE(nus && temps && ray_dist && wts && alphas && ald >= n_nu, "raytrace: null pointer");
+    REQUIRE(nus && temps && ray_dist && wts && ((alphas && ald >= n_nu) || ft.cont), "raytrace: null pointer");
+    REQUIRE(!ft.cont || n_theta <= 64, "raytrace: the fused total needs all angles in one launch");
     REQUIRE((F && fld >= n_nu) || I_nus, "raytrace: no output requested");
     // Angles per lane P and lanes per frequency G = ceil(n_theta / P): one angle per lane fills the chip when the
     // grid is small; more angles per lane share the staged column when it is large.
@@ -991,10 +1017,11 @@ static int raytrace_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, c
             LaunchScope ls(ctx, "k_raytrace");
 #define SDX_RT_ARGS n_depth, n_nu, nth, n_theta, G, nus, temps, rd, w, alphas, ald, F, fld, inus, acc
             if (shmem <= 64 * 1024) {
-                if (P == 1) hipLaunchKernelGGL(k_raytrace<1>, dim3(blocks), dim3(kBlock), shmem, ctx->stream, SDX_RT_ARGS, inward, gpw);
-                else if (P == 2) hipLaunchKernelGGL(k_raytrace<2>, dim3(blocks), dim3(kBlock), shmem, ctx->stream, SDX_RT_ARGS, inward, gpw);
-                else hipLaunchKernelGGL(k_raytrace<4>, dim3(blocks), dim3(kBlock), shmem, ctx->stream, SDX_RT_ARGS, inward, gpw);
+                if (P == 1) hipLaunchKernelGGL(k_raytrace<1>, dim3(blocks), dim3(kBlock), shmem, ctx->stream, SDX_RT_ARGS, inward, gpw, ft);
+                else if (P == 2) hipLaunchKernelGGL(k_raytrace<2>, dim3(blocks), dim3(kBlock), shmem, ctx->stream, SDX_RT_ARGS, inward, gpw, ft);
+                else hipLaunchKernelGGL(k_raytrace<4>, dim3(blocks), dim3(kBlock), shmem, ctx->stream, SDX_RT_ARGS, inward, gpw, ft);
             } else {  // very deep models: the column does not fit LDS, recompute per lane instead
+                REQUIRE(!ft.cont, "raytrace: fused total not available for models this deep");
                 REQUIRE(!inward, "raytrace: spherical geometry needs (3*n_depth*64/n_theta + 2*n_depth*n_theta) doubles of LDS per wave; model too deep");
                 if (P == 1) hipLaunchKernelGGL(k_raytrace_basic<1>, dim3(blocks_basic), dim3(kBlock), 0, ctx->stream, SDX_RT_ARGS);
                 else if (P == 2) hipLaunchKernelGGL(k_raytrace_basic<2>, dim3(blocks_basic), dim3(kBlock), 0, ctx->stream, SDX_RT_ARGS);
@@ -1060,24 +1087,58 @@ int sdx_synthesize_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nu
     REQUIRE(nu_begin >= 0 && nu_count >= 0 && nu_begin + nu_count <= n_nu, "synthesize: shard outside the grid");
     REQUIRE(nu_count == 0 || (total_alphas && F_nu && ld >= nu_count), "synthesize: bad output buffers");
     if (nu_count == 0) return SDX_OK;
+    // Three launches on one stream: [pre-pass + continuum plane] -> [wide + narrow line kernels] -> [raytrace, which
+    // forms total = continuum + line while staging its columns].  Independent work shares a launch instead of a
+    // second stream: inter-queue edges cost ~12 us each on this platform, a whole kernel's worth at this size.
+    int rc2 = ensure(ctx, &ctx->cont_ws, &ctx->cont_ws_bytes, (size_t)n_depth * nu_count * sizeof(double));
+    if (rc2) return rc2;
+    double* cont_plane = (double*)ctx->cont_ws;
+    const bool fuse = n_theta <= 64 && ((size_t)2 * (n_depth - 1) * n_theta + (size_t)4 * (4 * (size_t)n_depth + 8 * 64)) * sizeof(double) <= 64 * 1024;
+    const ContinuumJob job{cont, nu_begin, nu_count, cont_plane};
     const double* part = nullptr;
     int64_t pld = 0;
-    int n_split = 1;
+    int n_planes = 0;
     if (n_lines > 0) {
         LineWork w;
-        rc = line_partials(ctx, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, doppler, gammas, gamma_cols, alphas,
-                           nullptr, 0, &part, &pld, &n_split, &w, n_evaluations_dev != nullptr);
+        rc = line_partials(ctx, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, &part, &pld,
+                           &n_planes, &w, n_evaluations_dev != nullptr, &job);
         if (rc) return rc;
         if (n_evaluations_dev)
             HIP_TRY(hipMemcpyAsync(n_evaluations_dev, w.evals, sizeof(int64_t), hipMemcpyDeviceToDevice, ctx->stream));
-    } else if (alpha_line_out) {
-        HIP_TRY(hipMemset2DAsync(alpha_line_out, ld * sizeof(double), 0, nu_count * sizeof(double), n_depth, ctx->stream));
+    } else {
+        rc = launch_total(ctx, n_depth, nus, nu_begin, nu_count, cont, nullptr, 0, 1, nullptr, 0, cont_plane, nu_count);
+        if (rc) return rc;
+        if (alpha_line_out)
+            HIP_TRY(hipMemset2DAsync(alpha_line_out, ld * sizeof(double), 0, nu_count * sizeof(double), n_depth, ctx->stream));
     }
-    rc = launch_total(ctx, n_depth, nus, nu_begin, nu_count, cont, part, pld, n_split, n_lines > 0 ? alpha_line_out : nullptr, ld,
-                      total_alphas, ld);
-    if (rc) return rc;
-    return sdx_raytrace_dev(ctx, n_depth, nu_count, n_theta, nus + nu_begin, temps, ray_dist, wts, total_alphas, ld, F_nu, ld,
-                            nullptr, 0);
+    if (!fuse) {
+        {
+            LaunchScope ls(ctx, "k_reduce_partials");  // total = continuum (+ line planes), element-wise
+            HIP_TRY(hipMemcpy2DAsync(total_alphas, ld * sizeof(double), cont_plane, nu_count * sizeof(double), nu_count * sizeof(double),
+                                     n_depth, hipMemcpyDeviceToDevice, ctx->stream));
+            if (part) {
+                if (alpha_line_out)
+                    hipLaunchKernelGGL(k_reduce_partials, grid2(nu_count, n_depth), dim3(kBlock), 0, ctx->stream, n_depth, nu_count,
+                                       n_planes, part, pld, alpha_line_out, ld, 0);
+                hipLaunchKernelGGL(k_reduce_partials, grid2(nu_count, n_depth), dim3(kBlock), 0, ctx->stream, n_depth, nu_count, n_planes,
+                                   part, pld, total_alphas, ld, 1);
+            }
+        }
+        rc = check_launch("k_reduce_partials");
+        if (rc) return rc;
+        return sdx_raytrace_dev(ctx, n_depth, nu_count, n_theta, nus + nu_begin, temps, ray_dist, wts, total_alphas, ld, F_nu, ld,
+                                nullptr, 0);
+    }
+    FusedTotal ft{};
+    ft.cont = cont_plane;
+    ft.cld = nu_count;
+    ft.planes = part;
+    ft.n_planes = n_planes;
+    ft.pld = pld;
+    ft.total_out = total_alphas;
+    ft.line_out = part ? alpha_line_out : nullptr;
+    ft.out_ld = ld;
+    return raytrace_impl(ctx, n_depth, nu_count, n_theta, nus + nu_begin, temps, ray_dist, wts, nullptr, 0, F_nu, ld, nullptr, 0, 0, &ft);
 }
 
 }  // extern "C"
