@@ -53,6 +53,8 @@ void sdx_destroy(sdx_ctx* ctx);
 int sdx_set_stream(sdx_ctx* ctx, void* stream);
 void* sdx_get_stream(sdx_ctx* ctx);
 int sdx_synchronize(sdx_ctx* ctx);
+/* tuning knobs; "indexed_min_lines" (default 8192): line lists at least this long use the dense-list wide-window path */
+int sdx_set_int_option(sdx_ctx* ctx, const char* name, int64_t value);
 
 /* device memory for callers that do not bring their own (numpy-only users) */
 void* sdx_malloc(sdx_ctx* ctx, size_t bytes);

@@ -55,6 +55,7 @@ PROTOTYPES = {
     "sdx_set_stream": (_int, [_vp, _vp]),
     "sdx_get_stream": (_vp, [_vp]),
     "sdx_synchronize": (_int, [_vp]),
+    "sdx_set_int_option": (_int, [_vp, C.c_char_p, _i64]),
     "sdx_malloc": (_vp, [_vp, C.c_size_t]),
     "sdx_free": (_int, [_vp, _vp]),
     "sdx_memcpy_h2d": (_int, [_vp, _vp, _vp, C.c_size_t]),
@@ -161,6 +162,9 @@ class Context:
 
     def synchronize(self):
         check(self.lib.sdx_synchronize(self.handle))
+
+    def set_option(self, name, value):
+        check(self.lib.sdx_set_int_option(self.handle, name.encode(), int(value)))
 
     # -- arrays -------------------------------------------------------------------------------
     def empty(self, shape, dtype=np.float64):

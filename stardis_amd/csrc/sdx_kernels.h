@@ -89,7 +89,8 @@ __device__ __forceinline__ int64_t window_rule(int64_t c, int64_t n_nu, double d
 constexpr int kPreLines = 16;
 constexpr int kPreDepths = 64;
 
-constexpr int kNarrowHalfWidth = 64;  // windows with half-width <= this go to k_line_narrow
+constexpr int kNarrowHalfWidth = 64;    // windows with half-width <= this go to the narrow-window kernel
+constexpr int kMediumHalfWidth = 4096;  // class bound of the indexed wide path: medium lines are found by centre range
 
 struct LineWork {
     double* inv_dw;  // [N_d][N_l]
@@ -106,6 +107,23 @@ struct LineWork {
     int* cnt_ge;     // [N_nu + 2]: number of lines whose centre index is >= p (lines are a prefix: centres descend)
     int* centre;     // [N_l] centre index of each line
     int* nhw_max;    // [N_l] largest NARROW half-width of the line over all depths (0: no narrow item)
+    // one bit per (depth, line), 16 lines per entry, for non-empty windows of the MEDIUM class (kNarrowHalfWidth < hw <=
+    // kMediumHalfWidth) and of the HUGE class (hw > kMediumHalfWidth); rows of mask_ld entries, a multiple of 4 so that a
+    // 64-line chunk is one aligned 64-bit word
+    unsigned short* wmask_med;
+    unsigned short* wmask_huge;
+    int64_t mask_ld;
+    // dense per-depth lists built from the masks by k_build_lists (large line lists only): row d holds the medium items
+    // at [0, cnt[d]) and the huge items at [cap - cnt[n_depth + d], cap), both in ascending line order
+    int* d_lo;
+    int* d_hi;
+    int* d_centre;
+    double* d_lnu;
+    double* d_inv;
+    double* d_y;
+    double* d_amp;
+    int* d_cnt;  // [2][N_d]
+    int64_t cap;
     unsigned long long* evals;
 };
 
@@ -165,6 +183,9 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
     }
     __syncthreads();
 
+    __shared__ unsigned int s_wmask[2][kPreDepths];
+    if (threadIdx.x < 2 * kPreDepths) (&s_wmask[0][0])[threadIdx.x] = 0u;
+    __syncthreads();
     unsigned long long ev = 0;
     for (int k = threadIdx.x; k < nl * nd; k += kBlock) {
         const int dd = k / nl, ll = k - dd * nl;
@@ -185,9 +206,17 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
                 w.inv_dw[o] = inv;
                 w.y[o] = yy;
                 w.amp[o] = amp;
+                if (hi > lo) atomicOr(&s_wmask[hw > kMediumHalfWidth ? 1 : 0][dd], 1u << ll);
             }
         }
         if (hi > lo) ev += (unsigned long long)(hi - lo);
+    }
+    if (w.wmask_med) {
+        __syncthreads();
+        if (threadIdx.x < nd) {
+            w.wmask_med[(size_t)(d0 + threadIdx.x) * w.mask_ld + bx] = (unsigned short)s_wmask[0][threadIdx.x];
+            w.wmask_huge[(size_t)(d0 + threadIdx.x) * w.mask_ld + bx] = (unsigned short)s_wmask[1][threadIdx.x];
+        }
     }
     // per-line summary for the narrow kernel's candidate test: centre index and the largest narrow half-width
     if (w.nhw_max) {
@@ -369,6 +398,189 @@ __global__ __launch_bounds__(64, 4) void k_line_wide(int64_t n_nu, const double*
                        n_depth);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Large line lists: dense per-depth lists of the wide items, one per class, in ascending line order.
+// grid = (blocks of kListChunks 64-line chunks, depth, class).  A block first counts the set bits of its row that lie
+// before its chunks (and, for the huge class, in the whole row), then a wave per chunk scatters the flagged lines'
+// constants to prefix + rank: a stable compaction without atomics.
+constexpr int kListChunks = 64;
+
+__global__ __launch_bounds__(kBlock) void k_build_lists(int n_depth, int64_t n_lines, const double* __restrict__ line_nus, LineWork w)
+{
+    __shared__ int s_red[kBlock / 64];
+    __shared__ int s_cnt[kListChunks];
+    const int d = blockIdx.y, cls = blockIdx.z;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t n_chunks = (n_lines + 63) >> 6;
+    const int64_t c_first = (int64_t)blockIdx.x * kListChunks;
+    const unsigned long long* masks =
+        reinterpret_cast<const unsigned long long*>((cls ? w.wmask_huge : w.wmask_med) + (size_t)d * w.mask_ld);
+    // set bits before this block's chunks, and in the whole row
+    int before = 0, all = 0;
+    for (int64_t c = threadIdx.x; c < n_chunks; c += kBlock) {
+        const int n = __popcll(masks[c]);
+        all += n;
+        before += c < c_first ? n : 0;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        before += __shfl_xor(before, off);
+        all += __shfl_xor(all, off);
+    }
+    if (lane == 0) s_red[wave] = before;
+    __syncthreads();
+    before = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    __syncthreads();
+    if (lane == 0) s_red[wave] = all;
+    __syncthreads();
+    all = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    if (blockIdx.x == 0 && threadIdx.x == 0) w.d_cnt[cls * n_depth + d] = all;
+    // exclusive scan of this block's chunk counts
+    if (threadIdx.x < kListChunks) {
+        const int64_t c = c_first + threadIdx.x;
+        s_cnt[threadIdx.x] = c < n_chunks ? __popcll(masks[c]) : 0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int k = 0; k < kListChunks; ++k) {
+            const int n = s_cnt[k];
+            s_cnt[k] = run;
+            run += n;
+        }
+    }
+    __syncthreads();
+    const size_t row = (size_t)d * w.cap;
+    const size_t origin = row + (cls ? (size_t)(w.cap - all) : 0);  // huge items fill the end of the row
+    const size_t src_row = (size_t)d * n_lines;
+    for (int k = wave; k < kListChunks; k += kBlock / 64) {
+        const int64_t c = c_first + k;
+        if (c >= n_chunks) break;
+        const unsigned long long m = masks[c];
+        const int64_t l = c * 64 + lane;
+        if (((m >> lane) & 1ull) && l < n_lines) {
+            const size_t dst = origin + before + s_cnt[k] + __popcll(m & ((1ull << lane) - 1ull));
+            const size_t src = src_row + l;
+            w.d_lo[dst] = w.lo[src];
+            w.d_hi[dst] = w.hi[src];
+            w.d_centre[dst] = w.centre[l];
+            w.d_lnu[dst] = line_nus[l];
+            w.d_inv[dst] = w.inv_dw[src];
+            w.d_y[dst] = w.y[src];
+            w.d_amp[dst] = w.amp[src];
+        }
+    }
+}
+
+// first k in [0, n) with key[k] < bound, for keys in DESCENDING order (centre indices of ascending lines)
+__device__ __forceinline__ int first_below(const int* __restrict__ key, int n, int64_t bound)
+{
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (key[mid] >= bound) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// Wide windows through the dense lists: the huge class is scanned completely (most of it overlaps any tile), the medium
+// class only over the entries whose centre lies within kMediumHalfWidth of the tile.  List chunk q (64 entries, by
+// absolute list position) belongs to subset q mod S, so the partition — and with it the summation order of a grid
+// point — does not depend on the tile or on how the grid is sharded.
+template <int R>
+__device__ __forceinline__ void line_wide_block_indexed(const int tile_idx, const int split, const int n_split, const int d,
+                                                        const double* __restrict__ nus, int64_t nu_begin, int64_t nu_count,
+                                                        LineWork w, double* __restrict__ partial, int64_t pld, int n_depth)
+{
+    constexpr int kTile = 64 * R;
+    __shared__ double s_nu[64], s_inv[64], s_y[64], s_amp[64], s_yk[64], s_c2[64], s_c3[64], s_c4[64];
+    __shared__ int s_lo[64], s_hi[64], s_fast[64];
+    const int64_t t0 = nu_begin + (int64_t)tile_idx * kTile;
+    const int64_t t1 = min(t0 + kTile, nu_begin + nu_count);
+    const int lane = threadIdx.x;
+    double nu_i[R], acc[R];
+    int idx[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t i = t0 + lane + r * 64;
+        idx[r] = i < t1 ? (int)i : -1;
+        nu_i[r] = i < t1 ? nus[i] : 0.0;
+        acc[r] = 0.0;
+    }
+    const double nu_first = nus[t0], nu_last = nus[t1 - 1];
+    const size_t row = (size_t)d * w.cap;
+    const int cnt_med = w.d_cnt[d], cnt_huge = w.d_cnt[n_depth + d];
+    for (int cls = 1; cls >= 0; --cls) {  // huge first, then medium: a fixed order
+        size_t origin;
+        int k_begin, k_end;
+        if (cls) {
+            origin = row + (size_t)(w.cap - cnt_huge);
+            k_begin = 0;
+            k_end = cnt_huge;
+        } else {
+            origin = row;
+            k_begin = first_below(w.d_centre + row, cnt_med, t1 + kMediumHalfWidth);
+            k_end = first_below(w.d_centre + row, cnt_med, t0 - kMediumHalfWidth + 1);
+        }
+        if (k_end <= k_begin) continue;
+        const int q_first = k_begin >> 6, q_last = (k_end - 1) >> 6;
+        int q = q_first + ((split - q_first % n_split) + n_split) % n_split;  // first chunk >= q_first of this subset
+        for (; q <= q_last; q += n_split) {
+            const int k = q * 64 + lane;
+            int lo = 0, hi = 0;
+            const bool in = k >= k_begin && k < k_end;
+            if (in) {
+                lo = w.d_lo[origin + k];
+                hi = w.d_hi[origin + k];
+            }
+            const bool hit = in & (lo < t1) & (hi > t0);
+            const unsigned long long m = __ballot(hit);
+            if (m == 0) continue;
+            const int total = __popcll(m);
+            if (hit) {
+                const int pos = __popcll(m & ((1ull << lane) - 1ull));
+                const double y = w.d_y[origin + k], inv = w.d_inv[origin + k], lnu = w.d_lnu[origin + k];
+                const RegionI k1 = region1_setup(y);
+                const double e_first = nu_first - lnu, e_last = nu_last - lnu;
+                const bool beside = e_last > 0.0 || e_first < 0.0;
+                const double nearest = fmin(fabs(e_first), fabs(e_last));
+                s_fast[pos] = (lo <= t0) & (hi >= t1) & beside & (nearest * inv + y > 15.001);
+                s_nu[pos] = lnu;
+                s_inv[pos] = inv;
+                s_y[pos] = y;
+                s_amp[pos] = w.d_amp[origin + k];
+                s_yk[pos] = k1.yk;
+                s_c2[pos] = k1.c2;
+                s_c3[pos] = k1.c3;
+                s_c4[pos] = k1.c4;
+                s_lo[pos] = lo;
+                s_hi[pos] = hi;
+            }
+            __syncthreads();
+            for (int j = 0; j < total; ++j) {
+                const double lnu = s_nu[j], inv = s_inv[j], amp = s_amp[j];
+                const RegionI k1 = {s_yk[j], s_c2[j], s_c3[j], s_c4[j]};
+                if (__builtin_amdgcn_readfirstlane(s_fast[j])) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const double x = (nu_i[r] - lnu) * inv;
+                        acc[r] += amp * region1_re(x * x, k1);
+                    }
+                } else {
+                    const double y = s_y[j];
+                    const int jlo = s_lo[j], jhi = s_hi[j];
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+                        if (idx[r] >= jlo && idx[r] < jhi) acc[r] += voigt_term(nu_i[r] - lnu, inv, y, amp, k1);
+                }
+            }
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (idx[r] >= 0) partial[((size_t)split * n_depth + d) * pld + (idx[r] - nu_begin)] = acc[r];
+}
+
 // Narrow windows (half-width <= kNarrowHalfWidth, e.g. the reference's 10-pixel floor for weak lines, :565-567):
 // a 256-point tile would be almost empty for them.  Here a wave owns ONE frequency and its lanes are the depth
 // points (lane <-> depth, line-major parameter arrays so the loads coalesce): a weak line covers either all
@@ -430,7 +642,7 @@ __global__ __launch_bounds__(64) void k_line_narrow(int n_depth, int64_t n_nu, c
 // Both line kernels in ONE launch: blocks [0, n_wide) take the wide role (depth slowest, hottest layers first), the
 // rest the narrow role.  The two only share the pre-pass, and each leaves issue slots idle on its own; a
 // cross-stream fork/join would cost two ~12 us inter-queue edges per step, one grid costs nothing.
-template <int R>
+template <int R, bool INDEXED>
 __global__ __launch_bounds__(64, 4) void k_line_all(int n_wide, int tiles, int n_split, int n_depth, int64_t n_nu,
                                                     const double* __restrict__ nus, int64_t nu_begin, int64_t nu_count,
                                                     int64_t n_lines, const double* __restrict__ line_nus, LineWork w,
@@ -439,8 +651,11 @@ __global__ __launch_bounds__(64, 4) void k_line_all(int n_wide, int tiles, int n
     const int b = blockIdx.x;
     if (b < n_wide) {
         const int tile = b % tiles, rest = b / tiles;
-        line_wide_block<R>(tile, rest % n_split, n_split, rest / n_split, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, partial,
-                           pld, n_depth);
+        if (INDEXED)
+            line_wide_block_indexed<R>(tile, rest % n_split, n_split, rest / n_split, nus, nu_begin, nu_count, w, partial, pld, n_depth);
+        else
+            line_wide_block<R>(tile, rest % n_split, n_split, rest / n_split, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w,
+                               partial, pld, n_depth);
     } else {
         const int64_t c = b - n_wide;
         line_narrow_wave(nu_begin + c % nu_count, (int)(c / nu_count), n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w,

@@ -61,6 +61,12 @@ struct sdx_ctx {
     void* cnt_ws = nullptr;
     size_t cnt_ws_bytes = 0;
     size_t cnt_ge_len = 0;
+    void* mask_ws = nullptr;  // wide-item bit masks, 2 classes x [n_depth][mask_ld] (uint16)
+    size_t mask_ws_bytes = 0;
+    void* dense_ws = nullptr;  // dense per-depth wide lists of the indexed path
+    size_t dense_ws_bytes = 0;
+    // tuning options (sdx_set_int_option)
+    int64_t indexed_min_lines = 8192;  // line lists at least this long go through the dense-list (indexed) wide path
     // timing
     hipEvent_t t0 = nullptr, t1 = nullptr;
     // side stream + fork/join events: independent kernels of one step (wide / narrow line opacity) overlap
@@ -115,6 +121,11 @@ LineWork carve(sdx_ctx* ctx, int n_depth, int64_t n_lines)
     w.cnt_ge = (int*)ctx->cnt_ws;
     w.centre = w.cnt_ge + ctx->cnt_ge_len;
     w.nhw_max = w.centre + n_lines;
+    w.mask_ld = ((n_lines + 63) / 64) * 4;
+    w.wmask_med = (unsigned short*)ctx->mask_ws;
+    w.wmask_huge = w.wmask_med + (size_t)n_depth * w.mask_ld;
+    w.d_lo = nullptr;
+    w.cap = n_lines;
     w.evals = (unsigned long long*)((char*)ctx->small_ws + 2048);
     return w;
 }
@@ -289,6 +300,8 @@ void sdx_destroy(sdx_ctx* ctx)
     if (ctx->small_ws) hipFree(ctx->small_ws);
     if (ctx->part_ws) hipFree(ctx->part_ws);
     if (ctx->cnt_ws) hipFree(ctx->cnt_ws);
+    if (ctx->mask_ws) hipFree(ctx->mask_ws);
+    if (ctx->dense_ws) hipFree(ctx->dense_ws);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -311,6 +324,16 @@ int sdx_set_stream(sdx_ctx* ctx, void* stream)
 }
 
 void* sdx_get_stream(sdx_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int sdx_set_int_option(sdx_ctx* ctx, const char* name, int64_t value)
+{
+    REQUIRE(ctx && name, "sdx_set_int_option: null pointer");
+    if (std::strcmp(name, "indexed_min_lines") == 0) {
+        ctx->indexed_min_lines = value;
+        return SDX_OK;
+    }
+    return fail(SDX_ERR_ARG, std::string("unknown option ") + name);
+}
 
 int sdx_synchronize(sdx_ctx* ctx)
 {
@@ -490,6 +513,15 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
         ctx->cnt_ge_len = (size_t)(n_nu + 2 + 63) / 64 * 64;
         rc = ensure(ctx, &ctx->cnt_ws, &ctx->cnt_ws_bytes, (ctx->cnt_ge_len + 2 * (size_t)n_lines) * sizeof(int));
         if (rc) return rc;
+        {
+            const size_t need = (size_t)2 * n_depth * (((size_t)n_lines + 63) / 64) * 4 * sizeof(unsigned short) + 64;
+            if (ctx->mask_ws_bytes < need) {
+                rc = ensure(ctx, &ctx->mask_ws, &ctx->mask_ws_bytes, need);
+                if (rc) return rc;
+                // padding entries (beyond the last 16-line group) are never written by the pre-pass: zero them once
+                HIP_TRY(hipMemsetAsync(ctx->mask_ws, 0, ctx->mask_ws_bytes, ctx->stream));
+            }
+        }
         w = carve(ctx, n_depth, n_lines);
         if (n_depth > kPreDepths) HIP_TRY(hipMemsetAsync(w.nhw_max, 0, (size_t)n_lines * sizeof(int), ctx->stream));
         if (count_evals) HIP_TRY(hipMemsetAsync(w.evals, 0, sizeof(unsigned long long), ctx->stream));
@@ -538,9 +570,11 @@ static int check_line_args(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double
 }
 
 // number of line subsets: enough single-wave blocks to fill the chip when the (tile, depth) grid alone is small
-static int choose_splits(int n_depth, int64_t nu_count, int64_t n_lines, int R)
+// (decided from the GLOBAL grid size, not the shard's: the partition fixes the summation order of every grid point,
+// which must not depend on how the grid is sharded)
+static int choose_splits(int n_depth, int64_t n_nu_global, int64_t n_lines, int R)
 {
-    const int64_t tiles = (nu_count + 64 * R - 1) / (64 * R);
+    const int64_t tiles = (n_nu_global + 64 * R - 1) / (64 * R);
     const int64_t chunks = (n_lines + 63) / 64;
     int64_t target = 8192;
     if (const char* e = std::getenv("SDX_WIDE_BLOCKS")) target = std::max(1, std::atoi(e));  // tuning knob
@@ -561,7 +595,26 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
     int rc = line_prepass(ctx, n_depth, n_nu, nus, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, true, nullptr, nullptr, &w,
                           count_evals, job);
     if (rc) return rc;
-    const int n_split = choose_splits(n_depth, nu_count, n_lines, R);
+    const int n_split = choose_splits(n_depth, n_nu, n_lines, R);
+    // large line lists: build dense per-depth lists of the medium / huge items so tiles stop scanning the whole list
+    const int indexed = n_lines >= ctx->indexed_min_lines ? 1 : 0;
+    if (indexed) {
+        const size_t cells = (size_t)n_depth * (size_t)n_lines;
+        rc = ensure(ctx, &ctx->dense_ws, &ctx->dense_ws_bytes, cells * 44 + (size_t)2 * n_depth * sizeof(int) + 256);
+        if (rc) return rc;
+        w.d_lnu = (double*)ctx->dense_ws;
+        w.d_inv = w.d_lnu + cells;
+        w.d_y = w.d_inv + cells;
+        w.d_amp = w.d_y + cells;
+        w.d_lo = (int*)(w.d_amp + cells);
+        w.d_hi = w.d_lo + cells;
+        w.d_centre = w.d_hi + cells;
+        w.d_cnt = w.d_centre + cells;
+        w.cap = n_lines;
+        LaunchScope ls(ctx, "k_build_lists");
+        const dim3 grid((unsigned)(((n_lines + 63) / 64 + kListChunks - 1) / kListChunks), (unsigned)n_depth, 2u);
+        hipLaunchKernelGGL(k_build_lists, grid, dim3(kBlock), 0, ctx->stream, n_depth, n_lines, line_nus, w);
+    }
     rc = ensure(ctx, &ctx->part_ws, &ctx->part_ws_bytes, (size_t)(n_split + 1) * n_depth * nu_count * sizeof(double));
     if (rc) return rc;
     double* part = (double*)ctx->part_ws;
@@ -570,10 +623,14 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
     const int64_t n_wide = (int64_t)tiles * n_split * n_depth;
     const int64_t n_narrow = nu_count * ((n_depth + 63) / 64);
     static const bool split_launches = std::getenv("SDX_SPLIT_LAUNCHES") != nullptr;  // analysis knob: time the two roles apart
-    if (!split_launches && n_wide + n_narrow < ((int64_t)1 << 31)) {
+    if ((!split_launches || indexed) && n_wide + n_narrow < ((int64_t)1 << 31)) {
         LaunchScope ls(ctx, "k_line_all");
-        hipLaunchKernelGGL(k_line_all<R>, dim3((unsigned)(n_wide + n_narrow)), dim3(64), 0, ctx->stream, (int)n_wide, tiles, n_split,
-                           n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, part, pld);
+        if (indexed)
+            hipLaunchKernelGGL((k_line_all<R, true>), dim3((unsigned)(n_wide + n_narrow)), dim3(64), 0, ctx->stream, (int)n_wide, tiles,
+                               n_split, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, part, pld);
+        else
+            hipLaunchKernelGGL((k_line_all<R, false>), dim3((unsigned)(n_wide + n_narrow)), dim3(64), 0, ctx->stream, (int)n_wide, tiles,
+                               n_split, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, part, pld);
     } else {
         {
             LaunchScope ls(ctx, "k_line_wide");

@@ -117,3 +117,51 @@ def test_full_size_properties(ctx):
     s2.step()
     ref = oracle.calc_alan_entries(56, nus, sub["line_nus"], sub["doppler_widths"], sub["gammas"], sub["alphas"])
     assert rel_err(s2.alpha_line(), ref) < 1e-12
+
+
+def test_indexed_wide_path_matches_direct_path_and_oracle(ctx):
+    """Long line lists go through dense per-depth lists (medium lines found by centre range, huge ones scanned);
+    forced here on a small list: same windows, same evaluations, results equal to the direct path up to the summation
+    order (huge before medium instead of pure line order) and to the oracle within the opacity tolerance."""
+    atm, nus, lines, cont, th, w = small_workload(n_lines=700, step=0.005, seed=21)
+    ref = oracle.calc_alan_entries(56, nus, lines["line_nus"], lines["doppler_widths"], lines["gammas"], lines["alphas"])
+    out = {}
+    try:
+        for name, minimum in (("indexed", 1), ("direct", 1 << 40)):
+            ctx.set_option("indexed_min_lines", minimum)
+            syn = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], th, w, lines, cont, ctx=ctx)
+            syn.step()
+            out[name] = (syn.alpha_line(), syn.F_nu())
+            assert rel_err(out[name][0], ref) < 1e-12, name
+        assert rel_err(out["indexed"][0], out["direct"][0]) < 1e-13
+        assert rel_err(out["indexed"][1][1:], out["direct"][1][1:]) < 1e-12
+        # shard invariance of the indexed path
+        ctx.set_option("indexed_min_lines", 1)
+        parts = []
+        for rank in range(3):
+            s = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], th, w, lines, cont, ctx=ctx, shard=shard_bounds(nus.size, 3, rank))
+            s.step()
+            parts.append(s.alpha_line())
+        assert np.array_equal(np.concatenate(parts, axis=1), out["indexed"][0])
+    finally:
+        ctx.set_option("indexed_min_lines", 8192)
+
+
+def test_long_line_list_on_the_wide_grid(ctx):
+    """BASELINE configs[2]/[3] shape: the 3000-10000 A grid at R = 1e5 (120 398 frequencies) with a line list long
+    enough (20 000 lines, gamma given as an (N_l, 1) column like the molecular case) to take the indexed wide-window
+    path by default.  Line opacity against the oracle on the full grid; flux through the column-independence of the
+    formal solution (a strided subset of columns recomputed on the CPU from the GPU's own total opacity)."""
+    w = synth.make_workload("S-c4", n_lines=20000)
+    atm, nus, lines = w["atm"], w["nus"], w["lines"]
+    assert lines["gammas"].shape == (20000, 1) and nus.size == 120398
+    syn = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], w["thetas"], w["weights"], lines, w["cont"], ctx=ctx)
+    syn.step()
+    line, total, F = syn.alpha_line(), syn.total_alphas(), syn.F_nu()
+    ref, evals = oracle.calc_alan_entries(56, nus, lines["line_nus"], lines["doppler_widths"], lines["gammas"], lines["alphas"], return_evals=True)
+    assert syn.evaluations() == evals
+    assert np.array_equal(line == 0, ref == 0)
+    assert rel_err(line, ref) < 1e-12
+    cols = np.arange(0, nus.size, 601)
+    F_ref, _ = oracle.raytrace(nus[cols], atm["temperatures"], atm["dist"], w["thetas"], w["weights"], np.ascontiguousarray(total[:, cols]))
+    assert rel_err(F[1:, cols], F_ref[1:]) < 1e-10
