@@ -47,8 +47,20 @@ __device__ __forceinline__ double block_dnu(const double* __restrict__ partial, 
 
 __device__ __forceinline__ double block_dnu_scan(const double* __restrict__ nus, int64_t n_nu, double* s_red)
 {
-    double m = -INFINITY;
-    for (int64_t i = threadIdx.x; i + 1 < n_nu; i += blockDim.x) m = fmax(m, nus[i + 1] - nus[i]);
+    // eight independent loads in flight per thread: the scan is latency-, not bandwidth-bound (the grid sits in L2)
+    double m0 = -INFINITY, m1 = -INFINITY, m2 = -INFINITY, m3 = -INFINITY;
+    const int64_t step = blockDim.x;
+    int64_t i = threadIdx.x;
+    for (; i + 3 * step + 1 < n_nu; i += 4 * step) {
+        const double a0 = nus[i], b0 = nus[i + 1], a1 = nus[i + step], b1 = nus[i + step + 1];
+        const double a2 = nus[i + 2 * step], b2 = nus[i + 2 * step + 1], a3 = nus[i + 3 * step], b3 = nus[i + 3 * step + 1];
+        m0 = fmax(m0, b0 - a0);
+        m1 = fmax(m1, b1 - a1);
+        m2 = fmax(m2, b2 - a2);
+        m3 = fmax(m3, b3 - a3);
+    }
+    for (; i + 1 < n_nu; i += step) m0 = fmax(m0, nus[i + 1] - nus[i]);
+    double m = fmax(fmax(m0, m1), fmax(m2, m3));
     for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
     if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = m;
     __syncthreads();
@@ -88,6 +100,7 @@ __device__ __forceinline__ int64_t window_rule(int64_t c, int64_t n_nu, double d
 // writes the depth-major SoA coalesced.
 constexpr int kPreLines = 16;
 constexpr int kPreDepths = 64;
+constexpr int kPreBlock = 1024;  // threads per pre-pass block: one (line, depth) item per thread, 16 waves to hide latency
 
 constexpr int kNarrowHalfWidth = 64;    // windows with half-width <= this go to the narrow-window kernel
 constexpr int kMediumHalfWidth = 4096;  // class bound of the indexed wide path: medium lines are found by centre range
@@ -139,7 +152,7 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
     if (bx >= n_line_blocks) {
         // trailing blocks: cnt_ge[p] = #{l : centre_l >= p} = #{l : line_nu_l <= nus[p-1]}  (centre_l = #{i : nus[i] >= line_nu_l})
         if (by == 0 && w.cnt_ge) {
-            const int64_t pidx = (int64_t)(bx - n_line_blocks) * kBlock + threadIdx.x;
+            const int64_t pidx = (int64_t)(bx - n_line_blocks) * blockDim.x + threadIdx.x;
             if (pidx <= n_nu + 1) {
                 int64_t cnt;
                 if (pidx == 0) cnt = n_lines;
@@ -159,21 +172,29 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
         return;
     }
     constexpr int kStride = kPreDepths + 1;  // odd row stride: conflict-free transposed LDS reads
+    constexpr int kMaxWaves = kPreBlock / 64;
     __shared__ double s_dw[kPreLines * kStride], s_g[kPreLines * kStride], s_a[kPreLines * kStride];
+    __shared__ int s_lo[kPreLines * kStride], s_hi[kPreLines * kStride];
     __shared__ int64_t s_c[kPreLines];
-    __shared__ double s_red[kBlock / 64];
-    __shared__ unsigned long long s_ev[kBlock / 64];
+    __shared__ double s_red[kMaxWaves];
+    __shared__ unsigned long long s_ev[kMaxWaves];
+    __shared__ unsigned int s_wmask[2][kPreDepths];
+    __shared__ int s_hwmax[kPreLines];
 
+    const int nthreads = blockDim.x;
     const int64_t l0 = (int64_t)bx * kPreLines;
     const int d0 = by * kPreDepths;
     const int nl = (int)min((int64_t)kPreLines, n_lines - l0);
     const int nd = min(kPreDepths, n_depth - d0);
     // line centres first (a chain of dependent loads) so they overlap the grid scan of the other threads
     if (threadIdx.x < nl) s_c[threadIdx.x] = closest_index(nus, n_nu, line_nus[l0 + threadIdx.x]);
+    if (threadIdx.x < 2 * kPreDepths) (&s_wmask[0][0])[threadIdx.x] = 0u;
+    if (threadIdx.x < kPreLines) s_hwmax[threadIdx.x] = 0;
     // d_nu (:524-526): from the partial maxima of k_dnu_partial, or — small grids — scanned here directly
     const double d_nu = dnu_partial ? block_dnu(dnu_partial, n_partial, s_red) : block_dnu_scan(nus, n_nu, s_red);
 
-    for (int k = threadIdx.x; k < nl * nd; k += kBlock) {
+    // reference layout in, line fastest ... depth fastest: coalesced
+    for (int k = threadIdx.x; k < nl * nd; k += nthreads) {
         const int ll = k / nd, dd = k - ll * nd;
         const int64_t l = l0 + ll;
         const int d = d0 + dd;
@@ -183,23 +204,26 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
     }
     __syncthreads();
 
-    __shared__ unsigned int s_wmask[2][kPreDepths];
-    if (threadIdx.x < 2 * kPreDepths) (&s_wmask[0][0])[threadIdx.x] = 0u;
-    __syncthreads();
+    // ONE arithmetic pass, line fastest (depth-major stores coalesce).  The derived constants replace the inputs in
+    // LDS so that the line-major stores below need no second evaluation.
     unsigned long long ev = 0;
-    for (int k = threadIdx.x; k < nl * nd; k += kBlock) {
+    for (int k = threadIdx.x; k < nl * nd; k += nthreads) {
         const int dd = k / nl, ll = k - dd * nl;
-        const double dw = s_dw[ll * kStride + dd], g = s_g[ll * kStride + dd], a = s_a[ll * kStride + dd];
+        const int sidx = ll * kStride + dd;
+        const double dw = s_dw[sidx], g = s_g[sidx], a = s_a[sidx];
         int lo, hi;
         const int64_t hw = window_rule(s_c[ll], n_nu, d_nu, g, dw, a, lo, hi);
-        const int64_t l = l0 + ll;
-        const int d = d0 + dd;
+        const bool narrow = hw <= kNarrowHalfWidth;
+        const double inv = 1.0 / dw;
+        const double yy = (g / mul_rn(kSqrtPi, kPi)) / dw;  // voigt.py:148
+        const double amp = a / mul_rn(kSqrtPi, dw);         // voigt.py:149 x base.py:627
+        s_dw[sidx] = inv;
+        s_g[sidx] = yy;
+        s_a[sidx] = amp;
+        s_lo[sidx] = lo;
+        s_hi[sidx] = narrow ? hi : -hi - 1;  // sign bit carries the class to the second pass
         if (w.inv_dw) {
-            const size_t o = (size_t)d * n_lines + l;  // depth-major (wide kernel)
-            const bool narrow = hw <= kNarrowHalfWidth;
-            const double inv = 1.0 / dw;
-            const double yy = (g / mul_rn(kSqrtPi, kPi)) / dw;  // voigt.py:148
-            const double amp = a / mul_rn(kSqrtPi, dw);         // voigt.py:149 x base.py:627
+            const size_t o = (size_t)(d0 + dd) * n_lines + (l0 + ll);  // depth-major (wide kernel)
             w.lo[o] = narrow ? 0 : lo;
             w.hi[o] = narrow ? 0 : hi;
             if (!narrow) {
@@ -207,55 +231,43 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
                 w.y[o] = yy;
                 w.amp[o] = amp;
                 if (hi > lo) atomicOr(&s_wmask[hw > kMediumHalfWidth ? 1 : 0][dd], 1u << ll);
+            } else {
+                atomicMax(&s_hwmax[ll], (int)hw);
             }
         }
         if (hi > lo) ev += (unsigned long long)(hi - lo);
     }
-    if (w.wmask_med) {
-        __syncthreads();
-        if (threadIdx.x < nd) {
-            w.wmask_med[(size_t)(d0 + threadIdx.x) * w.mask_ld + bx] = (unsigned short)s_wmask[0][threadIdx.x];
-            w.wmask_huge[(size_t)(d0 + threadIdx.x) * w.mask_ld + bx] = (unsigned short)s_wmask[1][threadIdx.x];
-        }
+    __syncthreads();
+    if (w.wmask_med && threadIdx.x < nd) {
+        w.wmask_med[(size_t)(d0 + threadIdx.x) * w.mask_ld + bx] = (unsigned short)s_wmask[0][threadIdx.x];
+        w.wmask_huge[(size_t)(d0 + threadIdx.x) * w.mask_ld + bx] = (unsigned short)s_wmask[1][threadIdx.x];
     }
     // per-line summary for the narrow kernel's candidate test: centre index and the largest narrow half-width
-    if (w.nhw_max) {
-        __shared__ int s_hwmax[kPreLines];
-        if (threadIdx.x < kPreLines) s_hwmax[threadIdx.x] = 0;
-        __syncthreads();
-        for (int k = threadIdx.x; k < nl * nd; k += kBlock) {
-            const int ll = k / nd, dd = k - ll * nd;
-            int lo, hi;
-            const int64_t hw = window_rule(s_c[ll], n_nu, d_nu, s_g[ll * kStride + dd], s_dw[ll * kStride + dd], s_a[ll * kStride + dd], lo, hi);
-            if (hw <= kNarrowHalfWidth) atomicMax(&s_hwmax[ll], (int)hw);
-        }
-        __syncthreads();
-        if (threadIdx.x < nl) {
-            if (gy == 1) w.nhw_max[l0 + threadIdx.x] = s_hwmax[threadIdx.x];
-            else atomicMax(&w.nhw_max[l0 + threadIdx.x], s_hwmax[threadIdx.x]);  // deep models: zeroed by the host first
-            if (by == 0) w.centre[l0 + threadIdx.x] = (int)s_c[threadIdx.x];
-        }
+    if (w.nhw_max && threadIdx.x < nl) {
+        if (gy == 1) w.nhw_max[l0 + threadIdx.x] = s_hwmax[threadIdx.x];
+        else atomicMax(&w.nhw_max[l0 + threadIdx.x], s_hwmax[threadIdx.x]);  // deep models: zeroed by the host first
+        if (by == 0) w.centre[l0 + threadIdx.x] = (int)s_c[threadIdx.x];
     }
-    // line-major outputs: same items visited with depth fastest so the stores coalesce
+    // line-major outputs: the stashed values, depth fastest so the stores coalesce
     if (w.nlo || out_lo_ref) {
-        for (int k = threadIdx.x; k < nl * nd; k += kBlock) {
+        for (int k = threadIdx.x; k < nl * nd; k += nthreads) {
             const int ll = k / nd, dd = k - ll * nd;
-            const double dw = s_dw[ll * kStride + dd], g = s_g[ll * kStride + dd], a = s_a[ll * kStride + dd];
-            int lo, hi;
-            const int64_t hw = window_rule(s_c[ll], n_nu, d_nu, g, dw, a, lo, hi);
+            const int sidx = ll * kStride + dd;
+            const int lo = s_lo[sidx], hcode = s_hi[sidx];
+            const bool narrow = hcode >= 0;
+            const int hi = narrow ? hcode : -hcode - 1;
             const size_t o = (size_t)(l0 + ll) * n_depth + (d0 + dd);
             if (out_lo_ref) {  // sdx_line_windows_dev
                 out_lo_ref[o] = lo;
                 out_hi_ref[o] = hi;
             }
             if (w.nlo) {
-                const bool narrow = hw <= kNarrowHalfWidth;
                 w.nlo[o] = narrow ? lo : 0;
                 w.nhi[o] = narrow ? hi : 0;
                 if (narrow) {
-                    w.n_inv[o] = 1.0 / dw;
-                    w.n_y[o] = (g / mul_rn(kSqrtPi, kPi)) / dw;
-                    w.n_amp[o] = a / mul_rn(kSqrtPi, dw);
+                    w.n_inv[o] = s_dw[sidx];
+                    w.n_y[o] = s_g[sidx];
+                    w.n_amp[o] = s_a[sidx];
                 }
             }
         }
@@ -265,13 +277,13 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
         if ((threadIdx.x & 63) == 0) s_ev[threadIdx.x >> 6] = ev;
         __syncthreads();
         if (threadIdx.x == 0) {
-            for (int i = 1; i < kBlock / 64; ++i) ev += s_ev[i];
+            for (int i = 1; i < (nthreads >> 6); ++i) ev += s_ev[i];
             if (ev) atomicAdd(w.evals, ev);
         }
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_line_prepass(int n_depth, int64_t n_nu, const double* __restrict__ nus,
+__global__ __launch_bounds__(kPreBlock) void k_line_prepass(int n_depth, int64_t n_nu, const double* __restrict__ nus,
                                                          const double* __restrict__ dnu_partial, int n_partial,
                                                          int64_t n_lines, const double* __restrict__ line_nus,
                                                          const double* __restrict__ doppler,
@@ -1010,9 +1022,9 @@ __device__ __forceinline__ void total_alphas_block(const int bx, const int d, in
                                                          double* __restrict__ total, int64_t total_ld)
 {
     extern __shared__ double s_coef[];  // [n_levels] for depth d
-    const int64_t j = (int64_t)bx * kBlock + threadIdx.x;
+    const int64_t j = (int64_t)bx * blockDim.x + threadIdx.x;
     const int n_levels = a.bf_n_species > 0 ? a.bf_species_offsets[a.bf_n_species] : 0;
-    for (int L = threadIdx.x; L < n_levels; L += kBlock) {
+    for (int L = threadIdx.x; L < n_levels; L += blockDim.x) {
         int sp = 0;
         while (sp + 1 < a.bf_n_species && L >= a.bf_species_offsets[sp + 1]) ++sp;
         const int zi = a.bf_species_ion_number[sp] + 1;
@@ -1061,7 +1073,7 @@ __global__ __launch_bounds__(kBlock) void k_total_alphas(int n_depth, int64_t nu
 
 // Pre-pass and continuum in ONE launch: the pre-pass is a few latency-bound blocks (binary searches, a grid scan);
 // the continuum plane depends on nothing and fills the rest of the chip meanwhile.
-__global__ __launch_bounds__(kBlock) void k_prepass_continuum(int n_pre_x, int n_pre_y, int cont_tiles, int n_depth, int64_t n_nu,
+__global__ __launch_bounds__(kPreBlock) void k_prepass_continuum(int n_pre_x, int n_pre_y, int cont_tiles, int n_depth, int64_t n_nu,
                                                               const double* __restrict__ nus,
                                                               const double* __restrict__ dnu_partial, int n_partial,
                                                               int64_t n_lines, const double* __restrict__ line_nus,

@@ -526,7 +526,7 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
         if (n_depth > kPreDepths) HIP_TRY(hipMemsetAsync(w.nhw_max, 0, (size_t)n_lines * sizeof(int), ctx->stream));
         if (count_evals) HIP_TRY(hipMemsetAsync(w.evals, 0, sizeof(unsigned long long), ctx->stream));
         else w.evals = nullptr;
-        n_pixel_blocks = (int)((n_nu + 2 + kBlock - 1) / kBlock);
+        n_pixel_blocks = (int)((n_nu + 2 + kPreBlock - 1) / kPreBlock);
     }
     const dim3 grid((unsigned)(n_line_blocks + n_pixel_blocks), (unsigned)((n_depth + kPreDepths - 1) / kPreDepths));
     if (job) {
@@ -537,17 +537,18 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
             REQUIRE(job->cont->bf_n_levels > 0 && job->cont->bf_n_levels <= 4096, "synthesize: bf_n_levels must be set (1..4096)");
             shmem = (size_t)job->cont->bf_n_levels * sizeof(double);
         }
-        const int cont_tiles = (int)((job->nu_count + kBlock - 1) / kBlock);
-        const unsigned total_blocks = grid.x * grid.y + (unsigned)cont_tiles * (unsigned)n_depth;
+        const int cont_tiles = (int)((job->nu_count + kPreBlock - 1) / kPreBlock);
+        unsigned total_blocks = grid.x * grid.y + (unsigned)cont_tiles * (unsigned)n_depth;
+        if (std::getenv("SDX_ABLATE_CONT")) total_blocks = grid.x * grid.y;  // timing experiment only: wrong results
         LaunchScope ls(ctx, "k_prepass_continuum");
-        hipLaunchKernelGGL(k_prepass_continuum, dim3(total_blocks), dim3(kBlock), shmem, ctx->stream, (int)grid.x, (int)grid.y, cont_tiles,
+        hipLaunchKernelGGL(k_prepass_continuum, dim3(total_blocks), dim3(kPreBlock), shmem, ctx->stream, (int)grid.x, (int)grid.y, cont_tiles,
                            n_depth, n_nu, nus, scan_in_block ? (const double*)nullptr : (const double*)ctx->small_ws, n_partial, n_lines,
                            line_nus, doppler, gammas, gamma_cols, alphas, w, n_line_blocks, job->nu_begin, job->nu_count, ca, job->plane,
                            job->nu_count);
     } else {
         {
             LaunchScope ls(ctx, "k_line_prepass");
-            hipLaunchKernelGGL(k_line_prepass, grid, dim3(kBlock), 0, ctx->stream, n_depth, n_nu, nus,
+            hipLaunchKernelGGL(k_line_prepass, grid, dim3(kPreBlock), 0, ctx->stream, n_depth, n_nu, nus,
                                scan_in_block ? (const double*)nullptr : (const double*)ctx->small_ws, n_partial, n_lines, line_nus,
                                doppler, gammas, gamma_cols, alphas, w, (int*)lo_ref, (int*)hi_ref, n_line_blocks);
         }
