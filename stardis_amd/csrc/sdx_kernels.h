@@ -186,8 +186,31 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
     const int d0 = by * kPreDepths;
     const int nl = (int)min((int64_t)kPreLines, n_lines - l0);
     const int nd = min(kPreDepths, n_depth - d0);
-    // line centres first (a chain of dependent loads) so they overlap the grid scan of the other threads
-    if (threadIdx.x < nl) s_c[threadIdx.x] = closest_index(nus, n_nu, line_nus[l0 + threadIdx.x]);
+    // line centres: two-level binary search — a 128-entry sample of the grid in LDS, then the bracketed stretch in
+    // global memory — halves the chain of dependent global loads that dominates this block's latency
+    __shared__ double s_coarse[128];
+    const int64_t cstride = (n_nu + 127) / 128;
+    if (threadIdx.x < 128) {
+        const int64_t j = (int64_t)threadIdx.x * cstride;
+        s_coarse[threadIdx.x] = j < n_nu ? nus[j] : -INFINITY;
+    }
+    __syncthreads();
+    if (threadIdx.x < nl) {
+        const double v = line_nus[l0 + threadIdx.x];
+        int a = 0, b = 128;  // first sample strictly below v
+        while (a < b) {
+            const int mid = (a + b) >> 1;
+            if (s_coarse[mid] >= v) a = mid + 1; else b = mid;
+        }
+        // the answer lies in ((a-1)*cstride, a*cstride]
+        int64_t lo = a > 0 ? (int64_t)(a - 1) * cstride + 1 : 0;
+        int64_t hi = min((int64_t)a * cstride, n_nu);
+        while (lo < hi) {
+            const int64_t mid = lo + ((hi - lo) >> 1);
+            if (nus[mid] >= v) lo = mid + 1; else hi = mid;
+        }
+        s_c[threadIdx.x] = lo;
+    }
     if (threadIdx.x < 2 * kPreDepths) (&s_wmask[0][0])[threadIdx.x] = 0u;
     if (threadIdx.x < kPreLines) s_hwmax[threadIdx.x] = 0;
     // d_nu (:524-526): from the partial maxima of k_dnu_partial, or — small grids — scanned here directly

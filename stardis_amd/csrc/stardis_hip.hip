@@ -538,8 +538,7 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
             shmem = (size_t)job->cont->bf_n_levels * sizeof(double);
         }
         const int cont_tiles = (int)((job->nu_count + kPreBlock - 1) / kPreBlock);
-        unsigned total_blocks = grid.x * grid.y + (unsigned)cont_tiles * (unsigned)n_depth;
-        if (std::getenv("SDX_ABLATE_CONT")) total_blocks = grid.x * grid.y;  // timing experiment only: wrong results
+        const unsigned total_blocks = grid.x * grid.y + (unsigned)cont_tiles * (unsigned)n_depth;
         LaunchScope ls(ctx, "k_prepass_continuum");
         hipLaunchKernelGGL(k_prepass_continuum, dim3(total_blocks), dim3(kPreBlock), shmem, ctx->stream, (int)grid.x, (int)grid.y, cont_tiles,
                            n_depth, n_nu, nus, scan_in_block ? (const double*)nullptr : (const double*)ctx->small_ws, n_partial, n_lines,
