@@ -132,11 +132,35 @@ def main():
     if not args.no_graph:
         syn.capture()
 
-    gather = parallel.FluxGatherer(nus.size, world, flux.device)
+    # N > 1: two flux buffers alternate so that the all-gather of step k (RCCL, its own stream) overlaps the kernels
+    # of step k+1; a buffer is reused only after its gather has been waited for.  SDX_BENCH_SYNC_GATHER=1 falls back
+    # to a blocking gather per step.
+    overlap_gather = world > 1 and os.environ.get("SDX_BENCH_SYNC_GATHER") != "1"
+    lanes = [(syn, flux, parallel.FluxGatherer(nus.size, world, flux.device))]
+    if overlap_gather:
+        flux_b = torch.zeros_like(flux)
+        syn_b2 = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], w["thetas"], w["weights"], w["lines"], w["cont"],
+                                     ctx=ctx, shard=(begin, count), flux_out=flux_b, track_evaluations=False)
+        if not args.no_graph:
+            syn_b2.capture()
+        lanes.append((syn_b2, flux_b, parallel.FluxGatherer(nus.size, world, flux.device)))
+    counter = [0]
 
     def step():
-        syn.step()
-        return gather(flux[-1])
+        s_, f_, g_ = lanes[counter[0] % len(lanes)]
+        counter[0] += 1
+        if overlap_gather:
+            g_.finish()  # the gather that last read this lane's flux buffer
+            s_.step()
+            g_.start(f_[-1])
+            return None
+        s_.step()
+        return g_(f_[-1])
+
+    def drain():
+        if overlap_gather:
+            for _, _, g_ in lanes:
+                g_.finish()
 
     def fence():
         torch.cuda.synchronize()
@@ -146,10 +170,12 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    drain()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         spectrum = step()
+    drain()
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -228,7 +254,7 @@ def main():
                 "n_lines": int(n_l),
                 "n_theta": int(len(w["thetas"])),
                 "voigt_evaluations_global": int(evals),
-                "parallelism": f"nu-shard x{world}" + (", 1 all-gather of F_nu[-1] per step" if world > 1 else ""),
+                "parallelism": f"nu-shard x{world}" + (", 1 all-gather of F_nu[-1] per step" + (" overlapped with the next step" if overlap_gather else "") if world > 1 else ""),
                 "hip_graph": not args.no_graph,
             },
             "roofline": {

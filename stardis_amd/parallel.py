@@ -50,6 +50,32 @@ class FluxGatherer:
         self.recv = torch.empty(self.per * world_size, dtype=dtype, device=device)
         self.host = None
 
+    def start(self, local_flux):
+        """Enqueue the all-gather behind the work already on the current stream and return at once; the kernels of
+        the NEXT step (writing a different flux buffer) are not held back by it.  Call finish() before this
+        gatherer's buffers — or the flux buffer it read — are reused."""
+        import torch.distributed as dist
+
+        self._work = None
+        if self.world == 1:
+            return
+        if dist.get_backend() != "nccl":  # CPU collective (tests): nothing to overlap
+            self(local_flux)
+            return
+        src = local_flux
+        if local_flux.numel() != self.per:
+            self.send[: local_flux.numel()] = local_flux
+            src = self.send
+        self._work = dist.all_gather_into_tensor(self.recv, src, async_op=True)
+
+    def finish(self):
+        """Make the current stream wait for the gather started by start()."""
+        work = getattr(self, "_work", None)
+        if work is not None:
+            work.wait()
+            self._work = None
+        return self.recv[: self.n_nu]
+
     def __call__(self, local_flux):
         import torch
         import torch.distributed as dist
