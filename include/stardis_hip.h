@@ -53,7 +53,9 @@ void sdx_destroy(sdx_ctx* ctx);
 int sdx_set_stream(sdx_ctx* ctx, void* stream);
 void* sdx_get_stream(sdx_ctx* ctx);
 int sdx_synchronize(sdx_ctx* ctx);
-/* tuning knobs; "indexed_min_lines" (default 8192): line lists at least this long use the dense-list wide-window path */
+/* options: "indexed_min_lines" (default 8192): line lists at least this long use the dense-list wide-window path;
+ * "mixed_precision" (default 0): 1 evaluates the far-wing (Faddeeva region I) rational of whole-tile windows in fp32
+ * (frequency offsets and all sums stay fp64) — a tolerance mode, ~1e-6 relative on opacities instead of 1e-13 */
 int sdx_set_int_option(sdx_ctx* ctx, const char* name, int64_t value);
 
 /* device memory for callers that do not bring their own (numpy-only users) */

@@ -37,3 +37,13 @@ if w["lines"]["line_nus"].size <= 20000:
     t0 = time.time()
     ref = oracle.calc_alan_entries(56, w["nus"], w["lines"]["line_nus"], w["lines"]["doppler_widths"], w["lines"]["gammas"], w["lines"]["alphas"])
     print(f"oracle line opacity {time.time()-t0:.1f}s; rel err", float(np.max(np.abs(line - ref) / np.maximum(np.abs(ref), 1e-300))))
+if "--mixed" in sys.argv:
+    ctx.set_option("mixed_precision", 1)
+    syn.enqueue(); ctx.synchronize()
+    ctx.call("sdx_profile_enable", 1); ctx.call("sdx_profile_reset")
+    for _ in range(3): syn.enqueue()
+    ctx.synchronize()
+    cnt, ms = C.c_int64(), C.c_double()
+    _lib.check(ctx.lib.sdx_profile_get(ctx.handle, b"k_line_all", C.byref(cnt), C.byref(ms)))
+    print(f"mixed precision: k_line_all {ms.value/cnt.value*1e3:.1f} us; line opacity rel diff vs fp64 {float(np.max(np.abs(syn.alpha_line()-line)/np.maximum(np.abs(line),1e-300))):.2e}")
+    ctx.call("sdx_profile_enable", 0); ctx.set_option("mixed_precision", 0)

@@ -327,7 +327,7 @@ __global__ __launch_bounds__(kPreBlock) void k_line_prepass(int n_depth, int64_t
 // their depth-column constants, then every lane walks the compacted list.  Splitting the line list over S blocks
 // shortens the serial chain of the deepest (hottest) layers, whose windows are widest; the S partial planes are
 // added in subset order by the consumer (k_reduce_partials / k_total_alphas).  No atomics: bit-stable results.
-template <int R>
+template <int R, bool MIXED>
 __device__ __forceinline__ void line_wide_block(const int tile_idx, const int split, const int n_split, const int d, int64_t n_nu, const double* __restrict__ nus, int64_t nu_begin,
                                                   int64_t nu_count, int64_t n_lines, const double* __restrict__ line_nus,
                                                   LineWork w, double* __restrict__ partial, int64_t pld, int n_depth)
@@ -402,10 +402,12 @@ __device__ __forceinline__ void line_wide_block(const int tile_idx, const int sp
             const RegionI k1 = {s_yk[j], s_c2[j], s_c3[j], s_c4[j]};
             if (__builtin_amdgcn_readfirstlane(s_fast[j])) {
                 // same operations, in the same order, as voigt_term's region-I branch: bit-identical results
+                // (MIXED: the fp32 rational of the optional mixed-precision mode instead)
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const double x = (nu_i[r] - lnu) * inv;
-                    acc[r] += amp * region1_re(x * x, k1);
+                    if (MIXED) acc[r] = fma(amp, region1_re_mixed(x, k1), acc[r]);
+                    else acc[r] += amp * region1_re(x * x, k1);
                 }
             } else {
                 const double y = s_y[j];
@@ -429,8 +431,8 @@ __global__ __launch_bounds__(64, 4) void k_line_wide(int64_t n_nu, const double*
 {
     // grid = (tiles, subsets, depths): depth is the slowest index so the innermost (hottest, widest-window)
     // layers are dispatched first and the light outer layers fill the tail
-    line_wide_block<R>(blockIdx.x, blockIdx.y, gridDim.y, blockIdx.z, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, partial, pld,
-                       n_depth);
+    line_wide_block<R, false>(blockIdx.x, blockIdx.y, gridDim.y, blockIdx.z, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, partial,
+                              pld, n_depth);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -521,7 +523,7 @@ __device__ __forceinline__ int first_below(const int* __restrict__ key, int n, i
 // class only over the entries whose centre lies within kMediumHalfWidth of the tile.  List chunk q (64 entries, by
 // absolute list position) belongs to subset q mod S, so the partition — and with it the summation order of a grid
 // point — does not depend on the tile or on how the grid is sharded.
-template <int R>
+template <int R, bool MIXED>
 __device__ __forceinline__ void line_wide_block_indexed(const int tile_idx, const int split, const int n_split, const int d,
                                                         const double* __restrict__ nus, int64_t nu_begin, int64_t nu_count,
                                                         LineWork w, double* __restrict__ partial, int64_t pld, int n_depth)
@@ -598,7 +600,8 @@ __device__ __forceinline__ void line_wide_block_indexed(const int tile_idx, cons
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
                         const double x = (nu_i[r] - lnu) * inv;
-                        acc[r] += amp * region1_re(x * x, k1);
+                        if (MIXED) acc[r] = fma(amp, region1_re_mixed(x, k1), acc[r]);
+                        else acc[r] += amp * region1_re(x * x, k1);
                     }
                 } else {
                     const double y = s_y[j];
@@ -677,7 +680,7 @@ __global__ __launch_bounds__(64) void k_line_narrow(int n_depth, int64_t n_nu, c
 // Both line kernels in ONE launch: blocks [0, n_wide) take the wide role (depth slowest, hottest layers first), the
 // rest the narrow role.  The two only share the pre-pass, and each leaves issue slots idle on its own; a
 // cross-stream fork/join would cost two ~12 us inter-queue edges per step, one grid costs nothing.
-template <int R, bool INDEXED>
+template <int R, bool INDEXED, bool MIXED>
 __global__ __launch_bounds__(64, 4) void k_line_all(int n_wide, int tiles, int n_split, int n_depth, int64_t n_nu,
                                                     const double* __restrict__ nus, int64_t nu_begin, int64_t nu_count,
                                                     int64_t n_lines, const double* __restrict__ line_nus, LineWork w,
@@ -687,10 +690,11 @@ __global__ __launch_bounds__(64, 4) void k_line_all(int n_wide, int tiles, int n
     if (b < n_wide) {
         const int tile = b % tiles, rest = b / tiles;
         if (INDEXED)
-            line_wide_block_indexed<R>(tile, rest % n_split, n_split, rest / n_split, nus, nu_begin, nu_count, w, partial, pld, n_depth);
+            line_wide_block_indexed<R, MIXED>(tile, rest % n_split, n_split, rest / n_split, nus, nu_begin, nu_count, w, partial, pld,
+                                              n_depth);
         else
-            line_wide_block<R>(tile, rest % n_split, n_split, rest / n_split, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w,
-                               partial, pld, n_depth);
+            line_wide_block<R, MIXED>(tile, rest % n_split, n_split, rest / n_split, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w,
+                                      partial, pld, n_depth);
     } else {
         const int64_t c = b - n_wide;
         line_narrow_wave(nu_begin + c % nu_count, (int)(c / nu_count), n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w,

@@ -179,6 +179,18 @@ __device__ __forceinline__ double region1_re(double q, const RegionI& k)
     return num * recip(den);
 }
 
+// Mixed-precision variant of region1_re (the optional "fp32 mixed" tolerance path): x is formed in fp64 — fp32 cannot
+// resolve nu_i - nu_l — and the rational function is evaluated in fp32 (relative error ~3e-7 per term; the terms of a
+// grid point are all positive, so the sum keeps that relative error).  Accumulation stays fp64.
+__device__ __forceinline__ double region1_re_mixed(double x, const RegionI& k)
+{
+    const float xf = (float)x;
+    const float q = xf * xf;
+    const float num = (float)k.yk * (q + (float)k.c2);
+    const float den = fmaf(q, q + (float)k.c3, (float)k.c4);
+    return (double)(num * __builtin_amdgcn_rcpf(den));
+}
+
 // Re w for regions II-IV (real part only).
 __device__ inline double faddeeva_re_core(double x, double y, double ax)
 {

@@ -67,6 +67,7 @@ struct sdx_ctx {
     size_t dense_ws_bytes = 0;
     // tuning options (sdx_set_int_option)
     int64_t indexed_min_lines = 8192;  // line lists at least this long go through the dense-list (indexed) wide path
+    int64_t mixed_precision = 0;       // 1: fp32 rational for far-wing (region I) evaluations of whole-tile windows
     // timing
     hipEvent_t t0 = nullptr, t1 = nullptr;
     // side stream + fork/join events: independent kernels of one step (wide / narrow line opacity) overlap
@@ -330,6 +331,10 @@ int sdx_set_int_option(sdx_ctx* ctx, const char* name, int64_t value)
     REQUIRE(ctx && name, "sdx_set_int_option: null pointer");
     if (std::strcmp(name, "indexed_min_lines") == 0) {
         ctx->indexed_min_lines = value;
+        return SDX_OK;
+    }
+    if (std::strcmp(name, "mixed_precision") == 0) {
+        ctx->mixed_precision = value ? 1 : 0;
         return SDX_OK;
     }
     return fail(SDX_ERR_ARG, std::string("unknown option ") + name);
@@ -623,14 +628,15 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
     const int64_t n_wide = (int64_t)tiles * n_split * n_depth;
     const int64_t n_narrow = nu_count * ((n_depth + 63) / 64);
     static const bool split_launches = std::getenv("SDX_SPLIT_LAUNCHES") != nullptr;  // analysis knob: time the two roles apart
-    if ((!split_launches || indexed) && n_wide + n_narrow < ((int64_t)1 << 31)) {
+    if ((!split_launches || indexed || ctx->mixed_precision) && n_wide + n_narrow < ((int64_t)1 << 31)) {
         LaunchScope ls(ctx, "k_line_all");
-        if (indexed)
-            hipLaunchKernelGGL((k_line_all<R, true>), dim3((unsigned)(n_wide + n_narrow)), dim3(64), 0, ctx->stream, (int)n_wide, tiles,
-                               n_split, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, part, pld);
-        else
-            hipLaunchKernelGGL((k_line_all<R, false>), dim3((unsigned)(n_wide + n_narrow)), dim3(64), 0, ctx->stream, (int)n_wide, tiles,
-                               n_split, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, part, pld);
+        const dim3 g((unsigned)(n_wide + n_narrow));
+#define SDX_LINE_ARGS (int)n_wide, tiles, n_split, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, part, pld
+        if (indexed && ctx->mixed_precision) hipLaunchKernelGGL((k_line_all<R, true, true>), g, dim3(64), 0, ctx->stream, SDX_LINE_ARGS);
+        else if (indexed) hipLaunchKernelGGL((k_line_all<R, true, false>), g, dim3(64), 0, ctx->stream, SDX_LINE_ARGS);
+        else if (ctx->mixed_precision) hipLaunchKernelGGL((k_line_all<R, false, true>), g, dim3(64), 0, ctx->stream, SDX_LINE_ARGS);
+        else hipLaunchKernelGGL((k_line_all<R, false, false>), g, dim3(64), 0, ctx->stream, SDX_LINE_ARGS);
+#undef SDX_LINE_ARGS
     } else {
         {
             LaunchScope ls(ctx, "k_line_wide");

@@ -207,3 +207,25 @@ def test_deep_models_and_many_angles(ctx, n_depth, n_theta):
     for l in (0, 75, 149):
         for d in (0, n_depth // 2, n_depth - 1):
             assert (lo[l, d], hi[l, d]) == oracle.window(nus, lines["line_nus"][l], lines["gammas"][l, d], lines["doppler_widths"][l, d], lines["alphas"][l, d])
+
+
+def test_mixed_precision_mode_is_a_tolerance_path(ctx):
+    """BASELINE config 5's tolerance path: far-wing (region I) evaluations of whole-tile windows in fp32, frequency
+    offsets and sums in fp64.  Stated tolerance 1e-5 relative on opacity and flux (observed ~1e-7); fp64 remains the
+    default and the parity path."""
+    atm, nus, lines, cont, th, w = small_workload(n_lines=400, step=0.005, seed=23)
+    ref = oracle.calc_alan_entries(56, nus, lines["line_nus"], lines["doppler_widths"], lines["gammas"], lines["alphas"])
+    syn64 = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], th, w, lines, cont, ctx=ctx)
+    syn64.step()
+    a64, F64 = syn64.alpha_line(), syn64.F_nu()
+    try:
+        ctx.set_option("mixed_precision", 1)
+        syn = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], th, w, lines, cont, ctx=ctx)
+        syn.step()
+        a32, F32 = syn.alpha_line(), syn.F_nu()
+    finally:
+        ctx.set_option("mixed_precision", 0)
+    assert not np.array_equal(a32, a64)  # the mode really took the fp32 route
+    assert rel_err(a32, ref) < 1e-5
+    assert rel_err(F32[1:], F64[1:]) < 1e-5
+    print("mixed precision: opacity rel err", rel_err(a32, a64), "flux", rel_err(F32[1:], F64[1:]))
