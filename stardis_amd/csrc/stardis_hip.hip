@@ -1049,13 +1049,14 @@ static int raytrace_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, c
     REQUIRE(nus && temps && ray_dist && wts && ((alphas && ald >= n_nu) || ft.cont), "raytrace: null pointer");
     REQUIRE(!ft.cont || n_theta <= 64, "raytrace: the fused total needs all angles in one launch");
     REQUIRE((F && fld >= n_nu) || I_nus, "raytrace: no output requested");
-    // Angles per lane P and lanes per frequency G = ceil(n_theta / P): one angle per lane fills the chip when the
-    // grid is small; more angles per lane share the staged column when it is large.
+    // Angles per lane P and lanes per frequency G = ceil(n_theta / P).  P = 1 (one lane per (frequency, angle)) is the
+    // default at every size measured; SDX_RT_P overrides it for experiments.
     constexpr int kMaxChunk = 64;
     for (int th0 = 0; th0 < n_theta; th0 += kMaxChunk) {
         const int nth = std::min(kMaxChunk, n_theta - th0);
         const int64_t work = n_nu * (int64_t)nth;
-        int P = work < ((int64_t)1 << 19) ? 1 : (work < ((int64_t)1 << 21) ? 2 : 4);
+        (void)work;
+        int P = 1;  // measured on MI355X at 7.6e3 and 1.2e5 frequencies: one angle per lane wins (more waves in flight)
         if (const char* e = std::getenv("SDX_RT_P")) {  // tuning knob: angles per lane (1, 2 or 4)
             const int v = std::atoi(e);
             if (v == 1 || v == 2 || v == 4) P = v;
