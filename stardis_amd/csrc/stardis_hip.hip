@@ -581,7 +581,7 @@ static int choose_splits(int n_depth, int64_t n_nu_global, int64_t n_lines, int 
 {
     const int64_t tiles = (n_nu_global + 64 * R - 1) / (64 * R);
     const int64_t chunks = (n_lines + 63) / 64;
-    int64_t target = 8192;
+    int64_t target = 2560;  // measured optimum on S-c2: 2 subsets; more planes cost the raytrace staging more than the shorter chains gain
     if (const char* e = std::getenv("SDX_WIDE_BLOCKS")) target = std::max(1, std::atoi(e));  // tuning knob
     const int64_t want = (target + tiles * n_depth - 1) / (tiles * n_depth);
     return (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(want, chunks), 32));
