@@ -271,6 +271,9 @@ def main():
                 "voigt_evaluations_per_s": (evals / world) / ((kern.get("k_line_all", 0.0) + kern.get("k_line_wide", 0.0) + kern.get("k_line_narrow", 0.0)) * 1e-3),
             },
         }
+        valu = profiled_valu(kern) if (world == 1 and args.workload == "S-c2") else None
+        if valu is not None:
+            out["roofline_fp64_valu"] = valu
         if world == 1 and not args.no_cpu_baseline:
             base, F_cpu = cpu_baseline(w)
             out["cpu_baseline"] = base
@@ -304,6 +307,30 @@ def profiled_traffic(kernel):
             return None
         total += sum(vals) / len(vals) * 1024.0
     return total
+
+
+FP64_VALU_PEAK = 439.0e9  # wave-level fp64 VALU instructions/s the chip sustains (scripts/fp64_peak.hip: 55 TFLOP/s FMA)
+
+
+def profiled_valu(kern):
+    """The bound that actually limits this path: fp64 VALU issue.  Wave-level VALU instructions per step from the
+    committed SQ_INSTS_VALU pass (profiles/, S-c2) over the kernel time measured live in this run."""
+    import csv
+
+    path = os.path.join(ROOT, "profiles", "r01_S-c2_pmc_SQ.csv")
+    if not os.path.exists(path):
+        return None
+    rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == "SQ_INSTS_VALU"]
+    insts, t_ms = 0.0, 0.0
+    for name, ms in kern.items():
+        vals = [float(r["Counter_Value"]) for r in rows if name in r["Kernel_Name"]]
+        if not vals:
+            return None
+        insts += sum(vals) / len(vals)
+        t_ms += ms
+    achieved = insts / (t_ms * 1e-3)
+    return {"bound": "fp64-valu-issue", "achieved": achieved / 1e9, "peak": FP64_VALU_PEAK / 1e9, "unit": "G wave-instr/s",
+            "frac": achieved / FP64_VALU_PEAK, "valu_wave_instr_per_step": insts, "kernel_ms_per_step": t_ms}
 
 
 def synth_desc(tag):

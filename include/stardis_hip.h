@@ -239,6 +239,60 @@ int sdx_synthesize_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nu
                        double* alpha_line_out, double* total_alphas, double* F_nu, int64_t ld,
                        int64_t* n_evaluations_dev);
 
+/* ---- line parameters generated on the device ---------------------------------------
+ * Instead of the three dense (N_l, N_d) tables the reference builds on the host before calc_alan_entries —
+ * alpha_line (plasma/base.py:178-321 AlphaLineVald, :324-455 AlphaLineShortlistVald; plasma/molecules.py:192-320,
+ * :322-440 the molecular twins), gammas and doppler_widths (opacities_solvers/broadening.py:659-732
+ * calculate_broadening, :735-821 calculate_molecule_broadening, :1009-1085 calc_vald_gamma) — the caller passes
+ * ~80 B of per-line scalars plus per-depth state, and the pre-pass evaluates the three values per (line, depth) itself.
+ * Lines are sorted by ascending nu and already restricted to the grid's range, exactly as
+ * calc_alpha_line_at_nu prepares them (opacities_solvers/base.py:392-421).  All pointers are device pointers.
+ *   alpha = ((alpha_coefficient * ((exp(-e_low/(k T)) * pop[pop_row]) [* g_lo])) * strength) * (1 - exp(-h nu/(k T)))
+ * gamma_mode: 0 = calc_gamma (broadening.py:550-656), 1 = calc_vald_gamma (:1009-1085), 2 = A_ul only, one column
+ * (molecules, :799-801), 3 = zero.  broadening_flags: 1 linear Stark | 2 quadratic Stark | 4 van der Waals | 8 radiation.
+ * ion_number is the charge seen by the outer electron (`ion_number + 1`, broadening.py:708-709). */
+typedef struct sdx_linelist {
+    int64_t n_lines;
+    const double* nu;          /* [n_lines] Hz, ascending */
+    const double* e_low_ev;    /* [n_lines] lower level energy, eV */
+    const double* g_lo;        /* [n_lines] 2 j_lo + 1; NULL for short lists */
+    const double* strength;    /* [n_lines] f_lu = 10**log_gf / g_lo, or 10**log_gf for short lists */
+    const int32_t* pop_row;    /* [n_lines] row of pop for the line's ion or molecule */
+    const double* pop;         /* [n_pop_rows][n_depth] number density / partition function */
+    int n_pop_rows;
+    double alpha_coefficient;  /* pi e^2 / (m_e c), cgs */
+    const double* mass;        /* [n_lines] g */
+    double microturbulence;    /* cm/s */
+    int gamma_mode;
+    int broadening_flags;
+    const int32_t* atomic_number;
+    const int32_t* ion_number;
+    const double* ionization_energy; /* erg */
+    const double* upper_energy;      /* erg */
+    const double* lower_energy;      /* erg */
+    const double* A_ul;
+    const double* stark;       /* VALD log Stark parameter (gamma_mode 1) */
+    const double* waals;       /* VALD van der Waals parameter (gamma_mode 1) */
+    const double* temperature;       /* [n_depth] K */
+    const double* electron_density;  /* [n_depth] cm^-3 */
+    const double* h_density;         /* [n_depth] neutral hydrogen, cm^-3 */
+} sdx_linelist;
+
+/* The reference's dense tables from a line list (parity checks; any output may be NULL).  gammas is
+ * [n_lines][n_depth], or [n_lines][1] for gamma_mode 2 and 3. */
+int sdx_line_params_dev(sdx_ctx* ctx, int n_depth, const sdx_linelist* lines, double* alphas, double* gammas,
+                        double* doppler_widths);
+
+/* sdx_line_opacity_dev / sdx_synthesize_dev with the line parameters generated in the pre-pass. */
+int sdx_line_opacity_linelist_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin,
+                                  int64_t nu_count, const sdx_linelist* lines, double* out, int64_t out_ld, int accumulate,
+                                  int64_t* n_evaluations_dev);
+int sdx_synthesize_linelist_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin,
+                                int64_t nu_count, const sdx_linelist* lines, const sdx_continuum* cont, int n_theta,
+                                const double* temperature, const double* ray_dist, const double* theta_weights,
+                                double* alpha_line_out, double* total_alphas, double* F_nu, int64_t ld,
+                                int64_t* n_evaluations_dev);
+
 #ifdef __cplusplus
 }
 #endif

@@ -288,6 +288,24 @@ def calc_vald_gamma(atomic_number, ion_number, ionization_energy, upper_energy, 
     return out
 
 
+def alpha_line_linelist(e_low_ev, g_lo, strength, line_nus, pop_row, pop, temps, alpha_coefficient):
+    """plasma/base.py:200-321, :348-455; plasma/molecules.py:214-320, :345-440 — (N_l, N_d) alpha_line table.
+    g_lo None = short list (strength = 10**log_gf), else strength = f_lu."""
+    e, pe = _d(e_low_ev)
+    s, ps = _d(strength)
+    ln, pl = _d(line_nus)
+    r, pr = _i(pop_row)
+    pp, ppop = _d(pop)
+    t, pt = _d(temps)
+    pg = None
+    if g_lo is not None:
+        g, pg = _d(g_lo)
+    out = np.empty((e.size, t.size))
+    lib().orc_alpha_line_linelist(C.c_int64(e.size), C.c_int(t.size), pe, pg, ps, pl, pr, ppop, pt, C.c_double(alpha_coefficient),
+                                  out.ctypes.data_as(_dp))
+    return out
+
+
 def rotation_broadening(flux, velocity_per_pix, v_rot, limb_darkening=0.6):
     """broadening.py:824-877 (flux only; wavelengths pass through)"""
     f, pf = _d(flux)

@@ -45,6 +45,37 @@ class Continuum(C.Structure):
     ]
 
 
+class LineListStruct(C.Structure):
+    """struct sdx_linelist (include/stardis_hip.h)"""
+
+    _fields_ = [
+        ("n_lines", _i64),
+        ("nu", _vp),
+        ("e_low_ev", _vp),
+        ("g_lo", _vp),
+        ("strength", _vp),
+        ("pop_row", _vp),
+        ("pop", _vp),
+        ("n_pop_rows", _int),
+        ("alpha_coefficient", C.c_double),
+        ("mass", _vp),
+        ("microturbulence", C.c_double),
+        ("gamma_mode", _int),
+        ("broadening_flags", _int),
+        ("atomic_number", _vp),
+        ("ion_number", _vp),
+        ("ionization_energy", _vp),
+        ("upper_energy", _vp),
+        ("lower_energy", _vp),
+        ("A_ul", _vp),
+        ("stark", _vp),
+        ("waals", _vp),
+        ("temperature", _vp),
+        ("electron_density", _vp),
+        ("h_density", _vp),
+    ]
+
+
 # name -> (restype, argtypes); every function declared in include/stardis_hip.h
 PROTOTYPES = {
     "sdx_version": (C.c_char_p, []),
@@ -96,6 +127,10 @@ PROTOTYPES = {
     "sdx_convolve1d_reflect_dev": (_int, [_vp, _i64, _vp, _int, _vp, _int, _vp]),
     "sdx_synthesize_dev": (_int, [_vp, _int, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _int, _vp, C.POINTER(Continuum), _int,
                                   _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "sdx_line_params_dev": (_int, [_vp, _int, C.POINTER(LineListStruct), _vp, _vp, _vp]),
+    "sdx_line_opacity_linelist_dev": (_int, [_vp, _int, _i64, _vp, _i64, _i64, C.POINTER(LineListStruct), _vp, _i64, _int, _vp]),
+    "sdx_synthesize_linelist_dev": (_int, [_vp, _int, _i64, _vp, _i64, _i64, C.POINTER(LineListStruct), C.POINTER(Continuum), _int,
+                                           _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
 }
 
 _lib = None

@@ -26,7 +26,9 @@ VACUUM_ELECTRIC_PERMITTIVITY = 1.0 / (4.0 * math.pi)  # broadening.py:23
 C_KMS = 299792.458
 PI = math.pi
 SQRT_PI = math.sqrt(math.pi)  # 1.7724538509055159, voigt.py:12
+ALPHA_COEFFICIENT = 0.026540088545744744  # pi e^2 / (m_e c), plasma/base.py:35
 EV_CGS = 1.602176634e-12
+EV_TO_ERG_ASTROPY = 1.6021766340000001e-12  # the scale astropy applies in (e * u.eV).cgs (plasma/base.py:308-309); pinned by g11
 C_SI = 299792458.0
 # astropy's metre -> Angstrom scale, 1 / (0.1 * 1e-9): tracing_nus.to(u.AA, u.spectral()) evaluates
 # (c / nu) * this (opacities_solvers/base.py:62); the golden vectors pin it bit-for-bit.

@@ -1,0 +1,144 @@
+// sdx_broadening.h — per-(line, depth) scalar formulas of the reference's broadening module, shared by the dense
+// broadening kernels and by the pre-pass when it generates line parameters on the fly.
+#pragma once
+#include "sdx_math.h"
+
+namespace sdx {
+
+// broadening.py scalar formulas (:32-66, :114-137, :193-229, :281-343, :420-473)
+__device__ __forceinline__ double n_effective(int ion, double e_ion, double e_lev)
+{
+    return mul_rn(sqrt(kRydEnergy / sub_rn(e_ion, e_lev)), (double)ion);
+}
+__device__ __forceinline__ double gamma_linear_stark(double nu_, double nl_, double ne)
+{
+    const double a1 = (sub_rn(nu_, nl_) < 1.5) ? 0.642 : 1.0;
+    return mul_rn(mul_rn(mul_rn(0.60, a1), sub_rn(mul_rn(nu_, nu_), mul_rn(nl_, nl_))), pow(ne, 2.0 / 3.0));
+}
+__device__ __forceinline__ double gamma_quadratic_stark(int ion, double nu_, double nl_, double ne, double t)
+{
+    const double eps0 = 1.0 / (4.0 * kPi);
+    const double zi = (double)ion;
+    const double pre = mul_rn(mul_rn(mul_rn(mul_rn(kEesu, kEesu), kBohr), kBohr), kBohr) /
+                       mul_rn(mul_rn(mul_rn(mul_rn(mul_rn(mul_rn(36.0, kH), eps0), zi), zi), zi), zi);
+    const double t1 = mul_rn(nu_, add_rn(mul_rn(mul_rn(5.0, nu_), nu_), 1.0));
+    const double t2 = mul_rn(nl_, add_rn(mul_rn(mul_rn(5.0, nl_), nl_), 1.0));
+    const double c4 = mul_rn(pre, sub_rn(mul_rn(t1, t1), mul_rn(t2, t2)));
+    return mul_rn(mul_rn(mul_rn(mul_rn(1e19, kKB), ne), pow(c4, 2.0 / 3.0)), pow(t, 1.0 / 6.0));
+}
+__device__ __forceinline__ double gamma_van_der_waals(int ion, double nu_, double nl_, double t, double nh)
+{
+    const double u2 = mul_rn(nu_, nu_), l2 = mul_rn(nl_, nl_);
+    const double c6 = mul_rn(6.46e-34, sub_rn(add_rn(mul_rn(5.0, mul_rn(u2, u2)), u2), add_rn(mul_rn(5.0, mul_rn(l2, l2)), l2))) /
+                      (double)(2 * ion * ion);
+    return mul_rn(mul_rn(mul_rn(17.0, pow(mul_rn(mul_rn(8.0, kKB), t) / mul_rn(kPi, kMp), 0.3)), pow(c6, 0.4)), nh);
+}
+__device__ __forceinline__ double doppler_width(double nu, double t, double mass, double xi)
+{
+    return mul_rn(nu / kC, sqrt(add_rn(mul_rn(mul_rn(2.0, kKB), t) / mass, mul_rn(xi, xi))));
+}
+
+// broadening.py:880-1006
+__device__ __forceinline__ double vald_stark(double ne, double stark, double t)
+{
+    const double g = mul_rn(mul_rn(ne, pow(10.0, stark)), pow(t / 1e4, 1.0 / 6));
+    return (mul_rn(ne, stark) >= 0) ? 0.0 : g;
+}
+__device__ inline double vald_vdw(double vdw, double t, double mass, double e_up, double e_lo, double nh, int ion, double e_ion)
+{
+    double g = 0.0;
+    if (vdw < 0) g = mul_rn(pow(10.0, vdw), pow(t / 1e4, 0.38));
+    else if (vdw == 0.0) g = 0.0;
+    else if (vdw < 20) {
+        const double nu_ = n_effective(ion, e_ion, e_up);
+        const double nl_ = n_effective(ion, e_ion, e_lo);
+        g = mul_rn(gamma_van_der_waals(ion, nu_, nl_, t, 1.0), vdw);
+    } else {
+        const double vi = trunc(vdw);
+        const double sigma = mul_rn(mul_rn(vi, kBohr), kBohr);
+        const double alpha = sub_rn(vdw, vi);
+        const double inv_mu = add_rn(1.0 / mul_rn(1.008, kAmu), 1.0 / mass);
+        const double vbar = sqrt(mul_rn(mul_rn(mul_rn(8.0, kKB), t) / kPi, inv_mu));
+        g = mul_rn(mul_rn(mul_rn(mul_rn(mul_rn(2.0, pow(4.0 / kPi, alpha / 2)), tgamma(sub_rn(4.0, alpha) / 2)), 1e6), sigma),
+                   pow(vbar / 1e6, sub_rn(1.0, alpha)));
+    }
+    return mul_rn(g, nh);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Line parameters generated from per-line scalars and per-depth state: what the reference tabulates
+// as three dense (N_l, N_d) arrays before calc_alan_entries — alpha_line (plasma/base.py:200-321, :348-455;
+// plasma/molecules.py:214-320, :345-440), gammas and doppler_widths (broadening.py:659-732, :735-821, :1009-1085) —
+// evaluated for one (line, depth) item.  ~80 B per line cross HBM instead of 24 B x N_d.
+struct LineParams {
+    // alpha_line
+    const double* e_low_ev;   // [N_l] lower level energy, eV
+    const double* g_lo;       // [N_l] 2 j_lo + 1, or null for short lists
+    const double* strength;   // [N_l] f_lu = 10**log_gf / g_lo, or 10**log_gf for short lists; null = dense inputs
+    const int* pop_row;       // [N_l] row of `pop` for the line's ion / molecule
+    const double* pop;        // [rows][N_d] number density / partition function
+    double alpha_coefficient;
+    // doppler width
+    const double* mass;       // [N_l]
+    double xi;                // microturbulence, cm/s
+    // gamma
+    int gamma_mode;           // 0 calc_gamma, 1 calc_vald_gamma, 2 A_ul only (molecules, one column), 3 zero
+    int flags;                // 1 linear Stark, 2 quadratic Stark, 4 van der Waals, 8 radiation
+    const int* z;
+    const int* ion;           // charge seen by the outer electron (ion_number + 1)
+    const double* e_ion;
+    const double* e_up;
+    const double* e_lo;
+    const double* a_ul;
+    const double* stark;
+    const double* waals;
+    // per depth
+    const double* temps;
+    const double* n_e;
+    const double* n_h;
+};
+
+constexpr double kKBsi = 1.380649e-23;
+constexpr double kHsi = 6.62607015e-34;
+constexpr double kEvJ = 1.602176634e-19;
+
+__device__ inline double line_alpha_at(const LineParams& p, double line_nu, int64_t l, int d, int n_depth)
+{
+    const double t = p.temps[d];
+    const double inv_kt = 1.0 / mul_rn(t, kKBsi);
+    const double expo = exp(mul_rn(mul_rn(-p.e_low_ev[l], inv_kt), kEvJ));                 // base.py:247-251
+    double n_lower = mul_rn(expo, p.pop[(size_t)p.pop_row[l] * n_depth + d]);               // :254-266
+    if (p.g_lo) n_lower = mul_rn(n_lower, p.g_lo[l]);
+    const double corr = sub_rn(1.0, exp(mul_rn((-kHsi) / kKBsi, mul_rn(line_nu, 1.0 / t))));  // :276-286
+    return mul_rn(mul_rn(mul_rn(p.alpha_coefficient, n_lower), p.strength[l]), corr);       // :288-296
+}
+
+__device__ inline double line_gamma_at(const LineParams& p, int64_t l, int d)
+{
+    if (p.gamma_mode == 2) return p.a_ul[l];  // broadening.py:799-801
+    if (p.gamma_mode == 3) return 0.0;
+    const int ion = p.ion[l];
+    const double e_ion = p.e_ion[l], e_up = p.e_up[l], e_lo = p.e_lo[l];
+    if (p.gamma_mode == 0) {  // broadening.py:550-656
+        const double nu_ = n_effective(ion, e_ion, e_up);
+        const double nl_ = n_effective(ion, e_ion, e_lo);
+        const double g_lin = ((p.flags & 1) && p.z[l] == 1) ? gamma_linear_stark(nu_, nl_, p.n_e[d]) : 0.0;
+        const double g_q = (p.flags & 2) ? gamma_quadratic_stark(ion, nu_, nl_, p.n_e[d], p.temps[d]) : 0.0;
+        const double g_w = (p.flags & 4) ? gamma_van_der_waals(ion, nu_, nl_, p.temps[d], p.n_h[d]) : 0.0;
+        const double g_r = (p.flags & 8) ? p.a_ul[l] : 0.0;
+        return add_rn(add_rn(add_rn(g_lin, g_q), g_w), g_r);
+    }
+    double g = 0.0;  // broadening.py:1009-1085
+    if (p.flags & 8) g = add_rn(g, p.a_ul[l]);
+    if ((p.flags & 1) && p.z[l] == 1) {
+        const double nu_ = n_effective(ion, e_ion, e_up);
+        const double nl_ = n_effective(ion, e_ion, e_lo);
+        g = add_rn(g, gamma_linear_stark(nu_, nl_, p.n_e[d]));
+    }
+    if (p.flags & 2) g = add_rn(g, vald_stark(p.n_e[d], p.stark[l], p.temps[d]));
+    if (p.flags & 4) g = add_rn(g, vald_vdw(p.waals[l], p.temps[d], p.mass[l], e_up, e_lo, p.n_h[d], ion, e_ion));
+    return g / 2;
+}
+
+}  // namespace sdx

@@ -7,6 +7,7 @@
 //   outputs  [N_d][ld] with the frequency index contiguous: every kernel has lane <-> nu, coalesced.
 #pragma once
 #include "sdx_math.h"
+#include "sdx_broadening.h"
 
 namespace sdx {
 
@@ -140,6 +141,7 @@ struct LineWork {
     unsigned long long* evals;
 };
 
+template <bool GEN>
 __device__ __forceinline__ void prepass_block(const int bx, const int by, const int gy, int n_depth, int64_t n_nu, const double* __restrict__ nus,
                                                          const double* __restrict__ dnu_partial, int n_partial,
                                                          int64_t n_lines, const double* __restrict__ line_nus,
@@ -147,7 +149,7 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
                                                          const double* __restrict__ gammas, int gamma_cols,
                                                          const double* __restrict__ alphas, LineWork w,
                                                          int* __restrict__ out_lo_ref, int* __restrict__ out_hi_ref,
-                                                         int n_line_blocks)
+                                                         int n_line_blocks, const LineParams& lp)
 {
     if (bx >= n_line_blocks) {
         // trailing blocks: cnt_ge[p] = #{l : centre_l >= p} = #{l : line_nu_l <= nus[p-1]}  (centre_l = #{i : nus[i] >= line_nu_l})
@@ -216,14 +218,27 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
     // d_nu (:524-526): from the partial maxima of k_dnu_partial, or — small grids — scanned here directly
     const double d_nu = dnu_partial ? block_dnu(dnu_partial, n_partial, s_red) : block_dnu_scan(nus, n_nu, s_red);
 
-    // reference layout in, line fastest ... depth fastest: coalesced
-    for (int k = threadIdx.x; k < nl * nd; k += nthreads) {
-        const int ll = k / nd, dd = k - ll * nd;
-        const int64_t l = l0 + ll;
-        const int d = d0 + dd;
-        s_dw[ll * kStride + dd] = doppler[l * n_depth + d];
-        s_a[ll * kStride + dd] = alphas[l * n_depth + d];
-        s_g[ll * kStride + dd] = gamma_cols > 1 ? gammas[l * gamma_cols + d] : gammas[l * gamma_cols];
+    if constexpr (GEN) {
+        // line parameters from per-line scalars and per-depth state (f1): nothing dense to read
+        for (int k = threadIdx.x; k < nl * nd; k += nthreads) {
+            const int ll = k / nd, dd = k - ll * nd;
+            const int64_t l = l0 + ll;
+            const int d = d0 + dd;
+            const double lnu = line_nus[l];
+            s_dw[ll * kStride + dd] = doppler_width(lnu, lp.temps[d], lp.mass[l], lp.xi);
+            s_a[ll * kStride + dd] = line_alpha_at(lp, lnu, l, d, n_depth);
+            s_g[ll * kStride + dd] = line_gamma_at(lp, l, d);
+        }
+    } else {
+        // reference layout in, line fastest ... depth fastest: coalesced
+        for (int k = threadIdx.x; k < nl * nd; k += nthreads) {
+            const int ll = k / nd, dd = k - ll * nd;
+            const int64_t l = l0 + ll;
+            const int d = d0 + dd;
+            s_dw[ll * kStride + dd] = doppler[l * n_depth + d];
+            s_a[ll * kStride + dd] = alphas[l * n_depth + d];
+            s_g[ll * kStride + dd] = gamma_cols > 1 ? gammas[l * gamma_cols + d] : gammas[l * gamma_cols];
+        }
     }
     __syncthreads();
 
@@ -306,6 +321,7 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
     }
 }
 
+template <bool GEN>
 __global__ __launch_bounds__(kPreBlock) void k_line_prepass(int n_depth, int64_t n_nu, const double* __restrict__ nus,
                                                          const double* __restrict__ dnu_partial, int n_partial,
                                                          int64_t n_lines, const double* __restrict__ line_nus,
@@ -313,10 +329,10 @@ __global__ __launch_bounds__(kPreBlock) void k_line_prepass(int n_depth, int64_t
                                                          const double* __restrict__ gammas, int gamma_cols,
                                                          const double* __restrict__ alphas, LineWork w,
                                                          int* __restrict__ out_lo_ref, int* __restrict__ out_hi_ref,
-                                                         int n_line_blocks)
+                                                         int n_line_blocks, LineParams lp)
 {
-    prepass_block(blockIdx.x, blockIdx.y, gridDim.y, n_depth, n_nu, nus, dnu_partial, n_partial, n_lines, line_nus, doppler, gammas,
-                  gamma_cols, alphas, w, out_lo_ref, out_hi_ref, n_line_blocks);
+    prepass_block<GEN>(blockIdx.x, blockIdx.y, gridDim.y, n_depth, n_nu, nus, dnu_partial, n_partial, n_lines, line_nus, doppler, gammas,
+                       gamma_cols, alphas, w, out_lo_ref, out_hi_ref, n_line_blocks, lp);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -756,39 +772,7 @@ __global__ __launch_bounds__(kBlock) void k_weights(int64_t n, const double* __r
 }
 
 // ------------------------------------------------------------------------------------------------
-// broadening.py scalar formulas (:32-66, :114-137, :193-229, :281-343, :420-473)
-__device__ __forceinline__ double n_effective(int ion, double e_ion, double e_lev)
-{
-    return mul_rn(sqrt(kRydEnergy / sub_rn(e_ion, e_lev)), (double)ion);
-}
-__device__ __forceinline__ double gamma_linear_stark(double nu_, double nl_, double ne)
-{
-    const double a1 = (sub_rn(nu_, nl_) < 1.5) ? 0.642 : 1.0;
-    return mul_rn(mul_rn(mul_rn(0.60, a1), sub_rn(mul_rn(nu_, nu_), mul_rn(nl_, nl_))), pow(ne, 2.0 / 3.0));
-}
-__device__ __forceinline__ double gamma_quadratic_stark(int ion, double nu_, double nl_, double ne, double t)
-{
-    const double eps0 = 1.0 / (4.0 * kPi);
-    const double zi = (double)ion;
-    const double pre = mul_rn(mul_rn(mul_rn(mul_rn(kEesu, kEesu), kBohr), kBohr), kBohr) /
-                       mul_rn(mul_rn(mul_rn(mul_rn(mul_rn(mul_rn(36.0, kH), eps0), zi), zi), zi), zi);
-    const double t1 = mul_rn(nu_, add_rn(mul_rn(mul_rn(5.0, nu_), nu_), 1.0));
-    const double t2 = mul_rn(nl_, add_rn(mul_rn(mul_rn(5.0, nl_), nl_), 1.0));
-    const double c4 = mul_rn(pre, sub_rn(mul_rn(t1, t1), mul_rn(t2, t2)));
-    return mul_rn(mul_rn(mul_rn(mul_rn(1e19, kKB), ne), pow(c4, 2.0 / 3.0)), pow(t, 1.0 / 6.0));
-}
-__device__ __forceinline__ double gamma_van_der_waals(int ion, double nu_, double nl_, double t, double nh)
-{
-    const double u2 = mul_rn(nu_, nu_), l2 = mul_rn(nl_, nl_);
-    const double c6 = mul_rn(6.46e-34, sub_rn(add_rn(mul_rn(5.0, mul_rn(u2, u2)), u2), add_rn(mul_rn(5.0, mul_rn(l2, l2)), l2))) /
-                      (double)(2 * ion * ion);
-    return mul_rn(mul_rn(mul_rn(17.0, pow(mul_rn(mul_rn(8.0, kKB), t) / mul_rn(kPi, kMp), 0.3)), pow(c6, 0.4)), nh);
-}
-__device__ __forceinline__ double doppler_width(double nu, double t, double mass, double xi)
-{
-    return mul_rn(nu / kC, sqrt(add_rn(mul_rn(mul_rn(2.0, kKB), t) / mass, mul_rn(xi, xi))));
-}
-
+// broadening kernels (scalar formulas: sdx_broadening.h)
 __global__ __launch_bounds__(kBlock) void k_calc_gamma(int64_t n_lines, int n_depth, const int* __restrict__ z,
                                                        const int* __restrict__ ion, const double* __restrict__ e_ion,
                                                        const double* __restrict__ e_up, const double* __restrict__ e_lo,
@@ -820,6 +804,21 @@ __global__ __launch_bounds__(kBlock) void k_doppler_widths(int64_t n_lines, int 
     out[k] = doppler_width(lnu[l], temps[d], mass[l], xi);
 }
 
+// the three dense tables of the reference from a LineParams description (parity checks of the f1 path; any output may be null)
+__global__ __launch_bounds__(kBlock) void k_line_params(int64_t n_lines, int n_depth, const double* __restrict__ line_nus,
+                                                        LineParams lp, double* __restrict__ alphas, double* __restrict__ gammas,
+                                                        int gamma_cols, double* __restrict__ doppler)
+{
+    const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (k >= n_lines * n_depth) return;
+    const int64_t l = k / n_depth;
+    const int d = (int)(k - l * n_depth);
+    const double lnu = line_nus[l];
+    if (alphas) alphas[k] = line_alpha_at(lp, lnu, l, d, n_depth);
+    if (doppler) doppler[k] = doppler_width(lnu, lp.temps[d], lp.mass[l], lp.xi);
+    if (gammas && (gamma_cols > 1 || d == 0)) gammas[l * gamma_cols + (gamma_cols > 1 ? d : 0)] = line_gamma_at(lp, l, d);
+}
+
 // the reference's element-wise ufuncs (broadening.py:69-71, :140-146, :232-234, :346-360, :476-490)
 enum BroadeningOp { kOpDoppler = 0, kOpNEff = 1, kOpLinearStark = 2, kOpQuadraticStark = 3, kOpVanDerWaals = 4 };
 __global__ __launch_bounds__(kBlock) void k_broadening_scalar(int op, int64_t n, const double* __restrict__ a,
@@ -838,33 +837,6 @@ __global__ __launch_bounds__(kBlock) void k_broadening_scalar(int op, int64_t n,
         case kOpVanDerWaals: r = gamma_van_der_waals((int)a[i], b[i], c[i], d[i], e[i]); break;         // ion, n_up, n_lo, T, n_H
     }
     out[i] = r;
-}
-
-// broadening.py:880-1006
-__device__ __forceinline__ double vald_stark(double ne, double stark, double t)
-{
-    const double g = mul_rn(mul_rn(ne, pow(10.0, stark)), pow(t / 1e4, 1.0 / 6));
-    return (mul_rn(ne, stark) >= 0) ? 0.0 : g;
-}
-__device__ inline double vald_vdw(double vdw, double t, double mass, double e_up, double e_lo, double nh, int ion, double e_ion)
-{
-    double g = 0.0;
-    if (vdw < 0) g = mul_rn(pow(10.0, vdw), pow(t / 1e4, 0.38));
-    else if (vdw == 0.0) g = 0.0;
-    else if (vdw < 20) {
-        const double nu_ = n_effective(ion, e_ion, e_up);
-        const double nl_ = n_effective(ion, e_ion, e_lo);
-        g = mul_rn(gamma_van_der_waals(ion, nu_, nl_, t, 1.0), vdw);
-    } else {
-        const double vi = trunc(vdw);
-        const double sigma = mul_rn(mul_rn(vi, kBohr), kBohr);
-        const double alpha = sub_rn(vdw, vi);
-        const double inv_mu = add_rn(1.0 / mul_rn(1.008, kAmu), 1.0 / mass);
-        const double vbar = sqrt(mul_rn(mul_rn(mul_rn(8.0, kKB), t) / kPi, inv_mu));
-        g = mul_rn(mul_rn(mul_rn(mul_rn(mul_rn(2.0, pow(4.0 / kPi, alpha / 2)), tgamma(sub_rn(4.0, alpha) / 2)), 1e6), sigma),
-                   pow(vbar / 1e6, sub_rn(1.0, alpha)));
-    }
-    return mul_rn(g, nh);
 }
 
 __global__ __launch_bounds__(kBlock) void k_calc_vald_gamma(int64_t n_lines, int n_depth, const int* __restrict__ z,
@@ -1100,6 +1072,7 @@ __global__ __launch_bounds__(kBlock) void k_total_alphas(int n_depth, int64_t nu
 
 // Pre-pass and continuum in ONE launch: the pre-pass is a few latency-bound blocks (binary searches, a grid scan);
 // the continuum plane depends on nothing and fills the rest of the chip meanwhile.
+template <bool GEN>
 __global__ __launch_bounds__(kPreBlock) void k_prepass_continuum(int n_pre_x, int n_pre_y, int cont_tiles, int n_depth, int64_t n_nu,
                                                               const double* __restrict__ nus,
                                                               const double* __restrict__ dnu_partial, int n_partial,
@@ -1108,13 +1081,13 @@ __global__ __launch_bounds__(kPreBlock) void k_prepass_continuum(int n_pre_x, in
                                                               const double* __restrict__ gammas, int gamma_cols,
                                                               const double* __restrict__ alphas, LineWork w, int n_line_blocks,
                                                               int64_t nu_begin, int64_t nu_count, ContinuumArgs ca,
-                                                              double* __restrict__ cont_plane, int64_t cont_ld)
+                                                              double* __restrict__ cont_plane, int64_t cont_ld, LineParams lp)
 {
     const int b = blockIdx.x;
     const int n_pre = n_pre_x * n_pre_y;
     if (b < n_pre) {
-        prepass_block(b % n_pre_x, b / n_pre_x, n_pre_y, n_depth, n_nu, nus, dnu_partial, n_partial, n_lines, line_nus, doppler, gammas,
-                      gamma_cols, alphas, w, nullptr, nullptr, n_line_blocks);
+        prepass_block<GEN>(b % n_pre_x, b / n_pre_x, n_pre_y, n_depth, n_nu, nus, dnu_partial, n_partial, n_lines, line_nus, doppler,
+                           gammas, gamma_cols, alphas, w, nullptr, nullptr, n_line_blocks, lp);
     } else {
         const int c = b - n_pre;
         total_alphas_block(c % cont_tiles, c / cont_tiles, n_depth, nu_begin, nu_count, nus, ca, nullptr, 0, 1, nullptr, 0, cont_plane,

@@ -502,8 +502,9 @@ struct ContinuumJob {  // continuum plane computed by the trailing blocks of the
 static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t n_lines, const double* line_nus,
                         const double* doppler, const double* gammas, int gamma_cols, const double* alphas, bool fill_work,
                         int32_t* lo_ref, int32_t* hi_ref, LineWork* w_out, bool count_evals = true,
-                        const ContinuumJob* job = nullptr)
+                        const ContinuumJob* job = nullptr, const LineParams* gen = nullptr)
 {
+    const LineParams lp = gen ? *gen : LineParams{};
     int n_partial = 0;
     int rc = ensure(ctx, &ctx->small_ws, &ctx->small_ws_bytes, kSmallHeader);
     if (rc) return rc;
@@ -545,17 +546,19 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
         const int cont_tiles = (int)((job->nu_count + kPreBlock - 1) / kPreBlock);
         const unsigned total_blocks = grid.x * grid.y + (unsigned)cont_tiles * (unsigned)n_depth;
         LaunchScope ls(ctx, "k_prepass_continuum");
-        hipLaunchKernelGGL(k_prepass_continuum, dim3(total_blocks), dim3(kPreBlock), shmem, ctx->stream, (int)grid.x, (int)grid.y, cont_tiles,
-                           n_depth, n_nu, nus, scan_in_block ? (const double*)nullptr : (const double*)ctx->small_ws, n_partial, n_lines,
-                           line_nus, doppler, gammas, gamma_cols, alphas, w, n_line_blocks, job->nu_begin, job->nu_count, ca, job->plane,
-                           job->nu_count);
+#define SDX_PRE_ARGS (int)grid.x, (int)grid.y, cont_tiles, n_depth, n_nu, nus, scan_in_block ? (const double*)nullptr : (const double*)ctx->small_ws, \
+                     n_partial, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, w, n_line_blocks, job->nu_begin, job->nu_count, ca,          \
+                     job->plane, job->nu_count, lp
+        if (gen) hipLaunchKernelGGL(k_prepass_continuum<true>, dim3(total_blocks), dim3(kPreBlock), shmem, ctx->stream, SDX_PRE_ARGS);
+        else hipLaunchKernelGGL(k_prepass_continuum<false>, dim3(total_blocks), dim3(kPreBlock), shmem, ctx->stream, SDX_PRE_ARGS);
+#undef SDX_PRE_ARGS
     } else {
-        {
-            LaunchScope ls(ctx, "k_line_prepass");
-            hipLaunchKernelGGL(k_line_prepass, grid, dim3(kPreBlock), 0, ctx->stream, n_depth, n_nu, nus,
-                               scan_in_block ? (const double*)nullptr : (const double*)ctx->small_ws, n_partial, n_lines, line_nus,
-                               doppler, gammas, gamma_cols, alphas, w, (int*)lo_ref, (int*)hi_ref, n_line_blocks);
-        }
+        LaunchScope ls(ctx, "k_line_prepass");
+#define SDX_PRE_ARGS n_depth, n_nu, nus, scan_in_block ? (const double*)nullptr : (const double*)ctx->small_ws, n_partial, n_lines, line_nus, doppler, \
+                     gammas, gamma_cols, alphas, w, (int*)lo_ref, (int*)hi_ref, n_line_blocks, lp
+        if (gen) hipLaunchKernelGGL(k_line_prepass<true>, grid, dim3(kPreBlock), 0, ctx->stream, SDX_PRE_ARGS);
+        else hipLaunchKernelGGL(k_line_prepass<false>, grid, dim3(kPreBlock), 0, ctx->stream, SDX_PRE_ARGS);
+#undef SDX_PRE_ARGS
     }
     if (w_out) *w_out = w;
     return check_launch("k_line_prepass");
@@ -593,12 +596,12 @@ static int choose_splits(int n_depth, int64_t n_nu_global, int64_t n_lines, int 
 static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin, int64_t nu_count,
                          int64_t n_lines, const double* line_nus, const double* doppler, const double* gammas, int gamma_cols,
                          const double* alphas, const double** partial_out, int64_t* pld_out, int* n_planes_out, LineWork* w_out,
-                         bool count_evals, const ContinuumJob* job = nullptr)
+                         bool count_evals, const ContinuumJob* job = nullptr, const LineParams* gen = nullptr)
 {
     constexpr int R = 4;
     LineWork w;
     int rc = line_prepass(ctx, n_depth, n_nu, nus, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, true, nullptr, nullptr, &w,
-                          count_evals, job);
+                          count_evals, job, gen);
     if (rc) return rc;
     const int n_split = choose_splits(n_depth, n_nu, n_lines, R);
     // large line lists: build dense per-depth lists of the medium / huge items so tiles stop scanning the whole list
@@ -656,13 +659,12 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
     return check_launch("line kernels");
 }
 
-int sdx_line_opacity_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin, int64_t nu_count,
-                         int64_t n_lines, const double* line_nus, const double* doppler, const double* gammas,
-                         int gamma_cols, const double* alphas, double* out, int64_t out_ld, int accumulate,
-                         int64_t* n_evaluations_dev)
+static int line_opacity_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin, int64_t nu_count,
+                            int64_t n_lines, const double* line_nus, const double* doppler, const double* gammas,
+                            int gamma_cols, const double* alphas, double* out, int64_t out_ld, int accumulate,
+                            int64_t* n_evaluations_dev, const LineParams* gen)
 {
-    int rc = check_line_args(ctx, n_depth, n_nu, nus, n_lines, line_nus, doppler, gammas, gamma_cols, alphas);
-    if (rc) return rc;
+    int rc;
     REQUIRE(nu_begin >= 0 && nu_count >= 0 && nu_begin + nu_count <= n_nu, "line opacity: shard outside the grid");
     REQUIRE(nu_count == 0 || (out && out_ld >= nu_count), "line opacity: bad output buffer");
     if (nu_count == 0) return SDX_OK;
@@ -676,7 +678,7 @@ int sdx_line_opacity_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
     int n_split;
     LineWork w;
     rc = line_partials(ctx, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, &part, &pld,
-                       &n_split, &w, n_evaluations_dev != nullptr);
+                       &n_split, &w, n_evaluations_dev != nullptr, nullptr, gen);
     if (rc) return rc;
     {
         LaunchScope ls(ctx, "k_reduce_partials");
@@ -688,6 +690,86 @@ int sdx_line_opacity_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
     if (n_evaluations_dev)
         HIP_TRY(hipMemcpyAsync(n_evaluations_dev, w.evals, sizeof(int64_t), hipMemcpyDeviceToDevice, ctx->stream));
     return SDX_OK;
+}
+
+int sdx_line_opacity_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin, int64_t nu_count,
+                         int64_t n_lines, const double* line_nus, const double* doppler, const double* gammas,
+                         int gamma_cols, const double* alphas, double* out, int64_t out_ld, int accumulate,
+                         int64_t* n_evaluations_dev)
+{
+    int rc = check_line_args(ctx, n_depth, n_nu, nus, n_lines, line_nus, doppler, gammas, gamma_cols, alphas);
+    if (rc) return rc;
+    return line_opacity_impl(ctx, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, out, out_ld,
+                             accumulate, n_evaluations_dev, nullptr);
+}
+
+// ---- line parameters generated on the device
+static int to_line_params(const sdx_linelist* ll, int n_depth, LineParams* lp)
+{
+    REQUIRE(ll, "line list: null description");
+    REQUIRE(ll->n_lines >= 0 && n_depth > 0, "line list: bad sizes");
+    REQUIRE(ll->gamma_mode >= 0 && ll->gamma_mode <= 3, "line list: gamma_mode must be 0..3");
+    if (ll->n_lines == 0) return SDX_OK;
+    REQUIRE(ll->nu && ll->e_low_ev && ll->strength && ll->pop_row && ll->pop && ll->mass && ll->temperature,
+            "line list: null alpha_line / doppler inputs");
+    REQUIRE(ll->n_pop_rows > 0, "line list: n_pop_rows must be positive");
+    if (ll->gamma_mode <= 1) {
+        REQUIRE(ll->atomic_number && ll->ion_number && ll->ionization_energy && ll->upper_energy && ll->lower_energy && ll->A_ul &&
+                    ll->electron_density && ll->h_density,
+                "line list: null broadening inputs");
+        REQUIRE(ll->gamma_mode == 0 || (ll->stark && ll->waals), "line list: VALD broadening needs stark and waals");
+    }
+    REQUIRE(ll->gamma_mode != 2 || ll->A_ul, "line list: gamma_mode 2 needs A_ul");
+    lp->e_low_ev = ll->e_low_ev;
+    lp->g_lo = ll->g_lo;
+    lp->strength = ll->strength;
+    lp->pop_row = (const int*)ll->pop_row;
+    lp->pop = ll->pop;
+    lp->alpha_coefficient = ll->alpha_coefficient;
+    lp->mass = ll->mass;
+    lp->xi = ll->microturbulence;
+    lp->gamma_mode = ll->gamma_mode;
+    lp->flags = ll->broadening_flags;
+    lp->z = (const int*)ll->atomic_number;
+    lp->ion = (const int*)ll->ion_number;
+    lp->e_ion = ll->ionization_energy;
+    lp->e_up = ll->upper_energy;
+    lp->e_lo = ll->lower_energy;
+    lp->a_ul = ll->A_ul;
+    lp->stark = ll->stark;
+    lp->waals = ll->waals;
+    lp->temps = ll->temperature;
+    lp->n_e = ll->electron_density;
+    lp->n_h = ll->h_density;
+    return SDX_OK;
+}
+
+int sdx_line_params_dev(sdx_ctx* ctx, int n_depth, const sdx_linelist* ll, double* alphas, double* gammas, double* doppler)
+{
+    REQUIRE(ctx, "null context");
+    LineParams lp{};
+    int rc = to_line_params(ll, n_depth, &lp);
+    if (rc) return rc;
+    if (ll->n_lines == 0) return SDX_OK;
+    {
+        LaunchScope ls(ctx, "k_line_params");
+        hipLaunchKernelGGL(k_line_params, dim3(blocks1(ll->n_lines * n_depth)), dim3(kBlock), 0, ctx->stream, ll->n_lines, n_depth, ll->nu,
+                           lp, alphas, gammas, ll->gamma_mode >= 2 ? 1 : n_depth, doppler);
+    }
+    return check_launch("k_line_params");
+}
+
+int sdx_line_opacity_linelist_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin, int64_t nu_count,
+                                  const sdx_linelist* ll, double* out, int64_t out_ld, int accumulate, int64_t* n_evaluations_dev)
+{
+    REQUIRE(ctx, "null context");
+    REQUIRE(n_depth > 0 && n_nu >= 0 && n_nu < (int64_t)2147483647, "line opacity: bad sizes");
+    REQUIRE(n_nu == 0 || nus, "line opacity: null frequency grid");
+    LineParams lp{};
+    int rc = to_line_params(ll, n_depth, &lp);
+    if (rc) return rc;
+    return line_opacity_impl(ctx, n_depth, n_nu, nus, nu_begin, nu_count, ll->n_lines, ll->nu, nullptr, nullptr,
+                             ll->gamma_mode >= 2 ? 1 : n_depth, nullptr, out, out_ld, accumulate, n_evaluations_dev, &lp);
 }
 
 int sdx_line_windows_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t n_lines, const double* line_nus,
@@ -1139,14 +1221,13 @@ int sdx_convolve1d_reflect_dev(sdx_ctx* ctx, int64_t n, const double* in, int m,
 }
 
 // ================================================================================================ fused synthesis
-int sdx_synthesize_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin, int64_t nu_count,
-                       int64_t n_lines, const double* line_nus, const double* doppler, const double* gammas, int gamma_cols,
-                       const double* alphas, const sdx_continuum* cont, int n_theta, const double* temps,
-                       const double* ray_dist, const double* wts, double* alpha_line_out, double* total_alphas, double* F_nu,
-                       int64_t ld, int64_t* n_evaluations_dev)
+static int synthesize_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin, int64_t nu_count,
+                           int64_t n_lines, const double* line_nus, const double* doppler, const double* gammas, int gamma_cols,
+                           const double* alphas, const sdx_continuum* cont, int n_theta, const double* temps,
+                           const double* ray_dist, const double* wts, double* alpha_line_out, double* total_alphas, double* F_nu,
+                           int64_t ld, int64_t* n_evaluations_dev, const LineParams* gen)
 {
-    int rc = check_line_args(ctx, n_depth, n_nu, nus, n_lines, line_nus, doppler, gammas, gamma_cols, alphas);
-    if (rc) return rc;
+    int rc;
     REQUIRE(cont && temps && ray_dist && wts && n_theta > 0 && n_depth >= 2, "synthesize: bad arguments");
     REQUIRE(nu_begin >= 0 && nu_count >= 0 && nu_begin + nu_count <= n_nu, "synthesize: shard outside the grid");
     REQUIRE(nu_count == 0 || (total_alphas && F_nu && ld >= nu_count), "synthesize: bad output buffers");
@@ -1165,7 +1246,7 @@ int sdx_synthesize_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nu
     if (n_lines > 0) {
         LineWork w;
         rc = line_partials(ctx, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, &part, &pld,
-                           &n_planes, &w, n_evaluations_dev != nullptr, &job);
+                           &n_planes, &w, n_evaluations_dev != nullptr, &job, gen);
         if (rc) return rc;
         if (n_evaluations_dev)
             HIP_TRY(hipMemcpyAsync(n_evaluations_dev, w.evals, sizeof(int64_t), hipMemcpyDeviceToDevice, ctx->stream));
@@ -1203,6 +1284,34 @@ int sdx_synthesize_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nu
     ft.line_out = part ? alpha_line_out : nullptr;
     ft.out_ld = ld;
     return raytrace_impl(ctx, n_depth, nu_count, n_theta, nus + nu_begin, temps, ray_dist, wts, nullptr, 0, F_nu, ld, nullptr, 0, 0, &ft);
+}
+
+int sdx_synthesize_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin, int64_t nu_count,
+                       int64_t n_lines, const double* line_nus, const double* doppler, const double* gammas, int gamma_cols,
+                       const double* alphas, const sdx_continuum* cont, int n_theta, const double* temps,
+                       const double* ray_dist, const double* wts, double* alpha_line_out, double* total_alphas, double* F_nu,
+                       int64_t ld, int64_t* n_evaluations_dev)
+{
+    int rc = check_line_args(ctx, n_depth, n_nu, nus, n_lines, line_nus, doppler, gammas, gamma_cols, alphas);
+    if (rc) return rc;
+    return synthesize_impl(ctx, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, cont, n_theta,
+                           temps, ray_dist, wts, alpha_line_out, total_alphas, F_nu, ld, n_evaluations_dev, nullptr);
+}
+
+int sdx_synthesize_linelist_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin, int64_t nu_count,
+                                const sdx_linelist* ll, const sdx_continuum* cont, int n_theta, const double* temps,
+                                const double* ray_dist, const double* wts, double* alpha_line_out, double* total_alphas,
+                                double* F_nu, int64_t ld, int64_t* n_evaluations_dev)
+{
+    REQUIRE(ctx, "null context");
+    REQUIRE(n_depth > 0 && n_nu >= 0 && n_nu < (int64_t)2147483647, "synthesize: bad sizes");
+    REQUIRE(n_nu == 0 || nus, "synthesize: null frequency grid");
+    LineParams lp{};
+    int rc = to_line_params(ll, n_depth, &lp);
+    if (rc) return rc;
+    return synthesize_impl(ctx, n_depth, n_nu, nus, nu_begin, nu_count, ll->n_lines, ll->nu, nullptr, nullptr,
+                           ll->gamma_mode >= 2 ? 1 : n_depth, nullptr, cont, n_theta, temps, ray_dist, wts, alpha_line_out, total_alphas,
+                           F_nu, ld, n_evaluations_dev, &lp);
 }
 
 }  // extern "C"

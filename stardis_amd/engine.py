@@ -12,6 +12,7 @@ import numpy as np
 
 from . import _lib
 from . import constants as K
+from . import linelist as LL
 from ._lib import Continuum, default_context, ptr_of
 
 
@@ -26,7 +27,8 @@ class SpectralSynthesizer:
     def __init__(self, nus, temperatures, dist, thetas, theta_weights, lines, continuum=None, ctx=None, shard=None,
                  flux_out=None, track_evaluations=True, keep_line=True):
         """nus: global grid (descending).  lines: dict(line_nus, doppler_widths, gammas, alphas) in the
-        reference layout (N_l, N_d).  continuum: dict as produced by synth.synth_continuum_state or None.
+        reference layout (N_l, N_d), or a stardis_amd.linelist.LineList (per-line scalars; the pre-pass generates the
+        three values per (line, depth) itself).  continuum: dict as produced by synth.synth_continuum_state or None.
         shard: (begin, count) of the global frequency index computed here (default: everything).
         flux_out: optional contiguous CUDA tensor (N_d, count) to receive F_nu (e.g. for an RCCL gather)."""
         self.ctx = ctx or default_context()
@@ -34,7 +36,11 @@ class SpectralSynthesizer:
         nus = np.ascontiguousarray(nus, dtype=np.float64)
         if np.any(np.diff(nus) >= 0):
             raise ValueError("tracing frequencies must be strictly descending (stardis/base.py:34)")
-        if np.any(np.asarray(lines["doppler_widths"]) == 0):
+        self.linelist = None
+        if isinstance(lines, (LL.LineList, LL.DeviceLineList)):
+            (lines.host if isinstance(lines, LL.DeviceLineList) else lines).check_sorted()
+            self.linelist = lines if isinstance(lines, LL.DeviceLineList) else lines.upload(c)
+        elif np.any(np.asarray(lines["doppler_widths"]) == 0):
             raise ZeroDivisionError("float division by zero")  # voigt.py:148
         self.n_nu = nus.size
         self.begin, self.count = shard if shard is not None else (0, self.n_nu)
@@ -48,15 +54,20 @@ class SpectralSynthesizer:
         self.d_t = c.upload(t)
         self.d_ray = c.upload(ray)
         self.d_w = c.upload(np.asarray(theta_weights, dtype=np.float64))
-        ln = np.ascontiguousarray(lines["line_nus"], dtype=np.float64)
-        self.n_lines = ln.size
-        g = np.ascontiguousarray(lines["gammas"], dtype=np.float64)
-        g = g.reshape(self.n_lines, -1) if self.n_lines else np.zeros((0, 1))
-        self.gamma_cols = g.shape[1]
-        self.d_ln = c.upload(ln)
-        self.d_dw = c.upload(np.ascontiguousarray(lines["doppler_widths"], dtype=np.float64))
-        self.d_g = c.upload(g)
-        self.d_a = c.upload(np.ascontiguousarray(lines["alphas"], dtype=np.float64))
+        if self.linelist is not None:
+            if self.linelist.n_depth != self.n_depth:
+                raise ValueError("line list and model disagree on the number of depth points")
+            self.n_lines, self.gamma_cols = self.linelist.n_lines, self.linelist.gamma_cols
+        else:
+            ln = np.ascontiguousarray(lines["line_nus"], dtype=np.float64)
+            self.n_lines = ln.size
+            g = np.ascontiguousarray(lines["gammas"], dtype=np.float64)
+            g = g.reshape(self.n_lines, -1) if self.n_lines else np.zeros((0, 1))
+            self.gamma_cols = g.shape[1]
+            self.d_ln = c.upload(ln)
+            self.d_dw = c.upload(np.ascontiguousarray(lines["doppler_widths"], dtype=np.float64))
+            self.d_g = c.upload(g)
+            self.d_a = c.upload(np.ascontiguousarray(lines["alphas"], dtype=np.float64))
 
         self._keep = []
         self.cont = self._build_continuum(continuum, nus, t)
@@ -111,6 +122,12 @@ class SpectralSynthesizer:
     def enqueue(self):
         """One fused step on the context's stream: sdx_synthesize_dev (pre-pass, line gather, total, raytrace)."""
         c = self.ctx
+        if self.linelist is not None:
+            c.call("sdx_synthesize_linelist_dev", self.n_depth, self.n_nu, self.d_nus.ptr, self.begin, self.count,
+                   self.linelist.byref(), C.byref(self.cont), self.n_theta, self.d_t.ptr, self.d_ray.ptr, self.d_w.ptr,
+                   self.d_line.ptr if self.keep_line else None, self.d_total.ptr, self.flux_ptr, self.count,
+                   ptr_of(self.d_evals) if self.count_evaluations else None)
+            return
         c.call("sdx_synthesize_dev", self.n_depth, self.n_nu, self.d_nus.ptr, self.begin, self.count, self.n_lines,
                self.d_ln.ptr, self.d_dw.ptr, self.d_g.ptr, self.gamma_cols, self.d_a.ptr, C.byref(self.cont), self.n_theta,
                self.d_t.ptr, self.d_ray.ptr, self.d_w.ptr, self.d_line.ptr if self.keep_line else None, self.d_total.ptr,
@@ -120,8 +137,12 @@ class SpectralSynthesizer:
         """The same step through the individual entry points (what calc_alphas + raytrace issue)."""
         c = self.ctx
         nd, cnt = self.n_depth, self.count
-        c.call("sdx_line_opacity_dev", nd, self.n_nu, self.d_nus.ptr, self.begin, cnt, self.n_lines, self.d_ln.ptr,
-               self.d_dw.ptr, self.d_g.ptr, self.gamma_cols, self.d_a.ptr, self.d_line.ptr, cnt, 0, ptr_of(self.d_evals))
+        if self.linelist is not None:
+            c.call("sdx_line_opacity_linelist_dev", nd, self.n_nu, self.d_nus.ptr, self.begin, cnt, self.linelist.byref(),
+                   self.d_line.ptr, cnt, 0, ptr_of(self.d_evals))
+        else:
+            c.call("sdx_line_opacity_dev", nd, self.n_nu, self.d_nus.ptr, self.begin, cnt, self.n_lines, self.d_ln.ptr,
+                   self.d_dw.ptr, self.d_g.ptr, self.gamma_cols, self.d_a.ptr, self.d_line.ptr, cnt, 0, ptr_of(self.d_evals))
         c.call("sdx_total_alphas_dev", nd, self.n_nu, self.d_nus.ptr, self.begin, cnt, C.byref(self.cont), self.d_line.ptr, cnt,
                self.d_total.ptr, cnt)
         nus_shard = self.d_nus.ptr + 8 * self.begin
@@ -169,7 +190,11 @@ class SpectralSynthesizer:
 
     def algorithmic_bytes(self):
         """line list, grid read once; total_alphas and F_nu written once (this shard's columns)."""
-        return 8 * self.n_lines * (1 + 2 * self.n_depth + self.gamma_cols) + 8 * self.n_nu + 16 * self.n_depth * self.count
+        if self.linelist is not None:
+            lines = self.n_lines * self.linelist.host.bytes_per_line() + 8 * self.linelist.host.pop.size
+        else:
+            lines = 8 * self.n_lines * (1 + 2 * self.n_depth + self.gamma_cols)
+        return lines + 8 * self.n_nu + 16 * self.n_depth * self.count
 
     def close(self):
         if self.graph is not None:

@@ -164,6 +164,25 @@ def _atomic_line_table(stellar_plasma):
     return lines
 
 
+RETURN_BROADENING_TABLES = True  # the reference returns gammas and doppler_widths (N_l, N_d); set False to skip forming them
+
+
+def _line_opacity_from_list(spec, nus):
+    """(alpha_line_at_nu, gammas, doppler_widths) for a stardis_amd.linelist.LineList: one upload of per-line scalars,
+    parameters generated on the device (sdx_line_opacity_linelist_dev)."""
+    from stardis_amd import linelist as LL
+
+    ctx = default_context()
+    dev = spec.upload(ctx)
+    d_nus = ctx.upload(nus)
+    out = ctx.empty((dev.n_depth, nus.size))
+    ctx.call("sdx_line_opacity_linelist_dev", dev.n_depth, nus.size, d_nus.ptr, 0, nus.size, dev.byref(), out.ptr, nus.size, 0, None)
+    gammas = doppler = None
+    if RETURN_BROADENING_TABLES:
+        _, gammas, doppler = LL.line_params(dev, ctx, alphas=False)
+    return _download(out), gammas, doppler
+
+
 def calc_alpha_line_at_nu(stellar_plasma, stellar_model, tracing_nus, line_opacity_config):
     """-> (alpha_line_at_nu (N_d, N_nu), gammas (N_l, N_d), doppler_widths (N_l, N_d)); (0, 0, 0) if disabled.
     Reference :328-441."""
@@ -173,6 +192,13 @@ def calc_alpha_line_at_nu(stellar_plasma, stellar_model, tracing_nus, line_opaci
         return 0, 0, 0
     nus = _nus_of(tracing_nus)
     vald = line_opacity_config.vald_linelist
+    if vald.use_linelist and getattr(stellar_plasma, "alpha_line_from_linelist", None) is None:
+        # no dense alpha table on the plasma: generate alpha, gamma and the Doppler width in the kernel's pre-pass (f1)
+        from stardis_amd.plasma.base import deferred_line_list
+
+        spec = deferred_line_list(stellar_plasma.lines_from_linelist, nus, stellar_model, stellar_plasma,
+                                  line_opacity_config.broadening, vald.use_vald_broadening)
+        return _line_opacity_from_list(spec, nus)
     if vald.use_linelist:
         lines, alpha_table = stellar_plasma.lines_from_linelist, stellar_plasma.alpha_line_from_linelist
     else:
@@ -198,6 +224,12 @@ def calc_molecular_alpha_line_at_nu(stellar_plasma, stellar_model, tracing_nus, 
     if line_opacity_config.disable:
         return 0, 0, 0
     nus = _nus_of(tracing_nus)
+    if getattr(stellar_plasma, "molecule_alpha_line_from_linelist", None) is None:
+        from stardis_amd.plasma.molecules import deferred_molecule_line_list
+
+        spec = deferred_molecule_line_list(stellar_plasma.molecule_lines_from_linelist, nus, stellar_model, stellar_plasma,
+                                           line_opacity_config.broadening)
+        return _line_opacity_from_list(spec, nus)
     selected = _in_grid(stellar_plasma.molecule_lines_from_linelist, nus)
     alphas_array = _in_grid(stellar_plasma.molecule_alpha_line_from_linelist, nus).drop(labels="nu", axis=1).to_numpy()
     gammas, doppler_widths = calculate_molecule_broadening(selected, stellar_model, stellar_plasma, line_opacity_config.broadening)

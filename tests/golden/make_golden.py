@@ -77,6 +77,7 @@ def dump_constants():
         C_KMS=R.br.C_KMS,
         PI=R.vg.PI,
         SQRT_PI=float(R.vg.SQRT_PI),
+        ALPHA_COEFFICIENT=float(ref_loader.load_plasma().base.ALPHA_COEFFICIENT.value),
     )
     with open(os.path.join(HERE, "constants.json"), "w") as fh:
         json.dump({k: float(v).hex() for k, v in c.items()}, fh, indent=1)
@@ -656,6 +657,167 @@ def g10_spherical(atm):
         I_single_inward_theta5=one,
     )
 
+# ----------------------------------------------------------------------------- G11 line parameters from a line list
+ATOM_SPECIES = [(1, 0), (2, 0), (6, 0), (6, 1), (12, 0), (12, 1), (20, 0), (20, 1), (26, 0), (26, 1)]
+ION_ENERGY_EV = {
+    (1, 1): 13.598434, (2, 1): 24.587, (2, 2): 54.418, (6, 1): 11.26, (6, 2): 24.383, (12, 1): 7.646, (12, 2): 15.035,
+    (20, 1): 6.113, (20, 2): 11.872, (26, 1): 7.902, (26, 2): 16.199,
+}
+
+
+def species_tables(atm, cont):
+    """Synthetic ion number densities and partition functions, (species, depth), smooth in T."""
+    t = atm["temperatures"]
+    n_h = cont["n_h1"] + cont["n_h2"]
+    abundance = {1: 1.0, 2: 0.085, 6: 2.7e-4, 12: 4.0e-5, 20: 2.2e-6, 26: 3.2e-5}
+    idx = pd.MultiIndex.from_tuples(ATOM_SPECIES, names=["atomic_number", "ion_number"])
+    dens, part = [], []
+    for z, ion in ATOM_SPECIES:
+        x = 1.0 / (1.0 + np.exp(-(t - 5200.0 - 90.0 * z) / 700.0))  # ionised fraction
+        frac = x if ion == 1 else 1.0 - x
+        if z in (1, 2):
+            frac = np.ones_like(t)
+        dens.append(abundance[z] * n_h * frac)
+        part.append((1.0 + (z % 5) + ion) + 0.35 * (1 + 0.1 * z) * (t / 5000.0) ** (1.5 + 0.05 * ion))
+    cols = np.arange(len(t))
+    return pd.DataFrame(np.array(dens), index=idx, columns=cols), pd.DataFrame(np.array(part), index=idx, columns=cols)
+
+
+def fake_vald_linelist(rng, nus, n_lines, molecules=False):
+    lam_lo, lam_hi = 2.99792458e18 / nus.max(), 2.99792458e18 / nus.min()
+    span = lam_hi - lam_lo
+    lam = rng.uniform(lam_lo - 0.08 * span, lam_hi + 0.08 * span, n_lines)
+    lam[0], lam[1] = lam_lo + 1e-9, lam_hi - 1e-9
+    e_low = rng.uniform(0.0, 4.5, n_lines)
+    e_low[2] = 0.0
+    hc_ev_aa = 12398.419843320026
+    e_up = e_low + hc_ev_aa / lam * (1 + 1e-6 * rng.standard_normal(n_lines))
+    u_ = rng.random(n_lines)
+    log_gf = np.where(u_ < 0.8, rng.uniform(-5, -1, n_lines), rng.uniform(-1, 0.6, n_lines))
+    stark = np.where(rng.random(n_lines) < 0.2, 0.0, -rng.uniform(4.5, 6.5, n_lines))
+    w = np.empty(n_lines)
+    pick = rng.random(n_lines)
+    w[pick < 0.3] = -rng.uniform(7.0, 8.0, (pick < 0.3).sum())
+    w[(pick >= 0.3) & (pick < 0.4)] = 0.0
+    m = (pick >= 0.4) & (pick < 0.7)
+    w[m] = rng.uniform(0.5, 3.0, m.sum())
+    m = pick >= 0.7
+    w[m] = rng.integers(150, 900, m.sum()) + rng.uniform(0.2, 0.35, m.sum())
+    common = dict(
+        wavelength=lam, log_gf=log_gf, e_low=e_low, e_up=e_up,
+        j_lo=rng.integers(0, 10, n_lines) / 2.0, j_up=rng.integers(0, 10, n_lines) / 2.0,
+        rad=rng.uniform(6.0, 9.0, n_lines), stark=stark, waals=w,
+    )
+    if molecules:
+        return pd.DataFrame(dict(molecule=rng.choice(["CH", "MgH", "CN"], n_lines), **common))
+    z = rng.choice([1, 2, 6, 12, 20, 26, 28], n_lines, p=[0.1, 0.04, 0.1, 0.2, 0.2, 0.3, 0.06])  # 28 > selected max: dropped
+    ion = np.where(np.isin(z, (1, 2)), 0, rng.integers(0, 2, n_lines))
+    df = pd.DataFrame(dict(atomic_number=z, ion_charge=ion, **common))
+    # keep the upper level below the ionisation limit except for three deliberate auto-ionising lines
+    chi = np.array([ION_ENERGY_EV.get((a, i + 1), 50.0) for a, i in zip(z, ion)])
+    over = df.e_up.values >= chi
+    shift = np.where(over, df.e_up.values - 0.9 * chi, 0.0)
+    df["e_low"] = np.maximum(df.e_low.values - shift, 0.0)
+    df["e_up"] = df.e_low.values + (e_up - e_low)
+    still = df.e_up.values >= chi
+    df.loc[still, "wavelength"] = df.wavelength[still]  # (H I near 6563 A from n=2 is fine: 10.2 + 1.9 < 13.6)
+    for k in (5, 6, 7):
+        df.loc[k, ["atomic_number", "ion_charge"]] = (26, 0)
+        df.loc[k, "e_up"] = 7.902 * 1.04
+        df.loc[k, "e_low"] = df.loc[k, "e_up"] - hc_ev_aa / df.loc[k, "wavelength"]
+        df.loc[k, "waals"] = -7.5
+    vdw_unsold = (df.waals > 0) & (df.waals < 20)
+    chi = np.array([ION_ENERGY_EV.get((a, i + 1), 50.0) for a, i in zip(df.atomic_number, df.ion_charge)])
+    df.loc[vdw_unsold & (df.e_up.values >= chi), "waals"] = -7.6
+    return df
+
+
+def g11_linelist(atm, cont):
+    """AlphaLineVald / AlphaLineShortlistVald (plasma/base.py:178-455), AlphaLineValdMolecule /
+    AlphaLineShortlistValdMolecule (plasma/molecules.py:192-450) executed on a synthetic VALD-style list, then the
+    reference's own calc_alpha_line_at_nu / calc_molecular_alpha_line_at_nu (opacities_solvers/base.py:328-485) on
+    what they return."""
+    from stardis_amd import synth
+
+    P = ref_loader.load_plasma()
+    rng = np.random.default_rng(11)
+    nus = synth.tracing_grid(6560.0, 6566.0, step=0.02)
+    t = atm["temperatures"]
+    model = fake_model(atm)
+    ion_density, partition = species_tables(atm, cont)
+    ionization_data = pd.Series(
+        np.array(list(ION_ENERGY_EV.values())) * 1.602176634e-12,
+        index=pd.MultiIndex.from_tuples(list(ION_ENERGY_EV.keys()), names=["atomic_number", "ion_number"]),
+        name="ionization_energy",
+    )
+    atoms = fake_vald_linelist(rng, nus, 160)
+    mols = fake_vald_linelist(rng, nus, 60, molecules=True)
+    atomic_data = NS(linelist_atoms=atoms, linelist_molecules=mols, selected_atomic_numbers=pd.Index([1, 2, 6, 12, 20, 26]))
+    mol_names = ["CH", "CN", "MgH"]
+    cols = np.arange(len(t))
+    mol_density = pd.DataFrame(
+        np.array([1e-7 * cont["n_h1"] * (5000.0 / t) ** k for k in (3.0, 4.0, 5.0)]), index=mol_names, columns=cols
+    )
+    mol_partition = pd.DataFrame(np.array([50.0 + 0.04 * t, 120.0 + 0.09 * t, 30.0 + 0.02 * t]), index=mol_names, columns=cols)
+
+    out = dict(
+        nus=nus, temperatures=t, n_e=atm["n_e"], n_h1=cont["n_h1"], microturbulence=np.float64(1.0e5),
+        species=np.array(ATOM_SPECIES), ion_number_density=ion_density.values, partition_function=partition.values,
+        ionization_keys=np.array(list(ION_ENERGY_EV.keys())), ionization_energy=ionization_data.values,
+        selected_atomic_numbers=np.array([1, 2, 6, 12, 20, 26]),
+        molecule_names=np.array(mol_names), molecule_number_density=mol_density.values,
+        molecule_partition_function=mol_partition.values,
+        molecule_ion1=np.array([6, 6, 12]), molecule_ion2=np.array([1, 7, 1]),
+        mass_keys=np.append(NUCLIDE_MASSES.index.values, 7), mass_vals=np.append(NUCLIDE_MASSES.values, 14.007 * 1.6605390666e-24),
+    )
+    masses = pd.Series(out["mass_vals"], index=pd.Index(out["mass_keys"], name="atomic_number"))
+    model.composition = NS(nuclide_masses=masses)
+    for c in atoms.columns:
+        out["atoms_" + c] = atoms[c].values
+    for c in mols.columns:
+        out["mols_" + c] = mols[c].values.astype(str) if c == "molecule" else mols[c].values
+
+    def run_atoms(cls, tag):
+        alphas, lines = cls.__new__(cls).calculate(atomic_data, ion_density, t, ionization_data, partition)
+        out[tag + "_alphas"] = alphas.drop(columns="nu").to_numpy(dtype=np.float64)
+        out[tag + "_nu"] = alphas.nu.values
+        out[tag + "_index"] = np.asarray(alphas.index)
+        for c in ("nu", "level_energy_lower", "level_energy_upper", "A_ul", "ionization_energy", "e_up"):
+            out[tag + "_lines_" + c] = lines[c].values.astype(np.float64)
+        out[tag + "_lines_index"] = np.asarray(lines.index)
+        for vb in (True, False):
+            plasma = fake_plasma(atm, cont)
+            plasma.ion_number_density = pd.concat([plasma.ion_number_density.iloc[:0], ion_density])
+            plasma.lines_from_linelist = lines
+            plasma.alpha_line_from_linelist = alphas
+            cfg = opacity_config(vald=True, vald_broadening=vb).line
+            a, g, d = R.ob.calc_alpha_line_at_nu(plasma, model, nus * u.Hz, cfg)
+            k = f"{tag}_{'vb' if vb else 'nb'}_"
+            out[k + "alpha_line_at_nu"], out[k + "gammas"], out[k + "doppler"] = a, np.asarray(g, float), np.asarray(d, float)
+
+    def run_mols(cls, tag):
+        alphas, lines = cls.__new__(cls).calculate(atomic_data, mol_density, t, mol_partition)
+        out[tag + "_alphas"] = alphas.drop(columns="nu").to_numpy(dtype=np.float64)
+        out[tag + "_nu"] = alphas.nu.values
+        for c in ("nu", "level_energy_lower", "level_energy_upper", "A_ul", "e_up"):
+            out[tag + "_lines_" + c] = lines[c].values.astype(np.float64)
+        plasma = fake_plasma(atm, cont)
+        plasma.molecule_lines_from_linelist = lines
+        plasma.molecule_alpha_line_from_linelist = alphas
+        plasma.molecule_ion_map = pd.DataFrame(dict(Ion1=out["molecule_ion1"], Ion2=out["molecule_ion2"]), index=mol_names)
+        cfg = opacity_config(vald=True, vald_broadening=False).line
+        cfg.broadening = ["radiation"]
+        a, g, d = R.ob.calc_molecular_alpha_line_at_nu(plasma, model, nus * u.Hz, cfg)
+        out[tag + "_alpha_line_at_nu"], out[tag + "_gammas"], out[tag + "_doppler"] = a, np.asarray(g, float), np.asarray(d, float)
+
+    with np.errstate(all="ignore"):
+        run_atoms(P.base.AlphaLineVald, "full")
+        run_atoms(P.base.AlphaLineShortlistVald, "short")
+        run_mols(P.mol.AlphaLineValdMolecule, "molfull")
+        run_mols(P.mol.AlphaLineShortlistValdMolecule, "molshort")
+    out["alpha_coefficient"] = np.float64(P.base.ALPHA_COEFFICIENT.value)
+    save("g11_linelist", **out)
+
 
 def main():
     rng = np.random.default_rng(20250926)
@@ -665,7 +827,7 @@ def main():
 
     atm = atmosphere()
     cont = synth.synth_continuum_state(atm)
-    which = set(sys.argv[1:]) or {"g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"}
+    which = set(sys.argv[1:]) or {"g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"}
     if "g1" in which:
         g1_faddeeva(rng)
     if "g2" in which:
@@ -686,6 +848,8 @@ def main():
         g9_end_to_end(rng, atm, cont)
     if "g10" in which:
         g10_spherical(atm)
+    if "g11" in which:
+        g11_linelist(atm, cont)
 
 
 if __name__ == "__main__":

@@ -137,3 +137,36 @@ def load():
     ns.rf = imp("stardis.radiation_field.base")
     _loaded = ns
     return ns
+
+
+_plasma = None
+
+
+def load_plasma():
+    """The reference's plasma property classes (stardis/plasma/base.py, molecules.py).  TARDIS is absent: its plasma
+    base classes are replaced by empty stand-ins in sys.modules, which is enough because every `calculate` method
+    used here is a self-contained numpy/pandas/astropy function of its arguments."""
+    global _plasma
+    if _plasma is not None:
+        return _plasma
+    load()
+    blank = type("ProcessingPlasmaProperty", (), {})
+    for n in ("tardis.plasma", "tardis.plasma.properties", "tardis.opacities"):
+        _module(n)
+    _module("tardis.plasma.base", BasePlasma=type("BasePlasma", (), {}))
+    _module("tardis.plasma.properties.base", ProcessingPlasmaProperty=blank, DataFrameInput=type("DataFrameInput", (), {}))
+    _module(
+        "tardis.plasma.properties.property_collections",
+        **{k: [] for k in ("basic_inputs basic_properties lte_excitation_properties lte_ionization_properties "
+                           "non_nlte_properties helium_lte_properties").split()},
+    )
+    _module("tardis.opacities.tau_sobolev", TauSobolev=type("TauSobolev", (), {}))
+    sys.modules["tardis"].plasma = sys.modules["tardis.plasma"]
+    m = types.ModuleType("stardis.plasma")
+    m.__path__ = [REF_ROOT + "/plasma"]
+    sys.modules["stardis.plasma"] = m
+    _plasma = types.SimpleNamespace(
+        mol=importlib.import_module("stardis.plasma.molecules"),
+        base=importlib.import_module("stardis.plasma.base"),
+    )
+    return _plasma

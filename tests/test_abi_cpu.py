@@ -40,6 +40,14 @@ def test_continuum_struct_matches_header():
     assert fields == [f[0] for f in _lib.Continuum._fields_]
 
 
+def test_linelist_struct_matches_header():
+    text = open(HEADER).read()
+    body = re.search(r"typedef struct sdx_linelist \{(.*?)\} sdx_linelist;", text, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = re.findall(r"\b([A-Za-z_0-9]+)\s*;", body)
+    assert fields == [f[0] for f in _lib.LineListStruct._fields_]
+
+
 def test_library_reports_no_device_and_product_raises():
     lib = _lib.load()
     assert lib.sdx_version().startswith(b"stardis_hip")
