@@ -108,6 +108,55 @@ def synth_lines(nus, atm, n_lines, seed=SEED, gamma_per_depth=True, mix=(0.90, 0
     )
 
 
+def synth_linelist(nus, atm, n_lines, seed=SEED, vald_broadening=True, mix=(0.90, 0.09, 0.01)):
+    """The same kind of list as synth_lines, as per-line scalars (stardis_amd.linelist.LineList): VALD-style atoms of
+    five elements in two ionisation stages, oscillator strengths scaled so that alpha_line at the hottest depth follows
+    the strength mix of synth_lines."""
+    from . import linelist as LL
+
+    rng = np.random.default_rng(seed)
+    t = np.asarray(atm["temperatures"], dtype=np.float64)
+    nu_lo, nu_hi = float(nus.min()), float(nus.max())
+    nu = np.sort(nu_lo + (nu_hi - nu_lo) * rng.random(n_lines))
+    elements = np.array([1, 6, 12, 20, 26])
+    amu = np.array([1.008, 12.011, 24.305, 40.078, 55.845])
+    abundance = np.array([1.0, 2.7e-4, 4.0e-5, 2.2e-6, 3.2e-5])
+    chi_ev = np.array([[13.598, 13.598], [11.26, 24.383], [7.646, 15.035], [6.113, 11.872], [7.902, 16.199]])
+    el = rng.choice(len(elements), n_lines, p=[0.04, 0.16, 0.2, 0.2, 0.4])
+    stage = np.where(el == 0, 0, rng.integers(0, 2, n_lines))
+    chi = chi_ev[el, stage] * K.EV_TO_ERG_ASTROPY
+    e_up = (0.25 + 0.7 * rng.random(n_lines)) * chi
+    e_lo = np.maximum(e_up - K.H_CGS * nu, 0.0)
+    e_up = e_lo + K.H_CGS * nu
+    ok = e_up < chi
+    e_up = np.where(ok, e_up, 0.98 * chi)
+    e_lo = np.where(ok, e_lo, np.maximum(0.98 * chi - K.H_CGS * nu, 0.0))
+    x = 1.0 / (1.0 + np.exp(-(t[None, :] - 5200.0 - 90.0 * elements[:, None]) / 700.0))
+    n_h = np.asarray(atm["n_h"], dtype=np.float64)
+    pop = np.empty((2 * len(elements), t.size))
+    for k in range(len(elements)):
+        part = 2.0 + 0.35 * (t / 5000.0) ** 1.5
+        pop[2 * k] = abundance[k] * n_h * (1.0 if k == 0 else (1.0 - x[k])) / part
+        pop[2 * k + 1] = abundance[k] * n_h * x[k] / part
+    row = (2 * el + stage).astype(np.int32)
+    g_lo = rng.integers(1, 11, n_lines).astype(np.float64)
+    u, v = rng.random(n_lines), rng.random(n_lines)
+    s_ = np.where(u < mix[0], -6.0 + 5.0 * v, np.where(u < mix[0] + mix[1], -1.0 + 3.0 * v, 2.0 + 3.0 * v))
+    d_hot = int(np.argmax(t))
+    kt = 1.380649e-23 * t[d_hot]
+    hot = K.ALPHA_COEFFICIENT * np.exp(-(e_lo / K.EV_TO_ERG_ASTROPY) * 1.602176634e-19 / kt) * pop[row, d_hot] * g_lo * (
+        1.0 - np.exp(-6.62607015e-34 * nu / kt))
+    f_lu = 10.0**s_ / hot
+    pick = rng.random(n_lines)
+    waals = np.where(pick < 0.5, -(7.0 + rng.random(n_lines)), rng.integers(150, 900, n_lines) + 0.2 + 0.15 * rng.random(n_lines))
+    return LL.LineList(
+        nu, e_lo / K.EV_TO_ERG_ASTROPY, f_lu, row, pop, amu[el] * K.AMU_CGS, t, g_lo=g_lo, microturbulence=float(atm["microturbulence"]),
+        gamma_mode=LL.GAMMA_VALD if vald_broadening else LL.GAMMA_CLASSIC, flags=15, atomic_number=elements[el], ion_number=stage + 1,
+        ionization_energy=chi, upper_energy=e_up, lower_energy=e_lo, A_ul=10.0 ** (7.0 + 2.0 * rng.random(n_lines)),
+        stark=-(4.5 + 2.0 * rng.random(n_lines)), waals=waals, electron_density=atm["n_e"], h_density=n_h,
+    )
+
+
 def synth_continuum_state(atm, n_levels=10):
     """Per-depth densities for H I bf/ff, H- bf (Wishart table), Thomson: an LTE-like
     hydrogen state good enough to give a solar-looking continuum."""

@@ -79,7 +79,7 @@ def test_molecular_line_opacity_matches_reference(fx, short):
     spec = deferred_molecule_line_list(lines, g["nus"], fx.model, fx.plasma, ["radiation"])
     assert spec.gamma_cols == 1
     _, gammas, doppler = LL.line_params(spec, alphas=False)
-    assert np.array_equal(gammas, g[tag + "_gammas"])
+    assert rel_err(gammas, g[tag + "_gammas"]) < 4e-16  # A_ul = 10**rad: numpy pow differs by an ulp between versions
     assert rel_err(doppler, g[tag + "_doppler"]) < 1e-15
     assert rel_err(LL.line_opacity(g["nus"], spec), g[tag + "_alpha_line_at_nu"]) < 1e-12
 
