@@ -142,6 +142,18 @@ int sdx_alpha_file_1d_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double*
 /* calc_alpha_file :70 with sigma already tabulated per (depth, nu) (util.py:35-91 host interpolation) */
 int sdx_alpha_file_2d_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* sigma, int64_t sigma_ld,
                           const double* density, double* out, int64_t ld);
+/* sigma_file for the two 2-D tables (opacities_solvers/util.py:35-91): scipy's
+ * LinearNDInterpolator(points, values, fill_value=0) on the Delaunay triangulation of the rectilinear table, evaluated at
+ * the mesh (lambdas[k], second[d]) with second = T (H2+ bf) or 5040/T (H- ff).  The caller passes the triangulation its
+ * scipy/Qhull built, indexed by grid cell: cell_simplices[(i*(n_y-1)+j)*2 + {0,1}] are the two triangles of cell (i, j),
+ * transform[s] is Qhull's 3x2 barycentric transform of triangle s (scipy.spatial.Delaunay.transform),
+ * simplex_values[s][v] the table value at its v-th vertex.  scale_kind 0: raw; 1: x 1e-18 (util.py:58);
+ * 2: x 1e-26 x k_B x T[d] (util.py:83-88).  zero_rows (optional, [n_depth]) is set to 1 for rows that contain an exact
+ * zero — the rows the reference names in its "outside of interpolation range" warning.  sigma is [n_depth][ld]. */
+int sdx_sigma_table_2d_dev(sdx_ctx* ctx, int n_x, const double* x_axis, int n_y, const double* y_axis,
+                           const int32_t* cell_simplices, const double* transform, const double* simplex_values,
+                           int n_depth, int64_t n_nu, const double* lambdas, const double* second, int scale_kind,
+                           const double* temperature, double* sigma, int64_t ld, int32_t* zero_rows);
 /* calc_alpha_bf :178-271: levels grouped by species; cutoff[L] = (E_ion - E_exc)/h; level_density [n_levels][n_depth] */
 int sdx_alpha_bf_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int n_species,
                      const int32_t* species_offsets, const int32_t* species_ion_number, const double* cutoff,

@@ -306,6 +306,21 @@ def alpha_line_linelist(e_low_ev, g_lo, strength, line_nus, pop_row, pop, temps,
     return out
 
 
+def interp_triangulated(x_axis, y_axis, cell_simplices, transform, simplex_values, qx, qy):
+    """util.py:47-56, :75-86 — LinearNDInterpolator(points, values, fill_value=0) at the mesh (qx, qy) -> (len(qy), len(qx))."""
+    xa, pxa = _d(x_axis)
+    ya, pya = _d(y_axis)
+    cs, pcs = _i(cell_simplices)
+    tr, ptr = _d(transform)
+    sv, psv = _d(simplex_values)
+    x, px = _d(qx)
+    y, py = _d(qy)
+    out = np.empty((y.size, x.size))
+    lib().orc_interp_triangulated(C.c_int(xa.size), pxa, C.c_int(ya.size), pya, pcs, ptr, psv, C.c_int(y.size), C.c_int64(x.size), px, py,
+                                  out.ctypes.data_as(_dp))
+    return out
+
+
 def rotation_broadening(flux, velocity_per_pix, v_rot, limb_darkening=0.6):
     """broadening.py:824-877 (flux only; wavelengths pass through)"""
     f, pf = _d(flux)

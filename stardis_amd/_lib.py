@@ -112,6 +112,7 @@ PROTOTYPES = {
     "sdx_calc_vald_gamma_dev": (_int, [_vp, _i64, _int] + [_vp] * 12 + [_int, _vp]),
     "sdx_broadening_scalar_dev": (_int, [_vp, _int, _i64] + [_vp] * 6),
     "sdx_alpha_file_1d_dev": (_int, [_vp, _int, _i64, _vp, _int, _vp, _vp, _vp, _vp, _i64]),
+    "sdx_sigma_table_2d_dev": (_int, [_vp, _int, _vp, _int, _vp, _vp, _vp, _vp, _int, _i64, _vp, _vp, _int, _vp, _vp, _i64, _vp]),
     "sdx_alpha_file_2d_dev": (_int, [_vp, _int, _i64, _vp, _i64, _vp, _vp, _i64]),
     "sdx_alpha_bf_dev": (_int, [_vp, _int, _i64, _vp, _int, _vp, _vp, _vp, _vp, _vp, _i64]),
     "sdx_alpha_ff_dev": (_int, [_vp, _int, _i64, _vp, _vp, _int, _vp, _vp, _vp, _i64]),

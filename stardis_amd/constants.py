@@ -33,6 +33,9 @@ C_SI = 299792458.0
 # astropy's metre -> Angstrom scale, 1 / (0.1 * 1e-9): tracing_nus.to(u.AA, u.spectral()) evaluates
 # (c / nu) * this (opacities_solvers/base.py:62); the golden vectors pin it bit-for-bit.
 M_TO_ANGSTROM = 1.0 / (0.1 * 1e-9)
+# astropy's nm -> Angstrom scale is not 10: (x * u.nm).to(u.AA) multiplies by this (util.py:43).  It matters: the H2+ bf
+# table's nodes move by an ulp, and with them Qhull's choice of cell diagonals (2 % on individual cross-sections).
+NM_TO_ANGSTROM = 9.999999999999998
 
 
 def nu_to_angstrom(nus):

@@ -981,6 +981,68 @@ __global__ __launch_bounds__(kBlock) void k_continuum_source(int src, int n_dept
     out[(size_t)d * ld + i] = v;
 }
 
+// sigma_file for the 2-D cross-section tables (opacities_solvers/util.py:35-91): scipy's LinearNDInterpolator on the
+// table's Delaunay triangulation, evaluated at the mesh (lambda_k, second_d) — second is T (H2+ bf) or 5040/T (H- ff).
+// scipy (interpnd.pyx _evaluate_double, qhull.pyx _barycentric_coordinates): barycentric coordinates from Qhull's
+// transform of the simplex, c_i = sum_j T[i][j] (x_j - T[2][j]), c_2 = 1 - c_0 - c_1; a point is inside when every
+// c >= -eps (eps = 100 DBL_EPSILON); value = sum_j c_j v_j; outside the hull 0 (the reference's fill value).  The
+// triangles of a rectilinear table lie two per cell, so the search is a cell look-up and at most two tests.
+// scale_kind 1: x 1e-18 (:58); 2: x 1e-26 x k_B x T (:83-88).  zero_rows[d] is raised when a row holds an exact zero
+// (the reference's "outside of interpolation range" warning, :59-62, :89-92).
+constexpr int kTableAxisMax = 512;
+__device__ __forceinline__ int last_le_clipped(const double* a, int n, double v)
+{
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] <= v) lo = mid + 1; else hi = mid;
+    }
+    return max(0, min(lo - 1, n - 2));
+}
+__global__ __launch_bounds__(kBlock) void k_sigma_table_2d(int n_x, const double* __restrict__ x_axis, int n_y,
+                                                           const double* __restrict__ y_axis, const int* __restrict__ cell_simplices,
+                                                           const double* __restrict__ transform,
+                                                           const double* __restrict__ simplex_values, int n_depth, int64_t n_nu,
+                                                           const double* __restrict__ lambdas, const double* __restrict__ second,
+                                                           int scale_kind, const double* __restrict__ temperature,
+                                                           double* __restrict__ sigma, int64_t ld, int* __restrict__ zero_rows)
+{
+    __shared__ double s_x[kTableAxisMax];
+    __shared__ int s_zero;
+    for (int i = threadIdx.x; i < n_x; i += kBlock) s_x[i] = x_axis[i];
+    if (threadIdx.x == 0) s_zero = 0;
+    __syncthreads();
+    const int d = blockIdx.y;
+    const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (k < n_nu) {
+        const double qx = lambdas[k], qy = second[d];
+        const int i = last_le_clipped(s_x, n_x, qx);
+        const int j = last_le_clipped(y_axis, n_y, qy);
+        constexpr double eps = 100.0 * 2.220446049250313e-16;
+        double val = 0.0;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int sidx = cell_simplices[(i * (n_y - 1) + j) * 2 + c];
+            const double* t = transform + (size_t)sidx * 6;
+            const double dx = sub_rn(qx, t[4]), dy = sub_rn(qy, t[5]);
+            const double c0 = add_rn(mul_rn(t[0], dx), mul_rn(t[1], dy));
+            const double c1 = add_rn(mul_rn(t[2], dx), mul_rn(t[3], dy));
+            const double c2 = sub_rn(sub_rn(1.0, c0), c1);
+            if (c0 >= -eps && c1 >= -eps && c2 >= -eps && c0 <= 1.0 + eps && c1 <= 1.0 + eps && c2 <= 1.0 + eps) {
+                const double* v = simplex_values + (size_t)sidx * 3;
+                val = add_rn(add_rn(mul_rn(c0, v[0]), mul_rn(c1, v[1])), mul_rn(c2, v[2]));
+                break;
+            }
+        }
+        if (scale_kind == 1) val = mul_rn(val, 1e-18);
+        else if (scale_kind == 2) val = mul_rn(mul_rn(mul_rn(val, 1e-26), kKB), temperature[d]);
+        sigma[(size_t)d * ld + k] = val;
+        if (val == 0.0) s_zero = 1;
+    }
+    __syncthreads();
+    if (zero_rows && threadIdx.x == 0 && s_zero) zero_rows[d] = 1;
+}
+
 __global__ __launch_bounds__(kBlock) void k_rayleigh_clip(int64_t n_nu, double* __restrict__ nus)
 {  // base.py:99: tracing_nus[tracing_nus > 2.3e15] = 0, in the caller's array
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;

@@ -969,6 +969,27 @@ int sdx_alpha_file_2d_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double*
     return check_launch("k_scale_rows");
 }
 
+int sdx_sigma_table_2d_dev(sdx_ctx* ctx, int n_x, const double* x_axis, int n_y, const double* y_axis, const int32_t* cell_simplices,
+                           const double* transform, const double* simplex_values, int n_depth, int64_t n_nu, const double* lambdas,
+                           const double* second, int scale_kind, const double* temperature, double* sigma, int64_t ld,
+                           int32_t* zero_rows)
+{
+    REQUIRE(ctx && n_x >= 2 && n_y >= 2 && n_x <= kTableAxisMax, "sigma_table_2d: table axes must have 2..512 nodes");
+    REQUIRE(x_axis && y_axis && cell_simplices && transform && simplex_values, "sigma_table_2d: null table");
+    REQUIRE(n_depth > 0 && n_nu >= 0 && scale_kind >= 0 && scale_kind <= 2, "sigma_table_2d: bad sizes");
+    REQUIRE(scale_kind != 2 || temperature, "sigma_table_2d: scale_kind 2 needs the temperatures");
+    if (n_nu == 0) return SDX_OK;
+    REQUIRE(lambdas && second && sigma && ld >= n_nu, "sigma_table_2d: bad query / output");
+    if (zero_rows) HIP_TRY(hipMemsetAsync(zero_rows, 0, (size_t)n_depth * sizeof(int32_t), ctx->stream));
+    {
+        LaunchScope ls(ctx, "k_sigma_table_2d");
+        hipLaunchKernelGGL(k_sigma_table_2d, grid2(n_nu, n_depth), dim3(kBlock), 0, ctx->stream, n_x, x_axis, n_y, y_axis,
+                           (const int*)cell_simplices, transform, simplex_values, n_depth, n_nu, lambdas, second, scale_kind, temperature,
+                           sigma, ld, (int*)zero_rows);
+    }
+    return check_launch("k_sigma_table_2d");
+}
+
 int sdx_alpha_bf_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int n_species, const int32_t* offs,
                      const int32_t* ions, const double* cutoff, const double* level_density, double* out, int64_t ld)
 {

@@ -174,14 +174,30 @@ def alpha_file_1d(lambdas, table_wavelength, table_sigma, density, ctx=None):
 
 
 def alpha_file_2d(sigma, density, ctx=None):
-    """opacities/opacities_solvers/base.py:70 with a (N_d, N_nu) sigma (util.py:35-91)"""
+    """opacities/opacities_solvers/base.py:70 with a (N_d, N_nu) sigma (util.py:35-91); sigma may already be on the device"""
     ctx = ctx or default_context()
-    s = _host(sigma)
+    d_s = sigma if isinstance(sigma, DeviceArray) else ctx.upload(_host(sigma))
     n = _host(density).reshape(-1)
-    d_s, d_n = ctx.upload(s), ctx.upload(n)
-    out = ctx.empty(s.shape)
-    ctx.call("sdx_alpha_file_2d_dev", s.shape[0], s.shape[1], d_s.ptr, s.shape[1], d_n.ptr, out.ptr, s.shape[1])
+    d_n = ctx.upload(n)
+    out = ctx.empty(d_s.shape)
+    ctx.call("sdx_alpha_file_2d_dev", d_s.shape[0], d_s.shape[1], d_s.ptr, d_s.shape[1], d_n.ptr, out.ptr, d_s.shape[1])
     return out
+
+
+def sigma_table_2d(wave, axis2, cell_simplices, transform, simplex_values, lambdas, second, scale_kind=0, temperatures=None, ctx=None):
+    """opacities/opacities_solvers/util.py:35-91: LinearNDInterpolator on the table's triangulation at the mesh
+    (lambdas, second) -> (sigma DeviceArray (len(second), len(lambdas)), rows that contain an exact zero)."""
+    ctx = ctx or default_context()
+    wave, axis2 = _host(wave).reshape(-1), _host(axis2).reshape(-1)
+    lam, sec = _host(lambdas).reshape(-1), _host(second).reshape(-1)
+    d = [ctx.upload(x) for x in (wave, axis2, _host(transform), _host(simplex_values), lam, sec)]
+    d_cells = ctx.upload(_host(cell_simplices, np.int32), np.int32)
+    d_t = ctx.upload(_host(temperatures).reshape(-1)) if temperatures is not None else None
+    out = ctx.empty((sec.size, lam.size))
+    zero = ctx.empty((sec.size,), np.int32)
+    ctx.call("sdx_sigma_table_2d_dev", wave.size, d[0].ptr, axis2.size, d[1].ptr, d_cells.ptr, d[2].ptr, d[3].ptr, sec.size, lam.size,
+             d[4].ptr, d[5].ptr, int(scale_kind), d_t.ptr if d_t is not None else None, out.ptr, lam.size, zero.ptr)
+    return out, np.flatnonzero(zero.numpy())
 
 
 def alpha_bf(tracing_nus, species_offsets, species_ion_number, cutoff_frequency, level_number_density, n_depth, ctx=None):

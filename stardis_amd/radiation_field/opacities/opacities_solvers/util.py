@@ -1,10 +1,10 @@
 """Cross-section tables and density look-ups feeding calc_alpha_file; host-side I/O that mirrors
 stardis/radiation_field/opacities/opacities_solvers/util.py (sigma_file :14-108, get_number_density :111-166).
 
-The tables are a few hundred numbers read once per run.  The 2-D tables (H- ff, H2+ bf) are interpolated
-with the same scipy LinearNDInterpolator call the reference makes, because that interpolant's Delaunay
-diagonals are implementation-defined (SURVEY hazard 4); the 1-D H- bf table is returned raw and
-interpolated on the GPU (np.interp semantics)."""
+The tables are a few hundred numbers read once per run.  The 2-D tables (H- ff, H2+ bf) are triangulated once by
+scipy/Qhull on the host — the same Delaunay call LinearNDInterpolator makes, because the cell diagonals are Qhull's
+choice — and the N_d x N_nu evaluations run on the GPU (sdx_sigma_table_2d_dev restates scipy's barycentric
+evaluation).  The 1-D H- bf table is interpolated on the GPU with np.interp semantics."""
 import logging
 
 import numpy as np
@@ -31,10 +31,38 @@ def read_table(fpath, opacity_source):
     if opacity_source == "H2plus_bf":
         tab = pd.read_csv(fpath, delimiter=r"\s+", index_col=0, comment="#")
         tab = tab.replace({"-": "e-"}, regex=True).astype(float)
-        wave = tab.index.to_numpy(dtype=float) * 10.0  # nm -> Angstrom
+        wave = tab.index.to_numpy(dtype=float) * K.NM_TO_ANGSTROM  # (index * u.nm).to(u.AA) (util.py:43)
         temps = tab.columns.to_numpy().astype(int)
         return "2d", wave, temps, tab.to_numpy()
     raise ValueError(f"Unknown opacity_source: {opacity_source}")
+
+
+def cell_lookup(wave, axis2, simplices, values):
+    """Index a Delaunay triangulation of the rectilinear table by grid cell: every triangle lies in one cell, two per
+    cell (which diagonal is Qhull's choice).  -> (cell_simplices (n_cells, 2) int32, simplex_values (n_s, 3)), or None
+    when the triangulation does not have that structure (the caller then lets scipy evaluate on the host)."""
+    wave, axis2 = np.asarray(wave, dtype=float), np.asarray(axis2, dtype=float)
+    nx, ny = wave.size, axis2.size
+    simplices = np.asarray(simplices)
+    pi, pj = np.divmod(simplices, ny)  # point k of the ravelled "ij" mesh is (k // ny, k % ny)
+    ci, cj = pi.min(axis=1), pj.min(axis=1)
+    if np.any(np.ptp(pi, axis=1) != 1) or np.any(np.ptp(pj, axis=1) != 1):
+        return None
+    cell = ci * (ny - 1) + cj
+    n_cells = (nx - 1) * (ny - 1)
+    if simplices.shape[0] != 2 * n_cells or np.any(np.bincount(cell, minlength=n_cells) != 2):
+        return None
+    order = np.argsort(cell, kind="stable")
+    return order.reshape(n_cells, 2).astype(np.int32), np.asarray(values, dtype=float).ravel()[simplices]
+
+
+def triangulate(wave, axis2, values):
+    """The triangulation LinearNDInterpolator builds for the table (util.py:47-53, :75-81), as arrays."""
+    from scipy.spatial import Delaunay
+
+    w_mesh, a_mesh = np.meshgrid(wave, axis2, indexing="ij")
+    tri = Delaunay(np.vstack([w_mesh.ravel(), a_mesh.ravel()]).T)
+    return tri.simplices, tri.transform
 
 
 def _interp2d(wave, axis2, values, lambdas, second):
@@ -46,27 +74,45 @@ def _interp2d(wave, axis2, values, lambdas, second):
     return f(lam, sec)
 
 
-def sigma_file(tracing_lambdas, temperatures, fpath, opacity_source=None):
-    """Cross-sections (N_T, N_lambda) for the 2-D tables, (N_lambda,) for Hminus_bf — as util.py:14-108."""
+def sigma_file_device(tracing_lambdas, temperatures, fpath, opacity_source):
+    """sigma_file for the 2-D tables with the result left in HBM -> DeviceArray (N_T, N_lambda)."""
+    from stardis_amd import ops
+
     tracing_lambdas = np.asarray(tracing_lambdas, dtype=float)
     temperatures = np.asarray(temperatures, dtype=float)
+    _, wave, axis2, values = read_table(fpath, opacity_source)
+    axis2 = np.asarray(axis2, dtype=float)
+    simplices, transform = triangulate(wave, axis2, values)
+    lookup = cell_lookup(wave, axis2, simplices, values)
+    if opacity_source == "Hminus_ff":
+        second, kind, what = 5040 / temperatures, 2, "H- FF"
+    else:
+        second, kind, what = temperatures, 1, "H2+ BF"
+    if lookup is None:
+        # a triangulation that is not two-triangles-per-cell (never seen for these tables): let scipy evaluate, as the
+        # reference does, and say so
+        logger.warning("unexpected triangulation of the %s table: interpolating on the host with scipy", what)
+        sig = _interp2d(wave, axis2, values, tracing_lambdas, second)
+        sig = sig * 1e-26 * K.K_B_CGS * temperatures[:, np.newaxis] if kind == 2 else sig * 1e-18
+        zero_rows = np.unique(np.where(sig == 0)[0])
+        from stardis_amd._lib import default_context
+
+        dev = default_context().upload(sig)
+    else:
+        dev, zero_rows = ops.sigma_table_2d(wave, axis2, lookup[0], transform, lookup[1], tracing_lambdas, second, kind, temperatures)
+    if zero_rows.size:
+        logger.warning(
+            "Outside of interpolation range for %s cross-sections at depth points %s. Assuming 0 opacity there.", what, zero_rows
+        )
+    return dev
+
+
+def sigma_file(tracing_lambdas, temperatures, fpath, opacity_source=None):
+    """Cross-sections (N_T, N_lambda) for the 2-D tables, (N_lambda,) for Hminus_bf — as util.py:14-108."""
     table = read_table(fpath, opacity_source)
     if table[0] == "1d":
-        return np.interp(tracing_lambdas, table[1], table[2])
-    _, wave, axis2, values = table
-    if opacity_source == "Hminus_ff":
-        sig = _interp2d(wave, axis2, values, tracing_lambdas, 5040 / temperatures)
-        sig = sig * 1e-26 * K.K_B_CGS * temperatures[:, np.newaxis]
-        what = "H- FF"
-    else:
-        sig = _interp2d(wave, axis2, values, tracing_lambdas, temperatures) * 1e-18
-        what = "H2+ BF"
-    if np.any(sig == 0):
-        logger.warning(
-            "Outside of interpolation range for %s cross-sections at depth points %s. Assuming 0 opacity there.",
-            what, np.unique(np.where(sig == 0)[0]),
-        )
-    return sig
+        return np.interp(np.asarray(tracing_lambdas, dtype=float), table[1], table[2])
+    return sigma_file_device(tracing_lambdas, temperatures, fpath, opacity_source).numpy()
 
 
 def get_number_density(stellar_plasma, opacity_source):

@@ -818,6 +818,35 @@ def g11_linelist(atm, cont):
     out["alpha_coefficient"] = np.float64(P.base.ALPHA_COEFFICIENT.value)
     save("g11_linelist", **out)
 
+# ----------------------------------------------------------------------------- G12 triangulated cross-section tables
+def g12_sigma_tables(atm):
+    """sigma_file (opacities_solvers/util.py:14-91) for the two 2-D tables, together with the tables themselves and
+    the Delaunay triangulation this interpreter's scipy/Qhull builds for them (LinearNDInterpolator's diagonals are
+    implementation-defined; the triangulation is part of the input of a faithful restatement)."""
+    import scipy
+    from scipy.interpolate import LinearNDInterpolator
+
+    from stardis_amd.radiation_field.opacities.opacities_solvers.util import read_table
+
+    rng = np.random.default_rng(12)
+    t = atm["temperatures"]
+    out = dict(temperatures=t, scipy_version=np.array(scipy.__version__))
+    for src, fname in (("H2plus_bf", "h2_plus_bf_S1994.dat"), ("Hminus_ff", "h_minus_ff_B1987.dat")):
+        _, wave, axis2, values = read_table(REF_DATA / fname, src)
+        lam = np.sort(np.concatenate([rng.uniform(wave.min() * 0.9, wave.max() * 1.05, 500), wave, wave[:-1] + 0.5 * np.diff(wave)]))
+        temps = np.concatenate([t, [2500.0, 3150.0, 4200.0, 5040.0, 8400.0, 10080.0, 12600.0, 26000.0]])
+        with np.errstate(all="ignore"):
+            sig = R.ut.sigma_file(lam, temps, REF_DATA / fname, src)
+        w_mesh, a_mesh = np.meshgrid(wave, axis2, indexing="ij")
+        pts = np.vstack([w_mesh.ravel(), a_mesh.ravel()]).T
+        tri = LinearNDInterpolator(pts, values.flatten(), fill_value=0).tri
+        out.update({
+            src + "_wave": wave, src + "_axis2": np.asarray(axis2, dtype=np.float64), src + "_values": values,
+            src + "_simplices": tri.simplices.astype(np.int32), src + "_transform": tri.transform,
+            src + "_lambdas": lam, src + "_query_temperatures": temps, src + "_sigma": sig,
+        })
+    save("g12_sigma_tables", **out)
+
 
 def main():
     rng = np.random.default_rng(20250926)
@@ -827,7 +856,7 @@ def main():
 
     atm = atmosphere()
     cont = synth.synth_continuum_state(atm)
-    which = set(sys.argv[1:]) or {"g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"}
+    which = set(sys.argv[1:]) or {"g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"}
     if "g1" in which:
         g1_faddeeva(rng)
     if "g2" in which:
@@ -850,6 +879,8 @@ def main():
         g10_spherical(atm)
     if "g11" in which:
         g11_linelist(atm, cont)
+    if "g12" in which:
+        g12_sigma_tables(atm)
 
 
 if __name__ == "__main__":
