@@ -295,6 +295,14 @@ typedef struct sdx_linelist {
 int sdx_line_params_dev(sdx_ctx* ctx, int n_depth, const sdx_linelist* lines, double* alphas, double* gammas,
                         double* doppler_widths);
 
+/* AlphaLine.calculate (plasma/base.py:146-175), lines from TARDIS atomic data: alphas[l][d] =
+ * ((alpha_coefficient * level_density[lower_index[l]][d]) * stim[l][d]) * f_lu[l].  level_density is
+ * [n_levels][n_depth]; stim (the stimulated-emission factor TARDIS supplies) and alphas are [n_lines][n_depth].
+ * lower_index must lie in [0, n_levels) (numpy take(mode="raise") on the host side). */
+int sdx_alpha_line_levels_dev(sdx_ctx* ctx, int64_t n_lines, int n_depth, int n_levels, const double* level_density,
+                              const int32_t* lower_index, const double* stim, const double* f_lu,
+                              double alpha_coefficient, double* alphas);
+
 /* sdx_line_opacity_dev / sdx_synthesize_dev with the line parameters generated in the pre-pass. */
 int sdx_line_opacity_linelist_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin,
                                   int64_t nu_count, const sdx_linelist* lines, double* out, int64_t out_ld, int accumulate,

@@ -306,6 +306,18 @@ def alpha_line_linelist(e_low_ev, g_lo, strength, line_nus, pop_row, pop, temps,
     return out
 
 
+def alpha_line_levels(level_density, lower_index, stim, f_lu, alpha_coefficient):
+    """plasma/base.py:146-175 — (N_l, N_d)"""
+    ld, pld = _d(level_density)
+    li, pli = _i(lower_index)
+    st, pst = _d(stim)
+    f, pf = _d(f_lu)
+    nd = ld.shape[1]
+    out = np.empty((li.size, nd))
+    lib().orc_alpha_line_levels(C.c_int64(li.size), C.c_int(nd), pld, pli, pst, pf, C.c_double(alpha_coefficient), out.ctypes.data_as(_dp))
+    return out
+
+
 def interp_triangulated(x_axis, y_axis, cell_simplices, transform, simplex_values, qx, qy):
     """util.py:47-56, :75-86 — LinearNDInterpolator(points, values, fill_value=0) at the mesh (qx, qy) -> (len(qy), len(qx))."""
     xa, pxa = _d(x_axis)

@@ -819,6 +819,21 @@ __global__ __launch_bounds__(kBlock) void k_line_params(int64_t n_lines, int n_d
     if (gammas && (gamma_cols > 1 || d == 0)) gammas[l * gamma_cols + (gamma_cols > 1 ? d : 0)] = line_gamma_at(lp, l, d);
 }
 
+// plasma/base.py:130-175 AlphaLine: alpha = ((ALPHA_COEFFICIENT * n_lower) * stimulated_emission_factor) * f_lu, n_lower
+// gathered from the level populations by lines_lower_level_index (numpy take, mode="raise": the host checks the range)
+__global__ __launch_bounds__(kBlock) void k_alpha_line_levels(int64_t n_lines, int n_depth, const double* __restrict__ level_density,
+                                                              const int* __restrict__ lower_index, const double* __restrict__ stim,
+                                                              const double* __restrict__ f_lu, double coefficient,
+                                                              double* __restrict__ alphas)
+{
+    const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (k >= n_lines * n_depth) return;
+    const int64_t l = k / n_depth;
+    const int d = (int)(k - l * n_depth);
+    const double n_lower = level_density[(size_t)lower_index[l] * n_depth + d];
+    alphas[k] = mul_rn(mul_rn(mul_rn(coefficient, n_lower), stim[k]), f_lu[l]);
+}
+
 // the reference's element-wise ufuncs (broadening.py:69-71, :140-146, :232-234, :346-360, :476-490)
 enum BroadeningOp { kOpDoppler = 0, kOpNEff = 1, kOpLinearStark = 2, kOpQuadraticStark = 3, kOpVanDerWaals = 4 };
 __global__ __launch_bounds__(kBlock) void k_broadening_scalar(int op, int64_t n, const double* __restrict__ a,

@@ -759,6 +759,21 @@ int sdx_line_params_dev(sdx_ctx* ctx, int n_depth, const sdx_linelist* ll, doubl
     return check_launch("k_line_params");
 }
 
+int sdx_alpha_line_levels_dev(sdx_ctx* ctx, int64_t n_lines, int n_depth, int n_levels, const double* level_density,
+                              const int32_t* lower_index, const double* stim, const double* f_lu, double alpha_coefficient,
+                              double* alphas)
+{
+    REQUIRE(ctx && n_lines >= 0 && n_depth > 0 && n_levels >= 0, "alpha_line_levels: bad sizes");
+    if (n_lines == 0) return SDX_OK;
+    REQUIRE(level_density && lower_index && stim && f_lu && alphas && n_levels > 0, "alpha_line_levels: null pointer");
+    {
+        LaunchScope ls(ctx, "k_alpha_line_levels");
+        hipLaunchKernelGGL(k_alpha_line_levels, dim3(blocks1(n_lines * n_depth)), dim3(kBlock), 0, ctx->stream, n_lines, n_depth, level_density,
+                           (const int*)lower_index, stim, f_lu, alpha_coefficient, alphas);
+    }
+    return check_launch("k_alpha_line_levels");
+}
+
 int sdx_line_opacity_linelist_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin, int64_t nu_count,
                                   const sdx_linelist* ll, double* out, int64_t out_ld, int accumulate, int64_t* n_evaluations_dev)
 {

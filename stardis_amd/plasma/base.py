@@ -95,6 +95,37 @@ def _species_keys(ll):
     return list(seen)
 
 
+class AlphaLine:
+    """plasma/base.py:130-175: lines of the TARDIS atomic data.  The level populations and the stimulated-emission factor
+    are TARDIS plasma properties (dense inputs, as in the reference); the gather and the products run in
+    sdx_alpha_line_levels_dev."""
+
+    outputs = ("alpha_line",)
+
+    def calculate(self, lines, level_number_density, lines_lower_level_index, stimulated_emission_factor, f_lu):
+        import pandas as pd
+
+        from stardis_amd._lib import default_context
+
+        ctx = default_context()
+        levels = np.ascontiguousarray(plain(level_number_density), dtype=np.float64)
+        index = np.asarray(plain(lines_lower_level_index))
+        if index.size and (index.min() < -levels.shape[0] or index.max() >= levels.shape[0]):
+            raise IndexError("index out of range")  # numpy take(..., mode="raise") (:157-159)
+        index = np.where(index < 0, index + levels.shape[0], index).astype(np.int32)
+        stim = np.ascontiguousarray(plain(stimulated_emission_factor), dtype=np.float64).reshape(index.size, levels.shape[1])
+        d = [ctx.upload(levels), ctx.upload(index, np.int32), ctx.upload(stim), ctx.upload(np.ascontiguousarray(plain(f_lu), dtype=np.float64))]
+        out = ctx.empty(stim.shape)
+        ctx.call("sdx_alpha_line_levels_dev", index.size, levels.shape[1], levels.shape[0], d[0].ptr, d[1].ptr, d[2].ptr, d[3].ptr,
+                 ALPHA_COEFFICIENT, out.ptr)
+        alpha = out.numpy()
+        if np.any(np.isnan(alpha)) or np.any(np.isinf(np.abs(alpha))):
+            raise ValueError("Some alpha_line are nan, inf, -inf " " Something went wrong!")  # :162-165
+        df = pd.DataFrame(alpha, index=lines.index, columns=np.array(level_number_density.columns))
+        df["nu"] = lines.nu
+        return df
+
+
 class AlphaLineVald:
     """plasma/base.py:178-321."""
 

@@ -847,6 +847,32 @@ def g12_sigma_tables(atm):
         })
     save("g12_sigma_tables", **out)
 
+# ----------------------------------------------------------------------------- G13 AlphaLine (TARDIS atomic data)
+def g13_alpha_line_levels(atm, cont):
+    """AlphaLine.calculate (plasma/base.py:130-175): alpha = ALPHA_COEFFICIENT * n_lower * stimulated_emission * f_lu with
+    n_lower gathered from the level populations by lines_lower_level_index."""
+    P = ref_loader.load_plasma()
+    rng = np.random.default_rng(13)
+    t = atm["temperatures"]
+    nd, n_levels, n_lines = len(t), 37, 400
+    cols = np.arange(nd)
+    level_density = pd.DataFrame(
+        10.0 ** rng.uniform(2, 14, (n_levels, 1)) * np.exp(-rng.uniform(0, 6, (n_levels, 1)) * 1.602176634e-12 / (1.380649e-16 * t[None, :])),
+        columns=cols,
+    )
+    lower = rng.integers(0, n_levels, n_lines)
+    stim = 1.0 - np.exp(-rng.uniform(1.5, 3.5, (n_lines, 1)) * 1.602176634e-12 / (1.380649e-16 * t[None, :]))
+    stim[7] = 0.0  # TARDIS zeroes the factor of inverted populations
+    f_lu = pd.Series(10.0 ** rng.uniform(-5, 0.3, n_lines))
+    lines = pd.DataFrame(dict(nu=rng.uniform(4.5e14, 4.6e14, n_lines)), index=pd.Index(np.arange(n_lines) * 3 + 11, name="line_id"))
+    out = P.base.AlphaLine.__new__(P.base.AlphaLine).calculate(lines, level_density, lower, stim, f_lu)
+    save(
+        "g13_alpha_line_levels", temperatures=t, level_number_density=level_density.values, lines_lower_level_index=lower,
+        stimulated_emission_factor=stim, f_lu=f_lu.values, lines_nu=lines.nu.values, lines_index=np.asarray(lines.index),
+        alpha_line=out.drop(columns="nu").to_numpy(dtype=np.float64), alpha_line_nu=out.nu.values, alpha_line_index=np.asarray(out.index),
+        alpha_line_columns=np.array([str(c) for c in out.columns]),
+    )
+
 
 def main():
     rng = np.random.default_rng(20250926)
@@ -856,7 +882,7 @@ def main():
 
     atm = atmosphere()
     cont = synth.synth_continuum_state(atm)
-    which = set(sys.argv[1:]) or {"g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"}
+    which = set(sys.argv[1:]) or {"g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"}
     if "g1" in which:
         g1_faddeeva(rng)
     if "g2" in which:
@@ -881,6 +907,8 @@ def main():
         g11_linelist(atm, cont)
     if "g12" in which:
         g12_sigma_tables(atm)
+    if "g13" in which:
+        g13_alpha_line_levels(atm, cont)
 
 
 if __name__ == "__main__":

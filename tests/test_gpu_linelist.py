@@ -214,3 +214,23 @@ def test_bad_line_lists_are_rejected(ctx):
                         atm["temperatures"])
     out = LL.line_opacity(nus, empty)
     assert out.shape == (atm["temperatures"].size, nus.size) and not out.any()
+
+
+def test_alpha_line_of_tardis_lines_bit_exact():
+    """AlphaLine.calculate (plasma/base.py:146-175) through the mirror: same frame, same bits."""
+    import pandas as pd
+
+    from conftest import load_golden
+    from stardis_amd.plasma import AlphaLine
+
+    g = load_golden("g13_alpha_line_levels")
+    cols = np.arange(g["temperatures"].size)
+    lines = pd.DataFrame(dict(nu=g["lines_nu"]), index=pd.Index(g["lines_index"], name="line_id"))
+    out = AlphaLine().calculate(lines, pd.DataFrame(g["level_number_density"], columns=cols), g["lines_lower_level_index"],
+                                g["stimulated_emission_factor"], pd.Series(g["f_lu"]))
+    assert np.array_equal(out.drop(columns="nu").to_numpy(), g["alpha_line"])
+    assert np.array_equal(out.nu.values, g["alpha_line_nu"]) and np.array_equal(np.asarray(out.index), g["alpha_line_index"])
+    assert [str(c) for c in out.columns] == list(g["alpha_line_columns"])
+    with pytest.raises(IndexError):
+        AlphaLine().calculate(lines, pd.DataFrame(g["level_number_density"], columns=cols), g["lines_lower_level_index"] + 1000,
+                              g["stimulated_emission_factor"], pd.Series(g["f_lu"]))

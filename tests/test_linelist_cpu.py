@@ -96,3 +96,13 @@ def test_oracle_chain_reproduces_reference_line_opacity(fx):
         assert rel_err(dop, g[tag + "_doppler"]) < 1e-15
         out = oracle.calc_alan_entries(fx.t.size, nus, sel.nu.values, dop, gam, alphas)
         assert rel_err(out, g[tag + "_alpha_line_at_nu"]) < 1e-12
+
+
+def test_oracle_alpha_line_levels_bit_exact():
+    """AlphaLine.calculate (plasma/base.py:146-175): products only, so bit-exact."""
+    from conftest import load_golden
+
+    g = load_golden("g13_alpha_line_levels")
+    a = oracle.alpha_line_levels(g["level_number_density"], g["lines_lower_level_index"], g["stimulated_emission_factor"], g["f_lu"],
+                                 0.026540088545744744)
+    assert np.array_equal(a, g["alpha_line"])
