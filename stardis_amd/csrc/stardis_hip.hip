@@ -586,7 +586,9 @@ static int choose_splits(int n_depth, int64_t n_nu_global, int64_t n_lines, int 
     const int64_t chunks = (n_lines + 63) / 64;
     int64_t target = 2560;  // measured optimum on S-c2: 2 subsets; more planes cost the raytrace staging more than the shorter chains gain
     if (const char* e = std::getenv("SDX_WIDE_BLOCKS")) target = std::max(1, std::atoi(e));  // tuning knob
-    const int64_t want = (target + tiles * n_depth - 1) / (tiles * n_depth);
+    // at least two subsets: the choice must not depend on the shard (it fixes the summation order), and a rank that owns
+    // 1/8 of a large grid still needs enough blocks; on a large unsharded grid the second plane costs ~1 % (S-c3)
+    const int64_t want = std::max<int64_t>(2, (target + tiles * n_depth - 1) / (tiles * n_depth));
     return (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(want, chunks), 32));
 }
 
