@@ -65,15 +65,6 @@ def triangulate(wave, axis2, values):
     return tri.simplices, tri.transform
 
 
-def _interp2d(wave, axis2, values, lambdas, second):
-    from scipy.interpolate import LinearNDInterpolator
-
-    w_mesh, a_mesh = np.meshgrid(wave, axis2, indexing="ij")
-    f = LinearNDInterpolator(np.vstack([w_mesh.ravel(), a_mesh.ravel()]).T, values.flatten(), fill_value=0)
-    lam, sec = np.meshgrid(lambdas, second)
-    return f(lam, sec)
-
-
 def sigma_file_device(tracing_lambdas, temperatures, fpath, opacity_source):
     """sigma_file for the 2-D tables with the result left in HBM -> DeviceArray (N_T, N_lambda)."""
     from stardis_amd import ops
@@ -89,17 +80,9 @@ def sigma_file_device(tracing_lambdas, temperatures, fpath, opacity_source):
     else:
         second, kind, what = temperatures, 1, "H2+ BF"
     if lookup is None:
-        # a triangulation that is not two-triangles-per-cell (never seen for these tables): let scipy evaluate, as the
-        # reference does, and say so
-        logger.warning("unexpected triangulation of the %s table: interpolating on the host with scipy", what)
-        sig = _interp2d(wave, axis2, values, tracing_lambdas, second)
-        sig = sig * 1e-26 * K.K_B_CGS * temperatures[:, np.newaxis] if kind == 2 else sig * 1e-18
-        zero_rows = np.unique(np.where(sig == 0)[0])
-        from stardis_amd._lib import default_context
-
-        dev = default_context().upload(sig)
-    else:
-        dev, zero_rows = ops.sigma_table_2d(wave, axis2, lookup[0], transform, lookup[1], tracing_lambdas, second, kind, temperatures)
+        # never seen for these tables; there is no host evaluation path to fall back to
+        raise NotImplementedError(f"the Delaunay triangulation of the {what} table is not two triangles per grid cell")
+    dev, zero_rows = ops.sigma_table_2d(wave, axis2, lookup[0], transform, lookup[1], tracing_lambdas, second, kind, temperatures)
     if zero_rows.size:
         logger.warning(
             "Outside of interpolation range for %s cross-sections at depth points %s. Assuming 0 opacity there.", what, zero_rows

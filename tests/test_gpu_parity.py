@@ -31,6 +31,28 @@ def test_faddeeva_known_answers(ctx):
         ops.voigt_profile(1.0, 0.0, 1.0)  # :130-148
 
 
+def test_reference_unit_test_known_answers(ctx):
+    """Every sample value of the reference's own unit tests for this path, through the reference-named functions."""
+    import reference_known_answers as ka
+    from stardis_amd.radiation_field.opacities.opacities_solvers import broadening as B
+    from stardis_amd.radiation_field.opacities.opacities_solvers import voigt as V
+
+    fn = {"doppler_width": B.calc_doppler_width, "n_effective": B.calc_n_effective, "gamma_linear_stark": B.calc_gamma_linear_stark,
+          "gamma_quadratic_stark": B.calc_gamma_quadratic_stark, "gamma_van_der_waals": B.calc_gamma_van_der_waals}
+    for name, args, expected in ka.BROADENING:
+        got = fn[name](*args)
+        assert np.allclose(got, expected), (name, got, expected)
+        assert np.shape(got) == np.shape(expected)
+    for z, expected in ka.FADDEEVA:
+        assert np.allclose(V.faddeeva(z), expected)
+    for args, expected in ka.VOIGT:
+        assert np.allclose(V.voigt_profile(*args), expected)
+    for dnu in ka.VOIGT_DIVISION_BY_ZERO:
+        for gam in ka.VOIGT_DIVISION_BY_ZERO:
+            with pytest.raises(ZeroDivisionError):
+                V.voigt_profile(dnu, 0, gam)
+
+
 def test_faddeeva_golden(ctx):
     g = load_golden("g1_faddeeva")
     w = ops.faddeeva(g["z"])

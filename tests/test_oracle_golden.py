@@ -175,3 +175,32 @@ def test_spherical_raytrace_golden():
     assert rel_err(F, g["F_nu"]) < 5e-11
     assert rel_err(I, g["I_nus"]) < 1e-7
     assert rel_err(one, g["I_single_inward_theta5"]) < 1e-7
+
+
+def test_reference_unit_test_known_answers():
+    """Every sample value of the reference's own unit tests for this path (tests/reference_known_answers.py)."""
+    import reference_known_answers as ka
+
+    L = oracle.lib()
+    scalar = {
+        "doppler_width": lambda nu, t, m, xi: L.orc_doppler_width(nu, t, m, xi),
+        "n_effective": lambda ion, e_ion, e_lev: L.orc_n_effective(int(ion), e_ion, e_lev),
+        "gamma_linear_stark": lambda nu_, nl_, ne: L.orc_gamma_linear_stark(nu_, nl_, ne),
+        "gamma_quadratic_stark": lambda ion, nu_, nl_, ne, t: L.orc_gamma_quadratic_stark(int(ion), nu_, nl_, ne, t),
+        "gamma_van_der_waals": lambda ion, nu_, nl_, t, nh: L.orc_gamma_van_der_waals(int(ion), nu_, nl_, t, nh),
+    }
+    for name, args, expected in ka.BROADENING:
+        got = np.vectorize(scalar[name], otypes=[float])(*args)
+        assert np.allclose(got, expected), (name, got, expected)
+    for z, expected in ka.FADDEEVA:
+        assert np.allclose(oracle.faddeeva(np.atleast_1d(np.asarray(z, dtype=complex))), np.atleast_1d(expected))
+    voigt = lambda a, b, c: float(oracle.voigt_profile(float(a), float(b), float(c)))  # noqa: E731
+    for args, expected in ka.VOIGT:
+        got = np.vectorize(voigt, otypes=[float])(*args)
+        assert np.allclose(got, expected)
+        assert np.array_equal(got, np.broadcast_to(expected, got.shape))  # in fact exact
+    for dnu in ka.VOIGT_DIVISION_BY_ZERO:
+        for gam in ka.VOIGT_DIVISION_BY_ZERO:
+            for a, b in np.broadcast(dnu, gam):
+                with pytest.raises(ZeroDivisionError):
+                    oracle.voigt_profile(float(a), 0.0, float(b))
