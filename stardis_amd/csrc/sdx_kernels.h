@@ -219,15 +219,21 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
     const double d_nu = dnu_partial ? block_dnu(dnu_partial, n_partial, s_red) : block_dnu_scan(nus, n_nu, s_red);
 
     if constexpr (GEN) {
-        // line parameters from per-line scalars and per-depth state (f1): nothing dense to read
+        // line parameters from per-line scalars and per-depth state (f1): nothing dense to read.  The per-depth and the
+        // per-line factors (every pow / tgamma / n_eff) are evaluated once per block column / row and shared through LDS.
+        __shared__ GenDepth s_gd[kPreDepths];
+        __shared__ GenLine s_gl[kPreLines];
+        if (threadIdx.x < nd) s_gd[threadIdx.x] = gen_depth(lp, d0 + threadIdx.x);
+        else if (threadIdx.x >= 64 && threadIdx.x < 64 + nl) s_gl[threadIdx.x - 64] = gen_line(lp, line_nus[l0 + threadIdx.x - 64], l0 + threadIdx.x - 64);
+        __syncthreads();
         for (int k = threadIdx.x; k < nl * nd; k += nthreads) {
             const int ll = k / nd, dd = k - ll * nd;
             const int64_t l = l0 + ll;
-            const int d = d0 + dd;
-            const double lnu = line_nus[l];
-            s_dw[ll * kStride + dd] = doppler_width(lnu, lp.temps[d], lp.mass[l], lp.xi);
-            s_a[ll * kStride + dd] = line_alpha_at(lp, lnu, l, d, n_depth);
-            s_g[ll * kStride + dd] = line_gamma_at(lp, l, d);
+            const GenDepth D = s_gd[dd];
+            const GenLine L = s_gl[ll];
+            s_dw[ll * kStride + dd] = gen_doppler(lp, L, D, l);
+            s_a[ll * kStride + dd] = gen_alpha(lp, D, line_nus[l], l, d0 + dd, n_depth);
+            s_g[ll * kStride + dd] = gen_gamma(lp, L, D, l);
         }
     } else {
         // reference layout in, line fastest ... depth fastest: coalesced
@@ -814,9 +820,11 @@ __global__ __launch_bounds__(kBlock) void k_line_params(int64_t n_lines, int n_d
     const int64_t l = k / n_depth;
     const int d = (int)(k - l * n_depth);
     const double lnu = line_nus[l];
-    if (alphas) alphas[k] = line_alpha_at(lp, lnu, l, d, n_depth);
-    if (doppler) doppler[k] = doppler_width(lnu, lp.temps[d], lp.mass[l], lp.xi);
-    if (gammas && (gamma_cols > 1 || d == 0)) gammas[l * gamma_cols + (gamma_cols > 1 ? d : 0)] = line_gamma_at(lp, l, d);
+    const GenDepth D = gen_depth(lp, d);
+    const GenLine L = gen_line(lp, lnu, l);
+    if (alphas) alphas[k] = gen_alpha(lp, D, lnu, l, d, n_depth);
+    if (doppler) doppler[k] = gen_doppler(lp, L, D, l);
+    if (gammas && (gamma_cols > 1 || d == 0)) gammas[l * gamma_cols + (gamma_cols > 1 ? d : 0)] = gen_gamma(lp, L, D, l);
 }
 
 // plasma/base.py:130-175 AlphaLine: alpha = ((ALPHA_COEFFICIENT * n_lower) * stimulated_emission_factor) * f_lu, n_lower

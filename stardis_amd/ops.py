@@ -15,7 +15,8 @@ F8 = np.float64
 
 
 def _host(a, dtype=F8):
-    return np.ascontiguousarray(_lib.plain(a), dtype=dtype)
+    a = np.asarray(_lib.plain(a), dtype=dtype)
+    return a if a.ndim == 0 else np.ascontiguousarray(a)  # ascontiguousarray would turn a scalar into shape (1,)
 
 
 def _dev(ctx, a, dtype=F8):

@@ -145,6 +145,14 @@ def test_seeded_list_against_the_oracle(mode):
     assert rel_err(a, a_ref) < 3e-15
     assert rel_err(gm, g_ref) < 1e-13
     assert rel_err(d, d_ref) < 1e-15
+    # the factored generation (per-line x per-depth) has the bits of the dense broadening kernels
+    from stardis_amd import ops
+
+    args = (spec.atomic_number, spec.ion_number, spec.ionization_energy, spec.upper_energy, spec.lower_energy, spec.A_ul)
+    state = (spec.electron_density, spec.temperature, spec.h_density, True, True, True, True)
+    dense = ops.calc_vald_gamma_arrays(*args, spec.stark, spec.waals, spec.mass, *state) if mode == LL.GAMMA_VALD else ops.calc_gamma(*args, *state)
+    assert np.array_equal(gm, dense)
+    assert np.array_equal(d, ops.doppler_widths(spec.nu, spec.mass, spec.temperature, spec.microturbulence))
     out, evals = LL.line_opacity(nus, spec, return_evaluations=True)
     ref = oracle.calc_alan_entries(atm["temperatures"].size, nus, spec.nu, d_ref, g_ref, a_ref)
     assert rel_err(out, ref) < 1e-12
