@@ -710,7 +710,12 @@ __global__ __launch_bounds__(64, 4) void k_line_all(int n_wide, int tiles, int n
 {
     const int b = blockIdx.x;
     if (b < n_wide) {
-        const int tile = b % tiles, rest = b / tiles;
+        // XCD-aware tile order: workgroup i runs on XCD i % 8, each with its own L2.  Within a (depth, subset) group the
+        // blocks of one XCD take CONTIGUOUS tiles (position p -> tile prefix(p % 8) + p / 8), so neighbouring tiles, whose
+        // line ranges overlap, hit the same L2 instead of pulling the same constants into all eight.
+        const int p = b % tiles, rest = b / tiles;
+        int tile = p >> 3;
+        for (int f = 0; f < (p & 7); ++f) tile += (tiles - f + 7) >> 3;
         if (INDEXED)
             line_wide_block_indexed<R, MIXED>(tile, rest % n_split, n_split, rest / n_split, nus, nu_begin, nu_count, w, partial, pld,
                                               n_depth);
