@@ -242,3 +242,24 @@ def test_alpha_line_of_tardis_lines_bit_exact():
     with pytest.raises(IndexError):
         AlphaLine().calculate(lines, pd.DataFrame(g["level_number_density"], columns=cols), g["lines_lower_level_index"] + 1000,
                               g["stimulated_emission_factor"], pd.Series(g["f_lu"]))
+
+
+def test_line_opacity_is_linear_in_the_list_at_scale():
+    """A size-independent property at a size no CPU oracle finishes: 3e5 lines on the 1.2e5-point grid (the indexed wide
+    path, 1.4e10 Voigt evaluations) must give the sum of its even- and odd-numbered halves."""
+    atm = synth.solar_atmosphere()
+    cfg = synth.WORKLOADS["S-c3"]
+    nus = synth.tracing_grid(cfg["lam0"], cfg["lam1"], cfg.get("R"), cfg.get("step"))
+    spec = synth.synth_linelist(nus, atm, 300_000)
+
+    def subset(sel):
+        kw = {k: getattr(spec, k)[sel] for k in ("g_lo", "atomic_number", "ion_number", "ionization_energy", "upper_energy", "lower_energy",
+                                                "A_ul", "stark", "waals")}
+        return LL.LineList(spec.nu[sel], spec.e_low_ev[sel], spec.strength[sel], spec.pop_row[sel], spec.pop, spec.mass[sel],
+                           spec.temperature, microturbulence=spec.microturbulence, gamma_mode=spec.gamma_mode, flags=spec.flags,
+                           electron_density=spec.electron_density, h_density=spec.h_density, **kw)
+
+    full, evals = LL.line_opacity(nus, spec, return_evaluations=True)
+    parts = LL.line_opacity(nus, subset(slice(0, None, 2))) + LL.line_opacity(nus, subset(slice(1, None, 2)))
+    assert evals > 5e9 and np.isfinite(full).all() and (full > 0).any()
+    assert rel_err(full, parts) < 1e-12
