@@ -571,6 +571,7 @@ static int check_line_args(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double
     REQUIRE(ctx, "null context");
     REQUIRE(n_depth > 0 && n_nu >= 0 && n_lines >= 0, "line opacity: negative or zero sizes");
     REQUIRE(n_nu < (int64_t)2147483647, "line opacity: n_nu must fit int32");
+    REQUIRE(n_lines < (int64_t)2147483647, "line opacity: n_lines must fit int32");
     REQUIRE(gamma_cols == n_depth || gamma_cols == 1, "line opacity: gammas must have n_depth or 1 columns");
     REQUIRE(n_nu == 0 || nus, "line opacity: null frequency grid");
     REQUIRE(n_lines == 0 || (line_nus && doppler && gammas && alphas), "line opacity: null line arrays");
@@ -709,7 +710,7 @@ int sdx_line_opacity_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
 static int to_line_params(const sdx_linelist* ll, int n_depth, LineParams* lp)
 {
     REQUIRE(ll, "line list: null description");
-    REQUIRE(ll->n_lines >= 0 && n_depth > 0, "line list: bad sizes");
+    REQUIRE(ll->n_lines >= 0 && ll->n_lines < (int64_t)2147483647 && n_depth > 0, "line list: bad sizes (n_lines must fit int32)");
     REQUIRE(ll->gamma_mode >= 0 && ll->gamma_mode <= 3, "line list: gamma_mode must be 0..3");
     if (ll->n_lines == 0) return SDX_OK;
     REQUIRE(ll->nu && ll->e_low_ev && ll->strength && ll->pop_row && ll->pop && ll->mass && ll->temperature,
