@@ -343,3 +343,12 @@ def rotation_broadening(flux, velocity_per_pix, v_rot, limb_darkening=0.6):
     if rc:
         raise MemoryError
     return out
+
+
+def gaussian_filter1d(values, sigma, truncate=4.0):
+    """scipy.ndimage.gaussian_filter1d(values, sigma) (mode='reflect'): docs/rotation_broadening cell 11"""
+    v, pv = _d(values)
+    out = np.empty_like(v)
+    if lib().orc_gaussian_filter1d(C.c_int64(v.size), pv, C.c_double(sigma), C.c_double(truncate), out.ctypes.data_as(_dp)):
+        raise MemoryError
+    return out

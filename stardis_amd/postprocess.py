@@ -48,6 +48,23 @@ def convolve1d_reflect(values, weights, ctx=None):
     return out.numpy()
 
 
+def gaussian_kernel(sigma, truncate=4.0):
+    """The weights scipy.ndimage.gaussian_filter1d builds (order 0): radius int(truncate * sigma + 0.5)."""
+    sigma = float(sigma)
+    radius = int(truncate * sigma + 0.5)
+    x = np.arange(-radius, radius + 1)
+    phi = np.exp(-0.5 / (sigma * sigma) * x**2)
+    return phi / phi.sum()
+
+
+def gaussian_filter1d(flux, sigma, truncate=4.0, ctx=None):
+    """scipy.ndimage.gaussian_filter1d(flux, sigma) (mode='reflect') on the GPU: the instrumental line-spread function the
+    reference's rotation-broadening walk-through applies before the rotational kernel (docs/rotation_broadening, cell 11;
+    sigma in pixels = lambda / R / dispersion / 2.355)."""
+    values = np.asarray(getattr(flux, "value", flux), dtype=np.float64)
+    return convolve1d_reflect(values, gaussian_kernel(sigma, truncate), ctx)
+
+
 def rotation_broadening(velocity_per_pix, wavelength, flux, v_rot=0.0, limb_darkening=0.6):
     """-> (wavelength, broadened flux).  Inputs may be astropy quantities (km/s, Angstrom, flux density) or plain
     numbers in those units; like the reference the flux comes back untouched when |v_rot| < 1e-5 km/s (:866-867)."""

@@ -289,3 +289,24 @@ def test_spherical_raytrace_golden(ctx):
     one = single_theta_trace_parallel(g["ray_distances"][:, 5].copy(), g["temperatures"].reshape(-1, 1), g["total_alphas"], g["nus"],
                                       blackbody_flux_at_nu, inward_rays=True)
     assert rel_err(one, g["I_single_inward_theta5"]) < 1e-7
+
+
+def test_gaussian_line_spread_function(ctx):
+    """The instrumental LSF of the reference's rotation-broadening walk-through (docs/rotation_broadening cells 7-19):
+    gaussian_filter1d to the target resolution, then rotation_broadening — bit for bit what scipy returns."""
+    from scipy.ndimage import convolve1d, gaussian_filter1d
+
+    from stardis_amd import postprocess as pp
+
+    g = load_golden("g8_rotation")
+    flux = g["flux"]
+    fwhm = 6500.0 / 100000 / 0.01  # cells 7-8
+    sigma = fwhm / 2.355
+    for s_ in (sigma, 0.4, 27.6):
+        mine = pp.gaussian_filter1d(flux, s_)
+        assert np.array_equal(mine, gaussian_filter1d(flux, s_))
+        assert rel_err(mine, oracle.gaussian_filter1d(flux, s_)) < 1e-15
+    lsf = pp.gaussian_filter1d(flux, sigma)
+    vel_per_pix = 299792.458 / 100000 / fwhm  # cells 15-17
+    _, broad = pp.rotation_broadening(vel_per_pix, g["wavelength"], lsf, v_rot=20.0)
+    assert np.array_equal(broad, convolve1d(lsf, pp.rotation_profile(vel_per_pix, 20.0)))

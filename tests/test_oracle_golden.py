@@ -204,3 +204,13 @@ def test_reference_unit_test_known_answers():
             for a, b in np.broadcast(dnu, gam):
                 with pytest.raises(ZeroDivisionError):
                     oracle.voigt_profile(float(a), 0.0, float(b))
+
+
+def test_gaussian_line_spread_function_matches_scipy():
+    """docs/rotation_broadening (cell 11): scipy.ndimage.gaussian_filter1d(spectrum, sigma).  The reference calls scipy
+    itself; the installed scipy is the cross-check (libm exp against numpy's exp: <= 1 ulp on the weights)."""
+    from scipy.ndimage import gaussian_filter1d
+
+    g = load_golden("g8_rotation")
+    for sigma in (0.4, 2.76, 27.6):
+        assert rel_err(oracle.gaussian_filter1d(g["flux"], sigma), gaussian_filter1d(g["flux"], sigma)) < 1e-15
