@@ -28,14 +28,27 @@ WORKLOADS = {
     "S-c3": dict(lam0=3000.0, lam1=10000.0, R=1.0e5, n_lines=150000, gamma_per_depth=True),
     "S-c4": dict(lam0=3000.0, lam1=10000.0, R=1.0e5, n_lines=1000000, gamma_per_depth=False),
     "S-big": dict(lam0=3000.0, lam1=10000.0, R=1.0e6, n_lines=1000000, gamma_per_depth=False),
+    # BASELINE config 4 on the coolest MARCS structure the reference ships (3800 K dwarf): molecular-style list, gamma (N_l, 1)
+    "S-c4m": dict(lam0=3000.0, lam1=10000.0, R=1.0e5, n_lines=1000000, gamma_per_depth=False, atmosphere="cool_dwarf"),
 }
 SEED = 20250926
 N_THETAS = 20  # benchmarks/benchmark_config.yml:19
 
 
 def solar_atmosphere():
+    """Per-depth state of the solar MARCS model (docs/quickstart/sun.mod), innermost point first."""
+    return marcs_atmosphere("sun_marcs_columns.json")
+
+
+def cool_dwarf_atmosphere():
+    """The reference's own MARCS test model (io/model/tests/data/marcs_test.mod.gz): Teff 3800 K, log g 4.0,
+    2771-7713 K — the coolest structure in the tree, standing in for BASELINE's M-dwarf configuration."""
+    return marcs_atmosphere("marcs_t3800_g4_columns.json")
+
+
+def marcs_atmosphere(columns_file):
     """Per-depth state, innermost point first (io/model/marcs.py:45,204 flips MARCS order)."""
-    with open(os.path.join(_DATA, "sun_marcs_columns.json")) as fh:
+    with open(os.path.join(_DATA, columns_file)) as fh:
         col = json.load(fh)
     t = np.asarray(col["t"], dtype=np.float64)[::-1].copy()
     depth = np.asarray(col["depth"], dtype=np.float64)[::-1].copy()
@@ -193,7 +206,7 @@ def synth_continuum_state(atm, n_levels=10):
 
 def make_workload(tag, n_lines=None, seed=SEED, n_nu_override=None):
     cfg = dict(WORKLOADS[tag])
-    atm = solar_atmosphere()
+    atm = cool_dwarf_atmosphere() if cfg.get("atmosphere") == "cool_dwarf" else solar_atmosphere()
     nus = tracing_grid(cfg["lam0"], cfg["lam1"], cfg.get("R"), cfg.get("step"), n_nu_override)
     lines = synth_lines(
         nus, atm, cfg["n_lines"] if n_lines is None else n_lines, seed, cfg["gamma_per_depth"]

@@ -54,6 +54,10 @@ def capture_data():
             ),
             fh,
         )
+    # the reference's own MARCS test model (io/model/tests/data/marcs_test.mod.gz: Teff 3800 K, log g 4.0): a cool dwarf
+    cool = R.mk.read_marcs_model(Path("/root/reference/stardis/io/model/tests/data/marcs_test.mod.gz"), gzipped=True)
+    with open(os.path.join(REPO, "stardis_amd", "data", "marcs_t3800_g4_columns.json"), "w") as fh:
+        json.dump({c: [float(x) for x in cool.data[c].values] for c in ("t", "depth", "pe", "pg")}, fh)
     geometry = m.to_geometry()
     return m, geometry
 

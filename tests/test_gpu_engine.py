@@ -229,3 +229,21 @@ def test_mixed_precision_mode_is_a_tolerance_path(ctx):
     assert rel_err(a32, ref) < 1e-5
     assert rel_err(F32[1:], F64[1:]) < 1e-5
     print("mixed precision: opacity rel err", rel_err(a32, a64), "flux", rel_err(F32[1:], F64[1:]))
+
+
+def test_cool_dwarf_structure_matches_oracle(ctx):
+    """The same path on the coolest MARCS structure the reference ships (its own test model, Teff 3800 K, 2771-7713 K):
+    molecular-style list with gamma of shape (N_l, 1), other optical-depth regimes than the solar model."""
+    atm = synth.cool_dwarf_atmosphere()
+    nus = synth.tracing_grid(7050.0, 7065.0, step=0.01)  # a TiO band region
+    lines = synth.synth_lines(nus, atm, 600, seed=21, gamma_per_depth=False, mix=(0.8, 0.15, 0.05))
+    assert lines["gammas"].shape == (600, 1)
+    cont = synth.synth_continuum_state(atm)
+    th, w = synth.thetas_and_weights(10)
+    syn = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], th, w, lines, cont, ctx=ctx)
+    syn.step()
+    total_ref, line_ref = oracle_total(atm, nus, lines, cont)
+    assert rel_err(syn.alpha_line(), line_ref) < 1e-12
+    assert rel_err(syn.total_alphas(), total_ref) < 1e-12
+    F_ref, _ = oracle.raytrace(nus, atm["temperatures"], atm["dist"], th, w, total_ref)
+    assert rel_err(syn.F_nu()[1:], F_ref[1:]) < 1e-10

@@ -95,3 +95,25 @@ def test_calc_alpha_file_matches_reference(tmp_path, src):
 def test_bad_tables_are_rejected(ctx):
     with pytest.raises(ValueError, match="axes"):
         ops.sigma_table_2d(np.arange(1.0), np.arange(3.0), np.zeros((1, 2), np.int32), np.zeros((1, 3, 2)), np.zeros((1, 3)), [1.0], [1.0])
+
+
+def test_cool_layers_fall_off_the_h2plus_table():
+    """Temperatures below the first node of the H2+ table (3150 K): sigma 0 and the rows named, as the reference's
+    fill_value=0 + warning do (util.py:54-62) — the cool-dwarf structure has 8 such layers."""
+    from stardis_amd import synth
+
+    g = load_golden("g12_sigma_tables")
+    atm = synth.cool_dwarf_atmosphere()
+    t = atm["temperatures"]
+    wave, axis2, values = g["H2plus_bf_wave"], g["H2plus_bf_axis2"], g["H2plus_bf_values"]
+    cells, vertex_values = U.cell_lookup(wave, axis2, g["H2plus_bf_simplices"], values)
+    lam = np.linspace(wave.min(), wave.max(), 300)
+    dev, zero_rows = ops.sigma_table_2d(wave, axis2, cells, g["H2plus_bf_transform"], vertex_values, lam, t, 1, t)
+    sig = dev.numpy()
+    cold = t < axis2.min()
+    assert cold.sum() >= 5 and not sig[cold].any() and (sig[~cold] > 0).all()
+    assert np.array_equal(zero_rows, np.flatnonzero(cold))
+    import oracle
+
+    ref = oracle.interp_triangulated(wave, axis2, cells, g["H2plus_bf_transform"], vertex_values, lam, t) * 1e-18
+    assert np.array_equal(sig == 0, ref == 0) and max_rel(sig, ref) < 1e-15
