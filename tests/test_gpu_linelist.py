@@ -263,3 +263,21 @@ def test_line_opacity_is_linear_in_the_list_at_scale():
     parts = LL.line_opacity(nus, subset(slice(0, None, 2))) + LL.line_opacity(nus, subset(slice(1, None, 2)))
     assert evals > 5e9 and np.isfinite(full).all() and (full > 0).any()
     assert rel_err(full, parts) < 1e-12
+
+
+@pytest.mark.parametrize("n_depth", [65, 150])
+def test_generation_on_deep_models(n_depth):
+    """More than 64 depth points: several pre-pass depth blocks, each generating its own columns of the tables."""
+    from test_gpu_engine import deep_atmosphere
+
+    atm = deep_atmosphere(n_depth)
+    nus = synth.tracing_grid(6555.0, 6570.0, step=0.02)
+    spec = synth.synth_linelist(nus, atm, 700, seed=77)
+    a_ref, g_ref, d_ref = oracle_tables(spec)
+    a, gm, d = LL.line_params(spec)
+    assert rel_err(a, a_ref) < 3e-15 and rel_err(gm, g_ref) < 1e-13 and rel_err(d, d_ref) < 1e-15
+    out = LL.line_opacity(nus, spec)
+    from stardis_amd import ops
+
+    assert np.array_equal(out, ops.calc_alan_entries(n_depth, nus, spec.nu, d, gm, a))
+    assert rel_err(out, oracle.calc_alan_entries(n_depth, nus, spec.nu, d_ref, g_ref, a_ref)) < 1e-12
