@@ -103,6 +103,7 @@ constexpr int kPreLines = 16;
 constexpr int kPreDepths = 64;
 constexpr int kPreBlock = 1024;  // threads per pre-pass block: one (line, depth) item per thread, 16 waves to hide latency
 
+static_assert(kPreLines * kPreDepths == kPreBlock && kPreLines <= kPreBlock / 64, "one pre-pass item per thread, one wave per line");
 constexpr int kNarrowHalfWidth = 64;    // windows with half-width <= this go to the narrow-window kernel
 constexpr int kMediumHalfWidth = 4096;  // class bound of the indexed wide path: medium lines are found by centre range
 
@@ -188,8 +189,23 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
     const int d0 = by * kPreDepths;
     const int nl = (int)min((int64_t)kPreLines, n_lines - l0);
     const int nd = min(kPreDepths, n_depth - d0);
-    // line centres: two-level binary search — a 128-entry sample of the grid in LDS, then the bracketed stretch in
-    // global memory — halves the chain of dependent global loads that dominates this block's latency
+    // The block's dense inputs are requested first (one item per thread: kPreLines * kPreDepths == kPreBlock), so their
+    // latency hides behind the centre search below instead of following it.
+    double r_dw = 0.0, r_a = 0.0, r_g = 0.0;
+    if constexpr (!GEN) {
+        const int k = threadIdx.x;
+        if (k < nl * nd) {
+            const int ll = k / nd, dd = k - ll * nd;
+            const int64_t l = l0 + ll;
+            const int d = d0 + dd;
+            r_dw = doppler[l * n_depth + d];
+            r_a = alphas[l * n_depth + d];
+            r_g = gamma_cols > 1 ? gammas[l * gamma_cols + d] : gammas[l * gamma_cols];
+        }
+    }
+    // line centres: a 128-entry sample of the grid in LDS brackets the answer; wave ll then narrows the bracket of line
+    // ll to 64 points by bisection (none needed when the grid has <= 8192 points) and resolves it with ONE coalesced
+    // load and a ballot — a chain of one or two dependent global loads instead of log2(N_nu / 128)
     __shared__ double s_coarse[128];
     const int64_t cstride = (n_nu + 127) / 128;
     if (threadIdx.x < 128) {
@@ -197,21 +213,27 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
         s_coarse[threadIdx.x] = j < n_nu ? nus[j] : -INFINITY;
     }
     __syncthreads();
-    if (threadIdx.x < nl) {
-        const double v = line_nus[l0 + threadIdx.x];
-        int a = 0, b = 128;  // first sample strictly below v
-        while (a < b) {
-            const int mid = (a + b) >> 1;
-            if (s_coarse[mid] >= v) a = mid + 1; else b = mid;
+    {
+        const int ll = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        if (ll < nl) {
+            const double v = line_nus[l0 + ll];
+            int a = 0, b = 128;  // first sample strictly below v
+            while (a < b) {
+                const int mid = (a + b) >> 1;
+                if (s_coarse[mid] >= v) a = mid + 1; else b = mid;
+            }
+            // the answer lies in ((a-1)*cstride, a*cstride]
+            int64_t lo = a > 0 ? (int64_t)(a - 1) * cstride + 1 : 0;
+            int64_t hi = min((int64_t)a * cstride, n_nu);
+            while (hi - lo > 64) {
+                const int64_t mid = lo + ((hi - lo) >> 1);
+                if (nus[mid] >= v) lo = mid + 1; else hi = mid;
+            }
+            const int64_t idx = lo + lane;
+            const bool below = idx < hi && nus[idx] < v;
+            const unsigned long long m = __ballot(below);
+            if (lane == 0) s_c[ll] = m ? lo + __builtin_ctzll(m) : hi;
         }
-        // the answer lies in ((a-1)*cstride, a*cstride]
-        int64_t lo = a > 0 ? (int64_t)(a - 1) * cstride + 1 : 0;
-        int64_t hi = min((int64_t)a * cstride, n_nu);
-        while (lo < hi) {
-            const int64_t mid = lo + ((hi - lo) >> 1);
-            if (nus[mid] >= v) lo = mid + 1; else hi = mid;
-        }
-        s_c[threadIdx.x] = lo;
     }
     if (threadIdx.x < 2 * kPreDepths) (&s_wmask[0][0])[threadIdx.x] = 0u;
     if (threadIdx.x < kPreLines) s_hwmax[threadIdx.x] = 0;
@@ -236,14 +258,13 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
             s_g[ll * kStride + dd] = gen_gamma(lp, L, D, l);
         }
     } else {
-        // reference layout in, line fastest ... depth fastest: coalesced
-        for (int k = threadIdx.x; k < nl * nd; k += nthreads) {
+        // reference layout in (requested above), line fastest ... depth fastest: coalesced
+        const int k = threadIdx.x;
+        if (k < nl * nd) {
             const int ll = k / nd, dd = k - ll * nd;
-            const int64_t l = l0 + ll;
-            const int d = d0 + dd;
-            s_dw[ll * kStride + dd] = doppler[l * n_depth + d];
-            s_a[ll * kStride + dd] = alphas[l * n_depth + d];
-            s_g[ll * kStride + dd] = gamma_cols > 1 ? gammas[l * gamma_cols + d] : gammas[l * gamma_cols];
+            s_dw[ll * kStride + dd] = r_dw;
+            s_a[ll * kStride + dd] = r_a;
+            s_g[ll * kStride + dd] = r_g;
         }
     }
     __syncthreads();
@@ -1123,7 +1144,7 @@ __device__ __forceinline__ void total_alphas_block(const int bx, const int d, in
         s_coef[L] = mul_rn(mul_rn(kBfConst, (double)(zi * zi * zi * zi)), a.bf_level_density[(size_t)L * n_depth + d]) / n5;
     }
     __syncthreads();
-    if (j >= nu_count) return;
+    if (j < nu_count) {
     const int64_t i = nu_begin + j;
     const double nu = nus[i];
     double t = 0.0;
@@ -1148,6 +1169,8 @@ __device__ __forceinline__ void total_alphas_block(const int bx, const int d, in
         t = add_rn(t, v);
     }
     total[(size_t)d * total_ld + j] = t;
+    }
+    __syncthreads();  // s_coef may be refilled for another depth by the caller
 }
 
 __global__ __launch_bounds__(kBlock) void k_total_alphas(int n_depth, int64_t nu_begin, int64_t nu_count,
