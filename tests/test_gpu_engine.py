@@ -247,3 +247,30 @@ def test_cool_dwarf_structure_matches_oracle(ctx):
     assert rel_err(syn.total_alphas(), total_ref) < 1e-12
     F_ref, _ = oracle.raytrace(nus, atm["temperatures"], atm["dist"], th, w, total_ref)
     assert rel_err(syn.F_nu()[1:], F_ref[1:]) < 1e-10
+
+
+def test_pool_members_equal_their_standalone_results(ctx):
+    """Independent syntheses in flight on two streams (different line lists, one on the cool structure): each member's
+    result is bit for bit what it computes alone."""
+    from stardis_amd.engine import SynthesisPool
+
+    cases = []
+    for seed, cool in ((31, False), (32, False), (33, True)):
+        atm = synth.cool_dwarf_atmosphere() if cool else synth.solar_atmosphere()
+        nus = synth.tracing_grid(6560.0, 6570.0, step=0.02)
+        lines = synth.synth_lines(nus, atm, 250, seed=seed, mix=(0.8, 0.15, 0.05))
+        th, w = synth.thetas_and_weights(6)
+        cases.append((nus, atm["temperatures"], atm["dist"], th, w, lines, synth.synth_continuum_state(atm)))
+    alone = []
+    for args in cases:
+        syn = SpectralSynthesizer(*args, ctx=ctx)
+        syn.step()
+        alone.append(syn.F_nu())
+    pool = SynthesisPool(n_streams=2)
+    for args in cases:
+        pool.add(*args)
+    for _ in range(3):
+        pool.step()
+    for got, want in zip(pool.fluxes(), alone):
+        assert np.array_equal(got, want)
+    pool.close()
