@@ -16,9 +16,9 @@ from ._lib import LineListStruct, default_context, plain
 
 GAMMA_CLASSIC, GAMMA_VALD, GAMMA_RADIATION_ONLY, GAMMA_ZERO = range(4)
 
-_F8_FIELDS = ("nu", "e_low_ev", "g_lo", "strength", "mass", "ionization_energy", "upper_energy", "lower_energy", "A_ul", "stark", "waals",
-              "temperature", "electron_density", "h_density")
-_I4_FIELDS = ("pop_row", "atomic_number", "ion_number")
+_PER_LINE_F8 = ("nu", "e_low_ev", "g_lo", "strength", "mass", "ionization_energy", "upper_energy", "lower_energy", "A_ul", "stark", "waals")
+_PER_DEPTH_F8 = ("temperature", "electron_density", "h_density")
+_PER_LINE_I4 = ("pop_row", "atomic_number", "ion_number")
 
 
 def broadening_flags(linear_stark=True, quadratic_stark=True, van_der_waals=True, radiation=True):
@@ -52,10 +52,14 @@ class LineList:
         self.A_ul, self.stark, self.waals = f8(A_ul), f8(stark), f8(waals)
         self.electron_density, self.h_density = f8(electron_density), f8(h_density)
         self.alpha_coefficient = float(alpha_coefficient)
-        for name in _F8_FIELDS[:11] + _I4_FIELDS:
+        for name in _PER_LINE_F8 + _PER_LINE_I4:
             a = getattr(self, name)
             if a is not None and a.size != self.n_lines:
                 raise ValueError(f"{name}: expected {self.n_lines} per-line values, got {a.size}")
+        for name in _PER_DEPTH_F8:
+            a = getattr(self, name)
+            if a is not None and a.size != self.n_depth:
+                raise ValueError(f"{name}: expected {self.n_depth} per-depth values, got {a.size}")
         if self.n_lines and np.any(self.mass <= 0):
             raise ZeroDivisionError("float division by zero")  # a zero Doppler width (voigt.py:148)
 
@@ -68,7 +72,7 @@ class LineList:
         return 1 if self.gamma_mode >= GAMMA_RADIATION_ONLY else self.n_depth
 
     def bytes_per_line(self):
-        return sum(getattr(self, n).itemsize for n in _F8_FIELDS[:11] + _I4_FIELDS if getattr(self, n) is not None)
+        return sum(getattr(self, n).itemsize for n in _PER_LINE_F8 + _PER_LINE_I4 if getattr(self, n) is not None)
 
     def upload(self, ctx=None):
         return DeviceLineList(self, ctx or default_context())
@@ -83,12 +87,12 @@ class DeviceLineList:
         self._keep = {}
         s = LineListStruct()
         s.n_lines = host.n_lines
-        for name in _F8_FIELDS:
+        for name in _PER_LINE_F8 + _PER_DEPTH_F8:
             a = getattr(host, name)
             if a is not None:
                 self._keep[name] = ctx.upload(a)
                 setattr(s, name, self._keep[name].ptr)
-        for name in _I4_FIELDS:
+        for name in _PER_LINE_I4:
             a = getattr(host, name)
             if a is not None:
                 self._keep[name] = ctx.upload(a, np.int32)
