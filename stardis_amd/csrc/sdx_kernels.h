@@ -349,7 +349,7 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
 }
 
 template <bool GEN>
-__global__ __launch_bounds__(kPreBlock) void k_line_prepass(int n_depth, int64_t n_nu, const double* __restrict__ nus,
+__global__ __launch_bounds__(kPreBlock) __attribute__((amdgpu_num_sgpr(80))) void k_line_prepass(int n_depth, int64_t n_nu, const double* __restrict__ nus,
                                                          const double* __restrict__ dnu_partial, int n_partial,
                                                          int64_t n_lines, const double* __restrict__ line_nus,
                                                          const double* __restrict__ doppler,
@@ -1125,15 +1125,23 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(int n_depth, int64_t n_nu
 // then Opacities.calc_total_alphas insertion order, opacities/base.py:24-28).  `line` holds n_split partial
 // planes [n_split][n_depth][line_ld] summed here in subset order; line_out (optional) receives that sum.
 // The bound-free per-level coefficients of this block's depth are formed in LDS first (k_bf_coef's formula).
+template <int NP = 1>
 __device__ __forceinline__ void total_alphas_block(const int bx, const int d, int n_depth, int64_t nu_begin, int64_t nu_count,
                                                          const double* __restrict__ nus, ContinuumArgs a,
                                                          const double* __restrict__ line, int64_t line_ld, int n_split,
                                                          double* __restrict__ line_out, int64_t line_out_ld,
-                                                         double* __restrict__ total, int64_t total_ld)
+                                                         double* __restrict__ total, int64_t total_ld, const bool stage_table = false)
 {
-    extern __shared__ double s_coef[];  // [n_levels] for depth d
-    const int64_t j = (int64_t)bx * blockDim.x + threadIdx.x;
+    extern __shared__ double s_coef[];  // [n_levels] for depth d, then (stage_table) the 1-D cross-section table
     const int n_levels = a.bf_n_species > 0 ? a.bf_species_offsets[a.bf_n_species] : 0;
+    // the tabulated cross-section is searched per point: from LDS the bisection costs ~10x less latency than from L2
+    double* s_xp = s_coef + n_levels;
+    double* s_fp = s_xp + a.n_table;
+    if (stage_table && a.table_sigma)
+        for (int k = threadIdx.x; k < a.n_table; k += blockDim.x) {
+            s_xp[k] = a.table_wavelength[k];
+            s_fp[k] = a.table_sigma[k];
+        }
     for (int L = threadIdx.x; L < n_levels; L += blockDim.x) {
         int sp = 0;
         while (sp + 1 < a.bf_n_species && L >= a.bf_species_offsets[sp + 1]) ++sp;
@@ -1144,11 +1152,16 @@ __device__ __forceinline__ void total_alphas_block(const int bx, const int d, in
         s_coef[L] = mul_rn(mul_rn(kBfConst, (double)(zi * zi * zi * zi)), a.bf_level_density[(size_t)L * n_depth + d]) / n5;
     }
     __syncthreads();
+#pragma unroll
+    for (int pt = 0; pt < NP; ++pt) {
+    const int64_t j = ((int64_t)bx * NP + pt) * blockDim.x + threadIdx.x;
     if (j < nu_count) {
     const int64_t i = nu_begin + j;
     const double nu = nus[i];
     double t = 0.0;
-    if (a.table_sigma) t = add_rn(t, mul_rn(interp1(a.lambdas[i], a.n_table, a.table_wavelength, a.table_sigma), a.table_density[d]));
+    if (a.table_sigma)
+        t = add_rn(t, mul_rn(stage_table ? interp1(a.lambdas[i], a.n_table, s_xp, s_fp) : interp1(a.lambdas[i], a.n_table, a.table_wavelength, a.table_sigma),
+                             a.table_density[d]));
     {
         double bf = 0.0;
         for (int sp = 0; sp < a.bf_n_species; ++sp) {
@@ -1170,6 +1183,7 @@ __device__ __forceinline__ void total_alphas_block(const int bx, const int d, in
     }
     total[(size_t)d * total_ld + j] = t;
     }
+    }
     __syncthreads();  // s_coef may be refilled for another depth by the caller
 }
 
@@ -1183,10 +1197,15 @@ __global__ __launch_bounds__(kBlock) void k_total_alphas(int n_depth, int64_t nu
                        total_ld);
 }
 
+// Frequencies per thread of a continuum block in the fused pre-pass launch (2 was measured: no gain).
+// The pre-pass kernels cap their SGPRs at 80: a 1024-thread block is 4 waves per SIMD, and at the 94 SGPRs the compiler
+// would use only ONE such block fits a CU (7 waves per SIMD), which ran this launch in three block generations at S-c2
+// size (scripts/occupancy_probe.hip: two fit below 64 VGPRs and 81 SGPRs).
+constexpr int kContPoints = 1;
 // Pre-pass and continuum in ONE launch: the pre-pass is a few latency-bound blocks (binary searches, a grid scan);
 // the continuum plane depends on nothing and fills the rest of the chip meanwhile.
 template <bool GEN>
-__global__ __launch_bounds__(kPreBlock) void k_prepass_continuum(int n_pre_x, int n_pre_y, int cont_tiles, int n_depth, int64_t n_nu,
+__global__ __launch_bounds__(kPreBlock) __attribute__((amdgpu_num_sgpr(80))) void k_prepass_continuum(int n_pre_x, int n_pre_y, int cont_tiles, int n_depth, int64_t n_nu,
                                                               const double* __restrict__ nus,
                                                               const double* __restrict__ dnu_partial, int n_partial,
                                                               int64_t n_lines, const double* __restrict__ line_nus,
@@ -1194,7 +1213,7 @@ __global__ __launch_bounds__(kPreBlock) void k_prepass_continuum(int n_pre_x, in
                                                               const double* __restrict__ gammas, int gamma_cols,
                                                               const double* __restrict__ alphas, LineWork w, int n_line_blocks,
                                                               int64_t nu_begin, int64_t nu_count, ContinuumArgs ca,
-                                                              double* __restrict__ cont_plane, int64_t cont_ld, LineParams lp)
+                                                              double* __restrict__ cont_plane, int64_t cont_ld, LineParams lp, int stage_table)
 {
     const int b = blockIdx.x;
     const int n_pre = n_pre_x * n_pre_y;
@@ -1203,8 +1222,8 @@ __global__ __launch_bounds__(kPreBlock) void k_prepass_continuum(int n_pre_x, in
                            gammas, gamma_cols, alphas, w, nullptr, nullptr, n_line_blocks, lp);
     } else {
         const int c = b - n_pre;
-        total_alphas_block(c % cont_tiles, c / cont_tiles, n_depth, nu_begin, nu_count, nus, ca, nullptr, 0, 1, nullptr, 0, cont_plane,
-                           cont_ld);
+        total_alphas_block<kContPoints>(c % cont_tiles, c / cont_tiles, n_depth, nu_begin, nu_count, nus, ca, nullptr, 0, 1, nullptr, 0,
+                                        cont_plane, cont_ld, stage_table != 0);
     }
 }
 

@@ -543,12 +543,14 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
             REQUIRE(job->cont->bf_n_levels > 0 && job->cont->bf_n_levels <= 4096, "synthesize: bf_n_levels must be set (1..4096)");
             shmem = (size_t)job->cont->bf_n_levels * sizeof(double);
         }
-        const int cont_tiles = (int)((job->nu_count + kPreBlock - 1) / kPreBlock);
+        const int stage_table = ca.table_sigma && ca.n_table > 0 && ca.n_table <= 1024;  // 1-D cross-section table searched from LDS
+        if (stage_table) shmem = ((ca.bf_n_species > 0 ? (size_t)job->cont->bf_n_levels : 0) + 2 * (size_t)ca.n_table) * sizeof(double);
+        const int cont_tiles = (int)((job->nu_count + kPreBlock * kContPoints - 1) / (kPreBlock * kContPoints));
         const unsigned total_blocks = grid.x * grid.y + (unsigned)cont_tiles * (unsigned)n_depth;
         LaunchScope ls(ctx, "k_prepass_continuum");
 #define SDX_PRE_ARGS (int)grid.x, (int)grid.y, cont_tiles, n_depth, n_nu, nus, scan_in_block ? (const double*)nullptr : (const double*)ctx->small_ws, \
                      n_partial, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, w, n_line_blocks, job->nu_begin, job->nu_count, ca,          \
-                     job->plane, job->nu_count, lp
+                     job->plane, job->nu_count, lp, stage_table
         if (gen) hipLaunchKernelGGL(k_prepass_continuum<true>, dim3(total_blocks), dim3(kPreBlock), shmem, ctx->stream, SDX_PRE_ARGS);
         else hipLaunchKernelGGL(k_prepass_continuum<false>, dim3(total_blocks), dim3(kPreBlock), shmem, ctx->stream, SDX_PRE_ARGS);
 #undef SDX_PRE_ARGS
