@@ -251,8 +251,8 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
         for (int k = threadIdx.x; k < nl * nd; k += nthreads) {
             const int ll = k / nd, dd = k - ll * nd;
             const int64_t l = l0 + ll;
-            const GenDepth D = s_gd[dd];
-            const GenLine L = s_gl[ll];
+            const GenDepth& D = s_gd[dd];  // fields are read from LDS where they are used: copies would cost ~40 VGPRs
+            const GenLine& L = s_gl[ll];
             s_dw[ll * kStride + dd] = gen_doppler(lp, L, D, l);
             s_a[ll * kStride + dd] = gen_alpha(lp, D, line_nus[l], l, d0 + dd, n_depth);
             s_g[ll * kStride + dd] = gen_gamma(lp, L, D, l);
