@@ -420,7 +420,7 @@ __device__ __forceinline__ void line_wide_block(const int tile_idx, const int sp
             const double y = w.y[base + l];
             const double inv = w.inv_dw[base + l];
             const double lnu = line_nus[l];
-            const RegionI k1 = region1_setup(y);
+            const RegionI k1 = region1_setup(y, w.amp[base + l]);
             // Whole tile inside the window and every point of it in Faddeeva region I (|x| + y > 15, voigt.py:39)?
             // The smallest |x| of the tile is at the edge nearer to the line; the 1e-3 margin dwarfs rounding, so
             // every lane's own test would take the same branch: the per-lane tests can be skipped.
@@ -441,7 +441,7 @@ __device__ __forceinline__ void line_wide_block(const int tile_idx, const int sp
         }
         __syncthreads();  // one wave: orders the LDS writes above before the reads below
         for (int j = 0; j < total; ++j) {
-            const double lnu = s_nu[j], inv = s_inv[j], amp = s_amp[j];
+            const double lnu = s_nu[j], inv = s_inv[j];
             const RegionI k1 = {s_yk[j], s_c2[j], s_c3[j], s_c4[j]};
             if (__builtin_amdgcn_readfirstlane(s_fast[j])) {
                 // same operations, in the same order, as voigt_term's region-I branch: bit-identical results
@@ -449,11 +449,11 @@ __device__ __forceinline__ void line_wide_block(const int tile_idx, const int sp
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const double x = (nu_i[r] - lnu) * inv;
-                    if (MIXED) acc[r] = fma(amp, region1_re_mixed(x, k1), acc[r]);
-                    else acc[r] += amp * region1_re(x * x, k1);
+                    if (MIXED) acc[r] += region1_re_mixed(x, k1);
+                    else acc[r] += region1_re(x * x, k1);
                 }
             } else {
-                const double y = s_y[j];
+                const double y = s_y[j], amp = s_amp[j];
                 const int jlo = s_lo[j], jhi = s_hi[j];
 #pragma unroll
                 for (int r = 0; r < R; ++r)
@@ -619,7 +619,7 @@ __device__ __forceinline__ void line_wide_block_indexed(const int tile_idx, cons
             if (hit) {
                 const int pos = __popcll(m & ((1ull << lane) - 1ull));
                 const double y = w.d_y[origin + k], inv = w.d_inv[origin + k], lnu = w.d_lnu[origin + k];
-                const RegionI k1 = region1_setup(y);
+                const RegionI k1 = region1_setup(y, w.d_amp[origin + k]);
                 const double e_first = nu_first - lnu, e_last = nu_last - lnu;
                 const bool beside = e_last > 0.0 || e_first < 0.0;
                 const double nearest = fmin(fabs(e_first), fabs(e_last));
@@ -637,17 +637,17 @@ __device__ __forceinline__ void line_wide_block_indexed(const int tile_idx, cons
             }
             __syncthreads();
             for (int j = 0; j < total; ++j) {
-                const double lnu = s_nu[j], inv = s_inv[j], amp = s_amp[j];
+                const double lnu = s_nu[j], inv = s_inv[j];
                 const RegionI k1 = {s_yk[j], s_c2[j], s_c3[j], s_c4[j]};
                 if (__builtin_amdgcn_readfirstlane(s_fast[j])) {
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
                         const double x = (nu_i[r] - lnu) * inv;
-                        if (MIXED) acc[r] = fma(amp, region1_re_mixed(x, k1), acc[r]);
-                        else acc[r] += amp * region1_re(x * x, k1);
+                        if (MIXED) acc[r] += region1_re_mixed(x, k1);
+                        else acc[r] += region1_re(x * x, k1);
                     }
                 } else {
-                    const double y = s_y[j];
+                    const double y = s_y[j], amp = s_amp[j];
                     const int jlo = s_lo[j], jhi = s_hi[j];
 #pragma unroll
                     for (int r = 0; r < R; ++r)
@@ -704,9 +704,9 @@ __device__ __forceinline__ void line_narrow_wave(const int64_t i, const int dept
             const size_t o = (size_t)l * n_depth + dc;
             const int lo = w.nlo[o], hi = w.nhi[o];
             if (valid && ii >= lo && ii < hi) {
-                const double y = w.n_y[o];
-                const RegionI k1 = region1_setup(y);
-                acc += voigt_term(nu_i - line_nus[l], w.n_inv[o], y, w.n_amp[o], k1);
+                const double y = w.n_y[o], amp = w.n_amp[o];
+                const RegionI k1 = region1_setup(y, amp);
+                acc += voigt_term(nu_i - line_nus[l], w.n_inv[o], y, amp, k1);
             }
         }
     }

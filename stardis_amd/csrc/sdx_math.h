@@ -158,20 +158,21 @@ __device__ __forceinline__ double recip(double d)
     return fma(r, e, r);
 }
 
-// Re w(x + i y) for region I given q = x*x:  y (q + y^2 + 1/2) / ((q - y^2 - 1/2)^2 + 4 q y^2) / sqrt(pi)
+// amp * Re w(x + i y) for region I given q = x*x:  y (q + y^2 + 1/2) / ((q - y^2 - 1/2)^2 + 4 q y^2) / sqrt(pi)
 //   = Re[ (i/sqrt(pi)) z / (z^2 - 1/2) ]  (voigt.py:47), written without cancellation.
 struct RegionI {
-    double yk;   // y / sqrt(pi)
+    double yk;   // amp * y / sqrt(pi): the line's amplitude is folded into the numerator (one multiplication per point less)
     double c2;   // y^2 + 1/2
     double c3;   // 2 y^2 - 1
     double c4;   // c2^2
 };
-__device__ __forceinline__ RegionI region1_setup(double y)
+__device__ __forceinline__ RegionI region1_setup(double y, double amp)
 {
     const double y2 = y * y;
     const double c2 = y2 + 0.5;
-    return {y * kInvSqrtPi, c2, fma(2.0, y2, -1.0), c2 * c2};
+    return {amp * (y * kInvSqrtPi), c2, fma(2.0, y2, -1.0), c2 * c2};
 }
+// amp * Re w for region I
 __device__ __forceinline__ double region1_re(double q, const RegionI& k)
 {
     const double num = k.yk * (q + k.c2);
@@ -186,7 +187,7 @@ __device__ __forceinline__ double region1_re_mixed(double x, const RegionI& k)
 {
     const float xf = (float)x;
     const float q = xf * xf;
-    const float num = (float)k.yk * (q + (float)k.c2);
+    const float num = (float)k.yk * (q + (float)k.c2);  // amp folded in: fp32 range is ample for amp * y
     const float den = fmaf(q, q + (float)k.c3, (float)k.c4);
     return (double)(num * __builtin_amdgcn_rcpf(den));
 }
@@ -245,7 +246,7 @@ __device__ __forceinline__ double voigt_term(double delta_nu, double inv_dw, dou
 {
     const double x = delta_nu * inv_dw;
     const double ax = fabs(x);
-    if (add_rn(ax, y) > 15.0) return amp * region1_re(x * x, k);
+    if (add_rn(ax, y) > 15.0) return region1_re(x * x, k);  // amp is inside k
     return amp * faddeeva_re_core(x, y, ax);
 }
 
