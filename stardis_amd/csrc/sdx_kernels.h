@@ -697,17 +697,29 @@ __device__ __forceinline__ void line_narrow_wave(const int64_t i, const int dept
             rel = hwm > 0 && ii >= c - hwm && ii < c + hwm;
         }
         unsigned long long m = __ballot(rel);
-        while (m) {
-            const int j = __builtin_ctzll(m);
-            m &= m - 1;
-            const int l = base + j;
+        // the parameters of the NEXT relevant line are requested before the current one is evaluated (all six loads at
+        // once, used or not): one global-memory round trip per line hides behind the previous line's arithmetic
+        int lo = 0, hi = 0;
+        double y = 0.0, amp = 0.0, inv = 0.0, lnu = 0.0;
+        if (m) {
+            const int l = base + __builtin_ctzll(m);
             const size_t o = (size_t)l * n_depth + dc;
-            const int lo = w.nlo[o], hi = w.nhi[o];
-            if (valid && ii >= lo && ii < hi) {
-                const double y = w.n_y[o], amp = w.n_amp[o];
-                const RegionI k1 = region1_setup(y, amp);
-                acc += voigt_term(nu_i - line_nus[l], w.n_inv[o], y, amp, k1);
+            lo = w.nlo[o], hi = w.nhi[o], y = w.n_y[o], amp = w.n_amp[o], inv = w.n_inv[o], lnu = line_nus[l];
+        }
+        while (m) {
+            m &= m - 1;
+            int lo_n = 0, hi_n = 0;
+            double y_n = 0.0, amp_n = 0.0, inv_n = 0.0, lnu_n = 0.0;
+            if (m) {
+                const int l = base + __builtin_ctzll(m);
+                const size_t o = (size_t)l * n_depth + dc;
+                lo_n = w.nlo[o], hi_n = w.nhi[o], y_n = w.n_y[o], amp_n = w.n_amp[o], inv_n = w.n_inv[o], lnu_n = line_nus[l];
             }
+            if (valid && ii >= lo && ii < hi) {
+                const RegionI k1 = region1_setup(y, amp);
+                acc += voigt_term(nu_i - lnu, inv, y, amp, k1);
+            }
+            lo = lo_n, hi = hi_n, y = y_n, amp = amp_n, inv = inv_n, lnu = lnu_n;
         }
     }
     if (valid) plane[(size_t)d * pld + (i - nu_begin)] = acc;
