@@ -193,7 +193,7 @@ __device__ __forceinline__ double region1_re_mixed(double x, const RegionI& k)
 }
 
 // Re w for regions II-IV (real part only).
-__device__ inline double faddeeva_re_core(double x, double y, double ax)
+__device__ __attribute__((noinline)) double faddeeva_re_core(double x, double y, double ax)
 {
     const c64 z = {x, y};
     const double s = add_rn(ax, y);
