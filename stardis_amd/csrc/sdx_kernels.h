@@ -397,19 +397,27 @@ __device__ __forceinline__ void line_wide_block(const int tile_idx, const int sp
     const size_t base = (size_t)d * n_lines;
     const double nu_first = nus[t0], nu_last = nus[t1 - 1];  // tile edges (descending grid)
     const int64_t cstep = (int64_t)n_split * 64;
+    // the next chunk's windows AND constants are requested behind this chunk's arithmetic (used or not: most chunks hold
+    // a line that reaches the tile), so a chunk costs no dependent round trip to memory
     int lo_next = 0, hi_next = 0;
+    double y_next = 0.0, inv_next = 0.0, amp_next = 0.0, lnu_next = 0.0;
     if ((int64_t)split * 64 + lane < n_lines) {
-        lo_next = w.lo[base + (int64_t)split * 64 + lane];
-        hi_next = w.hi[base + (int64_t)split * 64 + lane];
+        const int64_t l = (int64_t)split * 64 + lane;
+        lo_next = w.lo[base + l];
+        hi_next = w.hi[base + l];
+        y_next = w.y[base + l], inv_next = w.inv_dw[base + l], amp_next = w.amp[base + l], lnu_next = line_nus[l];
     }
     for (int64_t c0 = (int64_t)split * 64; c0 < n_lines; c0 += cstep) {
         const int64_t l = c0 + lane;
         const int lo = lo_next, hi = hi_next;
+        const double y_cur = y_next, inv_cur = inv_next, amp_cur = amp_next, lnu_cur = lnu_next;
         lo_next = 0;
         hi_next = 0;
-        if (l + cstep < n_lines) {  // prefetch the next chunk's windows behind this chunk's arithmetic
+        if (l + cstep < n_lines) {
             lo_next = w.lo[base + l + cstep];
             hi_next = w.hi[base + l + cstep];
+            y_next = w.y[base + l + cstep], inv_next = w.inv_dw[base + l + cstep], amp_next = w.amp[base + l + cstep];
+            lnu_next = line_nus[l + cstep];
         }
         const bool hit = (l < n_lines) & (lo < t1) & (hi > t0) & (hi > lo);
         const unsigned long long m = __ballot(hit);
@@ -417,10 +425,8 @@ __device__ __forceinline__ void line_wide_block(const int tile_idx, const int sp
         const int total = __popcll(m);
         if (hit) {
             const int pos = __popcll(m & ((1ull << lane) - 1ull));
-            const double y = w.y[base + l];
-            const double inv = w.inv_dw[base + l];
-            const double lnu = line_nus[l];
-            const RegionI k1 = region1_setup(y, w.amp[base + l]);
+            const double y = y_cur, inv = inv_cur, lnu = lnu_cur;
+            const RegionI k1 = region1_setup(y, amp_cur);
             // Whole tile inside the window and every point of it in Faddeeva region I (|x| + y > 15, voigt.py:39)?
             // The smallest |x| of the tile is at the edge nearer to the line; the 1e-3 margin dwarfs rounding, so
             // every lane's own test would take the same branch: the per-lane tests can be skipped.
@@ -431,7 +437,7 @@ __device__ __forceinline__ void line_wide_block(const int tile_idx, const int sp
             s_nu[pos] = lnu;
             s_inv[pos] = inv;
             s_y[pos] = y;
-            s_amp[pos] = w.amp[base + l];
+            s_amp[pos] = amp_cur;
             s_yk[pos] = k1.yk;
             s_c2[pos] = k1.c2;
             s_c3[pos] = k1.c3;
