@@ -212,12 +212,17 @@ __device__ inline GenLine gen_line(const LineParams& p, double line_nu, int64_t 
     return L;
 }
 
+// out-of-line library calls for the pre-pass: inlined, pow / exp push the generating pre-pass past 64 VGPRs, and beyond
+// that only ONE 1024-thread block fits a CU
+__device__ __attribute__((noinline)) double pow_call(double a, double b) { return pow(a, b); }
+__device__ __attribute__((noinline)) double exp_call(double a) { return exp(a); }
+
 __device__ inline double gen_alpha(const LineParams& p, const GenDepth& D, double line_nu, int64_t l, int d, int n_depth)
 {
-    const double expo = exp(mul_rn(mul_rn(-p.e_low_ev[l], D.inv_kt), kEvJ));                  // base.py:247-251
+    const double expo = exp_call(mul_rn(mul_rn(-p.e_low_ev[l], D.inv_kt), kEvJ));             // base.py:247-251
     double n_lower = mul_rn(expo, p.pop[(size_t)p.pop_row[l] * n_depth + d]);                  // :254-266
     if (p.g_lo) n_lower = mul_rn(n_lower, p.g_lo[l]);
-    const double corr = sub_rn(1.0, exp(mul_rn((-kHsi) / kKBsi, mul_rn(line_nu, D.inv_t))));  // :276-286
+    const double corr = sub_rn(1.0, exp_call(mul_rn((-kHsi) / kKBsi, mul_rn(line_nu, D.inv_t))));  // :276-286
     return mul_rn(mul_rn(mul_rn(p.alpha_coefficient, n_lower), p.strength[l]), corr);          // :288-296
 }
 
@@ -251,7 +256,7 @@ __device__ inline double gen_gamma(const LineParams& p, const GenLine& L, const 
         if (vdw < 0) gw = mul_rn(L.p10w, D.t38);
         else if (vdw == 0.0) gw = 0.0;
         else if (vdw < 20) gw = mul_rn(mul_rn(mul_rn(D.vw, L.c6p), 1.0), vdw);
-        else gw = mul_rn(L.ab, pow(sqrt(mul_rn(D.vb, L.inv_mu)) / 1e6, L.oma));
+        else gw = mul_rn(L.ab, pow_call(sqrt(mul_rn(D.vb, L.inv_mu)) / 1e6, L.oma));
         g = add_rn(g, mul_rn(gw, D.nh));
     }
     return g / 2;
