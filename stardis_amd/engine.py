@@ -206,7 +206,7 @@ class SynthesisPool:
     """Several independent syntheses in flight on one GPU — a grid of stars, abundances or line lists.  Members are
     dealt round-robin onto `n_streams` contexts (each its own HIP stream and scratch), so kernels of different members
     overlap on the device: the formal solution of one fills the issue slots the line kernel of another leaves idle
-    (S-c2: 4.6e9 spectral points/s with two in flight against 3.6e9 one after the other).  Every member computes exactly
+    (S-c2: about 4.7e9 spectral points/s with two in flight against 3.8e9 one after the other).  Every member computes exactly
     what it would alone."""
 
     def __init__(self, device=None, n_streams=2):
