@@ -490,8 +490,24 @@ __global__ __launch_bounds__(64, 4) void k_line_wide(int64_t n_nu, const double*
 // before its chunks (and, for the huge class, in the whole row), then a wave per chunk scatters the flagged lines'
 // constants to prefix + rank: a stable compaction without atomics.
 constexpr int kListChunks = 64;
+static_assert(kListChunks <= 64, "k_count_lists counts one chunk per lane");
 
-__global__ __launch_bounds__(kBlock) void k_build_lists(int n_depth, int64_t n_lines, const double* __restrict__ line_nus, LineWork w)
+// set bits of each block's kListChunks chunks, [class][depth][block]: the scatter kernel then sums a few hundred counts
+// instead of re-reading the whole mask row in every block (which made it quadratic in the number of lines)
+__global__ __launch_bounds__(64) void k_count_lists(int n_depth, int64_t n_lines, LineWork w, int* __restrict__ block_cnt)
+{
+    const int d = blockIdx.y, cls = blockIdx.z;
+    const int64_t n_chunks = (n_lines + 63) >> 6;
+    const int64_t c = (int64_t)blockIdx.x * kListChunks + threadIdx.x;
+    const unsigned long long* masks =
+        reinterpret_cast<const unsigned long long*>((cls ? w.wmask_huge : w.wmask_med) + (size_t)d * w.mask_ld);
+    int n = (threadIdx.x < kListChunks && c < n_chunks) ? __popcll(masks[c]) : 0;
+    for (int off = 32; off > 0; off >>= 1) n += __shfl_xor(n, off);
+    if (threadIdx.x == 0) block_cnt[((size_t)cls * n_depth + d) * gridDim.x + blockIdx.x] = n;
+}
+
+__global__ __launch_bounds__(kBlock) void k_build_lists(int n_depth, int64_t n_lines, const double* __restrict__ line_nus, LineWork w,
+                                                        const int* __restrict__ block_cnt)
 {
     __shared__ int s_red[kBlock / 64];
     __shared__ int s_cnt[kListChunks];
@@ -503,10 +519,11 @@ __global__ __launch_bounds__(kBlock) void k_build_lists(int n_depth, int64_t n_l
         reinterpret_cast<const unsigned long long*>((cls ? w.wmask_huge : w.wmask_med) + (size_t)d * w.mask_ld);
     // set bits before this block's chunks, and in the whole row
     int before = 0, all = 0;
-    for (int64_t c = threadIdx.x; c < n_chunks; c += kBlock) {
-        const int n = __popcll(masks[c]);
+    const int* row_cnt = block_cnt + ((size_t)cls * n_depth + d) * gridDim.x;
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += kBlock) {
+        const int n = row_cnt[b];
         all += n;
-        before += c < c_first ? n : 0;
+        before += b < (int)blockIdx.x ? n : 0;
     }
     for (int off = 32; off > 0; off >>= 1) {
         before += __shfl_xor(before, off);

@@ -613,7 +613,9 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
     const int indexed = n_lines >= ctx->indexed_min_lines ? 1 : 0;
     if (indexed) {
         const size_t cells = (size_t)n_depth * (size_t)n_lines;
-        rc = ensure(ctx, &ctx->dense_ws, &ctx->dense_ws_bytes, cells * 44 + (size_t)2 * n_depth * sizeof(int) + 256);
+        const unsigned list_blocks = (unsigned)(((n_lines + 63) / 64 + kListChunks - 1) / kListChunks);
+        rc = ensure(ctx, &ctx->dense_ws, &ctx->dense_ws_bytes,
+                    cells * 44 + (size_t)2 * n_depth * sizeof(int) + 256 + (size_t)2 * n_depth * list_blocks * sizeof(int));
         if (rc) return rc;
         w.d_lnu = (double*)ctx->dense_ws;
         w.d_inv = w.d_lnu + cells;
@@ -625,8 +627,10 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
         w.d_cnt = w.d_centre + cells;
         w.cap = n_lines;
         LaunchScope ls(ctx, "k_build_lists");
-        const dim3 grid((unsigned)(((n_lines + 63) / 64 + kListChunks - 1) / kListChunks), (unsigned)n_depth, 2u);
-        hipLaunchKernelGGL(k_build_lists, grid, dim3(kBlock), 0, ctx->stream, n_depth, n_lines, line_nus, w);
+        const dim3 grid(list_blocks, (unsigned)n_depth, 2u);
+        int* block_cnt = w.d_cnt + 2 * n_depth + 32;
+        hipLaunchKernelGGL(k_count_lists, grid, dim3(64), 0, ctx->stream, n_depth, n_lines, w, block_cnt);
+        hipLaunchKernelGGL(k_build_lists, grid, dim3(kBlock), 0, ctx->stream, n_depth, n_lines, line_nus, w, (const int*)block_cnt);
     }
     rc = ensure(ctx, &ctx->part_ws, &ctx->part_ws_bytes, (size_t)(n_split + 1) * n_depth * nu_count * sizeof(double));
     if (rc) return rc;
