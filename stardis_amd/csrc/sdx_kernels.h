@@ -994,6 +994,7 @@ struct ContinuumArgs {
     const int* bf_species_offsets;
     const int* bf_species_ion_number;
     const double* bf_cutoff;
+    int bf_n_levels;                 // = bf_species_offsets[bf_n_species] when the host knows it, else 0
     const double* bf_coef;           // [n_levels][n_depth] from k_bf_coef (stand-alone bf source)
     const double* bf_level_density;  // [n_levels][n_depth] (fused total: coefficients formed in LDS)
     int ff_n_species;
@@ -1168,7 +1169,7 @@ __device__ __forceinline__ void total_alphas_block(const int bx, const int d, in
                                                          double* __restrict__ total, int64_t total_ld, const bool stage_table = false)
 {
     extern __shared__ double s_coef[];  // [n_levels] for depth d, then (stage_table) the 1-D cross-section table
-    const int n_levels = a.bf_n_species > 0 ? a.bf_species_offsets[a.bf_n_species] : 0;
+    const int n_levels = a.bf_n_species > 0 ? (a.bf_n_levels > 0 ? a.bf_n_levels : a.bf_species_offsets[a.bf_n_species]) : 0;  // host value: no load to wait for
     // the tabulated cross-section is searched per point: from LDS the bisection costs ~10x less latency than from L2
     double* s_xp = s_coef + n_levels;
     double* s_fp = s_xp + a.n_table;

@@ -201,6 +201,7 @@ ContinuumArgs to_args(const sdx_continuum* c, const double* bf_coef)
     a.bf_species_offsets = c->bf_species_offsets;
     a.bf_species_ion_number = c->bf_species_ion_number;
     a.bf_cutoff = c->bf_cutoff;
+    a.bf_n_levels = a.bf_n_species > 0 ? c->bf_n_levels : 0;
     a.bf_coef = bf_coef;
     a.ff_n_species = c->ff_number_density ? c->ff_n_species : 0;
     a.ff_species_ion_number = c->ff_species_ion_number;
