@@ -28,16 +28,19 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 FP64_VECTOR_PEAK_TFLOPS = 78.6
 
 
-def build_workload(tag, world):
+def build_workload(tag, world, inputs="dense"):
     from stardis_amd import synth
 
     cfg = synth.WORKLOADS[tag]
-    atm = synth.solar_atmosphere()
+    atm = synth.cool_dwarf_atmosphere() if cfg.get("atmosphere") == "cool_dwarf" else synth.solar_atmosphere()
     base = synth.tracing_grid(cfg["lam0"], cfg["lam1"], cfg.get("R"), cfg.get("step"))
     n_per_gpu = base.size
     # weak scaling: same window and line list, N x the resolving power -> N x the grid points
     nus = base if world == 1 else synth.tracing_grid(cfg["lam0"], cfg["lam1"], cfg.get("R", 1.0), None, n_override=n_per_gpu * world)
-    lines = synth.synth_lines(nus, atm, cfg["n_lines"], synth.SEED, cfg["gamma_per_depth"])
+    if inputs == "linelist":  # per-line scalars: alpha, gamma and the Doppler width are generated in the pre-pass
+        lines = synth.synth_linelist(nus, atm, cfg["n_lines"], synth.SEED)
+    else:
+        lines = synth.synth_lines(nus, atm, cfg["n_lines"], synth.SEED, cfg["gamma_per_depth"])
     cont = synth.synth_continuum_state(atm)
     thetas, weights = synth.thetas_and_weights(synth.N_THETAS)
     return dict(atm=atm, nus=nus, lines=lines, cont=cont, thetas=thetas, weights=weights, n_per_gpu=n_per_gpu)
@@ -53,8 +56,20 @@ def cpu_baseline(w, budget_s=25.0):
     atm, nus, ln, cont = w["atm"], w["nus"], w["lines"], w["cont"]
     nd = atm["temperatures"].size
     max_threads = oracle.num_threads()
+    spec = None if isinstance(ln, dict) else ln
+
+    def dense_tables():
+        """what the reference forms on the host before its line kernel (plasma/base.py:200-321, broadening.py:659-732)"""
+        args = (spec.atomic_number, spec.ion_number, spec.ionization_energy, spec.upper_energy, spec.lower_energy, spec.A_ul)
+        state = (spec.electron_density, spec.temperature, spec.h_density)
+        gam = (oracle.calc_vald_gamma(*args, spec.stark, spec.waals, spec.mass, *state, flags=spec.flags) if spec.gamma_mode == 1
+               else oracle.calc_gamma(*args, *state, flags=spec.flags))
+        return dict(line_nus=spec.nu, gammas=gam, doppler_widths=oracle.doppler_widths(spec.nu, spec.mass, spec.temperature, spec.microturbulence),
+                    alphas=oracle.alpha_line_linelist(spec.e_low_ev, spec.g_lo, spec.strength, spec.nu, spec.pop_row, spec.pop, spec.temperature,
+                                                      spec.alpha_coefficient))
 
     def one_pass():
+        ln = dense_tables() if spec is not None else w["lines"]
         line = oracle.calc_alan_entries(nd, nus, ln["line_nus"], ln["doppler_widths"], ln["gammas"], ln["alphas"])
         lam = K.nu_to_angstrom(nus)
         cutoff = (cont["ionization_energy"] - cont["level_excitation"]) / K.H_CGS
@@ -82,7 +97,7 @@ def cpu_baseline(w, budget_s=25.0):
     best = min(sweep, key=sweep.get)
     return dict(
         value=pts / sweep[best], unit="spectral points/s", cores=best, kind="port",
-        sample=f"full workload ({nus.size} nu x {nd} depths, {ln['line_nus'].size} lines, {len(w['thetas'])} angles), best pass of each thread count; "
+        sample=f"full workload ({nus.size} nu x {nd} depths, {spec.n_lines if spec is not None else ln['line_nus'].size} lines, {len(w['thetas'])} angles), best pass of each thread count; "
                + ", ".join(f"{n} thr: {t * 1e3:.0f} ms" for n, t in sweep.items()),
         host_cores=max_threads,
     ), F
@@ -94,6 +109,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="S-c2")
+    ap.add_argument("--inputs", choices=("dense", "linelist"), default="dense",
+                    help="line list as the reference's dense (N_l, N_d) tables, or as per-line scalars expanded on the device")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -112,7 +129,7 @@ def main():
     torch.cuda.set_device(local)
     import torch.distributed as dist
 
-    w = build_workload(args.workload, world)
+    w = build_workload(args.workload, world, args.inputs)
     nus, atm = w["nus"], w["atm"]
     nd = atm["temperatures"].size
     begin, count = shard_bounds(nus.size, world, rank)
@@ -247,7 +264,7 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.workload}: solar MARCS structure, {synth_desc(args.workload)}, fp64",
+                "workload": f"{args.workload}: {'cool-dwarf' if 'm' == args.workload[-1] else 'solar'} MARCS structure, {synth_desc(args.workload)}, fp64",
                 "n_nu_global": int(nus.size),
                 "n_nu_per_gpu": int(count),
                 "n_depth": int(nd),
@@ -256,6 +273,7 @@ def main():
                 "voigt_evaluations_global": int(evals),
                 "parallelism": f"nu-shard x{world}" + (", 1 all-gather of F_nu[-1] per step" + (" overlapped with the next step" if overlap_gather else "") if world > 1 else ""),
                 "hip_graph": not args.no_graph,
+                "line_inputs": args.inputs,
             },
             "roofline": {
                 "bound": "hbm",
