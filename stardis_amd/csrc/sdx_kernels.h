@@ -99,11 +99,12 @@ __device__ __forceinline__ int64_t window_rule(int64_t c, int64_t n_nu, double d
 // ------------------------------------------------------------------------------------------------
 // Pre-pass: one block = 32 lines x up to 64 depths.  Reads the reference layout coalesced into LDS,
 // writes the depth-major SoA coalesced.
-constexpr int kPreLines = 16;
+constexpr int kPreLines = 32;  // two (line, depth) items per thread: the block's latency chain is paid once for twice the items
 constexpr int kPreDepths = 64;
 constexpr int kPreBlock = 1024;  // threads per pre-pass block: one (line, depth) item per thread, 16 waves to hide latency
 
-static_assert(kPreLines * kPreDepths == kPreBlock && kPreLines <= kPreBlock / 64, "one pre-pass item per thread, one wave per line");
+constexpr int kPreItems = kPreLines * kPreDepths / kPreBlock;  // items per thread
+static_assert(kPreLines * kPreDepths == kPreItems * kPreBlock && kPreLines % 16 == 0 && kPreLines <= 32, "whole items per thread; 16-line mask words");
 constexpr int kNarrowHalfWidth = 64;    // windows with half-width <= this go to the narrow-window kernel
 constexpr int kMediumHalfWidth = 4096;  // class bound of the indexed wide path: medium lines are found by centre range
 
@@ -189,18 +190,22 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
     const int d0 = by * kPreDepths;
     const int nl = (int)min((int64_t)kPreLines, n_lines - l0);
     const int nd = min(kPreDepths, n_depth - d0);
-    // The block's dense inputs are requested first (one item per thread: kPreLines * kPreDepths == kPreBlock), so their
-    // latency hides behind the centre search below instead of following it.
-    double r_dw = 0.0, r_a = 0.0, r_g = 0.0;
+    // The block's dense inputs are requested first (kPreItems per thread), so their latency hides behind the centre search
+    // below instead of following it.
+    double r_dw[kPreItems], r_a[kPreItems], r_g[kPreItems];
     if constexpr (!GEN) {
-        const int k = threadIdx.x;
-        if (k < nl * nd) {
-            const int ll = k / nd, dd = k - ll * nd;
-            const int64_t l = l0 + ll;
-            const int d = d0 + dd;
-            r_dw = doppler[l * n_depth + d];
-            r_a = alphas[l * n_depth + d];
-            r_g = gamma_cols > 1 ? gammas[l * gamma_cols + d] : gammas[l * gamma_cols];
+#pragma unroll
+        for (int it = 0; it < kPreItems; ++it) {
+            const int k = threadIdx.x + it * kPreBlock;
+            r_dw[it] = r_a[it] = r_g[it] = 0.0;
+            if (k < nl * nd) {
+                const int ll = k / nd, dd = k - ll * nd;
+                const int64_t l = l0 + ll;
+                const int d = d0 + dd;
+                r_dw[it] = doppler[l * n_depth + d];
+                r_a[it] = alphas[l * n_depth + d];
+                r_g[it] = gamma_cols > 1 ? gammas[l * gamma_cols + d] : gammas[l * gamma_cols];
+            }
         }
     }
     // line centres: a 128-entry sample of the grid in LDS brackets the answer; wave ll then narrows the bracket of line
@@ -213,9 +218,9 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
         s_coarse[threadIdx.x] = j < n_nu ? nus[j] : -INFINITY;
     }
     __syncthreads();
-    {
-        const int ll = threadIdx.x >> 6, lane = threadIdx.x & 63;
-        if (ll < nl) {
+    for (int ll = threadIdx.x >> 6; ll < nl; ll += kPreBlock / 64) {
+        const int lane = threadIdx.x & 63;
+        {
             const double v = line_nus[l0 + ll];
             int a = 0, b = 128;  // first sample strictly below v
             while (a < b) {
@@ -259,12 +264,15 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
         }
     } else {
         // reference layout in (requested above), line fastest ... depth fastest: coalesced
-        const int k = threadIdx.x;
-        if (k < nl * nd) {
-            const int ll = k / nd, dd = k - ll * nd;
-            s_dw[ll * kStride + dd] = r_dw;
-            s_a[ll * kStride + dd] = r_a;
-            s_g[ll * kStride + dd] = r_g;
+#pragma unroll
+        for (int it = 0; it < kPreItems; ++it) {
+            const int k = threadIdx.x + it * kPreBlock;
+            if (k < nl * nd) {
+                const int ll = k / nd, dd = k - ll * nd;
+                s_dw[ll * kStride + dd] = r_dw[it];
+                s_a[ll * kStride + dd] = r_a[it];
+                s_g[ll * kStride + dd] = r_g[it];
+            }
         }
     }
     __syncthreads();
@@ -303,9 +311,13 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
         if (hi > lo) ev += (unsigned long long)(hi - lo);
     }
     __syncthreads();
-    if (w.wmask_med && threadIdx.x < nd) {
-        w.wmask_med[(size_t)(d0 + threadIdx.x) * w.mask_ld + bx] = (unsigned short)s_wmask[0][threadIdx.x];
-        w.wmask_huge[(size_t)(d0 + threadIdx.x) * w.mask_ld + bx] = (unsigned short)s_wmask[1][threadIdx.x];
+    if (w.wmask_med && threadIdx.x < nd) {  // one 16-bit word per 16 lines
+#pragma unroll
+        for (int h = 0; h < kPreLines / 16; ++h) {
+            const size_t o = (size_t)(d0 + threadIdx.x) * w.mask_ld + (size_t)bx * (kPreLines / 16) + h;
+            w.wmask_med[o] = (unsigned short)(s_wmask[0][threadIdx.x] >> (16 * h));
+            w.wmask_huge[o] = (unsigned short)(s_wmask[1][threadIdx.x] >> (16 * h));
+        }
     }
     // per-line summary for the narrow kernel's candidate test: centre index and the largest narrow half-width
     if (w.nhw_max && threadIdx.x < nl) {
