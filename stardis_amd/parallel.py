@@ -37,14 +37,52 @@ def padded_count(n_nu, world_size):
     return -(-n_nu // world_size)
 
 
+def window_work(nus, line_nus, doppler_widths, gammas, alphas):
+    """Voigt evaluations per grid column, sum over (line, depth) of [lo <= i < hi] with the window rule of
+    calc_alan_entries (opacities_solvers/base.py:524-575).  A planning estimate on the host (numpy, O(N_l N_d)): it only
+    decides where shard boundaries go, never what is computed."""
+    nus = np.asarray(nus, dtype=np.float64)
+    n = nus.size
+    if n < 2 or np.asarray(line_nus).size == 0:
+        return np.ones(n)
+    d_nu = -np.max(np.diff(nus))
+    centre = n - np.searchsorted(nus[::-1], np.asarray(line_nus, dtype=np.float64))  # first index with nu < line_nu
+    g = np.asarray(gammas, dtype=np.float64).reshape(centre.size, -1)
+    pixels = (g + np.asarray(doppler_widths, dtype=np.float64)) * np.asarray(alphas, dtype=np.float64) / d_nu * 20.0
+    hw = np.minimum(np.where(pixels > 10.0, pixels, 10.0), float(n)).astype(np.int64)
+    lo = np.clip(centre[:, None] - hw, 0, n)
+    hi = np.clip(centre[:, None] + hw, 0, n)
+    cover = np.zeros(n + 1)
+    np.add.at(cover, lo.ravel(), 1.0)
+    np.add.at(cover, hi.ravel(), -1.0)
+    return np.cumsum(cover)[:n]
+
+
+def balanced_shards(work, world_size, fixed_cost=0.0):
+    """Contiguous shards of (nearly) equal work: -> list of (begin, count), one per rank.  `work` is a per-column cost
+    (e.g. window_work(...) + a constant per column for the continuum and the formal solution); equal-width shards of a
+    long spectrum differ by 30 % in work because windows are wider, in grid points, at the blue end."""
+    w = np.asarray(work, dtype=np.float64) + float(fixed_cost)
+    n = w.size
+    cum = np.concatenate([[0.0], np.cumsum(w)])
+    cuts = [0]
+    for r in range(1, world_size):
+        c = int(np.searchsorted(cum, cum[-1] * r / world_size))
+        cuts.append(min(max(c, cuts[-1]), n))
+    cuts.append(n)
+    return [(cuts[r], cuts[r + 1] - cuts[r]) for r in range(world_size)]
+
+
 class FluxGatherer:
     """Reusable buffers for the per-step all-gather of emergent-flux shards (no allocation inside the timed loop)."""
 
-    def __init__(self, n_nu, world_size, device, dtype=None):
+    def __init__(self, n_nu, world_size, device, dtype=None, shards=None):
+        """shards: optional list of (begin, count) per rank for unequal shards (balanced_shards); default equal blocks."""
         import torch
 
         self.n_nu, self.world = n_nu, world_size
-        self.per = padded_count(n_nu, world_size)
+        self.shards = shards
+        self.per = padded_count(n_nu, world_size) if shards is None else max(c for _, c in shards)
         dtype = dtype or torch.float64
         self.send = torch.zeros(self.per, dtype=dtype, device=device)
         self.recv = torch.empty(self.per * world_size, dtype=dtype, device=device)
@@ -74,7 +112,14 @@ class FluxGatherer:
         if work is not None:
             work.wait()
             self._work = None
-        return self.recv[: self.n_nu]
+        return self._assemble()
+
+    def _assemble(self):
+        if self.shards is None:
+            return self.recv[: self.n_nu]
+        import torch
+
+        return torch.cat([self.recv[r * self.per : r * self.per + c] for r, (_, c) in enumerate(self.shards)])
 
     def __call__(self, local_flux):
         import torch
@@ -93,13 +138,13 @@ class FluxGatherer:
             self.recv.copy_(self.host)
         else:
             dist.all_gather_into_tensor(self.recv, src)
-        return self.recv[: self.n_nu]
+        return self._assemble()
 
 
-def gather_flux(local_flux, n_nu, world_size):
+def gather_flux(local_flux, n_nu, world_size, shards=None):
     """All-gather per-rank emergent-flux shards (1-D tensors of this rank's `count` columns, on the device the
-    backend wants) into the full (n_nu,) spectrum on every rank."""
-    return FluxGatherer(n_nu, world_size, local_flux.device, local_flux.dtype)(local_flux).clone()
+    backend wants) into the full (n_nu,) spectrum on every rank.  shards: (begin, count) per rank when unequal."""
+    return FluxGatherer(n_nu, world_size, local_flux.device, local_flux.dtype, shards)(local_flux).clone()
 
 
 def assemble_shards(shards, n_nu, world_size):

@@ -71,3 +71,60 @@ def test_sharded_oracle_equals_global_oracle():
     keep = (ln["line_nus"] >= sub.min()) & (ln["line_nus"] <= sub.max())
     independent = oracle.calc_alan_entries(56, sub, ln["line_nus"][keep], ln["doppler_widths"][keep], ln["gammas"][keep], ln["alphas"][keep])
     assert not np.allclose(independent, full[:, b : b + c], rtol=1e-6, atol=0.0)  # lines outside the sub-grid are dropped (base.py:393-395)
+
+
+def _worker_uneven(rank, world, port, n_nu, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch
+
+    from stardis_amd import parallel
+
+    parallel.init_from_env("gloo")
+    work = np.linspace(3.0, 1.0, n_nu)  # heavier at the blue end, like window counts
+    shards = parallel.balanced_shards(work, world)
+    begin, count = shards[rank]
+    full = np.arange(n_nu, dtype=np.float64) * 1.5 + 3.0
+    spectrum = parallel.gather_flux(torch.from_numpy(full[begin : begin + count].copy()), n_nu, world, shards)
+    np.save(os.path.join(out_dir, f"rank{rank}.npy"), spectrum.numpy())
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_gather_with_work_balanced_shards(tmp_path):
+    import torch.multiprocessing as mp
+
+    n_nu, port = 1001, _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_worker_uneven, args=(r, 2, port, n_nu, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    want = np.arange(n_nu, dtype=np.float64) * 1.5 + 3.0
+    for r in range(2):
+        assert np.array_equal(np.load(tmp_path / f"rank{r}.npy"), want)
+
+
+def test_balanced_shards_partition_and_balance():
+    """balanced_shards tiles the grid exactly, and on the window-count estimate of a line list (checked against the
+    oracle's own windows) evens out the work that equal-width shards leave 30 % apart."""
+    import oracle
+    from stardis_amd import parallel, synth
+
+    atm = synth.solar_atmosphere()
+    nus = synth.tracing_grid(4000.0, 8000.0, R=2.0e4)
+    ln = synth.synth_lines(nus, atm, 1500, seed=5)
+    work = parallel.window_work(nus, ln["line_nus"], ln["doppler_widths"], ln["gammas"], ln["alphas"])
+    _, evals = oracle.calc_alan_entries(56, nus, ln["line_nus"], ln["doppler_widths"], ln["gammas"], ln["alphas"], return_evals=True)
+    assert int(work.sum()) == evals  # the estimate IS the window rule
+    for world in (1, 2, 3, 8):
+        shards = parallel.balanced_shards(work, world)
+        assert shards[0][0] == 0 and sum(c for _, c in shards) == nus.size
+        for (b0, c0), (b1, _) in zip(shards, shards[1:]):
+            assert b0 + c0 == b1
+        per = [work[b : b + c].sum() for b, c in shards]
+        assert max(per) <= 1.02 * np.mean(per) + work.max()
+    equal = [work[b : b + c].sum() for b, c in (parallel.shard_bounds(nus.size, 8, r) for r in range(8))]
+    assert max(equal) > 1.1 * np.mean(equal)
