@@ -99,12 +99,11 @@ __device__ __forceinline__ int64_t window_rule(int64_t c, int64_t n_nu, double d
 // ------------------------------------------------------------------------------------------------
 // Pre-pass: one block = 32 lines x up to 64 depths.  Reads the reference layout coalesced into LDS,
 // writes the depth-major SoA coalesced.
-constexpr int kPreLines = 32;  // two (line, depth) items per thread: the block's latency chain is paid once for twice the items
+// lines per pre-pass block: 16 (one (line, depth) item per thread) for short lists whose blocks all fit the chip at once, 32 (two
+// items per thread: the block's latency chain is paid once for twice the items) for long ones — a template parameter
 constexpr int kPreDepths = 64;
 constexpr int kPreBlock = 1024;  // threads per pre-pass block: one (line, depth) item per thread, 16 waves to hide latency
 
-constexpr int kPreItems = kPreLines * kPreDepths / kPreBlock;  // items per thread
-static_assert(kPreLines * kPreDepths == kPreItems * kPreBlock && kPreLines % 16 == 0 && kPreLines <= 32, "whole items per thread; 16-line mask words");
 constexpr int kNarrowHalfWidth = 64;    // windows with half-width <= this go to the narrow-window kernel
 constexpr int kMediumHalfWidth = 4096;  // class bound of the indexed wide path: medium lines are found by centre range
 
@@ -143,7 +142,7 @@ struct LineWork {
     unsigned long long* evals;
 };
 
-template <bool GEN>
+template <bool GEN, int kPreLines>
 __device__ __forceinline__ void prepass_block(const int bx, const int by, const int gy, int n_depth, int64_t n_nu, const double* __restrict__ nus,
                                                          const double* __restrict__ dnu_partial, int n_partial,
                                                          int64_t n_lines, const double* __restrict__ line_nus,
@@ -176,6 +175,8 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
         return;
     }
     constexpr int kStride = kPreDepths + 1;  // odd row stride: conflict-free transposed LDS reads
+    constexpr int kPreItems = kPreLines * kPreDepths / kPreBlock;  // items per thread
+    static_assert(kPreLines * kPreDepths == kPreItems * kPreBlock && kPreLines % 16 == 0 && kPreLines <= 32, "whole items per thread; 16-line mask words");
     constexpr int kMaxWaves = kPreBlock / 64;
     __shared__ double s_dw[kPreLines * kStride], s_g[kPreLines * kStride], s_a[kPreLines * kStride];
     __shared__ int s_lo[kPreLines * kStride], s_hi[kPreLines * kStride];
@@ -360,7 +361,7 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
     }
 }
 
-template <bool GEN>
+template <bool GEN, int LINES>
 __global__ __launch_bounds__(kPreBlock) __attribute__((amdgpu_num_sgpr(80))) void k_line_prepass(int n_depth, int64_t n_nu, const double* __restrict__ nus,
                                                          const double* __restrict__ dnu_partial, int n_partial,
                                                          int64_t n_lines, const double* __restrict__ line_nus,
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(kPreBlock) __attribute__((amdgpu_num_sgpr(80))) voi
                                                          int* __restrict__ out_lo_ref, int* __restrict__ out_hi_ref,
                                                          int n_line_blocks, LineParams lp)
 {
-    prepass_block<GEN>(blockIdx.x, blockIdx.y, gridDim.y, n_depth, n_nu, nus, dnu_partial, n_partial, n_lines, line_nus, doppler, gammas,
+    prepass_block<GEN, LINES>(blockIdx.x, blockIdx.y, gridDim.y, n_depth, n_nu, nus, dnu_partial, n_partial, n_lines, line_nus, doppler, gammas,
                        gamma_cols, alphas, w, out_lo_ref, out_hi_ref, n_line_blocks, lp);
 }
 
@@ -1252,7 +1253,7 @@ __global__ __launch_bounds__(kBlock) void k_total_alphas(int n_depth, int64_t nu
 constexpr int kContPoints = 1;
 // Pre-pass and continuum in ONE launch: the pre-pass is a few latency-bound blocks (binary searches, a grid scan);
 // the continuum plane depends on nothing and fills the rest of the chip meanwhile.
-template <bool GEN>
+template <bool GEN, int LINES>
 __global__ __launch_bounds__(kPreBlock) __attribute__((amdgpu_num_sgpr(80))) void k_prepass_continuum(int n_pre_x, int n_pre_y, int cont_tiles, int n_depth, int64_t n_nu,
                                                               const double* __restrict__ nus,
                                                               const double* __restrict__ dnu_partial, int n_partial,
@@ -1266,7 +1267,7 @@ __global__ __launch_bounds__(kPreBlock) __attribute__((amdgpu_num_sgpr(80))) voi
     const int b = blockIdx.x;
     const int n_pre = n_pre_x * n_pre_y;
     if (b < n_pre) {
-        prepass_block<GEN>(b % n_pre_x, b / n_pre_x, n_pre_y, n_depth, n_nu, nus, dnu_partial, n_partial, n_lines, line_nus, doppler,
+        prepass_block<GEN, LINES>(b % n_pre_x, b / n_pre_x, n_pre_y, n_depth, n_nu, nus, dnu_partial, n_partial, n_lines, line_nus, doppler,
                            gammas, gamma_cols, alphas, w, nullptr, nullptr, n_line_blocks, lp);
     } else {
         const int c = b - n_pre;

@@ -46,6 +46,7 @@ struct ProfileRecord {
 
 struct sdx_ctx {
     int device = 0;
+    int n_cu = 256;  // compute units of the device
     hipStream_t stream = nullptr;
     bool own_stream = false;
     // line-opacity scratch (depth-major pre-pass arrays)
@@ -259,6 +260,7 @@ sdx_ctx* sdx_create(int device, void* stream)
     }
     sdx_ctx* ctx = new sdx_ctx();
     ctx->device = device;
+    if (hipDeviceGetAttribute(&ctx->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ctx->n_cu <= 0) ctx->n_cu = 256;
     if (stream) {
         ctx->stream = (hipStream_t)stream;
     } else {
@@ -512,7 +514,9 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
     const bool scan_in_block = n_nu <= 16384;  // every pre-pass block re-scans a small grid instead of a separate launch
     if (!scan_in_block && (rc = launch_dnu(ctx, n_nu, nus, &n_partial))) return rc;
     LineWork w{};
-    const int n_line_blocks = (int)((n_lines + kPreLines - 1) / kPreLines);
+    // 16 lines per block while all such blocks are resident at once (two 1024-thread blocks per CU), else 32
+    const int pre_lines = ((n_lines + 15) / 16) * ((n_depth + kPreDepths - 1) / kPreDepths) <= 2 * (int64_t)ctx->n_cu ? 16 : 32;
+    const int n_line_blocks = (int)((n_lines + pre_lines - 1) / pre_lines);
     int n_pixel_blocks = 0;
     if (fill_work) {
         rc = ensure(ctx, &ctx->line_ws, &ctx->line_ws_bytes, line_ws_need(n_depth, n_lines));
@@ -552,15 +556,19 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
 #define SDX_PRE_ARGS (int)grid.x, (int)grid.y, cont_tiles, n_depth, n_nu, nus, scan_in_block ? (const double*)nullptr : (const double*)ctx->small_ws, \
                      n_partial, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, w, n_line_blocks, job->nu_begin, job->nu_count, ca,          \
                      job->plane, job->nu_count, lp, stage_table
-        if (gen) hipLaunchKernelGGL(k_prepass_continuum<true>, dim3(total_blocks), dim3(kPreBlock), shmem, ctx->stream, SDX_PRE_ARGS);
-        else hipLaunchKernelGGL(k_prepass_continuum<false>, dim3(total_blocks), dim3(kPreBlock), shmem, ctx->stream, SDX_PRE_ARGS);
+        if (gen && pre_lines == 16) hipLaunchKernelGGL((k_prepass_continuum<true, 16>), dim3(total_blocks), dim3(kPreBlock), shmem, ctx->stream, SDX_PRE_ARGS);
+        else if (gen) hipLaunchKernelGGL((k_prepass_continuum<true, 32>), dim3(total_blocks), dim3(kPreBlock), shmem, ctx->stream, SDX_PRE_ARGS);
+        else if (pre_lines == 16) hipLaunchKernelGGL((k_prepass_continuum<false, 16>), dim3(total_blocks), dim3(kPreBlock), shmem, ctx->stream, SDX_PRE_ARGS);
+        else hipLaunchKernelGGL((k_prepass_continuum<false, 32>), dim3(total_blocks), dim3(kPreBlock), shmem, ctx->stream, SDX_PRE_ARGS);
 #undef SDX_PRE_ARGS
     } else {
         LaunchScope ls(ctx, "k_line_prepass");
 #define SDX_PRE_ARGS n_depth, n_nu, nus, scan_in_block ? (const double*)nullptr : (const double*)ctx->small_ws, n_partial, n_lines, line_nus, doppler, \
                      gammas, gamma_cols, alphas, w, (int*)lo_ref, (int*)hi_ref, n_line_blocks, lp
-        if (gen) hipLaunchKernelGGL(k_line_prepass<true>, grid, dim3(kPreBlock), 0, ctx->stream, SDX_PRE_ARGS);
-        else hipLaunchKernelGGL(k_line_prepass<false>, grid, dim3(kPreBlock), 0, ctx->stream, SDX_PRE_ARGS);
+        if (gen && pre_lines == 16) hipLaunchKernelGGL((k_line_prepass<true, 16>), grid, dim3(kPreBlock), 0, ctx->stream, SDX_PRE_ARGS);
+        else if (gen) hipLaunchKernelGGL((k_line_prepass<true, 32>), grid, dim3(kPreBlock), 0, ctx->stream, SDX_PRE_ARGS);
+        else if (pre_lines == 16) hipLaunchKernelGGL((k_line_prepass<false, 16>), grid, dim3(kPreBlock), 0, ctx->stream, SDX_PRE_ARGS);
+        else hipLaunchKernelGGL((k_line_prepass<false, 32>), grid, dim3(kPreBlock), 0, ctx->stream, SDX_PRE_ARGS);
 #undef SDX_PRE_ARGS
     }
     if (w_out) *w_out = w;
