@@ -28,7 +28,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 FP64_VECTOR_PEAK_TFLOPS = 78.6
 
 
-def build_workload(tag, world, inputs="dense"):
+def build_workload(tag, world, inputs="dense", scaling="weak"):
     from stardis_amd import synth
 
     cfg = synth.WORKLOADS[tag]
@@ -36,7 +36,8 @@ def build_workload(tag, world, inputs="dense"):
     base = synth.tracing_grid(cfg["lam0"], cfg["lam1"], cfg.get("R"), cfg.get("step"))
     n_per_gpu = base.size
     # weak scaling: same window and line list, N x the resolving power -> N x the grid points
-    nus = base if world == 1 else synth.tracing_grid(cfg["lam0"], cfg["lam1"], cfg.get("R", 1.0), None, n_override=n_per_gpu * world)
+    # strong scaling: the workload's own grid, split N ways
+    nus = base if (world == 1 or scaling == "strong") else synth.tracing_grid(cfg["lam0"], cfg["lam1"], cfg.get("R", 1.0), None, n_override=n_per_gpu * world)
     if inputs == "linelist":  # per-line scalars: alpha, gamma and the Doppler width are generated in the pre-pass
         lines = synth.synth_linelist(nus, atm, cfg["n_lines"], synth.SEED)
     else:
@@ -111,6 +112,9 @@ def main():
     ap.add_argument("--workload", default="S-c2")
     ap.add_argument("--inputs", choices=("dense", "linelist"), default="dense",
                     help="line list as the reference's dense (N_l, N_d) tables, or as per-line scalars expanded on the device")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak (default): fixed grid points per GPU; strong: the workload's grid split across the GPUs in shards of equal "
+                         "estimated work (stardis_amd.parallel.balanced_shards)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -129,10 +133,14 @@ def main():
     torch.cuda.set_device(local)
     import torch.distributed as dist
 
-    w = build_workload(args.workload, world, args.inputs)
+    w = build_workload(args.workload, world, args.inputs, args.scaling)
     nus, atm = w["nus"], w["atm"]
     nd = atm["temperatures"].size
-    begin, count = shard_bounds(nus.size, world, rank)
+    shards = None
+    if args.scaling == "strong" and world > 1 and isinstance(w["lines"], dict):
+        ln_ = w["lines"]
+        shards = parallel.balanced_shards(parallel.window_work(nus, ln_["line_nus"], ln_["doppler_widths"], ln_["gammas"], ln_["alphas"]), world)
+    begin, count = shards[rank] if shards else shard_bounds(nus.size, world, rank)
 
     # the library enqueues on torch's current (non-default, capturable) stream, so the RCCL gather is
     # stream-ordered behind the kernels without a host sync
@@ -153,14 +161,14 @@ def main():
     # of step k+1; a buffer is reused only after its gather has been waited for.  SDX_BENCH_SYNC_GATHER=1 falls back
     # to a blocking gather per step.
     overlap_gather = world > 1 and os.environ.get("SDX_BENCH_SYNC_GATHER") != "1"
-    lanes = [(syn, flux, parallel.FluxGatherer(nus.size, world, flux.device))]
+    lanes = [(syn, flux, parallel.FluxGatherer(nus.size, world, flux.device, shards=shards))]
     if overlap_gather:
         flux_b = torch.zeros_like(flux)
         syn_b2 = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], w["thetas"], w["weights"], w["lines"], w["cont"],
                                      ctx=ctx, shard=(begin, count), flux_out=flux_b, track_evaluations=False)
         if not args.no_graph:
             syn_b2.capture()
-        lanes.append((syn_b2, flux_b, parallel.FluxGatherer(nus.size, world, flux.device)))
+        lanes.append((syn_b2, flux_b, parallel.FluxGatherer(nus.size, world, flux.device, shards=shards)))
     counter = [0]
 
     def step():
@@ -259,7 +267,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
