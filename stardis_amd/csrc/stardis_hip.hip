@@ -71,9 +71,6 @@ struct sdx_ctx {
     int64_t mixed_precision = 0;       // 1: fp32 rational for far-wing (region I) evaluations of whole-tile windows
     // timing
     hipEvent_t t0 = nullptr, t1 = nullptr;
-    // side stream + fork/join events: independent kernels of one step (wide / narrow line opacity) overlap
-    hipStream_t side = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr, fork0 = nullptr;
     void* cont_ws = nullptr;  // continuum plane [n_depth][nu_count] of the fused step
     size_t cont_ws_bytes = 0;
     bool profile = false;
@@ -273,10 +270,6 @@ sdx_ctx* sdx_create(int device, void* stream)
     }
     hipEventCreate(&ctx->t0);
     hipEventCreate(&ctx->t1);
-    hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking);
-    hipEventCreateWithFlags(&ctx->fork, hipEventDisableTiming);
-    hipEventCreateWithFlags(&ctx->join, hipEventDisableTiming);
-    hipEventCreateWithFlags(&ctx->fork0, hipEventDisableTiming);
     return ctx;
 }
 
@@ -290,13 +283,6 @@ void sdx_destroy(sdx_ctx* ctx)
         hipEventDestroy(r.stop);
     }
     for (auto e : ctx->event_pool) hipEventDestroy(e);
-    if (ctx->side) {
-        hipStreamSynchronize(ctx->side);
-        hipStreamDestroy(ctx->side);
-    }
-    if (ctx->fork) hipEventDestroy(ctx->fork);
-    if (ctx->join) hipEventDestroy(ctx->join);
-    if (ctx->fork0) hipEventDestroy(ctx->fork0);
     if (ctx->cont_ws) hipFree(ctx->cont_ws);
     if (ctx->t0) hipEventDestroy(ctx->t0);
     if (ctx->t1) hipEventDestroy(ctx->t1);
