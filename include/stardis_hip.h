@@ -251,6 +251,16 @@ int sdx_synthesize_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nu
                        double* alpha_line_out, double* total_alphas, double* F_nu, int64_t ld,
                        int64_t* n_evaluations_dev);
 
+/* The same synthesis for a caller whose data lives in host memory (plain C, or numpy through ctypes): every pointer,
+ * including those inside `cont`, is a HOST pointer; arrays are uploaded, sdx_synthesize_dev runs, results come back.
+ * total_alphas and F_nu are [n_depth][n_nu] (F_nu overwritten); alpha_line_out and n_evaluations are optional.
+ * ray_dist is the (n_depth-1, n_theta) table dist[:, None] / cos(theta) (radiation_field_solvers/base.py:302-305). */
+int sdx_synthesize_f64(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t n_lines, const double* line_nus,
+                       const double* doppler_widths, const double* gammas, int gamma_cols, const double* alphas,
+                       const sdx_continuum* cont, int n_theta, const double* temperature, const double* ray_dist,
+                       const double* theta_weights, double* alpha_line_out, double* total_alphas, double* F_nu,
+                       int64_t* n_evaluations);
+
 /* ---- line parameters generated on the device ---------------------------------------
  * Instead of the three dense (N_l, N_d) tables the reference builds on the host before calc_alan_entries —
  * alpha_line (plasma/base.py:178-321 AlphaLineVald, :324-455 AlphaLineShortlistVald; plasma/molecules.py:192-320,

@@ -128,6 +128,8 @@ PROTOTYPES = {
     "sdx_convolve1d_reflect_dev": (_int, [_vp, _i64, _vp, _int, _vp, _int, _vp]),
     "sdx_synthesize_dev": (_int, [_vp, _int, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _int, _vp, C.POINTER(Continuum), _int,
                                   _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "sdx_synthesize_f64": (_int, [_vp, _int, _i64, _vp, _i64, _vp, _vp, _vp, _int, _vp, C.POINTER(Continuum), _int, _vp, _vp, _vp, _vp, _vp,
+                                  _vp, _vp]),
     "sdx_alpha_line_levels_dev": (_int, [_vp, _i64, _int, _int, _vp, _vp, _vp, _vp, C.c_double, _vp]),
     "sdx_line_params_dev": (_int, [_vp, _int, C.POINTER(LineListStruct), _vp, _vp, _vp]),
     "sdx_line_opacity_linelist_dev": (_int, [_vp, _int, _i64, _vp, _i64, _i64, C.POINTER(LineListStruct), _vp, _i64, _int, _vp]),

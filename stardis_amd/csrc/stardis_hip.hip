@@ -1354,4 +1354,69 @@ int sdx_synthesize_linelist_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const d
                            F_nu, ld, n_evaluations_dev, &lp);
 }
 
+// The fused synthesis for a caller that holds everything in host memory (C, or numpy through ctypes): uploads, runs
+// sdx_synthesize_dev, downloads.  `cont` carries HOST pointers here; array lengths follow from the sizes in the struct.
+int sdx_synthesize_f64(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t n_lines, const double* line_nus,
+                       const double* doppler, const double* gammas, int gamma_cols, const double* alphas, const sdx_continuum* cont,
+                       int n_theta, const double* temps, const double* ray_dist, const double* wts, double* alpha_line_out,
+                       double* total_alphas, double* F_nu, int64_t* n_evaluations)
+{
+    int rc = check_line_args(ctx, n_depth, n_nu, nus, n_lines, line_nus, doppler, gammas, gamma_cols, alphas);
+    if (rc) return rc;
+    REQUIRE(cont && temps && ray_dist && wts && n_theta > 0 && n_depth >= 2, "synthesize: bad arguments");
+    REQUIRE(n_nu == 0 || (total_alphas && F_nu), "synthesize: null output");
+    if (n_nu == 0) return SDX_OK;
+    if ((rc = host_grid_check(n_nu, nus))) return rc;
+    for (int64_t k = 0; k < n_lines * n_depth; ++k)
+        if (doppler[k] == 0.0) return fail(SDX_ERR_ARG, "doppler_width == 0 (ZeroDivisionError in the reference, voigt.py:148)");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t f8 = sizeof(double), plane = (size_t)n_depth * n_nu * f8, ld = (size_t)n_lines * n_depth * f8;
+    DevBuf d_nus, d_ln, d_dw, d_g, d_a, d_t, d_rd, d_w, d_line, d_total, d_F, d_ev;
+    if ((rc = d_nus.upload(ctx, nus, n_nu * f8)) || (rc = d_ln.upload(ctx, line_nus, n_lines * f8)) || (rc = d_dw.upload(ctx, doppler, ld)) ||
+        (rc = d_g.upload(ctx, gammas, (size_t)n_lines * gamma_cols * f8)) || (rc = d_a.upload(ctx, alphas, ld)) ||
+        (rc = d_t.upload(ctx, temps, n_depth * f8)) || (rc = d_rd.upload(ctx, ray_dist, (size_t)(n_depth - 1) * n_theta * f8)) ||
+        (rc = d_w.upload(ctx, wts, n_theta * f8)) || (rc = d_line.alloc(plane)) || (rc = d_total.alloc(plane)) || (rc = d_F.alloc(plane)) ||
+        (rc = d_ev.alloc(sizeof(int64_t))))
+        return rc;
+    // continuum: every non-null host array goes up; lengths from the struct
+    sdx_continuum c = *cont;
+    DevBuf b[16];
+    int nb = 0;
+    auto up = [&](const void* src, size_t bytes, const void** dst) -> int {
+        if (!src) return SDX_OK;
+        int r = b[nb].upload(ctx, src, bytes);
+        *dst = b[nb++].p;
+        return r;
+    };
+    const int n_levels = c.bf_n_species > 0 ? c.bf_n_levels : 0;
+    REQUIRE(c.bf_n_species == 0 || !c.bf_cutoff || n_levels > 0, "synthesize: bf_n_levels must be set");
+    if ((rc = up(cont->lambdas, n_nu * f8, (const void**)&c.lambdas)) || (rc = up(cont->table_wavelength, c.n_table * f8, (const void**)&c.table_wavelength)) ||
+        (rc = up(cont->table_sigma, c.n_table * f8, (const void**)&c.table_sigma)) ||
+        (rc = up(cont->table_density, n_depth * f8, (const void**)&c.table_density)) ||
+        (rc = up(cont->bf_species_offsets, (size_t)(c.bf_n_species + 1) * sizeof(int32_t), (const void**)&c.bf_species_offsets)) ||
+        (rc = up(cont->bf_species_ion_number, (size_t)c.bf_n_species * sizeof(int32_t), (const void**)&c.bf_species_ion_number)) ||
+        (rc = up(cont->bf_cutoff, (size_t)n_levels * f8, (const void**)&c.bf_cutoff)) ||
+        (rc = up(cont->bf_level_density, (size_t)n_levels * n_depth * f8, (const void**)&c.bf_level_density)) ||
+        (rc = up(cont->ff_species_ion_number, (size_t)c.ff_n_species * sizeof(int32_t), (const void**)&c.ff_species_ion_number)) ||
+        (rc = up(cont->ff_number_density, (size_t)c.ff_n_species * n_depth * f8, (const void**)&c.ff_number_density)) ||
+        (rc = up(cont->ray_n_h, n_depth * f8, (const void**)&c.ray_n_h)) || (rc = up(cont->ray_n_he, n_depth * f8, (const void**)&c.ray_n_he)) ||
+        (rc = up(cont->ray_n_h2, n_depth * f8, (const void**)&c.ray_n_h2)) ||
+        (rc = up(cont->electron_density, n_depth * f8, (const void**)&c.electron_density)))
+        return rc;
+    c.temperature = (const double*)d_t.p;
+    rc = sdx_synthesize_dev(ctx, n_depth, n_nu, (const double*)d_nus.p, 0, n_nu, n_lines, (const double*)d_ln.p, (const double*)d_dw.p,
+                            (const double*)d_g.p, gamma_cols, (const double*)d_a.p, &c, n_theta, (const double*)d_t.p, (const double*)d_rd.p,
+                            (const double*)d_w.p, alpha_line_out ? (double*)d_line.p : nullptr, (double*)d_total.p, (double*)d_F.p, n_nu,
+                            n_evaluations ? (int64_t*)d_ev.p : nullptr);
+    if (rc) return rc;
+    if (alpha_line_out) HIP_TRY(hipMemcpyAsync(alpha_line_out, d_line.p, plane, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(total_alphas, d_total.p, plane, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(F_nu, d_F.p, plane, hipMemcpyDeviceToHost, ctx->stream));
+    int64_t ev = 0;
+    if (n_evaluations) HIP_TRY(hipMemcpyAsync(&ev, d_ev.p, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (n_evaluations) *n_evaluations = ev;
+    return SDX_OK;
+}
+
 }  // extern "C"

@@ -274,3 +274,50 @@ def test_pool_members_equal_their_standalone_results(ctx):
     for got, want in zip(pool.fluxes(), alone):
         assert np.array_equal(got, want)
     pool.close()
+
+
+def test_host_buffer_synthesis_entry_point(ctx):
+    """sdx_synthesize_f64: every array, including the continuum description, handed over as host (numpy) memory —
+    the results are those of the device-resident engine, bit for bit."""
+    import ctypes as C
+
+    from stardis_amd import _lib
+
+    atm, nus, lines, cont, th, w = small_workload(seed=17, n_theta=6)
+    nd, n_nu = atm["temperatures"].size, nus.size
+    syn = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], th, w, lines, cont, ctx=ctx)
+    syn.step()
+    keep = []
+
+    def host(a, dt=np.float64):
+        a = np.ascontiguousarray(a, dtype=dt)
+        keep.append(a)
+        return a.ctypes.data
+
+    cutoff = (cont["ionization_energy"] - np.asarray(cont["level_excitation"])) / K.H_CGS
+    c = _lib.Continuum()
+    c.lambdas = host(K.nu_to_angstrom(nus))
+    c.n_table = len(cont["hminus_bf_wavelength"])
+    c.table_wavelength, c.table_sigma = host(cont["hminus_bf_wavelength"]), host(cont["hminus_bf_cross_section"])
+    c.table_density = host(cont["n_hminus"])
+    c.bf_n_species, c.bf_n_levels = 1, len(cutoff)
+    c.bf_species_offsets, c.bf_species_ion_number = host([0, len(cutoff)], np.int32), host([0], np.int32)
+    c.bf_cutoff, c.bf_level_density = host(cutoff), host(cont["level_density"])
+    c.ff_n_species = 1
+    c.ff_species_ion_number, c.ff_number_density = host([1], np.int32), host(np.asarray(cont["n_e"]) * np.asarray(cont["n_h2"]))
+    c.electron_density = host(cont["n_e"])
+    ray = np.asarray(atm["dist"]).reshape(-1, 1) / np.cos(th)
+    line, total, F = np.empty((nd, n_nu)), np.empty((nd, n_nu)), np.empty((nd, n_nu))
+    ev = C.c_int64(0)
+    g = np.ascontiguousarray(lines["gammas"]).reshape(lines["line_nus"].size, -1)
+    _lib.check(ctx.lib.sdx_synthesize_f64(
+        ctx.handle, nd, n_nu, host(nus), lines["line_nus"].size, host(lines["line_nus"]), host(lines["doppler_widths"]), host(g), g.shape[1],
+        host(lines["alphas"]), C.byref(c), th.size, host(atm["temperatures"]), host(ray), host(w), line.ctypes.data, total.ctypes.data,
+        F.ctypes.data, C.byref(ev)))
+    assert ev.value == syn.evaluations()
+    assert np.array_equal(line, syn.alpha_line()) and np.array_equal(total, syn.total_alphas()) and np.array_equal(F, syn.F_nu())
+    bad = nus[::-1].copy()
+    with pytest.raises(ValueError, match="descending"):
+        _lib.check(ctx.lib.sdx_synthesize_f64(
+            ctx.handle, nd, n_nu, host(bad), lines["line_nus"].size, host(lines["line_nus"]), host(lines["doppler_widths"]), host(g), g.shape[1],
+            host(lines["alphas"]), C.byref(c), th.size, host(atm["temperatures"]), host(ray), host(w), None, total.ctypes.data, F.ctypes.data, None))
