@@ -673,6 +673,25 @@ __device__ __forceinline__ void line_wide_block_indexed(const int tile_idx, cons
             }
             __syncthreads();
             for (int j = 0; j < total; ++j) {
+                // two consecutive test-free lines share one trip through the loop (their constants are fetched together and
+                // one branch decides for both); the additions keep list order, so the sums are unchanged
+                if (j + 1 < total && __builtin_amdgcn_readfirstlane(s_fast[j] & s_fast[j + 1])) {
+                    const double lnu0 = s_nu[j], inv0 = s_inv[j], lnu1 = s_nu[j + 1], inv1 = s_inv[j + 1];
+                    const RegionI ka = {s_yk[j], s_c2[j], s_c3[j], s_c4[j]}, kb = {s_yk[j + 1], s_c2[j + 1], s_c3[j + 1], s_c4[j + 1]};
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const double x0 = (nu_i[r] - lnu0) * inv0, x1 = (nu_i[r] - lnu1) * inv1;
+                        if (MIXED) {
+                            acc[r] += region1_re_mixed(x0, ka);
+                            acc[r] += region1_re_mixed(x1, kb);
+                        } else {
+                            acc[r] += region1_re(x0 * x0, ka);
+                            acc[r] += region1_re(x1 * x1, kb);
+                        }
+                    }
+                    ++j;
+                    continue;
+                }
                 const double lnu = s_nu[j], inv = s_inv[j];
                 const RegionI k1 = {s_yk[j], s_c2[j], s_c3[j], s_c4[j]};
                 if (__builtin_amdgcn_readfirstlane(s_fast[j])) {
