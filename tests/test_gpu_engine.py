@@ -321,3 +321,22 @@ def test_host_buffer_synthesis_entry_point(ctx):
         _lib.check(ctx.lib.sdx_synthesize_f64(
             ctx.handle, nd, n_nu, host(bad), lines["line_nus"].size, host(lines["line_nus"]), host(lines["doppler_widths"]), host(g), g.shape[1],
             host(lines["alphas"]), C.byref(c), th.size, host(atm["temperatures"]), host(ray), host(w), None, total.ctypes.data, F.ctypes.data, None))
+
+
+def test_long_list_on_a_deep_model(ctx):
+    """More than 64 depth points AND enough lines for the 32-lines-per-block pre-pass (two items per thread, several depth
+    blocks per line group): windows bit-exact against the oracle, opacity within tolerance."""
+    from stardis_amd import ops
+
+    atm = deep_atmosphere(130)
+    nus = synth.tracing_grid(6560.0, 6564.0, step=0.01)
+    lines = synth.synth_lines(nus, atm, 6000, seed=53, mix=(0.85, 0.12, 0.03))
+    lo, hi = ops.line_windows(130, nus, lines["line_nus"], lines["doppler_widths"], lines["gammas"], lines["alphas"])
+    for k in (0, 1, 17, 2999, 5998, 5999):
+        for d in (0, 63, 64, 65, 129):
+            ref_lo, ref_hi = oracle.window(nus, lines["line_nus"][k], lines["gammas"][k, d], lines["doppler_widths"][k, d], lines["alphas"][k, d])
+            assert (lo[k, d], hi[k, d]) == (ref_lo, ref_hi)
+    out, evals = ops.calc_alan_entries(130, nus, lines["line_nus"], lines["doppler_widths"], lines["gammas"], lines["alphas"], return_evaluations=True)
+    ref, ref_evals = oracle.calc_alan_entries(130, nus, lines["line_nus"], lines["doppler_widths"], lines["gammas"], lines["alphas"], return_evals=True)
+    assert evals == ref_evals and evals == int((hi - lo).clip(min=0).sum())
+    assert rel_err(out, ref) < 1e-12
