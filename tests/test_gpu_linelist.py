@@ -265,14 +265,15 @@ def test_line_opacity_is_linear_in_the_list_at_scale():
     assert rel_err(full, parts) < 1e-12
 
 
-@pytest.mark.parametrize("n_depth", [65, 150])
-def test_generation_on_deep_models(n_depth):
-    """More than 64 depth points: several pre-pass depth blocks, each generating its own columns of the tables."""
+@pytest.mark.parametrize("n_depth,n_lines", [(65, 700), (150, 700), (130, 6000)])
+def test_generation_on_deep_models(n_depth, n_lines):
+    """More than 64 depth points: several pre-pass depth blocks, each generating its own columns of the tables (the
+    last case is long enough for the 32-lines-per-block pre-pass)."""
     from test_gpu_engine import deep_atmosphere
 
     atm = deep_atmosphere(n_depth)
     nus = synth.tracing_grid(6555.0, 6570.0, step=0.02)
-    spec = synth.synth_linelist(nus, atm, 700, seed=77)
+    spec = synth.synth_linelist(nus, atm, n_lines, seed=77)
     a_ref, g_ref, d_ref = oracle_tables(spec)
     a, gm, d = LL.line_params(spec)
     assert rel_err(a, a_ref) < 3e-15 and rel_err(gm, g_ref) < 1e-13 and rel_err(d, d_ref) < 1e-15
