@@ -265,15 +265,22 @@ __device__ __forceinline__ double exp_neg(double tau)
     const double n = rint(mul_rn(tau, -0x1.71547652b82fep+0));       // -log2(e)
     double r = fma(n, -0x1.62e42fefa39efp-1, -tau);                    // -ln2 (high part)
     r = fma(-0x1.abc9e3b39803fp-56, n, r);                             // -ln2 (low part)
-    double p = fma3(0x1.ade156a5dcb37p-26, r, 0x1.28af3fca7ab0cp-22);
-    p = fma3(r, p, 0x1.71dee623fde64p-19);
-    p = fma3(r, p, 0x1.a01997c89e6b0p-16);
-    p = fma3(r, p, 0x1.a01a014761f6ep-13);
-    p = fma3(r, p, 0x1.6c16c1852b7b0p-10);
-    p = fma3(r, p, 0x1.1111111122322p-7);
-    p = fma3(r, p, 0x1.55555555502a1p-5);
-    p = fma3(r, p, 0x1.5555555555511p-3);
-    p = fma3(r, p, 0x1.000000000000bp-1);
+    // the nine three-address Horner steps as ONE asm block: after every separate asm statement the compiler inserts a
+    // defensive s_nop, which would hand back the issue slots the three-address form saves
+    double p;
+    asm("v_fma_f64 %0, %2, %1, %3\n\t"
+        "v_fma_f64 %0, %1, %0, %4\n\t"
+        "v_fma_f64 %0, %1, %0, %5\n\t"
+        "v_fma_f64 %0, %1, %0, %6\n\t"
+        "v_fma_f64 %0, %1, %0, %7\n\t"
+        "v_fma_f64 %0, %1, %0, %8\n\t"
+        "v_fma_f64 %0, %1, %0, %9\n\t"
+        "v_fma_f64 %0, %1, %0, %10\n\t"
+        "v_fma_f64 %0, %1, %0, %11"
+        : "=&v"(p)
+        : "v"(r), "v"(0x1.ade156a5dcb37p-26), "v"(0x1.28af3fca7ab0cp-22), "v"(0x1.71dee623fde64p-19), "v"(0x1.a01997c89e6b0p-16),
+          "v"(0x1.a01a014761f6ep-13), "v"(0x1.6c16c1852b7b0p-10), "v"(0x1.1111111122322p-7), "v"(0x1.55555555502a1p-5),
+          "v"(0x1.5555555555511p-3), "v"(0x1.000000000000bp-1));
     p = fma(r, p, 1.0);
     p = fma(r, p, 1.0);
     return ldexp(p, (int)n);
