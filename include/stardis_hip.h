@@ -106,6 +106,12 @@ int sdx_line_windows_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
 int sdx_faddeeva_dev(sdx_ctx* ctx, int64_t n, const double* z, double* w);
 int sdx_voigt_profile_dev(sdx_ctx* ctx, int64_t n, const double* delta_nu, const double* doppler_width,
                           const double* gamma, double* phi);
+/* The hot-path variant of the same function, element-wise: what the line kernels evaluate per (line, depth, frequency)
+ * from the pre-pass constants — out = amp * Re w(delta_nu * inv_doppler_width + i y), real part only, FMA arithmetic
+ * (voigt.py:17-86 regions and predicates; base.py:627 amplitude).  A test hook: it lets the kernel's own routine be
+ * compared point by point with the reference's Faddeeva / Voigt vectors. */
+int sdx_voigt_term_dev(sdx_ctx* ctx, int64_t n, const double* delta_nu, const double* inv_doppler_width, const double* y,
+                       const double* amp, double* out);
 
 /* ---- broadening (opacities_solvers/broadening.py) -------------------------------------------
  * calc_gamma :550-656 with calculate_broadening's argument preparation :706-721 (ion_number is the
@@ -240,6 +246,9 @@ int sdx_total_alphas_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
  * scipy's pairwise order for symmetric kernels (the caller applies scipy's DBL_EPSILON symmetry test). */
 int sdx_convolve1d_reflect_dev(sdx_ctx* ctx, int64_t n, const double* in, int m, const double* weights, int symmetric,
                                double* out);
+/* spectrum_lambda = F_nu * nu / lambda, element-wise (stardis/base.py:137-141) — keeps the emergent spectrum on the
+ * device between the formal solution and the instrumental / rotational convolutions */
+int sdx_flux_nu_to_lambda_dev(sdx_ctx* ctx, int64_t n, const double* f_nu, const double* nus, const double* lambdas, double* out);
 
 /* Everything in one call for resident data: pre-pass + line opacity + total (above) + raytrace (F_nu
  * overwritten).  alpha_line_out is optional; total_alphas and F_nu are [n_depth][ld].  This is the step

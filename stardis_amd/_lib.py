@@ -107,6 +107,7 @@ PROTOTYPES = {
     "sdx_line_windows_dev": (_int, [_vp, _int, _i64, _vp, _i64, _vp, _vp, _vp, _int, _vp, _vp, _vp]),
     "sdx_faddeeva_dev": (_int, [_vp, _i64, _vp, _vp]),
     "sdx_voigt_profile_dev": (_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
+    "sdx_voigt_term_dev": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "sdx_calc_gamma_dev": (_int, [_vp, _i64, _int] + [_vp] * 9 + [_int, _vp]),
     "sdx_doppler_widths_dev": (_int, [_vp, _i64, _int, _vp, _vp, _vp, C.c_double, _vp]),
     "sdx_calc_vald_gamma_dev": (_int, [_vp, _i64, _int] + [_vp] * 12 + [_int, _vp]),
@@ -126,6 +127,7 @@ PROTOTYPES = {
     "sdx_raytrace_f64": (_int, [_vp, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sdx_total_alphas_dev": (_int, [_vp, _int, _i64, _vp, _i64, _i64, C.POINTER(Continuum), _vp, _i64, _vp, _i64]),
     "sdx_convolve1d_reflect_dev": (_int, [_vp, _i64, _vp, _int, _vp, _int, _vp]),
+    "sdx_flux_nu_to_lambda_dev": (_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "sdx_synthesize_dev": (_int, [_vp, _int, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _int, _vp, C.POINTER(Continuum), _int,
                                   _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "sdx_synthesize_f64": (_int, [_vp, _int, _i64, _vp, _i64, _vp, _vp, _vp, _int, _vp, C.POINTER(Continuum), _int, _vp, _vp, _vp, _vp, _vp,

@@ -505,6 +505,16 @@ __global__ __launch_bounds__(64, 4) void k_line_wide(int64_t n_nu, const double*
 constexpr int kListChunks = 64;
 static_assert(kListChunks <= 64, "k_count_lists counts one chunk per lane");
 
+// Class-mask word of 64-line chunk c with the bits of lines >= n_lines cleared.  The pre-pass writes one 16-bit entry per
+// 16 lines it owns; the tail entries of the last 64-bit word (and bits beyond the last line) are never written, so on a
+// re-used context they can hold bits of an earlier, longer list: they must not be counted or scattered.
+__device__ __forceinline__ unsigned long long mask_word(const unsigned long long* __restrict__ masks, int64_t c, int64_t n_lines)
+{
+    const int64_t rem = n_lines - c * 64;
+    const unsigned long long valid = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
+    return masks[c] & valid;
+}
+
 // set bits of each block's kListChunks chunks, [class][depth][block]: the scatter kernel then sums a few hundred counts
 // instead of re-reading the whole mask row in every block (which made it quadratic in the number of lines)
 __global__ __launch_bounds__(64) void k_count_lists(int n_depth, int64_t n_lines, LineWork w, int* __restrict__ block_cnt)
@@ -514,7 +524,7 @@ __global__ __launch_bounds__(64) void k_count_lists(int n_depth, int64_t n_lines
     const int64_t c = (int64_t)blockIdx.x * kListChunks + threadIdx.x;
     const unsigned long long* masks =
         reinterpret_cast<const unsigned long long*>((cls ? w.wmask_huge : w.wmask_med) + (size_t)d * w.mask_ld);
-    int n = (threadIdx.x < kListChunks && c < n_chunks) ? __popcll(masks[c]) : 0;
+    int n = (threadIdx.x < kListChunks && c < n_chunks) ? __popcll(mask_word(masks, c, n_lines)) : 0;
     for (int off = 32; off > 0; off >>= 1) n += __shfl_xor(n, off);
     if (threadIdx.x == 0) block_cnt[((size_t)cls * n_depth + d) * gridDim.x + blockIdx.x] = n;
 }
@@ -553,7 +563,7 @@ __global__ __launch_bounds__(kBlock) void k_build_lists(int n_depth, int64_t n_l
     // exclusive scan of this block's chunk counts
     if (threadIdx.x < kListChunks) {
         const int64_t c = c_first + threadIdx.x;
-        s_cnt[threadIdx.x] = c < n_chunks ? __popcll(masks[c]) : 0;
+        s_cnt[threadIdx.x] = c < n_chunks ? __popcll(mask_word(masks, c, n_lines)) : 0;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -571,9 +581,9 @@ __global__ __launch_bounds__(kBlock) void k_build_lists(int n_depth, int64_t n_l
     for (int k = wave; k < kListChunks; k += kBlock / 64) {
         const int64_t c = c_first + k;
         if (c >= n_chunks) break;
-        const unsigned long long m = masks[c];
+        const unsigned long long m = mask_word(masks, c, n_lines);
         const int64_t l = c * 64 + lane;
-        if (((m >> lane) & 1ull) && l < n_lines) {
+        if ((m >> lane) & 1ull) {
             const size_t dst = origin + before + s_cnt[k] + __popcll(m & ((1ull << lane) - 1ull));
             const size_t src = src_row + l;
             w.d_lo[dst] = w.lo[src];
@@ -848,6 +858,29 @@ __global__ __launch_bounds__(kBlock) void k_voigt_profile(int64_t n, const doubl
 {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i < n) phi[i] = voigt_profile_full(dnu[i], dw[i], g[i]);
+}
+
+// The routine the line kernels evaluate per (line, depth, frequency) — region1_setup + voigt_term, i.e. the FMA /
+// real-part-only variant of voigt.py:17-86,113-150 — exposed element-wise so that it can be pinned point by point against
+// the reference's Faddeeva / Voigt golden vectors (the element-wise sdx_faddeeva_dev / sdx_voigt_profile_dev run the
+// reference-order routine faddeeva_full instead).  out = amp * Re w((delta_nu + i gamma / (sqrt(pi) pi)) / doppler_width)
+// with the pre-pass's derived constants: inv_dw = 1 / dw, y = (gamma / (sqrt(pi) pi)) / dw, amp as given.
+__global__ __launch_bounds__(kBlock) void k_voigt_term(int64_t n, const double* __restrict__ dnu, const double* __restrict__ inv_dw,
+                                                       const double* __restrict__ y, const double* __restrict__ amp,
+                                                       double* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const RegionI k1 = region1_setup(y[i], amp[i]);
+    out[i] = voigt_term(dnu[i], inv_dw[i], y[i], amp[i], k1);
+}
+
+// F_lambda = F_nu * nu / lambda (stardis/base.py:137-141: spectrum_lambda; the unit conversion there has scale 1)
+__global__ __launch_bounds__(kBlock) void k_flux_nu_to_lambda(int64_t n, const double* __restrict__ f_nu, const double* __restrict__ nus,
+                                                              const double* __restrict__ lambdas, double* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) out[i] = mul_rn(f_nu[i], nus[i]) / lambdas[i];
 }
 
 __global__ __launch_bounds__(kBlock) void k_blackbody(int n_depth, int64_t n_nu, const double* __restrict__ nus,

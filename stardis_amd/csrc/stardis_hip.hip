@@ -831,6 +831,16 @@ static int host_grid_check(int64_t n_nu, const double* nus)
     return SDX_OK;
 }
 
+// The kernels take the line list in ascending frequency (calc_alpha_line_at_nu sorts it, base.py:392-397): cnt_ge is a
+// binary search over line_nus and the narrow role walks a contiguous index range per frequency.
+static int host_lines_check(int64_t n_lines, const double* line_nus)
+{
+    for (int64_t l = 0; l + 1 < n_lines; ++l)
+        if (!(line_nus[l + 1] >= line_nus[l]))
+            return fail(SDX_ERR_ARG, "line_nus must be ascending (sort the line list by frequency, opacities_solvers/base.py:392-397)");
+    return SDX_OK;
+}
+
 int sdx_line_opacity_f64(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t n_lines, const double* line_nus,
                          const double* doppler, const double* gammas, int gamma_cols, const double* alphas, double* out,
                          int64_t* n_evaluations)
@@ -839,6 +849,7 @@ int sdx_line_opacity_f64(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
     if (rc) return rc;
     REQUIRE(n_nu == 0 || out, "line opacity: null output");
     if ((rc = host_grid_check(n_nu, nus))) return rc;
+    if ((rc = host_lines_check(n_lines, line_nus))) return rc;
     for (int64_t k = 0; k < n_lines * n_depth; ++k)
         if (doppler[k] == 0.0) return fail(SDX_ERR_ARG, "doppler_width == 0 (ZeroDivisionError in the reference, voigt.py:148)");
     HIP_TRY(hipSetDevice(ctx->device));
@@ -883,6 +894,18 @@ int sdx_voigt_profile_dev(sdx_ctx* ctx, int64_t n, const double* dnu, const doub
         hipLaunchKernelGGL(k_voigt_profile, dim3(blocks1(n)), dim3(kBlock), 0, ctx->stream, n, dnu, dw, gamma, phi);
     }
     return check_launch("k_voigt_profile");
+}
+
+int sdx_voigt_term_dev(sdx_ctx* ctx, int64_t n, const double* delta_nu, const double* inv_doppler_width, const double* y,
+                       const double* amp, double* out)
+{
+    REQUIRE(ctx && n >= 0 && (n == 0 || (delta_nu && inv_doppler_width && y && amp && out)), "voigt_term: bad arguments");
+    if (n == 0) return SDX_OK;
+    {
+        LaunchScope ls(ctx, "k_voigt_term");
+        hipLaunchKernelGGL(k_voigt_term, dim3(blocks1(n)), dim3(kBlock), 0, ctx->stream, n, delta_nu, inv_doppler_width, y, amp, out);
+    }
+    return check_launch("k_voigt_term");
 }
 
 // ================================================================================================ broadening
@@ -1260,6 +1283,17 @@ int sdx_convolve1d_reflect_dev(sdx_ctx* ctx, int64_t n, const double* in, int m,
     return check_launch("k_convolve1d_reflect");
 }
 
+int sdx_flux_nu_to_lambda_dev(sdx_ctx* ctx, int64_t n, const double* f_nu, const double* nus, const double* lambdas, double* out)
+{
+    REQUIRE(ctx && n >= 0 && (n == 0 || (f_nu && nus && lambdas && out)), "flux_nu_to_lambda: bad arguments");
+    if (n == 0) return SDX_OK;
+    {
+        LaunchScope ls(ctx, "k_flux_nu_to_lambda");
+        hipLaunchKernelGGL(k_flux_nu_to_lambda, dim3(blocks1(n)), dim3(kBlock), 0, ctx->stream, n, f_nu, nus, lambdas, out);
+    }
+    return check_launch("k_flux_nu_to_lambda");
+}
+
 // ================================================================================================ fused synthesis
 static int synthesize_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin, int64_t nu_count,
                            int64_t n_lines, const double* line_nus, const double* doppler, const double* gammas, int gamma_cols,
@@ -1367,6 +1401,7 @@ int sdx_synthesize_f64(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nu
     REQUIRE(n_nu == 0 || (total_alphas && F_nu), "synthesize: null output");
     if (n_nu == 0) return SDX_OK;
     if ((rc = host_grid_check(n_nu, nus))) return rc;
+    if ((rc = host_lines_check(n_lines, line_nus))) return rc;
     for (int64_t k = 0; k < n_lines * n_depth; ++k)
         if (doppler[k] == 0.0) return fail(SDX_ERR_ARG, "doppler_width == 0 (ZeroDivisionError in the reference, voigt.py:148)");
     HIP_TRY(hipSetDevice(ctx->device));

@@ -63,11 +63,18 @@ class SpectralSynthesizer:
             self.n_lines = ln.size
             g = np.ascontiguousarray(lines["gammas"], dtype=np.float64)
             g = g.reshape(self.n_lines, -1) if self.n_lines else np.zeros((0, 1))
+            dw = np.ascontiguousarray(lines["doppler_widths"], dtype=np.float64)
+            al = np.ascontiguousarray(lines["alphas"], dtype=np.float64)
+            if ln.size > 1 and np.any(ln[1:] < ln[:-1]):
+                # the kernels take the list in ascending frequency (what calc_alpha_line_at_nu passes, base.py:392-397); the
+                # reference's calc_alan_entries accepts any order, so an unsorted list is sorted (stably) here, not refused
+                order = np.argsort(ln, kind="stable")
+                ln, g, dw, al = (np.ascontiguousarray(a[order]) for a in (ln, g, dw, al))
             self.gamma_cols = g.shape[1]
             self.d_ln = c.upload(ln)
-            self.d_dw = c.upload(np.ascontiguousarray(lines["doppler_widths"], dtype=np.float64))
+            self.d_dw = c.upload(dw)
             self.d_g = c.upload(g)
-            self.d_a = c.upload(np.ascontiguousarray(lines["alphas"], dtype=np.float64))
+            self.d_a = c.upload(al)
 
         self._keep = []
         self.cont = self._build_continuum(continuum, nus, t)

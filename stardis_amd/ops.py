@@ -53,6 +53,25 @@ def voigt_profile(delta_nu, doppler_width, gamma, ctx=None):
     return r if r.ndim else r[()]
 
 
+def voigt_term(delta_nu, doppler_width, gamma, alpha=1.0, ctx=None):
+    """alpha * voigt_profile(delta_nu, doppler_width, gamma) through the routine the LINE KERNELS evaluate (real part only,
+    FMA arithmetic, one reciprocal per point; sdx_math.h voigt_term) instead of the reference-order element-wise one.
+    The derived constants are formed exactly as the pre-pass forms them (voigt.py:148-149, base.py:627)."""
+    ctx = ctx or default_context()
+    dnu, dw, g, a = (np.ascontiguousarray(v) for v in np.broadcast_arrays(_host(delta_nu), _host(doppler_width), _host(gamma), _host(alpha)))
+    if np.any(dw == 0):
+        raise ZeroDivisionError("float division by zero")
+    sqrt_pi = np.float64(1.7724538509055159)
+    inv = 1.0 / dw
+    y = (g / (sqrt_pi * np.float64(np.pi))) / dw
+    amp = a / (sqrt_pi * dw)
+    d = [ctx.upload(v) for v in (dnu, inv, y, amp)]
+    out = ctx.empty(dnu.shape)
+    ctx.call("sdx_voigt_term_dev", dnu.size, d[0].ptr, d[1].ptr, d[2].ptr, d[3].ptr, out.ptr)
+    r = out.numpy()
+    return r if r.ndim else r[()]
+
+
 # ------------------------------------------------------------------------------------------------ line opacity
 def _line_inputs(no_of_depth_points, line_nus, doppler_widths, gammas, alphas_array):
     ln = _host(line_nus).reshape(-1)
@@ -63,6 +82,12 @@ def _line_inputs(no_of_depth_points, line_nus, doppler_widths, gammas, alphas_ar
     g = g.reshape(ln.size, -1) if ln.size else g.reshape(0, 1)
     if g.shape[1] not in (1, nd):
         raise ValueError(f"gammas must have shape (n_lines, {nd}) or (n_lines, 1), got {g.shape}")
+    if ln.size > 1 and np.any(ln[1:] < ln[:-1]):
+        # The reference treats every line independently (base.py:548-590), so any order is legal there; the kernels want
+        # ascending frequency (what calc_alpha_line_at_nu hands over, :392-397).  A stable sort changes only the order of
+        # the per-point sum, which differs from the reference's per-thread slabs anyway.
+        order = np.argsort(ln, kind="stable")
+        ln, dw, g, al = (np.ascontiguousarray(a[order]) for a in (ln, dw, g, al))
     return ln, dw, g, al
 
 

@@ -147,6 +147,27 @@ def test_indexed_wide_path_matches_direct_path_and_oracle(ctx):
         ctx.set_option("indexed_min_lines", 8192)
 
 
+def test_indexed_path_on_a_reused_context_with_a_shorter_list(ctx):
+    """A context that ran a long list keeps its class-mask scratch: the tail entries of the last 64-line word are never
+    written by the pre-pass of a SHORTER list (n_lines % 64 in 1..32), so stale bits of the earlier list must be masked
+    off when the dense lists are counted and built (round-1 advisor finding)."""
+    atm = synth.solar_atmosphere()
+    nus = synth.tracing_grid(6560.0, 6570.0, step=0.01)
+    th, w = synth.thetas_and_weights(4)
+    cont = synth.synth_continuum_state(atm)
+    try:
+        ctx.set_option("indexed_min_lines", 1)
+        for n_lines, mix, seed in ((1400, (0.0, 0.5, 0.5), 31), (530, (0.3, 0.4, 0.3), 32), (8192 + 17, (0.9, 0.09, 0.01), 33), (65, (0.0, 0.5, 0.5), 34)):
+            lines = synth.synth_lines(nus, atm, n_lines, seed=seed, mix=mix)
+            syn = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], th, w, lines, cont, ctx=ctx)
+            syn.step()
+            ref, evals = oracle.calc_alan_entries(56, nus, lines["line_nus"], lines["doppler_widths"], lines["gammas"], lines["alphas"], return_evals=True)
+            assert syn.evaluations() == evals, n_lines
+            assert rel_err(syn.alpha_line(), ref) < 1e-12, n_lines
+    finally:
+        ctx.set_option("indexed_min_lines", 8192)
+
+
 def test_long_line_list_on_the_wide_grid(ctx):
     """BASELINE configs[2]/[3] shape: the 3000-10000 A grid at R = 1e5 (120 398 frequencies) with a line list long
     enough (20 000 lines, gamma given as an (N_l, 1) column like the molecular case) to take the indexed wide-window
