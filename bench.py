@@ -2,20 +2,32 @@
 """bench.py — spectral points / s of the STARDIS hot path on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload S-c2]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one full pass of the hot path over inputs already resident in HBM: window pre-pass + line
-opacity (Voigt/Faddeeva over the whole line list) + continuum (H- bf table, H I bf/ff, Thomson) + total +
-LTE formal solution over N_theta angles -> F_nu (N_d, N_nu).  Metric: spectral points per second =
-N_nu * N_depth * steps / time (BASELINE.json).  At N GPUs the frequency axis is sharded in contiguous
-blocks of the global index (fixed points per GPU: the window's resolving power grows with N), and every
-step ends with ONE all-gather of the emergent flux (RCCL).
+With --gpus N > 1 and no WORLD_SIZE in the environment the script starts the N ranks itself (fresh child processes
+through torch.distributed.run, before anything in this process touches the GPU) and relays rank 0's JSON line; under
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` it is one of the ranks.
+
+One "step" = one full pass of the hot path over inputs already resident in HBM: window pre-pass + line opacity
+(Voigt/Faddeeva over the whole line list) + continuum (H- bf table, H I bf/ff, Thomson) + total + LTE formal solution
+over N_theta angles -> F_nu (N_d, N_nu).  Metric: spectral points per second = N_nu * N_depth * steps / time
+(BASELINE.json).  `value` is measured on BASELINE configs[1] (S-c2) — weak scaling at N GPUs: fixed points per GPU, the
+window's resolving power grows with N; every step ends with ONE all-gather of the emergent flux (RCCL).
+
+Besides `value` the JSON line carries
+  roofline              HBM roofline of the dominant kernel (live HIP-event durations), traffic from profiles/
+  roofline_fp64_valu    the bound that really limits the path, against BOTH the spec issue rate and the measured ceiling
+  cpu_baseline          the oracle (reference algorithm restated in C) on this box's host cores: one_core / best / all_cores
+  secondary             BASELINE configs[2] and [3] at full size (S-c3: 1.5e5 lines, S-c4m: 1e6 lines): step time, per-kernel
+                        times, Voigt evaluations/s, strided-column parity against the oracle
+  strong                (N > 1) BASELINE configs[2] split N ways in shards of equal estimated work
+  dropin                wall time of the reference-shaped call path (RadiationField + calc_alphas + raytrace) at configs[0] and S-c2
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -26,6 +38,37 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 FP64_VECTOR_PEAK_TFLOPS = 78.6
+# wave-level fp64 VALU instructions per second: spec = 256 CU x 4 SIMD x 2.4 GHz / 4 cycles per wave64 fp64 instruction;
+# measured = what scripts/fp64_peak.hip sustains on this part (55 TFLOP/s of FMA at 8 waves per SIMD)
+FP64_VALU_SPEC = 256 * 4 * 2.4e9 / 4
+FP64_VALU_MEASURED = 439.0e9
+KERNELS = ("k_dnu_partial", "k_prepass_continuum", "k_line_prepass", "k_count_lists", "k_build_lists", "k_line_all", "k_line_wide",
+           "k_line_narrow", "k_reduce_partials", "k_total_alphas", "k_raytrace")
+
+
+# ------------------------------------------------------------------------------------------------ launch
+def self_launch(args, argv):
+    """--gpus N without a rendezvous: start the N ranks as fresh child processes.  Nothing in THIS process has touched
+    HIP or torch.cuda yet (a GPU-initialised process must not exec or fork ranks)."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line)
+    return proc.returncode if proc.returncode else (0 if line is not None else 1)
 
 
 def build_workload(tag, world, inputs="dense", scaling="weak"):
@@ -44,64 +87,359 @@ def build_workload(tag, world, inputs="dense", scaling="weak"):
         lines = synth.synth_lines(nus, atm, cfg["n_lines"], synth.SEED, cfg["gamma_per_depth"])
     cont = synth.synth_continuum_state(atm)
     thetas, weights = synth.thetas_and_weights(synth.N_THETAS)
-    return dict(atm=atm, nus=nus, lines=lines, cont=cont, thetas=thetas, weights=weights, n_per_gpu=n_per_gpu)
+    return dict(tag=tag, atm=atm, nus=nus, lines=lines, cont=cont, thetas=thetas, weights=weights, n_per_gpu=n_per_gpu)
 
 
-def cpu_baseline(w, budget_s=25.0):
-    """The reference algorithm restated in C (oracle/, OpenMP over lines / frequencies exactly like the numba
-    prange loops, per-thread accumulator slabs included), timed on this box's host cores on the same workload at
-    several thread counts; the fastest is reported.  A reported baseline, not the target."""
+def synth_desc(tag):
+    from stardis_amd import synth
+
+    c = synth.WORKLOADS[tag]
+    grid = f"R={c['R']:.0f}" if "R" in c else f"step {c['step']} A"
+    star = "cool-dwarf (3800 K)" if c.get("atmosphere") == "cool_dwarf" else "solar"
+    return f"{tag}: {star} MARCS structure, {c['lam0']:.0f}-{c['lam1']:.0f} A at {grid}, {c['n_lines']} lines, fp64"
+
+
+def kernel_times(ctx, syn, n=10):
+    """Average duration of every kernel of one step, HIP events on the launch stream (eager launches)."""
+    import ctypes as C
+
+    from stardis_amd import _lib
+
+    ctx.call("sdx_profile_enable", 1)
+    ctx.call("sdx_profile_reset")
+    for _ in range(n):
+        syn.enqueue()
+    ctx.synchronize()
+    out = {}
+    for name in KERNELS:
+        cnt, ms = C.c_int64(), C.c_double()
+        _lib.check(ctx.lib.sdx_profile_get(ctx.handle, name.encode(), C.byref(cnt), C.byref(ms)))
+        if cnt.value:
+            out[name] = ms.value / cnt.value * (cnt.value / n)  # per step (a kernel may run more than once per step)
+    ctx.call("sdx_profile_enable", 0)
+    ctx.call("sdx_profile_reset")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ CPU side (oracle = checker / baseline)
+def cpu_one_pass(w):
+    """The reference algorithm restated in C (oracle/): calc_alan_entries + continuum + raytrace, OpenMP where numba has prange."""
     import oracle
     from stardis_amd import constants as K
 
     atm, nus, ln, cont = w["atm"], w["nus"], w["lines"], w["cont"]
     nd = atm["temperatures"].size
-    max_threads = oracle.num_threads()
-    spec = None if isinstance(ln, dict) else ln
-
-    def dense_tables():
-        """what the reference forms on the host before its line kernel (plasma/base.py:200-321, broadening.py:659-732)"""
+    if not isinstance(ln, dict):  # per-line scalars: form what the reference forms on the host first (plasma/base.py:200-321, broadening.py:659-732)
+        spec = ln
         args = (spec.atomic_number, spec.ion_number, spec.ionization_energy, spec.upper_energy, spec.lower_energy, spec.A_ul)
         state = (spec.electron_density, spec.temperature, spec.h_density)
         gam = (oracle.calc_vald_gamma(*args, spec.stark, spec.waals, spec.mass, *state, flags=spec.flags) if spec.gamma_mode == 1
                else oracle.calc_gamma(*args, *state, flags=spec.flags))
-        return dict(line_nus=spec.nu, gammas=gam, doppler_widths=oracle.doppler_widths(spec.nu, spec.mass, spec.temperature, spec.microturbulence),
-                    alphas=oracle.alpha_line_linelist(spec.e_low_ev, spec.g_lo, spec.strength, spec.nu, spec.pop_row, spec.pop, spec.temperature,
-                                                      spec.alpha_coefficient))
+        ln = dict(line_nus=spec.nu, gammas=gam, doppler_widths=oracle.doppler_widths(spec.nu, spec.mass, spec.temperature, spec.microturbulence),
+                  alphas=oracle.alpha_line_linelist(spec.e_low_ev, spec.g_lo, spec.strength, spec.nu, spec.pop_row, spec.pop, spec.temperature,
+                                                    spec.alpha_coefficient))
+    line = oracle.calc_alan_entries(nd, nus, ln["line_nus"], ln["doppler_widths"], ln["gammas"], ln["alphas"])
+    lam = K.nu_to_angstrom(nus)
+    cutoff = (cont["ionization_energy"] - cont["level_excitation"]) / K.H_CGS
+    total = oracle.alpha_file_1d(lam, cont["hminus_bf_wavelength"], cont["hminus_bf_cross_section"], cont["n_hminus"])
+    total = total + oracle.alpha_bf(nus, [0, len(cutoff)], [0], cutoff, cont["level_density"])
+    total = total + oracle.alpha_ff(nus, atm["temperatures"], [1], cont["n_e"] * cont["n_h2"])
+    total = total + oracle.alpha_electron(nus.size, cont["n_e"])
+    total = total + line
+    F, _ = oracle.raytrace(nus, atm["temperatures"], atm["dist"], w["thetas"], w["weights"], total)
+    return F
 
-    def one_pass():
-        ln = dense_tables() if spec is not None else w["lines"]
-        line = oracle.calc_alan_entries(nd, nus, ln["line_nus"], ln["doppler_widths"], ln["gammas"], ln["alphas"])
-        lam = K.nu_to_angstrom(nus)
-        cutoff = (cont["ionization_energy"] - cont["level_excitation"]) / K.H_CGS
-        total = oracle.alpha_file_1d(lam, cont["hminus_bf_wavelength"], cont["hminus_bf_cross_section"], cont["n_hminus"])
-        total = total + oracle.alpha_bf(nus, [0, len(cutoff)], [0], cutoff, cont["level_density"])
-        total = total + oracle.alpha_ff(nus, atm["temperatures"], [1], cont["n_e"] * cont["n_h2"])
-        total = total + oracle.alpha_electron(nus.size, cont["n_e"])
-        total = total + line
-        F, _ = oracle.raytrace(nus, atm["temperatures"], atm["dist"], w["thetas"], w["weights"], total)
-        return F
 
+def cpu_baseline(w, budget_s=25.0):
+    """The oracle timed on this box's host cores on the same workload at several thread counts (a reported baseline, not the
+    target; kind "port": numba cannot be installed).  -O3 -march=native, no fast-math (oracle/Makefile)."""
+    import oracle
+
+    nus, nd = w["nus"], w["atm"]["temperatures"].size
+    max_threads = oracle.num_threads()
     pts = nus.size * nd
     sweep, F = {}, None
-    counts = sorted({1, min(16, max_threads), min(64, max_threads), max_threads})
+    counts = sorted({1, min(8, max_threads), min(16, max_threads), min(32, max_threads), max_threads})
     for n in counts:
         oracle.set_num_threads(n)
         times, spent = [], 0.0
         while len(times) < 2 or (spent < budget_s / len(counts) and len(times) < 6):
             t0 = time.perf_counter()
-            F = one_pass()
+            F = cpu_one_pass(w)
             times.append(time.perf_counter() - t0)
             spent += times[-1]
         sweep[n] = min(times)
     oracle.set_num_threads(max_threads)
     best = min(sweep, key=sweep.get)
+    n_l = w["lines"]["line_nus"].size if isinstance(w["lines"], dict) else w["lines"].n_lines
     return dict(
         value=pts / sweep[best], unit="spectral points/s", cores=best, kind="port",
-        sample=f"full workload ({nus.size} nu x {nd} depths, {spec.n_lines if spec is not None else ln['line_nus'].size} lines, {len(w['thetas'])} angles), best pass of each thread count; "
-               + ", ".join(f"{n} thr: {t * 1e3:.0f} ms" for n, t in sweep.items()),
-        host_cores=max_threads,
+        sample=f"full workload ({nus.size} nu x {nd} depths, {n_l} lines, {len(w['thetas'])} angles), best of >= 2 passes per thread count",
+        one_core=pts / sweep[1], best=pts / sweep[best], best_threads=best, all_cores=pts / sweep[max_threads], host_cores=max_threads,
+        ms_by_threads={str(n): round(t * 1e3, 2) for n, t in sweep.items()},
+        build="gcc -O3 -march=native -fopenmp, no fast-math, no FMA contraction (oracle/Makefile)",
     ), F
+
+
+def strided_parity(w, syn, stride):
+    """Flux of a strided subset of columns recomputed by the oracle from the GPU's own total opacity (the formal solution is
+    column-independent), and the GPU's evaluation count against the window rule on the host."""
+    import oracle
+    from stardis_amd import parallel
+
+    atm, nus = w["atm"], w["nus"]
+    F, total = syn.F_nu(), syn.total_alphas()
+    cols = np.arange(0, nus.size, stride)
+    F_ref, _ = oracle.raytrace(nus[cols], atm["temperatures"], atm["dist"], w["thetas"], w["weights"], np.ascontiguousarray(total[:, cols]))
+    ln = w["lines"]
+    return dict(columns=int(cols.size), flux_max_rel_err=float(np.max(np.abs(F[1:, cols] - F_ref[1:]) / np.abs(F_ref[1:]))),
+                evaluations_match_host_window_rule=bool(syn.evaluations() == parallel.window_evaluations(
+                    nus, ln["line_nus"], ln["doppler_widths"], ln["gammas"], ln["alphas"])))
+
+
+# ------------------------------------------------------------------------------------------------ secondary workloads
+def secondary_block(tag, device, steps, check):
+    from stardis_amd import _lib
+    from stardis_amd.engine import SpectralSynthesizer
+
+    t0 = time.perf_counter()
+    w = build_workload(tag, 1)
+    atm, nus = w["atm"], w["nus"]
+    ctx = _lib.Context(device)
+    syn = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], w["thetas"], w["weights"], w["lines"], w["cont"], ctx=ctx)
+    syn.step()
+    ctx.synchronize()
+    setup_s = time.perf_counter() - t0
+    evals = syn.evaluations()
+    parity = strided_parity(w, syn, 601) if check else None
+    syn.count_evaluations = False
+    kern = kernel_times(ctx, syn, 5)
+    syn.capture()
+    for _ in range(2):
+        syn.step()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        syn.step()
+    ctx.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    nd = atm["temperatures"].size
+    line_ms = kern.get("k_line_all", 0.0) + kern.get("k_line_wide", 0.0) + kern.get("k_line_narrow", 0.0)
+    out = {
+        "workload": synth_desc(tag), "n_nu": int(nus.size), "n_lines": int(syn.n_lines), "steps": steps, "ms_per_step": ms,
+        "spectral_points_per_s": nus.size * nd / (ms * 1e-3), "voigt_evaluations": int(evals),
+        "voigt_evaluations_per_s_line_kernel": evals / (line_ms * 1e-3) if line_ms else None,
+        "avg_kernel_ms": kern, "algorithmic_bytes": int(syn.algorithmic_bytes()),
+        "achieved_GBps": syn.algorithmic_bytes() / (ms * 1e-3) / 1e9, "frac_hbm": syn.algorithmic_bytes() / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+        "setup_s": setup_s,
+    }
+    if parity is not None:
+        out["parity_vs_cpu_oracle"] = parity
+    syn.close()
+    ctx.close()
+    return out
+
+
+def dropin_block(device, check):
+    """Wall time of the reference-shaped call path on a pandas stand-in for the plasma (synth.fake_plasma): what a user of
+    create_stellar_radiation_field pays, host buffers in and out through the C ABI, beside the oracle on the same arrays."""
+    from stardis_amd import synth
+    from stardis_amd.radiation_field import RadiationField
+    from stardis_amd.radiation_field.opacities.opacities_solvers import calc_alphas
+    from stardis_amd.radiation_field.radiation_field_solvers import raytrace
+    from stardis_amd.radiation_field.source_functions.blackbody import blackbody_flux_at_nu
+
+    out = {}
+    for label, tag, n_lines in (("configs[0] (1000-point grid)", "S-c1", 2000), ("S-c2", "S-c2", 2000)):
+        cfg = synth.WORKLOADS[tag]
+        atm = synth.solar_atmosphere()
+        nus = synth.tracing_grid(cfg["lam0"], cfg["lam1"], cfg.get("R"), cfg.get("step"))
+        plasma, model, config, arrays = synth.fake_plasma(nus, atm, n_lines, synth.SEED)
+
+        def one():
+            field = RadiationField(nus.copy(), blackbody_flux_at_nu, model, synth.N_THETAS)
+            calc_alphas(plasma, model, field, config.opacity)
+            raytrace(model, field)
+            return field
+
+        times = []
+        for _ in range(4):
+            t0 = time.perf_counter()
+            field = one()
+            times.append(time.perf_counter() - t0)
+        entry = {"n_nu": int(nus.size), "n_lines": int(n_lines), "first_call_ms": times[0] * 1e3, "steady_ms": min(times[1:]) * 1e3,
+                 "spectral_points_per_s": nus.size * 56 / min(times[1:])}
+        if check:
+            import oracle
+
+            od = field.opacities.opacities_dict  # broadening tables as the drop-in formed them (pinned to the reference by G3 / G9)
+            lines = dict(arrays, gammas=np.asarray(od["alpha_line_at_nu_gammas"]), doppler_widths=np.asarray(od["alpha_line_at_nu_doppler_widths"]))
+            w = dict(atm=atm, nus=nus, lines=lines, cont=synth.synth_continuum_state(atm), thetas=field.thetas, weights=field.I_nus_weights)
+            t0 = time.perf_counter()
+            F_cpu = cpu_one_pass(w)
+            entry["oracle_all_cores_ms"] = (time.perf_counter() - t0) * 1e3
+            entry["oracle_threads"] = oracle.num_threads()
+            entry["emergent_flux_max_rel_err_vs_oracle"] = float(np.max(np.abs(field.F_nu[-1] - F_cpu[-1]) / np.abs(F_cpu[-1])))
+        out[label] = entry
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ profiles/ (committed rocprofv3 passes)
+def _profile_rows(workload, name):
+    import csv
+    import glob
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{workload}_pmc_{name}.csv")), reverse=True):
+        return path, list(csv.DictReader(open(path)))
+    return None, []
+
+
+def profiled_traffic(workload, kernel):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC passes (profiles/, separate FETCH_SIZE and
+    WRITE_SIZE runs, raw counters: profiles/README.md).  None when absent or when the kernel is not in them."""
+    total = 0.0
+    for name in ("FETCH_SIZE", "WRITE_SIZE"):
+        _, rows = _profile_rows(workload, name)
+        vals = [float(r["Counter_Value"]) for r in rows if kernel_matches(kernel, r["Kernel_Name"]) and r["Counter_Name"] == name]
+        if not vals:
+            return None
+        total += sum(vals) / len(vals) * 1024.0
+    return total
+
+
+def kernel_matches(short, full):
+    alias = {"k_raytrace": ("k_raytrace", "k_formal")}
+    return any(a in full for a in alias.get(short, (short,)))
+
+
+def profiled_valu(workload, kern):
+    """The bound that actually limits this path: fp64 VALU issue.  Wave-level VALU instructions per step from the newest
+    committed SQ_INSTS_VALU pass over the kernel time measured live in this run — reported only when the committed pass
+    covers exactly the kernels that ran here (same names, same launches per step); otherwise the figure would silently lie."""
+    path, rows = _profile_rows(workload, "SQ")
+    rows = [r for r in rows if r["Counter_Name"] == "SQ_INSTS_VALU"]
+    if not rows:
+        return None
+    by_kernel = {}
+    for r in rows:
+        by_kernel.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
+    insts, t_ms = 0.0, 0.0
+    for name, ms in kern.items():
+        matches = [v for k, v in by_kernel.items() if kernel_matches(name, k)]
+        if len(matches) != 1:
+            return {"skipped": f"profiles/{os.path.basename(path)} does not cover kernel {name} exactly once: re-profile after changing the kernels"}
+        insts += sum(matches[0]) / len(matches[0])
+        t_ms += ms
+    counts = {len(v) for v in by_kernel.values()}
+    extra = [k for k in by_kernel if not any(kernel_matches(n, k) for n in kern)]
+    if len(counts) != 1 or extra:
+        return {"skipped": f"profiles/{os.path.basename(path)} holds other kernels or uneven launch counts ({sorted(extra)[:2]}): re-profile"}
+    achieved = insts / (t_ms * 1e-3)
+    return {"bound": "fp64-valu-issue", "achieved": achieved / 1e9, "unit": "G wave-instr/s",
+            "peak_spec": FP64_VALU_SPEC / 1e9, "frac_of_spec": achieved / FP64_VALU_SPEC,
+            "peak_measured": FP64_VALU_MEASURED / 1e9, "frac_of_measured": achieved / FP64_VALU_MEASURED,
+            "valu_wave_instr_per_step": insts, "kernel_ms_per_step": t_ms, "source": os.path.basename(path),
+            "note": "peak_spec = 256 CU x 4 SIMD x 2.4 GHz / 4 cycles per wave64 fp64 instruction; peak_measured = scripts/fp64_peak.hip on this part"}
+
+
+# ------------------------------------------------------------------------------------------------ timed region
+class Runner:
+    """One rank's synthesizer(s) + flux gather for a workload: step(), drain()."""
+
+    def __init__(self, w, world, rank, local, ctx, scaling, use_graph, overlap):
+        import torch
+
+        from stardis_amd import parallel
+        from stardis_amd.engine import SpectralSynthesizer, shard_bounds
+
+        nus, atm = w["nus"], w["atm"]
+        self.nd = atm["temperatures"].size
+        self.shards = None
+        if scaling == "strong" and world > 1 and isinstance(w["lines"], dict):
+            ln_ = w["lines"]
+            work = parallel.window_work(nus, ln_["line_nus"], ln_["doppler_widths"], ln_["gammas"], ln_["alphas"])
+            self.shards = parallel.balanced_shards(work, world, 6000.0)
+        self.begin, self.count = self.shards[rank] if self.shards else shard_bounds(nus.size, world, rank)
+        self.world, self.overlap = world, overlap and world > 1
+        dev = f"cuda:{local}"
+        self.lanes = []
+        for k in range(2 if self.overlap else 1):
+            flux = torch.zeros((self.nd, self.count), dtype=torch.float64, device=dev)
+            syn = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], w["thetas"], w["weights"], w["lines"], w["cont"], ctx=ctx,
+                                      shard=(self.begin, self.count), flux_out=flux, track_evaluations=(k == 0))
+            self.lanes.append([syn, flux, parallel.FluxGatherer(nus.size, world, flux.device, shards=self.shards)])
+        self.syn, self.flux = self.lanes[0][0], self.lanes[0][1]
+        self.syn.step()
+        ctx.synchronize()
+        self.evals = self.syn.evaluations()
+        self.syn.count_evaluations = False  # known now; the counter costs a memset + a copy per step
+        if use_graph:
+            for lane in self.lanes:
+                lane[0].capture()
+        self.counter = 0
+
+    def step(self):
+        syn, flux, gather = self.lanes[self.counter % len(self.lanes)]
+        self.counter += 1
+        if self.overlap:
+            gather.finish()  # the gather that last read this lane's flux buffer
+            syn.step()
+            gather.start(flux[-1])
+            return None
+        syn.step()
+        return gather(flux[-1])
+
+    def drain(self):
+        if self.overlap:
+            for _, _, gather in self.lanes:
+                gather.finish()
+
+    def close(self):
+        for syn, _, _ in self.lanes:
+            syn.close()
+
+
+def timed(runner, steps, warmup, world, local, settle_s=0.1):
+    import torch
+    import torch.distributed as dist
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        runner.step()
+    runner.drain()
+    fence()
+    # clocks and caches settle over the first ~0.1 s of work: a short --steps run would otherwise time the ramp
+    # (untimed extra steps; the same number on every rank)
+    t0 = time.perf_counter()
+    runner.step()
+    runner.drain()
+    torch.cuda.synchronize()
+    one = max(time.perf_counter() - t0, 1e-6)
+    extra = int(min(2000, settle_s / one))
+    if world > 1:
+        t = torch.tensor([extra], dtype=torch.int64, device=f"cuda:{local}" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        extra = int(t.item())
+    for _ in range(extra):
+        runner.step()
+    runner.drain()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        runner.step()
+    runner.drain()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, extra + 1
 
 
 def main():
@@ -113,123 +451,66 @@ def main():
     ap.add_argument("--inputs", choices=("dense", "linelist"), default="dense",
                     help="line list as the reference's dense (N_l, N_d) tables, or as per-line scalars expanded on the device")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
-                    help="weak (default): fixed grid points per GPU; strong: the workload's grid split across the GPUs in shards of equal "
-                         "estimated work (stardis_amd.parallel.balanced_shards)")
+                    help="what `value` measures at N > 1. weak (default): fixed grid points per GPU; strong: the workload's grid split across "
+                         "the GPUs in shards of equal estimated work (stardis_amd.parallel.balanced_shards)")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip every leg that runs the CPU oracle (baseline and parity checks)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the S-c3 / S-c4m / strong / drop-in blocks")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args, sys.argv[1:]))
 
     import torch
 
     from stardis_amd import _lib, parallel
-    from stardis_amd.engine import SpectralSynthesizer, shard_bounds
 
     # test hooks: SDX_BENCH_BACKEND=gloo and SDX_BENCH_SINGLE_DEVICE=1 let the N > 1 path run on a 1-GPU box
     rank, world, local = parallel.init_from_env(os.environ.get("SDX_BENCH_BACKEND", "nccl"))
     if os.environ.get("SDX_BENCH_SINGLE_DEVICE") == "1":
         local = 0
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     import torch.distributed as dist
 
+    check = not args.no_cpu_baseline
     w = build_workload(args.workload, world, args.inputs, args.scaling)
     nus, atm = w["nus"], w["atm"]
     nd = atm["temperatures"].size
-    shards = None
-    if args.scaling == "strong" and world > 1 and isinstance(w["lines"], dict):
-        ln_ = w["lines"]
-        shards = parallel.balanced_shards(parallel.window_work(nus, ln_["line_nus"], ln_["doppler_widths"], ln_["gammas"], ln_["alphas"]), world)
-    begin, count = shards[rank] if shards else shard_bounds(nus.size, world, rank)
 
     # the library enqueues on torch's current (non-default, capturable) stream, so the RCCL gather is
     # stream-ordered behind the kernels without a host sync
     stream = torch.cuda.Stream(device=local)
     torch.cuda.set_stream(stream)
     ctx = _lib.Context(local, stream=stream.cuda_stream)
-    flux = torch.zeros((nd, count), dtype=torch.float64, device=f"cuda:{local}")
-    syn = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], w["thetas"], w["weights"], w["lines"], w["cont"],
-                              ctx=ctx, shard=(begin, count), flux_out=flux)
-    syn.step()
-    ctx.synchronize()
-    evals = syn.evaluations()
-    syn.count_evaluations = False  # known now; the counter costs a memset + a copy per step
-    if not args.no_graph:
-        syn.capture()
-
     # N > 1: two flux buffers alternate so that the all-gather of step k (RCCL, its own stream) overlaps the kernels
-    # of step k+1; a buffer is reused only after its gather has been waited for.  SDX_BENCH_SYNC_GATHER=1 falls back
-    # to a blocking gather per step.
-    overlap_gather = world > 1 and os.environ.get("SDX_BENCH_SYNC_GATHER") != "1"
-    lanes = [(syn, flux, parallel.FluxGatherer(nus.size, world, flux.device, shards=shards))]
-    if overlap_gather:
-        flux_b = torch.zeros_like(flux)
-        syn_b2 = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], w["thetas"], w["weights"], w["lines"], w["cont"],
-                                     ctx=ctx, shard=(begin, count), flux_out=flux_b, track_evaluations=False)
-        if not args.no_graph:
-            syn_b2.capture()
-        lanes.append((syn_b2, flux_b, parallel.FluxGatherer(nus.size, world, flux.device, shards=shards)))
-    counter = [0]
+    # of step k+1; a buffer is reused only after its gather has been waited for.  SDX_BENCH_SYNC_GATHER=1: blocking gather.
+    overlap = os.environ.get("SDX_BENCH_SYNC_GATHER") != "1"
+    runner = Runner(w, world, rank, local, ctx, args.scaling, not args.no_graph, overlap)
+    elapsed, settle = timed(runner, args.steps, args.warmup, world, local)
+    syn, flux, count, evals = runner.syn, runner.flux, runner.count, runner.evals
+    kern = kernel_times(ctx, syn, 20)
 
-    def step():
-        s_, f_, g_ = lanes[counter[0] % len(lanes)]
-        counter[0] += 1
-        if overlap_gather:
-            g_.finish()  # the gather that last read this lane's flux buffer
-            s_.step()
-            g_.start(f_[-1])
-            return None
-        s_.step()
-        return g_(f_[-1])
-
-    def drain():
-        if overlap_gather:
-            for _, _, g_ in lanes:
-                g_.finish()
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    drain()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        spectrum = step()
-    drain()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # per-kernel durations, live, with HIP events on the launch stream (eager launches, separate from the timed region)
-    ctx.call("sdx_profile_enable", 1)
-    ctx.call("sdx_profile_reset")
-    n_prof = 20
-    for _ in range(n_prof):
-        syn.enqueue()
-    ctx.synchronize()
-    kern = {}
-    import ctypes as C
-
-    for name in ("k_dnu_partial", "k_prepass_continuum", "k_line_prepass", "k_line_all", "k_line_wide", "k_line_narrow", "k_reduce_partials", "k_total_alphas", "k_raytrace"):
-        n, ms = C.c_int64(), C.c_double()
-        _lib.check(ctx.lib.sdx_profile_get(ctx.handle, name.encode(), C.byref(n), C.byref(ms)))
-        if n.value:
-            kern[name] = ms.value / n.value
-    ctx.call("sdx_profile_enable", 0)
-    ctx.call("sdx_profile_reset")
+    # strong scaling of BASELINE configs[2] (fixed 120 398-point grid split N ways), next to the weak-scaling `value`
+    strong = None
+    if world > 1 and not args.no_secondary and not (args.scaling == "strong" and args.workload == "S-c3"):
+        w3 = build_workload("S-c3", world, "dense", "strong")
+        r3 = Runner(w3, world, rank, local, ctx, "strong", not args.no_graph, overlap)
+        k3 = max(5, min(args.steps, 40))
+        e3, _ = timed(r3, k3, 3, world, local, settle_s=0.05)
+        if rank == 0:
+            strong = {"workload": synth_desc("S-c3"), "scaling": "strong", "n_gpus": world, "steps": k3, "ms_per_step": e3 / k3 * 1e3,
+                      "spectral_points_per_s": w3["nus"].size * nd * k3 / e3, "shards": [[int(b), int(c)] for b, c in (r3.shards or [])],
+                      "note": "shards of equal estimated work (parallel.window_work + balanced_shards); speed-up = the N=1 S-c3 step time in `secondary` / this"}
+        r3.close()
 
     # secondary figure (not `value`): two independent syntheses in flight on two streams — what a parameter grid
     # of stars would use; each is still a full pass, they only overlap on the device
     pipelined = None
-    if world == 1:
+    if world == 1 and not args.no_secondary:
+        from stardis_amd.engine import SpectralSynthesizer
+
         ctx_b = _lib.Context(local)
         syn_b = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], w["thetas"], w["weights"], w["lines"], w["cont"],
                                     ctx=ctx_b, track_evaluations=False)
@@ -244,6 +525,8 @@ def main():
             (syn if k % 2 == 0 else syn_b).step()
         torch.cuda.synchronize()
         pipelined = nus.size * nd * args.steps / (time.perf_counter() - t0)
+        syn_b.close()
+        ctx_b.close()
 
     if rank == 0:
         pts_total = nus.size * nd
@@ -254,10 +537,10 @@ def main():
         alg_bytes = {
             # SURVEY §8d per-stage figures, for the columns this rank produced
             "k_line_all": 8 * (n_l * (1 + 2 * nd + g_cols) + nus.size + nd * count),
-            "k_line_wide": 8 * (n_l * (1 + 2 * nd + g_cols) + nus.size + nd * count),
             "k_raytrace": 16 * nd * count,
         }.get(dom, syn.algorithmic_bytes())
         achieved = alg_bytes / (kern[dom] * 1e-3) / 1e9
+        line_ms = kern.get("k_line_all", 0.0) + kern.get("k_line_wide", 0.0) + kern.get("k_line_narrow", 0.0)
         out = {
             "metric": "spectral points/sec (N_nu x N_depth)",
             "value": value,
@@ -272,16 +555,18 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.workload}: {'cool-dwarf' if 'm' == args.workload[-1] else 'solar'} MARCS structure, {synth_desc(args.workload)}, fp64",
+                "workload": synth_desc(args.workload),
+                "scaling": args.scaling + (" (fixed points per GPU: N x the resolving power on the same window)" if args.scaling == "weak" else " (fixed grid split N ways)"),
                 "n_nu_global": int(nus.size),
                 "n_nu_per_gpu": int(count),
                 "n_depth": int(nd),
                 "n_lines": int(n_l),
                 "n_theta": int(len(w["thetas"])),
                 "voigt_evaluations_global": int(evals),
-                "parallelism": f"nu-shard x{world}" + (", 1 all-gather of F_nu[-1] per step" + (" overlapped with the next step" if overlap_gather else "") if world > 1 else ""),
+                "parallelism": f"nu-shard x{world}" + (", 1 all-gather of F_nu[-1] per step" + (" overlapped with the next step" if runner.overlap else "") if world > 1 else ""),
                 "hip_graph": not args.no_graph,
                 "line_inputs": args.inputs,
+                "untimed_settle_steps_after_warmup": settle,
             },
             "roofline": {
                 "bound": "hbm",
@@ -290,17 +575,19 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": profiled_traffic(dom) if (world == 1 and args.workload == "S-c2") else None,
+                "traffic": profiled_traffic(args.workload, dom) if world == 1 else None,
                 "algorithmic_bytes_per_launch": int(alg_bytes),
                 "avg_kernel_ms": kern,
-                "note": "path is fp64-VALU bound (Faddeeva evaluations), not HBM bound: see DESIGN.md; evaluations/s below",
-                "voigt_evaluations_per_s": (evals / world) / ((kern.get("k_line_all", 0.0) + kern.get("k_line_wide", 0.0) + kern.get("k_line_narrow", 0.0)) * 1e-3),
+                "whole_step": {"algorithmic_bytes": int(syn.algorithmic_bytes()), "achieved": syn.algorithmic_bytes() / (ms_per_step * 1e-3) / 1e9,
+                               "frac": syn.algorithmic_bytes() / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+                "note": "path is fp64-VALU bound (Faddeeva evaluations), not HBM bound: see DESIGN.md and roofline_fp64_valu",
+                "voigt_evaluations_per_s": (evals / world) / (line_ms * 1e-3) if line_ms else None,
             },
         }
-        valu = profiled_valu(kern) if (world == 1 and args.workload == "S-c2") else None
+        valu = profiled_valu(args.workload, kern) if world == 1 else None
         if valu is not None:
             out["roofline_fp64_valu"] = valu
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and check:
             base, F_cpu = cpu_baseline(w)
             out["cpu_baseline"] = base
             F_gpu = flux.cpu().numpy()
@@ -311,60 +598,16 @@ def main():
             out["speedup_vs_cpu_baseline"] = value / base["value"]
         if pipelined is not None:
             out["throughput_two_syntheses_in_flight"] = pipelined
+        if strong is not None:
+            out["strong"] = strong
+        if world == 1 and not args.no_secondary:
+            runner.close()
+            out["secondary"] = {tag: secondary_block(tag, local, 10, check) for tag in ("S-c3", "S-c4m")}
+            out["dropin"] = dropin_block(local, check)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-
-
-def profiled_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/, S-c2, separate FETCH_SIZE
-    and WRITE_SIZE runs).  Raw counters: these kernels issue 8-byte-per-lane accesses, for which the gfx950
-    16-byte-stream correction does not apply (profiles/README.md).  None when the files are absent."""
-    import csv
-
-    total = 0.0
-    for name in ("FETCH_SIZE", "WRITE_SIZE"):
-        path = os.path.join(ROOT, "profiles", f"r01_S-c2_pmc_{name}.csv")
-        if not os.path.exists(path):
-            return None
-        vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if kernel in r["Kernel_Name"] and r["Counter_Name"] == name]
-        if not vals:
-            return None
-        total += sum(vals) / len(vals) * 1024.0
-    return total
-
-
-FP64_VALU_PEAK = 439.0e9  # wave-level fp64 VALU instructions/s the chip sustains (scripts/fp64_peak.hip: 55 TFLOP/s FMA)
-
-
-def profiled_valu(kern):
-    """The bound that actually limits this path: fp64 VALU issue.  Wave-level VALU instructions per step from the
-    committed SQ_INSTS_VALU pass (profiles/, S-c2) over the kernel time measured live in this run."""
-    import csv
-
-    path = os.path.join(ROOT, "profiles", "r01_S-c2_pmc_SQ.csv")
-    if not os.path.exists(path):
-        return None
-    rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == "SQ_INSTS_VALU"]
-    insts, t_ms = 0.0, 0.0
-    for name, ms in kern.items():
-        vals = [float(r["Counter_Value"]) for r in rows if name in r["Kernel_Name"]]
-        if not vals:
-            return None
-        insts += sum(vals) / len(vals)
-        t_ms += ms
-    achieved = insts / (t_ms * 1e-3)
-    return {"bound": "fp64-valu-issue", "achieved": achieved / 1e9, "peak": FP64_VALU_PEAK / 1e9, "unit": "G wave-instr/s",
-            "frac": achieved / FP64_VALU_PEAK, "valu_wave_instr_per_step": insts, "kernel_ms_per_step": t_ms}
-
-
-def synth_desc(tag):
-    from stardis_amd import synth
-
-    c = synth.WORKLOADS[tag]
-    grid = f"R={c['R']:.0f}" if "R" in c else f"step {c['step']} A"
-    return f"{c['lam0']:.0f}-{c['lam1']:.0f} A at {grid}"
 
 
 if __name__ == "__main__":

@@ -32,6 +32,7 @@ extern "C" {
 #define SDX_ERR_HIP (-2)  /* HIP runtime error (no device, launch failure, ...) */
 #define SDX_ERR_COMM (-3) /* reserved for collective errors (the flux gather lives in torch.distributed) */
 #define SDX_ERR_OOM (-4)  /* device or host allocation failed */
+#define SDX_ERR_STALE (-5) /* sdx_graph_launch: the context's scratch was reallocated after the graph was captured; capture again */
 
 /* broadening flags (broadening.py:688-691: which terms the config lists) */
 #define SDX_LINEAR_STARK 1
@@ -68,7 +69,9 @@ int sdx_memset(sdx_ctx* ctx, void* dst_dev, int value, size_t bytes);
 /* Scratch the line-opacity call needs for n_lines x n_depth; call once before stream capture. */
 int sdx_reserve_line_workspace(sdx_ctx* ctx, int n_depth, int64_t n_lines);
 
-/* stream capture -> hipGraph, so a launch-bound sequence of *_dev calls replays as one submit */
+/* stream capture -> hipGraph, so a launch-bound sequence of *_dev calls replays as one submit.  A graph bakes in the
+ * context's scratch pointers: if a later, larger call on the same context makes the library reallocate scratch, launching
+ * the old graph returns SDX_ERR_STALE instead of touching freed memory (reserve the largest workspace first, or re-capture). */
 int sdx_graph_begin(sdx_ctx* ctx);
 int sdx_graph_end(sdx_ctx* ctx, void** graph_exec_out);
 int sdx_graph_launch(sdx_ctx* ctx, void* graph_exec);
@@ -251,8 +254,9 @@ int sdx_convolve1d_reflect_dev(sdx_ctx* ctx, int64_t n, const double* in, int m,
 int sdx_flux_nu_to_lambda_dev(sdx_ctx* ctx, int64_t n, const double* f_nu, const double* nus, const double* lambdas, double* out);
 
 /* Everything in one call for resident data: pre-pass + line opacity + total (above) + raytrace (F_nu
- * overwritten).  alpha_line_out is optional; total_alphas and F_nu are [n_depth][ld].  This is the step
- * bench.py times; it skips the intermediate line-opacity plane when the line list was split over blocks. */
+ * overwritten).  F_nu is [n_depth][ld].  alpha_line_out and total_alphas ([n_depth][ld]) are OPTIONAL outputs (NULL: the
+ * plane is never written to HBM — the reference only reads them back through opacities_dict / Opacities.total_alphas;
+ * the formal solution forms total = continuum + line while staging its columns).  This is the step bench.py times. */
 int sdx_synthesize_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin, int64_t nu_count,
                        int64_t n_lines, const double* line_nus, const double* doppler_widths, const double* gammas,
                        int gamma_cols, const double* alphas, const sdx_continuum* cont, int n_theta,
@@ -262,7 +266,7 @@ int sdx_synthesize_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nu
 
 /* The same synthesis for a caller whose data lives in host memory (plain C, or numpy through ctypes): every pointer,
  * including those inside `cont`, is a HOST pointer; arrays are uploaded, sdx_synthesize_dev runs, results come back.
- * total_alphas and F_nu are [n_depth][n_nu] (F_nu overwritten); alpha_line_out and n_evaluations are optional.
+ * F_nu is [n_depth][n_nu] (overwritten); alpha_line_out, total_alphas ([n_depth][n_nu]) and n_evaluations are optional.
  * ray_dist is the (n_depth-1, n_theta) table dist[:, None] / cos(theta) (radiation_field_solvers/base.py:302-305). */
 int sdx_synthesize_f64(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t n_lines, const double* line_nus,
                        const double* doppler_widths, const double* gammas, int gamma_cols, const double* alphas,

@@ -20,9 +20,16 @@ _lp = C.POINTER(C.c_int64)
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "stardis_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
-        subprocess.run(["make", "-C", _HERE], check=True, stdout=subprocess.DEVNULL)
+    """make decides: the library is rebuilt when the source is newer or when it was built (-march=native) on another CPU
+    than this one (oracle/Makefile keys the build on the host CPU)."""
+    import shutil
+
+    if force and os.path.exists(_SO):
+        os.remove(_SO)
+    if shutil.which("make") is not None:
+        subprocess.run(["make", "-C", _HERE], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    elif not os.path.exists(_SO):
+        raise RuntimeError("oracle/_build/libstardis_oracle.so is missing and `make` is not available")
     return _SO
 
 

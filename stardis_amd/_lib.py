@@ -164,6 +164,10 @@ def load():
     return _lib
 
 
+class StaleGraphError(RuntimeError):
+    """sdx_graph_launch refused a graph captured before the context's scratch was reallocated (SDX_ERR_STALE)."""
+
+
 def check(rc):
     if rc == 0:
         return
@@ -172,6 +176,8 @@ def check(rc):
         raise ValueError(msg)
     if rc == -4:
         raise MemoryError(msg)
+    if rc == -5:
+        raise StaleGraphError(msg)
     raise RuntimeError(f"stardis_hip error {rc}: {msg}")
 
 

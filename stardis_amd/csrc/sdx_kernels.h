@@ -13,6 +13,16 @@ namespace sdx {
 
 constexpr int kBlock = 256;
 
+__device__ __forceinline__ void wave_sync()
+{
+    // LDS hand-over between lanes of ONE wave: the LDS unit executes a wave's instructions in order, so only the
+    // compiler has to be kept from moving accesses across this point
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+
 // ------------------------------------------------------------------------------------------------
 // d_nu = -max(diff(nus))  (opacities_solvers/base.py:524-526): partial maxima, finished by consumers.
 constexpr int kDnuPartials = 256;
@@ -383,20 +393,69 @@ __global__ __launch_bounds__(kPreBlock) __attribute__((amdgpu_num_sgpr(80))) voi
 // their depth-column constants, then every lane walks the compacted list.  Splitting the line list over S blocks
 // shortens the serial chain of the deepest (hottest) layers, whose windows are widest; the S partial planes are
 // added in subset order by the consumer (k_reduce_partials / k_total_alphas).  No atomics: bit-stable results.
+// LDS of one wide-role wave: the compacted list of up to 64 lines (8 doubles + 3 ints each), reused at the end of the
+// block for the wave's partial sums (64 R doubles, R <= 8)
+constexpr int kWideLdsDoubles = 8 * 64 + 3 * 32;
+struct WideLds {
+    double *nu, *inv, *y, *amp, *yk, *c2, *c3, *c4;
+    int *lo, *hi, *fast;
+    double* sums;
+};
+__device__ __forceinline__ WideLds wide_lds(double* base)
+{
+    WideLds l;
+    l.nu = base, l.inv = base + 64, l.y = base + 128, l.amp = base + 192, l.yk = base + 256, l.c2 = base + 320, l.c3 = base + 384, l.c4 = base + 448;
+    l.lo = (int*)(base + 512), l.hi = l.lo + 64, l.fast = l.hi + 64;
+    l.sums = base;
+    return l;
+}
+
+// The S subsets of a (depth, tile) are the S waves of ONE workgroup: every wave accumulates its subset in registers, then the
+// partial sums meet in LDS and wave 0 adds them in subset order and writes the tile — one line-opacity plane instead of
+// S partial planes in HBM (deterministic: the order is fixed, no atomics).
+template <int R>
+__device__ __forceinline__ void wide_reduce_and_store(const int split, const int n_split, double (&acc)[R], const int (&idx)[R], const WideLds& L,
+                                                      double* __restrict__ lds_all, int64_t nu_begin, double* __restrict__ plane, int64_t pld,
+                                                      const int d)
+{
+    const int lane = threadIdx.x & 63;
+    if (n_split > 1) {
+        wave_sync();  // this wave's last list reads precede the overwrite
+        if (split > 0) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) L.sums[r * 64 + lane] = acc[r];
+        }
+        __syncthreads();
+        if (split == 0) {
+            for (int s = 1; s < n_split; ++s) {
+                const double* other = lds_all + (size_t)s * kWideLdsDoubles;
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc[r] = add_rn(acc[r], other[r * 64 + lane]);
+            }
+        }
+    }
+    if (split == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (idx[r] >= 0) plane[(size_t)d * pld + (idx[r] - nu_begin)] = acc[r];
+    }
+}
+
 template <int R, bool MIXED>
 __device__ __forceinline__ void line_wide_block(const int tile_idx, const int split, const int n_split, const int d, int64_t n_nu, const double* __restrict__ nus, int64_t nu_begin,
                                                   int64_t nu_count, int64_t n_lines, const double* __restrict__ line_nus,
-                                                  LineWork w, double* __restrict__ partial, int64_t pld, int n_depth)
+                                                  LineWork w, double* __restrict__ partial, int64_t pld, int n_depth, double* __restrict__ lds_all)
 {
     constexpr int kTile = 64 * R;
-    __shared__ double s_nu[64], s_inv[64], s_y[64], s_amp[64], s_yk[64], s_c2[64], s_c3[64], s_c4[64];
-    __shared__ int s_lo[64], s_hi[64], s_fast[64];
+    const WideLds L = wide_lds(lds_all + (size_t)split * kWideLdsDoubles);
+    double *s_nu = L.nu, *s_inv = L.inv, *s_y = L.y, *s_amp = L.amp, *s_yk = L.yk, *s_c2 = L.c2, *s_c3 = L.c3, *s_c4 = L.c4;
+    int *s_lo = L.lo, *s_hi = L.hi, *s_fast = L.fast;
 
     // grid = (tiles, subsets, depths): depth is the slowest index so the innermost (hottest, widest-window)
     // layers are dispatched first and the light outer layers fill the tail
     const int64_t t0 = nu_begin + (int64_t)tile_idx * kTile;
     const int64_t t1 = min(t0 + kTile, nu_begin + nu_count);
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
 
     double nu_i[R], acc[R];
     int idx[R];
@@ -458,7 +517,7 @@ __device__ __forceinline__ void line_wide_block(const int tile_idx, const int sp
             s_lo[pos] = lo;
             s_hi[pos] = hi;
         }
-        __syncthreads();  // one wave: orders the LDS writes above before the reads below
+        wave_sync();  // orders the LDS writes above before the reads below (the list is this wave's own)
         for (int j = 0; j < total; ++j) {
             const double lnu = s_nu[j], inv = s_inv[j];
             const RegionI k1 = {s_yk[j], s_c2[j], s_c3[j], s_c4[j]};
@@ -479,22 +538,9 @@ __device__ __forceinline__ void line_wide_block(const int tile_idx, const int sp
                     if (idx[r] >= jlo && idx[r] < jhi) acc[r] += voigt_term(nu_i[r] - lnu, inv, y, amp, k1);
             }
         }
-        __syncthreads();
+        wave_sync();
     }
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-        if (idx[r] >= 0) partial[((size_t)split * n_depth + d) * pld + (idx[r] - nu_begin)] = acc[r];
-}
-
-template <int R>
-__global__ __launch_bounds__(64, 4) void k_line_wide(int64_t n_nu, const double* __restrict__ nus, int64_t nu_begin,
-                                                     int64_t nu_count, int64_t n_lines, const double* __restrict__ line_nus,
-                                                     LineWork w, double* __restrict__ partial, int64_t pld, int n_depth)
-{
-    // grid = (tiles, subsets, depths): depth is the slowest index so the innermost (hottest, widest-window)
-    // layers are dispatched first and the light outer layers fill the tail
-    line_wide_block<R, false>(blockIdx.x, blockIdx.y, gridDim.y, blockIdx.z, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, partial,
-                              pld, n_depth);
+    wide_reduce_and_store<R>(split, n_split, acc, idx, L, lds_all, nu_begin, partial, pld, d);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -615,14 +661,15 @@ __device__ __forceinline__ int first_below(const int* __restrict__ key, int n, i
 template <int R, bool MIXED>
 __device__ __forceinline__ void line_wide_block_indexed(const int tile_idx, const int split, const int n_split, const int d,
                                                         const double* __restrict__ nus, int64_t nu_begin, int64_t nu_count,
-                                                        LineWork w, double* __restrict__ partial, int64_t pld, int n_depth)
+                                                        LineWork w, double* __restrict__ partial, int64_t pld, int n_depth, double* __restrict__ lds_all)
 {
     constexpr int kTile = 64 * R;
-    __shared__ double s_nu[64], s_inv[64], s_y[64], s_amp[64], s_yk[64], s_c2[64], s_c3[64], s_c4[64];
-    __shared__ int s_lo[64], s_hi[64], s_fast[64];
+    const WideLds L = wide_lds(lds_all + (size_t)split * kWideLdsDoubles);
+    double *s_nu = L.nu, *s_inv = L.inv, *s_y = L.y, *s_amp = L.amp, *s_yk = L.yk, *s_c2 = L.c2, *s_c3 = L.c3, *s_c4 = L.c4;
+    int *s_lo = L.lo, *s_hi = L.hi, *s_fast = L.fast;
     const int64_t t0 = nu_begin + (int64_t)tile_idx * kTile;
     const int64_t t1 = min(t0 + kTile, nu_begin + nu_count);
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     double nu_i[R], acc[R];
     int idx[R];
 #pragma unroll
@@ -681,7 +728,7 @@ __device__ __forceinline__ void line_wide_block_indexed(const int tile_idx, cons
                 s_lo[pos] = lo;
                 s_hi[pos] = hi;
             }
-            __syncthreads();
+            wave_sync();
             for (int j = 0; j < total; ++j) {
                 // two consecutive test-free lines share one trip through the loop (their constants are fetched together and
                 // one branch decides for both); the additions keep list order, so the sums are unchanged
@@ -719,12 +766,10 @@ __device__ __forceinline__ void line_wide_block_indexed(const int tile_idx, cons
                         if (idx[r] >= jlo && idx[r] < jhi) acc[r] += voigt_term(nu_i[r] - lnu, inv, y, amp, k1);
                 }
             }
-            __syncthreads();
+            wave_sync();
         }
     }
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-        if (idx[r] >= 0) partial[((size_t)split * n_depth + d) * pld + (idx[r] - nu_begin)] = acc[r];
+    wide_reduce_and_store<R>(split, n_split, acc, idx, L, lds_all, nu_begin, partial, pld, d);
 }
 
 // Narrow windows (half-width <= kNarrowHalfWidth, e.g. the reference's 10-pixel floor for weak lines, :565-567):
@@ -790,40 +835,40 @@ __device__ __forceinline__ void line_narrow_wave(const int64_t i, const int dept
     if (valid) plane[(size_t)d * pld + (i - nu_begin)] = acc;
 }
 
-__global__ __launch_bounds__(64) void k_line_narrow(int n_depth, int64_t n_nu, const double* __restrict__ nus, int64_t nu_begin,
-                                                    int64_t nu_count, int64_t n_lines, const double* __restrict__ line_nus,
-                                                    LineWork w, double* __restrict__ plane, int64_t pld)
-{
-    line_narrow_wave(nu_begin + blockIdx.x, blockIdx.y, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, plane, pld);
-}
-
-// Both line kernels in ONE launch: blocks [0, n_wide) take the wide role (depth slowest, hottest layers first), the
-// rest the narrow role.  The two only share the pre-pass, and each leaves issue slots idle on its own; a
+// Both line kernels in ONE launch of workgroups of S waves (S = number of line subsets): workgroups [0, n_wide) take the
+// wide role — one (depth, tile) each, wave s walks subset s — depth slowest, hottest layers first; the rest take the narrow
+// role, one frequency per wave.  The two roles only share the pre-pass, and each leaves issue slots idle on its own; a
 // cross-stream fork/join would cost two ~12 us inter-queue edges per step, one grid costs nothing.
+// roles: bit 0 wide, bit 1 narrow (both by default; one at a time for split-launch profiling, SDX_SPLIT_LAUNCHES=1).
+// Output planes: [0] the wide windows (all subsets summed), [1] the narrow windows.
 template <int R, bool INDEXED, bool MIXED>
-__global__ __launch_bounds__(64, 4) void k_line_all(int n_wide, int tiles, int n_split, int n_depth, int64_t n_nu,
-                                                    const double* __restrict__ nus, int64_t nu_begin, int64_t nu_count,
-                                                    int64_t n_lines, const double* __restrict__ line_nus, LineWork w,
-                                                    double* __restrict__ partial, int64_t pld)
+__global__ __launch_bounds__(512) void k_line_all(int n_wide, int tiles, int n_split, int n_depth, int64_t n_nu,
+                                                   const double* __restrict__ nus, int64_t nu_begin, int64_t nu_count,
+                                                   int64_t n_lines, const double* __restrict__ line_nus, LineWork w,
+                                                   double* __restrict__ planes, int64_t pld, int roles)
 {
+    extern __shared__ double s_wide[];  // n_split x kWideLdsDoubles
     const int b = blockIdx.x;
+    const int wave = threadIdx.x >> 6;
     if (b < n_wide) {
-        // XCD-aware tile order: workgroup i runs on XCD i % 8, each with its own L2.  Within a (depth, subset) group the
-        // blocks of one XCD take CONTIGUOUS tiles (position p -> tile prefix(p % 8) + p / 8), so neighbouring tiles, whose
-        // line ranges overlap, hit the same L2 instead of pulling the same constants into all eight.
-        const int p = b % tiles, rest = b / tiles;
+        if (!(roles & 1)) return;
+        // XCD-aware tile order: workgroup i runs on XCD i % 8, each with its own L2.  Within a depth the workgroups of one XCD
+        // take CONTIGUOUS tiles (position p -> tile prefix(p % 8) + p / 8), so neighbouring tiles, whose line ranges
+        // overlap, hit the same L2 instead of pulling the same constants into all eight.
+        const int p = b % tiles, d = b / tiles;
         int tile = p >> 3;
         for (int f = 0; f < (p & 7); ++f) tile += (tiles - f + 7) >> 3;
         if (INDEXED)
-            line_wide_block_indexed<R, MIXED>(tile, rest % n_split, n_split, rest / n_split, nus, nu_begin, nu_count, w, partial, pld,
-                                              n_depth);
+            line_wide_block_indexed<R, MIXED>(tile, wave, n_split, d, nus, nu_begin, nu_count, w, planes, pld, n_depth, s_wide);
         else
-            line_wide_block<R, MIXED>(tile, rest % n_split, n_split, rest / n_split, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w,
-                                      partial, pld, n_depth);
+            line_wide_block<R, MIXED>(tile, wave, n_split, d, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, planes, pld, n_depth, s_wide);
     } else {
-        const int64_t c = b - n_wide;
-        line_narrow_wave(nu_begin + c % nu_count, (int)(c / nu_count), n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w,
-                         partial + (size_t)n_split * n_depth * pld, pld);
+        if (!(roles & 2)) return;
+        const int64_t c = (int64_t)(b - n_wide) * n_split + wave;
+        const int64_t n_narrow = nu_count * ((n_depth + 63) / 64);
+        if (c < n_narrow)
+            line_narrow_wave(nu_begin + c % nu_count, (int)(c / nu_count), n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w,
+                             planes + (size_t)n_depth * pld, pld);
     }
 }
 
@@ -1458,7 +1503,7 @@ struct FusedTotal {
     const double* planes;  // [n_planes][n_depth][pld] partial line-opacity planes, or nullptr (no lines)
     int n_planes;
     int64_t pld;
-    double* total_out;     // [n_depth][out_ld]
+    double* total_out;     // [n_depth][out_ld], optional
     double* line_out;      // optional
     int64_t out_ld;
 };
@@ -1523,7 +1568,7 @@ __global__ __launch_bounds__(kBlock) void k_raytrace(int n_depth, int64_t n_nu, 
                     a = add_rn(a, line);
                     if (valid && ft.line_out) ft.line_out[(size_t)d * ft.out_ld + i] = line;
                 }
-                if (valid) ft.total_out[(size_t)d * ft.out_ld + i] = a;
+                if (valid && ft.total_out) ft.total_out[(size_t)d * ft.out_ld + i] = a;
             } else {
                 a = alphas[(size_t)d * ald + ic];
             }
@@ -1646,6 +1691,193 @@ __global__ __launch_bounds__(kBlock) void k_raytrace(int n_depth, int64_t n_nu, 
             }
         }
         __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Formal solution, coefficient-parallel (the default for plane-parallel models).
+//
+// The second-order short-characteristic step (:200-266) is AFFINE in the incoming intensity,
+//     I[g+1] = (1 - w0) I[g] + ( w0 S[g+1] + second + third ),
+// and everything but I[g] — exp(-tau), the three weights, the two correction terms: ~55 of the ~60 instructions of a step —
+// depends only on (frequency, gap, angle).  So the N_gap x N_theta coefficient pairs (c, e) of a frequency are independent
+// work items: they are spread over all 64 lanes of a wave (lane <-> item, full lanes), a batch of B gaps at a time, and
+// only the two-instruction recurrence I <- fma(c, I, e) walks the gaps in order (lane <-> (frequency, angle)).
+// What that buys on this chip is WAVES: one SIMD issues one fp64 instruction per ~7.5 cycles for a single wave whatever
+// its instruction-level parallelism and needs ~8 resident waves for its full rate (scripts/issue_cost.hip); the lane <->
+// (frequency, angle) kernel above has 64 / N_theta frequencies per wave, i.e. N_nu N_theta / 64 waves — 2.5 per SIMD at
+// 7 634 frequencies — whereas here a wave owns `fpw` frequencies with fpw = 1 on small grids (7.5 waves per SIMD).
+//
+//   staging   lanes <-> (depth, frequency): total opacity (optionally continuum + line planes, as k_raytrace),
+//             log(alpha) and the Planck source -> LDS; then lanes <-> (gap, frequency): geometric-mean opacity (:121).
+//   batch     a) lanes <-> (gap of the batch, frequency, angle): tau (:123-129, the reference's product), weights
+//                (:22-45), c = 1 - w0, e = (w0 S1 + second) + third with ONE reciprocal for the three divisions of :208-242:
+//                    second = w1 (dS10 tau1^2 - dS21 tau0^2) / D,  third = w2 (dS21 tau0 + dS10 tau1) / D,
+//                    D = tau0 tau1 (tau0 + tau1),  dS10 = S[g] - S[g+1],  dS21 = S[g+2] - S[g+1]
+//                (last gap :256-266: e = w0 S1 + w2 dS10 / tau0^2; tau0 = 0 :203-206: c = 1, e = 0)   -> LDS
+//             b) lanes <-> (frequency, angle): I <- fma(c, I, e) over the B gaps; I w_theta -> LDS (same slot)
+//             c) lanes <-> (gap, frequency, half of the angles): flux sum in ascending theta per half, lower half first
+// The affine form rounds e once more than the reference's left-to-right sum; |dI/I| ~ 1e-16 per step, far inside the
+// 1e-10 flux tolerance (and the 6e-12 of the reference's own conditioning).
+constexpr int kFormalBlock = 512;  // 8 waves share one copy of the ray table: 4 such blocks (32 waves) fit a CU's LDS at MARCS depth
+template <int B>
+__global__ __launch_bounds__(kFormalBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_formal(
+    int n_depth, int64_t n_nu, int n_theta, int theta_stride, const double* __restrict__ nus, const double* __restrict__ temps,
+    const double* __restrict__ ray_dist, const double* __restrict__ wts, const double* __restrict__ alphas, int64_t ald,
+    double* __restrict__ F, int64_t fld, double* __restrict__ I_nus, int accumulate, int fpw, FusedTotal ft)
+{
+    extern __shared__ double smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n_gap = n_depth - 1;
+    const int col = n_depth + 2;             // padded rows: [g + 1], [g + 2] of the last gap stay inside the row
+    const int FT = fpw * n_theta;            // (frequency, angle) lanes of the recurrence, <= 64
+    const int GPR = 64 / FT;                 // gaps per coefficient round: lane <-> (gap of the round, frequency, angle)
+    const int64_t i0 = ((int64_t)blockIdx.x * (kFormalBlock / 64) + wave) * fpw;  // first frequency of this wave
+    double* sRD = smem;                      // ray_dist [n_gap + 1][n_theta] (last row repeated)
+    double* wbase = sRD + (n_gap + 1) * n_theta + (size_t)wave * (2 * fpw * col + max(2 * B * FT, fpw * col));
+    double* sS = wbase;                      // source function [fpw][col]
+    double* sM = sS + fpw * col;             // mean opacity per gap [fpw][col]
+    double* sC = sM + fpw * col;             // (c, e) [B][FT][2]; c is replaced by I w_theta once the recurrence has used it
+    double* sL = sC;                         // log(alpha) [fpw][col] during staging (the coefficient buffer is idle then)
+
+    for (int k = threadIdx.x; k < (n_gap + 1) * n_theta; k += kFormalBlock) {
+        const int gp = min(k / n_theta, n_gap - 1), t = k - (k / n_theta) * n_theta;
+        sRD[k] = ray_dist[(size_t)gp * theta_stride + t];
+    }
+    // ---- staging: lanes <-> (depth, frequency), frequency fastest (adjacent lanes read adjacent columns)
+    const float inv_fpw = 1.0f / (float)fpw;
+    for (int k = lane; k < fpw * n_depth; k += 64) {
+        const int d = (int)(((float)k + 0.5f) * inv_fpw), f = k - d * fpw;
+        const int64_t i = i0 + f;
+        const bool valid = i < n_nu;
+        const int64_t ic = valid ? i : n_nu - 1;
+        double a;
+        if (ft.cont) {
+            a = ft.cont[(size_t)d * ft.cld + ic];
+            if (ft.planes) {
+                double line = ft.planes[(size_t)d * ft.pld + ic];
+                for (int sp = 1; sp < ft.n_planes; ++sp) line = add_rn(line, ft.planes[((size_t)sp * n_depth + d) * ft.pld + ic]);
+                a = add_rn(a, line);
+                if (valid && ft.line_out) ft.line_out[(size_t)d * ft.out_ld + i] = line;
+            }
+            if (valid && ft.total_out) ft.total_out[(size_t)d * ft.out_ld + i] = a;
+        } else {
+            a = alphas[(size_t)d * ald + ic];
+        }
+        sL[f * col + d] = log(a);
+        const double src = planck(nus[ic], temps[d]);
+        sS[f * col + d] = src;
+        if (d == n_depth - 1) sS[f * col + d + 1] = src;  // pad
+    }
+    __syncthreads();  // sRD is shared by the block; sL / sS are this wave's own
+    for (int k = lane; k < fpw * n_gap; k += 64) {  // lanes <-> (gap, frequency)
+        const int gp = (int)(((float)k + 0.5f) * inv_fpw), f = k - gp * fpw;
+        const double m = exp(mul_rn(add_rn(sL[f * col + gp + 1], sL[f * col + gp]), 0.5));  // :121
+        sM[f * col + gp] = m;
+        if (gp == n_gap - 1) sM[f * col + gp + 1] = m;  // pad
+    }
+    wave_sync();
+
+    // ---- fixed roles of this lane
+    // coefficient rounds: lane <-> (gap of the round bsub, frequency cf, angle ct); q = cf n_theta + ct is the (f, theta) slot
+    const int bsub = (int)(((float)lane + 0.5f) * (1.0f / (float)FT)), q = lane - bsub * FT;
+    const int cf = (int)(((float)q + 0.5f) * (1.0f / (float)n_theta)), ct = q - cf * n_theta;
+    const bool citem = bsub < GPR;
+    const double* pS = sS + cf * col + bsub;        // + gap
+    const double* pM = sM + cf * col + bsub;
+    const double* pR = sRD + bsub * n_theta + ct;   // + gap * n_theta
+    double* pC = sC + 2 * (bsub * FT + q);          // + 2 FT * (gap of the batch)
+    // recurrence: lane <-> (f, theta) slot `lane`
+    const bool rec = lane < FT;
+    const int rf = rec ? cf : 0, rt = rec ? ct : 0;  // bsub = 0 for lane < FT, so (cf, ct) is this lane's own slot
+    const int64_t ri = i0 + rf;
+    const bool rvalid = rec && ri < n_nu;
+    const double wt = rec ? wts[rt] : 0.0;
+    double inten = 0.0;  // np.zeros (:134)
+    if (rvalid && I_nus) I_nus[(size_t)ri * theta_stride + rt] = 0.0;
+    if (rvalid && rt == 0 && F && !accumulate) F[ri] = 0.0;
+    // flux: lane <-> (gap of the batch, frequency, half of the angles)
+    const int half = (n_theta + 1) >> 1;
+    const int fh = lane & 1, fbf = lane >> 1;
+    const int fb = (int)(((float)fbf + 0.5f) * inv_fpw), ff = fbf - fb * fpw;
+    const double* pF = sC + 2 * (fb * FT + ff * n_theta + (fh ? half : 0));
+    const int fcount = fh ? n_theta - half : half;
+    const int64_t fi = i0 + ff;
+
+    for (int gap0 = 0; gap0 < n_gap; gap0 += B) {
+        const int nb = min(B, n_gap - gap0);
+        // a) coefficients
+        if (citem) {
+            const double* S = pS + gap0;
+            const double* M = pM + gap0;
+            const double* R = pR + gap0 * n_theta;
+            double* C = pC;
+            for (int b = bsub; b < nb; b += GPR, S += GPR, M += GPR, R += GPR * n_theta, C += 2 * GPR * FT) {
+                const double s0 = S[0], s1 = S[1], s2 = S[2];
+                const double t0 = mul_rn(M[0], R[0]);
+                const double t1 = mul_rn(M[1], R[n_theta]);
+                const double d10 = s0 - s1, d21 = s2 - s1;
+                const double D = (t0 * t1) * (t0 + t1);
+                double c, e;
+                if (gap0 + b != n_gap - 1 && D > 1e-290 && D < 1e290) {  // :208-249, the common case
+                    double w0, w1, w2;
+                    rt_weights(t0, w0, w1, w2);
+                    const double rD = recip(D);
+                    const double X = w1 * fma(-d21, t0 * t0, d10 * (t1 * t1)) * rD;
+                    const double Y = w2 * fma(d21, t0, d10 * t1) * rD;
+                    c = 1.0 - w0;
+                    e = fma(w0, s1, X) + Y;
+                } else if (t0 == 0.0) {  // no change (:203-206, :253-254)
+                    c = 1.0;
+                    e = 0.0;
+                } else {
+                    double w0, w1, w2;
+                    rt_weights(t0, w0, w1, w2);
+                    c = 1.0 - w0;
+                    if (gap0 + b == n_gap - 1) {  // :256-266
+                        e = fma(w0, s1, w2 * d10 * recip_guarded(t0 * t0));
+                    } else {  // tau1 = 0 or extreme magnitudes: the reference's own divisions, inf / NaN pattern included
+                        const double sum01 = t0 + t1;
+                        const double X = w1 * (d10 * (t1 / t0) - d21 * (t0 / t1)) / sum01;
+                        const double Y = w2 * (d21 / t1 + d10 / t0) / sum01;
+                        e = fma(w0, s1, X) + Y;
+                    }
+                }
+                C[0] = c;
+                C[1] = e;
+            }
+        }
+        wave_sync();
+        // b) recurrence
+        if (rec) {
+            double* slot = sC + 2 * lane;
+            if (I_nus) {
+                for (int b = 0; b < nb; ++b, slot += 2 * FT) {
+                    inten = fma(slot[0], inten, slot[1]);
+                    if (rvalid) I_nus[((size_t)(gap0 + b + 1) * n_nu + ri) * theta_stride + rt] = inten;
+                    slot[0] = inten * wt;
+                }
+            } else {
+#pragma unroll 3
+                for (int b = 0; b < nb; ++b, slot += 2 * FT) {
+                    inten = fma(slot[0], inten, slot[1]);
+                    slot[0] = inten * wt;
+                }
+            }
+        }
+        wave_sync();
+        // c) flux
+        if (F && fb < nb) {  // nb * fpw * 2 <= 64 (host): one item per lane
+            double sum = 0.0;
+            for (int t = 0; t < fcount; ++t) sum = add_rn(sum, pF[2 * t]);
+            const double other = __shfl_xor(sum, 1);  // the upper half sits in the neighbouring lane
+            if (fh == 0 && fi < n_nu) {
+                const double tot = add_rn(sum, other);
+                double* dst = F + (size_t)(gap0 + fb + 1) * fld + fi;
+                *dst = accumulate ? add_rn(*dst, tot) : tot;
+            }
+        }
+        wave_sync();
     }
 }
 

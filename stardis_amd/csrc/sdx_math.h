@@ -266,7 +266,9 @@ __device__ __forceinline__ double exp_neg(double tau)
     double r = fma(n, -0x1.62e42fefa39efp-1, -tau);                    // -ln2 (high part)
     r = fma(-0x1.abc9e3b39803fp-56, n, r);                             // -ln2 (low part)
     // the nine three-address Horner steps as ONE asm block: after every separate asm statement the compiler inserts a
-    // defensive s_nop, which would hand back the issue slots the three-address form saves
+    // defensive s_nop, which would hand back the issue slots the three-address form saves.  The coefficients sit in SGPR
+    // pairs (one scalar operand per VALU instruction is allowed): as VGPR operands they would pin 20 vector registers
+    // across the caller's whole loop; only the leading coefficient, the second constant of the first step, is a VGPR.
     double p;
     asm("v_fma_f64 %0, %2, %1, %3\n\t"
         "v_fma_f64 %0, %1, %0, %4\n\t"
@@ -278,9 +280,9 @@ __device__ __forceinline__ double exp_neg(double tau)
         "v_fma_f64 %0, %1, %0, %10\n\t"
         "v_fma_f64 %0, %1, %0, %11"
         : "=&v"(p)
-        : "v"(r), "v"(0x1.ade156a5dcb37p-26), "v"(0x1.28af3fca7ab0cp-22), "v"(0x1.71dee623fde64p-19), "v"(0x1.a01997c89e6b0p-16),
-          "v"(0x1.a01a014761f6ep-13), "v"(0x1.6c16c1852b7b0p-10), "v"(0x1.1111111122322p-7), "v"(0x1.55555555502a1p-5),
-          "v"(0x1.5555555555511p-3), "v"(0x1.000000000000bp-1));
+        : "v"(r), "v"(0x1.ade156a5dcb37p-26), "s"(0x1.28af3fca7ab0cp-22), "s"(0x1.71dee623fde64p-19), "s"(0x1.a01997c89e6b0p-16),
+          "s"(0x1.a01a014761f6ep-13), "s"(0x1.6c16c1852b7b0p-10), "s"(0x1.1111111122322p-7), "s"(0x1.55555555502a1p-5),
+          "s"(0x1.5555555555511p-3), "s"(0x1.000000000000bp-1));
     p = fma(r, p, 1.0);
     p = fma(r, p, 1.0);
     return ldexp(p, (int)n);

@@ -73,6 +73,13 @@ struct sdx_ctx {
     hipEvent_t t0 = nullptr, t1 = nullptr;
     void* cont_ws = nullptr;  // continuum plane [n_depth][nu_count] of the fused step
     size_t cont_ws_bytes = 0;
+    // staging of the host-pointer (*_f64) entry points: one device arena and one pinned host buffer, grown on demand and kept
+    void* io_dev = nullptr;
+    size_t io_dev_bytes = 0;
+    void* io_pin = nullptr;
+    size_t io_pin_bytes = 0;
+    // bumped whenever a scratch buffer is reallocated: hipGraphs captured earlier hold the old device pointers
+    uint64_t ws_generation = 0;
     bool profile = false;
     std::vector<ProfileRecord> records;
     std::vector<hipEvent_t> event_pool;
@@ -97,6 +104,7 @@ int ensure(sdx_ctx* ctx, void** buf, size_t* have, size_t need)
     }
     HIP_TRY(hipMalloc(buf, need));
     *have = need;
+    ++ctx->ws_generation;
     return SDX_OK;
 }
 
@@ -292,6 +300,8 @@ void sdx_destroy(sdx_ctx* ctx)
     if (ctx->cnt_ws) hipFree(ctx->cnt_ws);
     if (ctx->mask_ws) hipFree(ctx->mask_ws);
     if (ctx->dense_ws) hipFree(ctx->dense_ws);
+    if (ctx->io_dev) hipFree(ctx->io_dev);
+    if (ctx->io_pin) hipHostFree(ctx->io_pin);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -399,6 +409,13 @@ int sdx_graph_begin(sdx_ctx* ctx)
     return SDX_OK;
 }
 
+// A captured graph has the context's scratch pointers baked in: the handle remembers the workspace generation it was
+// captured under and sdx_graph_launch refuses to replay it after any scratch buffer has been reallocated since.
+struct GraphHandle {
+    hipGraphExec_t exec;
+    uint64_t generation;
+};
+
 int sdx_graph_end(sdx_ctx* ctx, void** graph_exec_out)
 {
     REQUIRE(ctx && graph_exec_out, "sdx_graph_end: null pointer");
@@ -408,21 +425,30 @@ int sdx_graph_end(sdx_ctx* ctx, void** graph_exec_out)
     hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     hipGraphDestroy(graph);
     if (e != hipSuccess) return fail(SDX_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
-    *graph_exec_out = (void*)exec;
+    *graph_exec_out = (void*)new GraphHandle{exec, ctx->ws_generation};
     return SDX_OK;
 }
 
 int sdx_graph_launch(sdx_ctx* ctx, void* graph_exec)
 {
     REQUIRE(ctx && graph_exec, "sdx_graph_launch: null pointer");
-    HIP_TRY(hipGraphLaunch((hipGraphExec_t)graph_exec, ctx->stream));
+    GraphHandle* h = (GraphHandle*)graph_exec;
+    if (h->generation != ctx->ws_generation)
+        return fail(SDX_ERR_STALE, "graph is stale: the context's workspace was reallocated after the capture (a larger problem ran on the "
+                                   "same context); capture again");
+    HIP_TRY(hipGraphLaunch(h->exec, ctx->stream));
     return SDX_OK;
 }
 
 int sdx_graph_destroy(sdx_ctx* ctx, void* graph_exec)
 {
     REQUIRE(ctx, "null context");
-    if (graph_exec) HIP_TRY(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+    if (graph_exec) {
+        GraphHandle* h = (GraphHandle*)graph_exec;
+        hipError_t e = hipGraphExecDestroy(h->exec);
+        delete h;
+        if (e != hipSuccess) return fail(SDX_ERR_HIP, std::string("hipGraphExecDestroy: ") + hipGetErrorString(e));
+    }
     return SDX_OK;
 }
 
@@ -587,7 +613,7 @@ static int choose_splits(int n_depth, int64_t n_nu_global, int64_t n_lines, int 
     // at least two subsets: the choice must not depend on the shard (it fixes the summation order), and a rank that owns
     // 1/8 of a large grid still needs enough blocks; on a large unsharded grid the second plane costs ~1 % (S-c3)
     const int64_t want = std::max<int64_t>(2, (target + tiles * n_depth - 1) / (tiles * n_depth));
-    return (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(want, chunks), 32));
+    return (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(want, chunks), 8));  // the subsets are the waves of one workgroup
 }
 
 // pre-pass + the two gather kernels; leaves *n_planes_out partial planes in *partial_out ([planes][n_depth][*pld_out]):
@@ -627,38 +653,31 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
         hipLaunchKernelGGL(k_count_lists, grid, dim3(64), 0, ctx->stream, n_depth, n_lines, w, block_cnt);
         hipLaunchKernelGGL(k_build_lists, grid, dim3(kBlock), 0, ctx->stream, n_depth, n_lines, line_nus, w, (const int*)block_cnt);
     }
-    rc = ensure(ctx, &ctx->part_ws, &ctx->part_ws_bytes, (size_t)(n_split + 1) * n_depth * nu_count * sizeof(double));
+    // two planes: [0] wide windows (the S subsets are summed inside their workgroup), [1] narrow windows
+    rc = ensure(ctx, &ctx->part_ws, &ctx->part_ws_bytes, (size_t)2 * n_depth * nu_count * sizeof(double));
     if (rc) return rc;
     double* part = (double*)ctx->part_ws;
     const int64_t pld = nu_count;
     const int tiles = (int)((nu_count + 64 * R - 1) / (64 * R));
-    const int64_t n_wide = (int64_t)tiles * n_split * n_depth;
-    const int64_t n_narrow = nu_count * ((n_depth + 63) / 64);
+    const int64_t n_wide = (int64_t)tiles * n_depth;
+    const int64_t n_narrow = (nu_count * ((n_depth + 63) / 64) + n_split - 1) / n_split;  // workgroups of n_split waves
+    REQUIRE(n_wide + n_narrow < ((int64_t)1 << 31), "line opacity: grid too large for one launch");
     static const bool split_launches = std::getenv("SDX_SPLIT_LAUNCHES") != nullptr;  // analysis knob: time the two roles apart
-    if ((!split_launches || indexed || ctx->mixed_precision) && n_wide + n_narrow < ((int64_t)1 << 31)) {
-        LaunchScope ls(ctx, "k_line_all");
-        const dim3 g((unsigned)(n_wide + n_narrow));
-#define SDX_LINE_ARGS (int)n_wide, tiles, n_split, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, part, pld
-        if (indexed && ctx->mixed_precision) hipLaunchKernelGGL((k_line_all<R, true, true>), g, dim3(64), 0, ctx->stream, SDX_LINE_ARGS);
-        else if (indexed) hipLaunchKernelGGL((k_line_all<R, true, false>), g, dim3(64), 0, ctx->stream, SDX_LINE_ARGS);
-        else if (ctx->mixed_precision) hipLaunchKernelGGL((k_line_all<R, false, true>), g, dim3(64), 0, ctx->stream, SDX_LINE_ARGS);
-        else hipLaunchKernelGGL((k_line_all<R, false, false>), g, dim3(64), 0, ctx->stream, SDX_LINE_ARGS);
+    const size_t shmem = (size_t)n_split * kWideLdsDoubles * sizeof(double);
+    const dim3 g((unsigned)(n_wide + n_narrow)), blk((unsigned)(64 * n_split));
+    for (int pass = 0; pass < (split_launches ? 2 : 1); ++pass) {
+        const int roles = split_launches ? (1 << pass) : 3;
+        LaunchScope ls(ctx, split_launches ? (pass ? "k_line_narrow" : "k_line_wide") : "k_line_all");
+#define SDX_LINE_ARGS (int)n_wide, tiles, n_split, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, part, pld, roles
+        if (indexed && ctx->mixed_precision) hipLaunchKernelGGL((k_line_all<R, true, true>), g, blk, shmem, ctx->stream, SDX_LINE_ARGS);
+        else if (indexed) hipLaunchKernelGGL((k_line_all<R, true, false>), g, blk, shmem, ctx->stream, SDX_LINE_ARGS);
+        else if (ctx->mixed_precision) hipLaunchKernelGGL((k_line_all<R, false, true>), g, blk, shmem, ctx->stream, SDX_LINE_ARGS);
+        else hipLaunchKernelGGL((k_line_all<R, false, false>), g, blk, shmem, ctx->stream, SDX_LINE_ARGS);
 #undef SDX_LINE_ARGS
-    } else {
-        {
-            LaunchScope ls(ctx, "k_line_wide");
-            hipLaunchKernelGGL(k_line_wide<R>, dim3((unsigned)tiles, (unsigned)n_split, (unsigned)n_depth), dim3(64), 0, ctx->stream, n_nu,
-                               nus, nu_begin, nu_count, n_lines, line_nus, w, part, pld, n_depth);
-        }
-        rc = check_launch("k_line_wide");
-        if (rc) return rc;
-        LaunchScope ls(ctx, "k_line_narrow");
-        hipLaunchKernelGGL(k_line_narrow, dim3((unsigned)nu_count, (unsigned)((n_depth + 63) / 64)), dim3(64), 0, ctx->stream, n_depth,
-                           n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, part + (size_t)n_split * n_depth * pld, pld);
     }
     *partial_out = part;
     *pld_out = pld;
-    *n_planes_out = n_split + 1;
+    *n_planes_out = 2;
     if (w_out) *w_out = w;
     return check_launch("line kernels");
 }
@@ -803,23 +822,91 @@ int sdx_line_windows_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
                         nullptr);
 }
 
-// host-pointer variant: what a numpy caller (the reference's calc_alpha_line_at_nu, base.py:432-439) binds
-struct DevBuf {
-    void* p = nullptr;
-    ~DevBuf()
+// Host-pointer (*_f64) entry points — what a numpy caller (the reference's calc_alpha_line_at_nu, base.py:432-439) binds.
+// Their device buffers are sub-allocated from ONE arena owned by the context and their transfers go through ONE pinned host
+// buffer, both grown on demand and kept across calls: a call costs no hipMalloc / hipFree and every copy is a DMA from / to
+// page-locked memory.  Inputs: memcpy user -> pinned, async DMA pinned -> device (the DMA of array k overlaps the memcpy of
+// array k + 1).  Outputs: async DMA device -> pinned, one synchronize, memcpy pinned -> user.  Transfers beyond
+// kPinnedStagingMax go straight from / to the caller's pages (the runtime pins them on the fly).
+constexpr size_t kPinnedStagingMax = (size_t)512 << 20;
+
+struct HostIo {
+    sdx_ctx* ctx;
+    size_t dev_off = 0, pin_off = 0;
+    bool pinned = true;
+    struct Pending {
+        void* dst;
+        const void* src_pin;
+        size_t bytes;
+    };
+    std::vector<Pending> pending;
+
+    static size_t pad(size_t b) { return (b + 255) & ~(size_t)255; }
+
+    // sizes: total device bytes and total staged host bytes of the call (padded per array by the caller through need())
+    int begin(size_t dev_need, size_t pin_need)
     {
-        if (p) hipFree(p);
+        static const bool no_pin = std::getenv("SDX_NO_PINNED_STAGING") != nullptr;
+        pinned = !no_pin && pin_need <= kPinnedStagingMax;
+        if (ctx->io_dev_bytes < dev_need) {
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            if (ctx->io_dev) HIP_TRY(hipFree(ctx->io_dev));
+            ctx->io_dev = nullptr;
+            ctx->io_dev_bytes = 0;
+            const size_t want = dev_need + dev_need / 4;  // head-room: repeated calls with slowly growing sizes do not reallocate each time
+            HIP_TRY(hipMalloc(&ctx->io_dev, want));
+            ctx->io_dev_bytes = want;
+        }
+        if (pinned && ctx->io_pin_bytes < pin_need) {
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            if (ctx->io_pin) HIP_TRY(hipHostFree(ctx->io_pin));
+            ctx->io_pin = nullptr;
+            ctx->io_pin_bytes = 0;
+            const size_t want = pin_need + pin_need / 4;
+            HIP_TRY(hipHostMalloc(&ctx->io_pin, want, hipHostMallocDefault));
+            ctx->io_pin_bytes = want;
+        }
+        return SDX_OK;
     }
-    int alloc(size_t bytes)
+    void* alloc(size_t bytes)
     {
-        hipError_t e = hipMalloc(&p, bytes ? bytes : 8);
-        return e == hipSuccess ? SDX_OK : fail(SDX_ERR_OOM, std::string("hipMalloc: ") + hipGetErrorString(e));
+        void* p = (char*)ctx->io_dev + dev_off;
+        dev_off += pad(bytes ? bytes : 8);
+        return p;
     }
-    int upload(sdx_ctx* ctx, const void* src, size_t bytes)
+    int upload(const void* src, size_t bytes, const void** dev_out)
     {
-        int rc = alloc(bytes);
-        if (rc) return rc;
-        if (bytes) HIP_TRY(hipMemcpyAsync(p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        void* d = alloc(bytes);
+        *dev_out = d;
+        if (!bytes) return SDX_OK;
+        const void* from = src;
+        if (pinned) {
+            void* h = (char*)ctx->io_pin + pin_off;
+            pin_off += pad(bytes);
+            std::memcpy(h, src, bytes);
+            from = h;
+        }
+        HIP_TRY(hipMemcpyAsync(d, from, bytes, hipMemcpyHostToDevice, ctx->stream));
+        return SDX_OK;
+    }
+    int download(void* dst, const void* dev_src, size_t bytes)
+    {
+        if (!bytes) return SDX_OK;
+        if (pinned) {
+            void* h = (char*)ctx->io_pin + pin_off;
+            pin_off += pad(bytes);
+            HIP_TRY(hipMemcpyAsync(h, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+            pending.push_back({dst, h, bytes});
+        } else {
+            HIP_TRY(hipMemcpyAsync(dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        return SDX_OK;
+    }
+    int finish()
+    {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        for (auto& p : pending) std::memcpy(p.dst, p.src_pin, p.bytes);
+        pending.clear();
         return SDX_OK;
     }
 };
@@ -853,23 +940,25 @@ int sdx_line_opacity_f64(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
     for (int64_t k = 0; k < n_lines * n_depth; ++k)
         if (doppler[k] == 0.0) return fail(SDX_ERR_ARG, "doppler_width == 0 (ZeroDivisionError in the reference, voigt.py:148)");
     HIP_TRY(hipSetDevice(ctx->device));
-    DevBuf d_nus, d_ln, d_dw, d_g, d_a, d_out, d_ev;
-    const size_t ld = (size_t)n_lines * n_depth * sizeof(double);
-    if ((rc = d_nus.upload(ctx, nus, n_nu * sizeof(double)))) return rc;
-    if ((rc = d_ln.upload(ctx, line_nus, n_lines * sizeof(double)))) return rc;
-    if ((rc = d_dw.upload(ctx, doppler, ld))) return rc;
-    if ((rc = d_g.upload(ctx, gammas, (size_t)n_lines * gamma_cols * sizeof(double)))) return rc;
-    if ((rc = d_a.upload(ctx, alphas, ld))) return rc;
-    if ((rc = d_out.alloc((size_t)n_depth * n_nu * sizeof(double)))) return rc;
-    if ((rc = d_ev.alloc(sizeof(int64_t)))) return rc;
-    rc = sdx_line_opacity_dev(ctx, n_depth, n_nu, (const double*)d_nus.p, 0, n_nu, n_lines, (const double*)d_ln.p,
-                              (const double*)d_dw.p, (const double*)d_g.p, gamma_cols, (const double*)d_a.p, (double*)d_out.p,
-                              n_nu, 0, (int64_t*)d_ev.p);
+    const size_t f8 = sizeof(double), ld = (size_t)n_lines * n_depth * f8, plane = (size_t)n_depth * n_nu * f8;
+    const size_t in_bytes[] = {(size_t)n_nu * f8, (size_t)n_lines * f8, ld, (size_t)n_lines * gamma_cols * f8, ld};
+    size_t dev_need = HostIo::pad(plane) + 256, pin_need = HostIo::pad(plane) + 256;
+    for (size_t b : in_bytes) dev_need += HostIo::pad(b ? b : 8), pin_need += HostIo::pad(b);
+    HostIo io{ctx};
+    if ((rc = io.begin(dev_need, pin_need))) return rc;
+    const double *d_nus, *d_ln, *d_dw, *d_g, *d_a;
+    if ((rc = io.upload(nus, in_bytes[0], (const void**)&d_nus)) || (rc = io.upload(line_nus, in_bytes[1], (const void**)&d_ln)) ||
+        (rc = io.upload(doppler, in_bytes[2], (const void**)&d_dw)) || (rc = io.upload(gammas, in_bytes[3], (const void**)&d_g)) ||
+        (rc = io.upload(alphas, in_bytes[4], (const void**)&d_a)))
+        return rc;
+    double* d_out = (double*)io.alloc(plane);
+    int64_t* d_ev = (int64_t*)io.alloc(sizeof(int64_t));
+    rc = sdx_line_opacity_dev(ctx, n_depth, n_nu, d_nus, 0, n_nu, n_lines, d_ln, d_dw, d_g, gamma_cols, d_a, d_out, n_nu, 0, d_ev);
     if (rc) return rc;
-    if (n_nu) HIP_TRY(hipMemcpyAsync(out, d_out.p, (size_t)n_depth * n_nu * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     int64_t ev = 0;
-    HIP_TRY(hipMemcpyAsync(&ev, d_ev.p, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if ((rc = io.download(out, d_out, plane))) return rc;
+    HIP_TRY(hipMemcpyAsync(&ev, d_ev, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = io.finish())) return rc;
     if (n_evaluations) *n_evaluations = ev;
     return SDX_OK;
 }
@@ -1194,13 +1283,57 @@ static int raytrace_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, c
     REQUIRE(nus && temps && ray_dist && wts && ((alphas && ald >= n_nu) || ft.cont), "raytrace: null pointer");
     REQUIRE(!ft.cont || n_theta <= 64, "raytrace: the fused total needs all angles in one launch");
     REQUIRE((F && fld >= n_nu) || I_nus, "raytrace: no output requested");
-    // Angles per lane P and lanes per frequency G = ceil(n_theta / P).  P = 1 (one lane per (frequency, angle)) is the
-    // default at every size measured; SDX_RT_P overrides it for experiments.
     constexpr int kMaxChunk = 64;
+    // Default: the coefficient-parallel kernel k_formal (plane-parallel sweep).  The lane <-> (frequency, angle) kernel
+    // k_raytrace remains for the inward sweep of spherical geometry, for models too deep for k_formal's LDS columns, and
+    // for A/B runs (SDX_RT_LEGACY=1).
+    static const bool legacy = std::getenv("SDX_RT_LEGACY") != nullptr;
     for (int th0 = 0; th0 < n_theta; th0 += kMaxChunk) {
         const int nth = std::min(kMaxChunk, n_theta - th0);
-        const int64_t work = n_nu * (int64_t)nth;
-        (void)work;
+        const double* rd = ray_dist + th0;
+        const double* w = wts + th0;
+        double* inus = I_nus ? I_nus + th0 : nullptr;
+        const int acc = (accumulate || th0 > 0) ? 1 : 0;
+        if (!inward && !legacy) {
+            // frequencies per wave: 1 while that still leaves fewer than ~8 waves per SIMD (a SIMD needs that many to issue at
+            // its full rate), more — fewer instructions per frequency in the recurrence and flux phases — on long grids.
+            // B = gaps per batch: a multiple of the gaps one coefficient round covers (64 / (fpw n_theta)) wastes no lanes
+            const int fpw_max = std::max(1, 64 / nth);
+            int fpw = (int)std::max<int64_t>(1, std::min<int64_t>(fpw_max, n_nu / (8 * 4 * (int64_t)ctx->n_cu)));
+            if (const char* e = std::getenv("SDX_RT_FPW")) fpw = std::max(1, std::min(fpw_max, std::atoi(e)));
+            int bsel = 0;
+            if (const char* e = std::getenv("SDX_RT_B")) bsel = std::atoi(e);
+            auto pick_b = [&](int f) {
+                if (bsel == 6 || bsel == 8 || bsel == 9 || bsel == 12) return bsel;
+                const int gpr = 64 / (f * nth);
+                return gpr == 3 ? 9 : 8;
+            };
+            auto lds = [&](int f, int B) {
+                const size_t col = (size_t)n_depth + 2;
+                return ((size_t)n_depth * nth + (size_t)(kFormalBlock / 64) * (2 * f * col + std::max<size_t>((size_t)2 * B * f * nth, f * col))) * sizeof(double);
+            };
+            // one flux item per lane: B fpw 2 <= 64
+            while (fpw > 1 && (lds(fpw, pick_b(fpw)) > 64 * 1024 || 2 * pick_b(fpw) * fpw > 64)) --fpw;
+            const int B = pick_b(fpw);
+            if (nth >= 8 && lds(fpw, B) <= 64 * 1024 && 2 * B * fpw <= 64) {
+                const size_t shmem = lds(fpw, B);
+                const unsigned blocks = (unsigned)((n_nu + (int64_t)fpw * (kFormalBlock / 64) - 1) / ((int64_t)fpw * (kFormalBlock / 64)));
+                {
+                    LaunchScope ls(ctx, "k_raytrace");
+#define SDX_RT_ARGS n_depth, n_nu, nth, n_theta, nus, temps, rd, w, alphas, ald, F, fld, inus, acc, fpw, ft
+                    if (B == 6) hipLaunchKernelGGL(k_formal<6>, dim3(blocks), dim3(kFormalBlock), shmem, ctx->stream, SDX_RT_ARGS);
+                    else if (B == 9) hipLaunchKernelGGL(k_formal<9>, dim3(blocks), dim3(kFormalBlock), shmem, ctx->stream, SDX_RT_ARGS);
+                    else if (B == 12) hipLaunchKernelGGL(k_formal<12>, dim3(blocks), dim3(kFormalBlock), shmem, ctx->stream, SDX_RT_ARGS);
+                    else hipLaunchKernelGGL(k_formal<8>, dim3(blocks), dim3(kFormalBlock), shmem, ctx->stream, SDX_RT_ARGS);
+#undef SDX_RT_ARGS
+                }
+                int rc = check_launch("k_formal");
+                if (rc) return rc;
+                continue;
+            }
+        }
+        // Angles per lane P and lanes per frequency G = ceil(n_theta / P).  P = 1 (one lane per (frequency, angle)) is the
+        // default at every size measured; SDX_RT_P overrides it for experiments.
         int P = 1;  // measured on MI355X at 7.6e3 and 1.2e5 frequencies: one angle per lane wins (more waves in flight)
         if (const char* e = std::getenv("SDX_RT_P")) {  // tuning knob: angles per lane (1, 2 or 4)
             const int v = std::atoi(e);
@@ -1218,10 +1351,6 @@ static int raytrace_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, c
         const size_t shmem = lds_bytes(gpw);
         const unsigned blocks = (unsigned)((n_nu + (int64_t)gpw * (kBlock / 64) - 1) / ((int64_t)gpw * (kBlock / 64)));
         const unsigned blocks_basic = (unsigned)((n_nu + (int64_t)(64 / G) * (kBlock / 64) - 1) / ((int64_t)(64 / G) * (kBlock / 64)));
-        const double* rd = ray_dist + th0;
-        const double* w = wts + th0;
-        double* inus = I_nus ? I_nus + th0 : nullptr;
-        const int acc = (accumulate || th0 > 0) ? 1 : 0;
         {
             LaunchScope ls(ctx, "k_raytrace");
 #define SDX_RT_ARGS n_depth, n_nu, nth, n_theta, G, nus, temps, rd, w, alphas, ald, F, fld, inus, acc
@@ -1252,22 +1381,24 @@ int sdx_raytrace_f64(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, const
     if (n_nu == 0) return SDX_OK;
     HIP_TRY(hipSetDevice(ctx->device));
     int rc;
-    DevBuf d_nus, d_t, d_rd, d_w, d_a, d_f, d_i;
-    const size_t plane = (size_t)n_depth * n_nu * sizeof(double);
-    if ((rc = d_nus.upload(ctx, nus, n_nu * sizeof(double)))) return rc;
-    if ((rc = d_t.upload(ctx, temps, n_depth * sizeof(double)))) return rc;
-    if ((rc = d_rd.upload(ctx, ray_dist, (size_t)(n_depth - 1) * n_theta * sizeof(double)))) return rc;
-    if ((rc = d_w.upload(ctx, wts, n_theta * sizeof(double)))) return rc;
-    if ((rc = d_a.upload(ctx, alphas, plane))) return rc;
-    if ((rc = d_f.upload(ctx, F, plane))) return rc;  // F_nu is accumulated into (base.py:336)
-    if (I_nus && (rc = d_i.alloc(plane * n_theta))) return rc;
-    rc = sdx_raytrace_dev(ctx, n_depth, n_nu, n_theta, (const double*)d_nus.p, (const double*)d_t.p, (const double*)d_rd.p,
-                          (const double*)d_w.p, (const double*)d_a.p, n_nu, (double*)d_f.p, n_nu, (double*)d_i.p, 1);
+    const size_t f8 = sizeof(double), plane = (size_t)n_depth * n_nu * f8;
+    const size_t in_bytes[] = {(size_t)n_nu * f8, (size_t)n_depth * f8, (size_t)(n_depth - 1) * n_theta * f8, (size_t)n_theta * f8, plane, plane};
+    size_t dev_need = 256, pin_need = HostIo::pad(plane) + 256;
+    for (size_t b : in_bytes) dev_need += HostIo::pad(b), pin_need += HostIo::pad(b);
+    if (I_nus) dev_need += HostIo::pad(plane * n_theta), pin_need += HostIo::pad(plane * n_theta);
+    HostIo io{ctx};
+    if ((rc = io.begin(dev_need, pin_need))) return rc;
+    const double *d_nus, *d_t, *d_rd, *d_w, *d_a, *d_f;
+    if ((rc = io.upload(nus, in_bytes[0], (const void**)&d_nus)) || (rc = io.upload(temps, in_bytes[1], (const void**)&d_t)) ||
+        (rc = io.upload(ray_dist, in_bytes[2], (const void**)&d_rd)) || (rc = io.upload(wts, in_bytes[3], (const void**)&d_w)) ||
+        (rc = io.upload(alphas, in_bytes[4], (const void**)&d_a)) || (rc = io.upload(F, in_bytes[5], (const void**)&d_f)))  // F_nu is accumulated into (base.py:336)
+        return rc;
+    double* d_i = I_nus ? (double*)io.alloc(plane * n_theta) : nullptr;
+    rc = sdx_raytrace_dev(ctx, n_depth, n_nu, n_theta, d_nus, d_t, d_rd, d_w, d_a, n_nu, (double*)d_f, n_nu, d_i, 1);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(F, d_f.p, plane, hipMemcpyDeviceToHost, ctx->stream));
-    if (I_nus) HIP_TRY(hipMemcpyAsync(I_nus, d_i.p, plane * n_theta, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return SDX_OK;
+    if ((rc = io.download(F, d_f, plane))) return rc;
+    if (I_nus && (rc = io.download(I_nus, d_i, plane * n_theta))) return rc;
+    return io.finish();
 }
 
 // ================================================================================================ post-processing
@@ -1304,7 +1435,7 @@ static int synthesize_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double
     int rc;
     REQUIRE(cont && temps && ray_dist && wts && n_theta > 0 && n_depth >= 2, "synthesize: bad arguments");
     REQUIRE(nu_begin >= 0 && nu_count >= 0 && nu_begin + nu_count <= n_nu, "synthesize: shard outside the grid");
-    REQUIRE(nu_count == 0 || (total_alphas && F_nu && ld >= nu_count), "synthesize: bad output buffers");
+    REQUIRE(nu_count == 0 || (F_nu && ld >= nu_count), "synthesize: bad output buffers");
     if (nu_count == 0) return SDX_OK;
     // Three launches on one stream: [pre-pass + continuum plane] -> [wide + narrow line kernels] -> [raytrace, which
     // forms total = continuum + line while staging its columns].  Independent work shares a launch instead of a
@@ -1312,7 +1443,12 @@ static int synthesize_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double
     int rc2 = ensure(ctx, &ctx->cont_ws, &ctx->cont_ws_bytes, (size_t)n_depth * nu_count * sizeof(double));
     if (rc2) return rc2;
     double* cont_plane = (double*)ctx->cont_ws;
-    const bool fuse = n_theta <= 64 && ((size_t)2 * (n_depth - 1) * n_theta + (size_t)4 * (4 * (size_t)n_depth + 8 * 64)) * sizeof(double) <= 64 * 1024;
+    // the formal solution can form total = continuum + line planes while staging its columns when those fit LDS
+    // (k_formal with one frequency per wave, or k_raytrace's layout)
+    const size_t lds_formal = n_theta >= 8 ? ((size_t)n_depth * n_theta + (size_t)(kFormalBlock / 64) * (2 * ((size_t)n_depth + 2) + std::max<size_t>((size_t)24 * n_theta, (size_t)n_depth + 2))) * sizeof(double)
+                                           : (size_t)-1;
+    const size_t lds_legacy = ((size_t)2 * (n_depth - 1) * n_theta + (size_t)4 * (4 * (size_t)n_depth + 8 * 64)) * sizeof(double);
+    const bool fuse = n_theta <= 64 && std::min(lds_formal, lds_legacy) <= 64 * 1024;
     const ContinuumJob job{cont, nu_begin, nu_count, cont_plane};
     const double* part = nullptr;
     int64_t pld = 0;
@@ -1331,22 +1467,25 @@ static int synthesize_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double
             HIP_TRY(hipMemset2DAsync(alpha_line_out, ld * sizeof(double), 0, nu_count * sizeof(double), n_depth, ctx->stream));
     }
     if (!fuse) {
+        // total = continuum (+ line planes), element-wise; without a caller buffer the continuum plane becomes the total in place
+        double* total = total_alphas ? total_alphas : cont_plane;
+        const int64_t tld = total_alphas ? ld : nu_count;
         {
-            LaunchScope ls(ctx, "k_reduce_partials");  // total = continuum (+ line planes), element-wise
-            HIP_TRY(hipMemcpy2DAsync(total_alphas, ld * sizeof(double), cont_plane, nu_count * sizeof(double), nu_count * sizeof(double),
-                                     n_depth, hipMemcpyDeviceToDevice, ctx->stream));
+            LaunchScope ls(ctx, "k_reduce_partials");
+            if (total_alphas)
+                HIP_TRY(hipMemcpy2DAsync(total_alphas, ld * sizeof(double), cont_plane, nu_count * sizeof(double), nu_count * sizeof(double),
+                                         n_depth, hipMemcpyDeviceToDevice, ctx->stream));
             if (part) {
                 if (alpha_line_out)
                     hipLaunchKernelGGL(k_reduce_partials, grid2(nu_count, n_depth), dim3(kBlock), 0, ctx->stream, n_depth, nu_count,
                                        n_planes, part, pld, alpha_line_out, ld, 0);
                 hipLaunchKernelGGL(k_reduce_partials, grid2(nu_count, n_depth), dim3(kBlock), 0, ctx->stream, n_depth, nu_count, n_planes,
-                                   part, pld, total_alphas, ld, 1);
+                                   part, pld, total, tld, 1);
             }
         }
         rc = check_launch("k_reduce_partials");
         if (rc) return rc;
-        return sdx_raytrace_dev(ctx, n_depth, nu_count, n_theta, nus + nu_begin, temps, ray_dist, wts, total_alphas, ld, F_nu, ld,
-                                nullptr, 0);
+        return sdx_raytrace_dev(ctx, n_depth, nu_count, n_theta, nus + nu_begin, temps, ray_dist, wts, total, tld, F_nu, ld, nullptr, 0);
     }
     FusedTotal ft{};
     ft.cont = cont_plane;
@@ -1398,7 +1537,7 @@ int sdx_synthesize_f64(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nu
     int rc = check_line_args(ctx, n_depth, n_nu, nus, n_lines, line_nus, doppler, gammas, gamma_cols, alphas);
     if (rc) return rc;
     REQUIRE(cont && temps && ray_dist && wts && n_theta > 0 && n_depth >= 2, "synthesize: bad arguments");
-    REQUIRE(n_nu == 0 || (total_alphas && F_nu), "synthesize: null output");
+    REQUIRE(n_nu == 0 || F_nu, "synthesize: null output");
     if (n_nu == 0) return SDX_OK;
     if ((rc = host_grid_check(n_nu, nus))) return rc;
     if ((rc = host_lines_check(n_lines, line_nus))) return rc;
@@ -1406,50 +1545,62 @@ int sdx_synthesize_f64(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nu
         if (doppler[k] == 0.0) return fail(SDX_ERR_ARG, "doppler_width == 0 (ZeroDivisionError in the reference, voigt.py:148)");
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t f8 = sizeof(double), plane = (size_t)n_depth * n_nu * f8, ld = (size_t)n_lines * n_depth * f8;
-    DevBuf d_nus, d_ln, d_dw, d_g, d_a, d_t, d_rd, d_w, d_line, d_total, d_F, d_ev;
-    if ((rc = d_nus.upload(ctx, nus, n_nu * f8)) || (rc = d_ln.upload(ctx, line_nus, n_lines * f8)) || (rc = d_dw.upload(ctx, doppler, ld)) ||
-        (rc = d_g.upload(ctx, gammas, (size_t)n_lines * gamma_cols * f8)) || (rc = d_a.upload(ctx, alphas, ld)) ||
-        (rc = d_t.upload(ctx, temps, n_depth * f8)) || (rc = d_rd.upload(ctx, ray_dist, (size_t)(n_depth - 1) * n_theta * f8)) ||
-        (rc = d_w.upload(ctx, wts, n_theta * f8)) || (rc = d_line.alloc(plane)) || (rc = d_total.alloc(plane)) || (rc = d_F.alloc(plane)) ||
-        (rc = d_ev.alloc(sizeof(int64_t))))
-        return rc;
-    // continuum: every non-null host array goes up; lengths from the struct
     sdx_continuum c = *cont;
-    DevBuf b[16];
-    int nb = 0;
-    auto up = [&](const void* src, size_t bytes, const void** dst) -> int {
-        if (!src) return SDX_OK;
-        int r = b[nb].upload(ctx, src, bytes);
-        *dst = b[nb++].p;
-        return r;
-    };
     const int n_levels = c.bf_n_species > 0 ? c.bf_n_levels : 0;
     REQUIRE(c.bf_n_species == 0 || !c.bf_cutoff || n_levels > 0, "synthesize: bf_n_levels must be set");
-    if ((rc = up(cont->lambdas, n_nu * f8, (const void**)&c.lambdas)) || (rc = up(cont->table_wavelength, c.n_table * f8, (const void**)&c.table_wavelength)) ||
-        (rc = up(cont->table_sigma, c.n_table * f8, (const void**)&c.table_sigma)) ||
-        (rc = up(cont->table_density, n_depth * f8, (const void**)&c.table_density)) ||
-        (rc = up(cont->bf_species_offsets, (size_t)(c.bf_n_species + 1) * sizeof(int32_t), (const void**)&c.bf_species_offsets)) ||
-        (rc = up(cont->bf_species_ion_number, (size_t)c.bf_n_species * sizeof(int32_t), (const void**)&c.bf_species_ion_number)) ||
-        (rc = up(cont->bf_cutoff, (size_t)n_levels * f8, (const void**)&c.bf_cutoff)) ||
-        (rc = up(cont->bf_level_density, (size_t)n_levels * n_depth * f8, (const void**)&c.bf_level_density)) ||
-        (rc = up(cont->ff_species_ion_number, (size_t)c.ff_n_species * sizeof(int32_t), (const void**)&c.ff_species_ion_number)) ||
-        (rc = up(cont->ff_number_density, (size_t)c.ff_n_species * n_depth * f8, (const void**)&c.ff_number_density)) ||
-        (rc = up(cont->ray_n_h, n_depth * f8, (const void**)&c.ray_n_h)) || (rc = up(cont->ray_n_he, n_depth * f8, (const void**)&c.ray_n_he)) ||
-        (rc = up(cont->ray_n_h2, n_depth * f8, (const void**)&c.ray_n_h2)) ||
-        (rc = up(cont->electron_density, n_depth * f8, (const void**)&c.electron_density)))
-        return rc;
-    c.temperature = (const double*)d_t.p;
-    rc = sdx_synthesize_dev(ctx, n_depth, n_nu, (const double*)d_nus.p, 0, n_nu, n_lines, (const double*)d_ln.p, (const double*)d_dw.p,
-                            (const double*)d_g.p, gamma_cols, (const double*)d_a.p, &c, n_theta, (const double*)d_t.p, (const double*)d_rd.p,
-                            (const double*)d_w.p, alpha_line_out ? (double*)d_line.p : nullptr, (double*)d_total.p, (double*)d_F.p, n_nu,
-                            n_evaluations ? (int64_t*)d_ev.p : nullptr);
+    // every non-null host array goes up; lengths follow from the sizes in the struct
+    struct In {
+        const void* src;
+        size_t bytes;
+        const void** dst;
+    };
+    const double *d_nus, *d_ln, *d_dw, *d_g, *d_a, *d_t, *d_rd, *d_w;
+    const In ins[] = {
+        {nus, (size_t)n_nu * f8, (const void**)&d_nus},
+        {line_nus, (size_t)n_lines * f8, (const void**)&d_ln},
+        {doppler, ld, (const void**)&d_dw},
+        {gammas, (size_t)n_lines * gamma_cols * f8, (const void**)&d_g},
+        {alphas, ld, (const void**)&d_a},
+        {temps, (size_t)n_depth * f8, (const void**)&d_t},
+        {ray_dist, (size_t)(n_depth - 1) * n_theta * f8, (const void**)&d_rd},
+        {wts, (size_t)n_theta * f8, (const void**)&d_w},
+        {cont->lambdas, (size_t)n_nu * f8, (const void**)&c.lambdas},
+        {cont->table_wavelength, (size_t)c.n_table * f8, (const void**)&c.table_wavelength},
+        {cont->table_sigma, (size_t)c.n_table * f8, (const void**)&c.table_sigma},
+        {cont->table_density, (size_t)n_depth * f8, (const void**)&c.table_density},
+        {cont->bf_species_offsets, (size_t)(c.bf_n_species + 1) * sizeof(int32_t), (const void**)&c.bf_species_offsets},
+        {cont->bf_species_ion_number, (size_t)c.bf_n_species * sizeof(int32_t), (const void**)&c.bf_species_ion_number},
+        {cont->bf_cutoff, (size_t)n_levels * f8, (const void**)&c.bf_cutoff},
+        {cont->bf_level_density, (size_t)n_levels * n_depth * f8, (const void**)&c.bf_level_density},
+        {cont->ff_species_ion_number, (size_t)c.ff_n_species * sizeof(int32_t), (const void**)&c.ff_species_ion_number},
+        {cont->ff_number_density, (size_t)c.ff_n_species * n_depth * f8, (const void**)&c.ff_number_density},
+        {cont->ray_n_h, (size_t)n_depth * f8, (const void**)&c.ray_n_h},
+        {cont->ray_n_he, (size_t)n_depth * f8, (const void**)&c.ray_n_he},
+        {cont->ray_n_h2, (size_t)n_depth * f8, (const void**)&c.ray_n_h2},
+        {cont->electron_density, (size_t)n_depth * f8, (const void**)&c.electron_density},
+    };
+    const int n_out = 1 + (alpha_line_out ? 1 : 0) + (total_alphas ? 1 : 0);
+    size_t dev_need = (size_t)n_out * HostIo::pad(plane) + 512, pin_need = (size_t)n_out * HostIo::pad(plane) + 512;
+    for (const In& in : ins)
+        if (in.src) dev_need += HostIo::pad(in.bytes ? in.bytes : 8), pin_need += HostIo::pad(in.bytes);
+    HostIo io{ctx};
+    if ((rc = io.begin(dev_need, pin_need))) return rc;
+    for (const In& in : ins)
+        if (in.src && (rc = io.upload(in.src, in.bytes, in.dst))) return rc;
+    c.temperature = d_t;
+    double* d_line = alpha_line_out ? (double*)io.alloc(plane) : nullptr;
+    double* d_total = total_alphas ? (double*)io.alloc(plane) : nullptr;
+    double* d_F = (double*)io.alloc(plane);
+    int64_t* d_ev = (int64_t*)io.alloc(sizeof(int64_t));
+    rc = sdx_synthesize_dev(ctx, n_depth, n_nu, d_nus, 0, n_nu, n_lines, d_ln, d_dw, d_g, gamma_cols, d_a, &c, n_theta, d_t, d_rd, d_w, d_line,
+                            d_total, d_F, n_nu, n_evaluations ? d_ev : nullptr);
     if (rc) return rc;
-    if (alpha_line_out) HIP_TRY(hipMemcpyAsync(alpha_line_out, d_line.p, plane, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(total_alphas, d_total.p, plane, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(F_nu, d_F.p, plane, hipMemcpyDeviceToHost, ctx->stream));
+    if (alpha_line_out && (rc = io.download(alpha_line_out, d_line, plane))) return rc;
+    if (total_alphas && (rc = io.download(total_alphas, d_total, plane))) return rc;
+    if ((rc = io.download(F_nu, d_F, plane))) return rc;
     int64_t ev = 0;
-    if (n_evaluations) HIP_TRY(hipMemcpyAsync(&ev, d_ev.p, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (n_evaluations) HIP_TRY(hipMemcpyAsync(&ev, d_ev, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = io.finish())) return rc;
     if (n_evaluations) *n_evaluations = ev;
     return SDX_OK;
 }

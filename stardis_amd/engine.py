@@ -25,7 +25,7 @@ def shard_bounds(n_nu, world_size, rank):
 
 class SpectralSynthesizer:
     def __init__(self, nus, temperatures, dist, thetas, theta_weights, lines, continuum=None, ctx=None, shard=None,
-                 flux_out=None, track_evaluations=True, keep_line=True):
+                 flux_out=None, track_evaluations=True, keep_line=True, keep_total=True):
         """nus: global grid (descending).  lines: dict(line_nus, doppler_widths, gammas, alphas) in the
         reference layout (N_l, N_d), or a stardis_amd.linelist.LineList (per-line scalars; the pre-pass generates the
         three values per (line, depth) itself).  continuum: dict as produced by synth.synth_continuum_state or None.
@@ -50,6 +50,7 @@ class SpectralSynthesizer:
         self.n_theta = thetas.size
         ray = np.asarray(dist, dtype=np.float64).reshape(-1, 1) / np.cos(thetas)  # radiation_field_solvers/base.py:302-305
 
+        self.nus_host = nus
         self.d_nus = c.upload(nus)
         self.d_t = c.upload(t)
         self.d_ray = c.upload(ray)
@@ -85,6 +86,7 @@ class SpectralSynthesizer:
         self.d_F = None if flux_out is not None else c.empty((self.n_depth, self.count))
         self.d_evals = c.zeros((1,), np.int64) if track_evaluations else None
         self.keep_line = keep_line  # also write the summed line opacity plane (alpha_line())
+        self.keep_total = keep_total  # also write total_alphas (the reference keeps it on Opacities; the flux does not need it in HBM)
         self.count_evaluations = track_evaluations  # sum(hi - lo) per step costs a memset + copy: switch off when timing
         self.graph = None
         c.call("sdx_reserve_line_workspace", self.n_depth, self.n_lines)
@@ -132,13 +134,13 @@ class SpectralSynthesizer:
         if self.linelist is not None:
             c.call("sdx_synthesize_linelist_dev", self.n_depth, self.n_nu, self.d_nus.ptr, self.begin, self.count,
                    self.linelist.byref(), C.byref(self.cont), self.n_theta, self.d_t.ptr, self.d_ray.ptr, self.d_w.ptr,
-                   self.d_line.ptr if self.keep_line else None, self.d_total.ptr, self.flux_ptr, self.count,
+                   self.d_line.ptr if self.keep_line else None, self.d_total.ptr if self.keep_total else None, self.flux_ptr, self.count,
                    ptr_of(self.d_evals) if self.count_evaluations else None)
             return
         c.call("sdx_synthesize_dev", self.n_depth, self.n_nu, self.d_nus.ptr, self.begin, self.count, self.n_lines,
                self.d_ln.ptr, self.d_dw.ptr, self.d_g.ptr, self.gamma_cols, self.d_a.ptr, C.byref(self.cont), self.n_theta,
-               self.d_t.ptr, self.d_ray.ptr, self.d_w.ptr, self.d_line.ptr if self.keep_line else None, self.d_total.ptr,
-               self.flux_ptr, self.count, ptr_of(self.d_evals) if self.count_evaluations else None)
+               self.d_t.ptr, self.d_ray.ptr, self.d_w.ptr, self.d_line.ptr if self.keep_line else None,
+               self.d_total.ptr if self.keep_total else None, self.flux_ptr, self.count, ptr_of(self.d_evals) if self.count_evaluations else None)
 
     def enqueue_unfused(self):
         """The same step through the individual entry points (what calc_alphas + raytrace issue)."""
@@ -172,7 +174,14 @@ class SpectralSynthesizer:
 
     def step(self):
         if self.graph is not None:
-            self.ctx.call("sdx_graph_launch", self.graph)
+            try:
+                self.ctx.call("sdx_graph_launch", self.graph)
+            except _lib.StaleGraphError:
+                # another, larger synthesis on this context made the library reallocate its scratch: the captured pointers
+                # are dead.  Capture again (the scratch is large enough for both now) and replay.
+                self.close()
+                self.capture()
+                self.ctx.call("sdx_graph_launch", self.graph)
         else:
             self.enqueue()
 

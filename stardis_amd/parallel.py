@@ -58,6 +58,30 @@ def window_work(nus, line_nus, doppler_widths, gammas, alphas):
     return np.cumsum(cover)[:n]
 
 
+def window_evaluations(nus, line_nus, doppler_widths, gammas, alphas):
+    """sum over (line, depth) of hi - lo with the window rule of calc_alan_entries (opacities_solvers/base.py:524-575): the
+    number of Voigt evaluations of the whole grid, counted on the host in chunks of lines (the kernels count the same
+    quantity in their pre-pass)."""
+    nus = np.asarray(nus, dtype=np.float64)
+    n = nus.size
+    ln = np.asarray(line_nus, dtype=np.float64)
+    if n < 2 or ln.size == 0:
+        return 0
+    d_nu = -np.max(np.diff(nus))
+    centre = n - np.searchsorted(nus[::-1], ln)
+    g = np.asarray(gammas, dtype=np.float64).reshape(ln.size, -1)
+    dw = np.asarray(doppler_widths, dtype=np.float64)
+    al = np.asarray(alphas, dtype=np.float64)
+    total = 0
+    for a in range(0, ln.size, 65536):
+        b = min(a + 65536, ln.size)
+        pixels = (g[a:b] + dw[a:b]) * al[a:b] / d_nu * 20.0
+        hw = np.minimum(np.where(pixels > 10.0, pixels, 10.0), float(n)).astype(np.int64)
+        c = centre[a:b, None]
+        total += int(np.sum(np.clip(c + hw, 0, n) - np.clip(c - hw, 0, n)))
+    return total
+
+
 def balanced_shards(work, world_size, fixed_cost=0.0):
     """Contiguous shards of (nearly) equal work: -> list of (begin, count), one per rank.  `work` is a per-column cost
     (e.g. window_work(...) + a constant per column for the continuum and the formal solution); equal-width shards of a
@@ -91,27 +115,41 @@ class FluxGatherer:
     def start(self, local_flux):
         """Enqueue the all-gather behind the work already on the current stream and return at once; the kernels of
         the NEXT step (writing a different flux buffer) are not held back by it.  Call finish() before this
-        gatherer's buffers — or the flux buffer it read — are reused."""
+        gatherer's buffers — or the flux buffer it read — are reused.  With the gloo backend and device tensors the
+        collective runs on host copies (tests / no RCCL); otherwise it is asynchronous on either backend."""
         import torch.distributed as dist
 
         self._work = None
+        self._staged = False
         if self.world == 1:
-            return
-        if dist.get_backend() != "nccl":  # CPU collective (tests): nothing to overlap
-            self(local_flux)
+            self._single = local_flux
             return
         src = local_flux
         if local_flux.numel() != self.per:
             self.send[: local_flux.numel()] = local_flux
             src = self.send
+        if dist.get_backend() == "gloo" and src.is_cuda:  # CPU-side collective: stage through the host, then gather asynchronously
+            import torch
+
+            if self.host is None:
+                self.host = torch.empty(self.per * self.world, dtype=src.dtype)
+            self._host_src = src.cpu()
+            self._work = dist.all_gather_into_tensor(self.host, self._host_src, async_op=True)
+            self._staged = True
+            return
         self._work = dist.all_gather_into_tensor(self.recv, src, async_op=True)
 
     def finish(self):
-        """Make the current stream wait for the gather started by start()."""
+        """Wait for the gather started by start() (RCCL: the current stream waits; gloo: the host does) and return the
+        assembled spectrum; returns the previous result again when nothing is in flight."""
+        if self.world == 1:
+            return getattr(self, "_single", None)
         work = getattr(self, "_work", None)
         if work is not None:
             work.wait()
             self._work = None
+            if getattr(self, "_staged", False):
+                self.recv.copy_(self.host)
         return self._assemble()
 
     def _assemble(self):

@@ -7,7 +7,7 @@ scipy's summation order, so results agree with the reference bit for bit on the 
 import numpy as np
 
 from . import constants as K
-from ._lib import default_context
+from ._lib import default_context, ptr_of
 
 
 def _kms(x):
@@ -33,19 +33,27 @@ def rotation_profile(velocity_per_pix, v_rot, limb_darkening=0.6):
     return kernel / kernel.sum()
 
 
-def convolve1d_reflect(values, weights, ctx=None):
-    """scipy.ndimage.convolve1d(values, weights) (mode='reflect') on the GPU."""
+def convolve1d_reflect_device(d_values, n, weights, ctx=None):
+    """scipy.ndimage.convolve1d(values, weights) (mode='reflect') for n values already in HBM (a DeviceArray, a CUDA
+    tensor or a raw device address) -> DeviceArray.  Nothing but the few-hundred-number kernel crosses PCIe."""
     ctx = ctx or default_context()
-    v = np.ascontiguousarray(values, dtype=np.float64).reshape(-1)
     w = np.ascontiguousarray(weights, dtype=np.float64).reshape(-1)
     if w.size % 2 == 0:
         raise ValueError("only odd kernel lengths are supported")
     h = w.size // 2
     symmetric = bool(np.all(np.abs(w[h + 1 :] - w[:h][::-1]) <= np.finfo(np.float64).eps))  # scipy's test
-    d_v, d_w = ctx.upload(v), ctx.upload(w)
-    out = ctx.empty(v.shape)
-    ctx.call("sdx_convolve1d_reflect_dev", v.size, d_v.ptr, w.size, d_w.ptr, int(symmetric), out.ptr)
-    return out.numpy()
+    d_w = ctx.upload(w)
+    out = ctx.empty((int(n),))
+    ctx.call("sdx_convolve1d_reflect_dev", int(n), d_values if isinstance(d_values, int) else ptr_of(d_values), w.size, d_w.ptr,
+             int(symmetric), out.ptr)
+    return out
+
+
+def convolve1d_reflect(values, weights, ctx=None):
+    """scipy.ndimage.convolve1d(values, weights) (mode='reflect') on the GPU."""
+    ctx = ctx or default_context()
+    v = np.ascontiguousarray(values, dtype=np.float64).reshape(-1)
+    return convolve1d_reflect_device(ctx.upload(v), v.size, weights, ctx).numpy()
 
 
 def gaussian_kernel(sigma, truncate=4.0):
@@ -74,3 +82,38 @@ def rotation_broadening(velocity_per_pix, wavelength, flux, v_rot=0.0, limb_dark
     weights = rotation_profile(vpp, v, limb_darkening)
     values = np.asarray(getattr(flux, "value", flux), dtype=np.float64)
     return wavelength, convolve1d_reflect(values, weights)
+
+
+class DeviceSpectrum:
+    """The emergent spectrum kept in HBM from the formal solution to the broadened result (BASELINE configs[4]): what the
+    reference's walk-through does on the host with sim.spectrum_lambda (docs/rotation_broadening cells 7-19) —
+    F_lambda = F_nu[-1] nu / lambda (stardis/base.py:137-141), scipy.ndimage.gaussian_filter1d for the instrumental
+    line-spread function, rotation_broadening (broadening.py:824-877) — as three small kernels behind the synthesis."""
+
+    def __init__(self, synthesizer):
+        """synthesizer: a stardis_amd.engine.SpectralSynthesizer that owns the whole grid (shard = everything)."""
+        syn = synthesizer
+        if syn.begin != 0 or syn.count != syn.n_nu:
+            raise ValueError("post-processing needs the whole spectrum: gather the shards first")
+        self.syn, self.ctx, self.n = syn, syn.ctx, syn.n_nu
+        self.lambdas = K.nu_to_angstrom(syn.nus_host)
+        self.d_lambdas = self.ctx.upload(self.lambdas)
+        self.d_spectrum = self.ctx.empty((self.n,))
+
+    def spectrum_lambda(self):
+        """-> DeviceArray (N_nu,): F_lambda of the outermost depth point."""
+        syn = self.syn
+        row = syn.flux_ptr + 8 * (syn.n_depth - 1) * syn.count  # F_nu[-1]
+        self.ctx.call("sdx_flux_nu_to_lambda_dev", self.n, row, syn.d_nus.ptr, self.d_lambdas.ptr, self.d_spectrum.ptr)
+        return self.d_spectrum
+
+    def broadened(self, sigma_pix=None, velocity_per_pix=None, v_rot=0.0, limb_darkening=0.6):
+        """spectrum_lambda -> gaussian_filter1d(sigma_pix) (the instrumental line-spread function, cells 7-11: sigma =
+        lambda / R / dispersion / 2.355 pixels) -> rotation_broadening(velocity_per_pix, ..., v_rot) (cells 15-19).
+        Either stage is skipped when its parameter is None / |v_rot| < 1e-5 km/s (:866-867).  Returns the DeviceArray."""
+        d = self.spectrum_lambda()
+        if sigma_pix:
+            d = convolve1d_reflect_device(d, self.n, gaussian_kernel(float(sigma_pix)), self.ctx)
+        if velocity_per_pix is not None and abs(_kms(v_rot)) >= 1e-5:
+            d = convolve1d_reflect_device(d, self.n, rotation_profile(_kms(velocity_per_pix), _kms(v_rot), limb_darkening), self.ctx)
+        return d

@@ -28,6 +28,9 @@ WORKLOADS = {
     "S-c3": dict(lam0=3000.0, lam1=10000.0, R=1.0e5, n_lines=150000, gamma_per_depth=True),
     "S-c4": dict(lam0=3000.0, lam1=10000.0, R=1.0e5, n_lines=1000000, gamma_per_depth=False),
     "S-big": dict(lam0=3000.0, lam1=10000.0, R=1.0e6, n_lines=1000000, gamma_per_depth=False),
+    # BASELINE config 5: the full solar spectrum of config 3, synthesised with the fp32-mixed tolerance path and followed on
+    # the device by the instrumental LSF and the rotational kernel (postprocess.DeviceSpectrum)
+    "S-c5": dict(lam0=3000.0, lam1=10000.0, R=1.0e5, n_lines=150000, gamma_per_depth=True, mixed_precision=1, lsf_resolution=5.0e4, v_rot_kms=20.0),
     # BASELINE config 4 on the coolest MARCS structure the reference ships (3800 K dwarf): molecular-style list, gamma (N_l, 1)
     "S-c4m": dict(lam0=3000.0, lam1=10000.0, R=1.0e5, n_lines=1000000, gamma_per_depth=False, atmosphere="cool_dwarf"),
 }
@@ -215,3 +218,68 @@ def make_workload(tag, n_lines=None, seed=SEED, n_nu_override=None):
     return dict(
         tag=tag, nus=nus, atm=atm, lines=lines, cont=synth_continuum_state(atm), thetas=thetas, weights=weights
     )
+
+
+def fake_plasma(nus, atm, n_lines, seed=SEED, vald_broadening=False, table_dir=None):
+    """A pandas stand-in for the TARDIS plasma, the stellar model and the opacity configuration, shaped as the reference's
+    calc_alphas / raytrace read them (opacities_solvers/base.py:630-740, radiation_field_solvers/base.py:271-346): the
+    continuum state of synth_continuum_state and a VALD-style line list with a dense alpha table (synth_lines' strengths on
+    synth_linelist's atoms: both draw the same line frequencies from the same seed).  Every line lies on the grid and none
+    auto-ionises, so the reference's selection keeps them all, in this order.
+    -> (plasma, model, config, arrays) with arrays = dict(line_nus, alphas) in the kernel's layout for cross-checks."""
+    import tempfile
+    import types
+
+    import pandas as pd
+
+    NS = types.SimpleNamespace
+    t = np.asarray(atm["temperatures"], dtype=np.float64)
+    cols = np.arange(t.size)
+    cont = synth_continuum_state(atm)
+    spec = synth_linelist(nus, atm, n_lines, seed, vald_broadening=vald_broadening)
+    dense = synth_lines(nus, atm, n_lines, seed)
+    assert np.array_equal(spec.nu, dense["line_nus"])
+    lines = pd.DataFrame(dict(
+        atomic_number=np.asarray(spec.atomic_number), ion_number=np.asarray(spec.ion_number) - 1, nu=spec.nu,
+        ionization_energy=spec.ionization_energy, level_energy_upper=spec.upper_energy, level_energy_lower=spec.lower_energy,
+        A_ul=spec.A_ul, stark=spec.stark, waals=spec.waals, e_low=spec.e_low_ev,
+    ))
+    alpha_table = pd.DataFrame(dense["alphas"], columns=cols)
+    alpha_table["nu"] = dense["line_nus"]
+    n_lev = cont["level_density"].shape[0]
+    ind = pd.MultiIndex.from_tuples([(1, 0), (1, 1), (2, 0), (2, 1)], names=["atomic_number", "ion_number"])
+    lev_index = pd.MultiIndex.from_tuples([(1, 0, k) for k in range(n_lev)], names=["atomic_number", "ion_number", "level_number"])
+    ionization_data = pd.Series(
+        np.array([cont["ionization_energy"], 24.587 * K.EV_CGS, 54.418 * K.EV_CGS]),
+        index=pd.MultiIndex.from_tuples([(1, 1), (2, 1), (2, 2)], names=["atomic_number", "ion_number"]), name="ionization_energy",
+    )
+    plasma = NS(
+        ion_number_density=pd.DataFrame(np.vstack([cont["n_h1"], cont["n_h2"], cont["n_he1"], 1e-6 * cont["n_he1"]]), index=ind, columns=cols),
+        electron_densities=pd.Series(cont["n_e"], index=cols),
+        levels=lev_index,
+        excitation_energy=pd.Series(cont["level_excitation"], index=lev_index),
+        level_number_density=pd.DataFrame(cont["level_density"], index=lev_index, columns=cols),
+        ionization_data=ionization_data,
+        h_minus_density=pd.Series(cont["n_hminus"], index=cols),
+        h2_density=pd.Series(np.zeros(t.size), index=cols),
+        lines_from_linelist=lines,
+        alpha_line_from_linelist=alpha_table,
+    )
+    masses = pd.Series(np.array([1.008, 12.011, 24.305, 40.078, 55.845]) * K.AMU_CGS, index=pd.Index([1, 6, 12, 20, 26], name="atomic_number"))
+    r = np.asarray(atm["r"], dtype=np.float64)
+    model = NS(
+        temperatures=t, no_of_depth_points=t.size, spherical=False,
+        geometry=NS(dist_to_next_depth_point=np.asarray(atm["dist"], dtype=np.float64), r=r, reference_r=None),
+        composition=NS(nuclide_masses=masses), microturbulence=float(atm["microturbulence"]),
+    )
+    table_dir = table_dir or tempfile.mkdtemp(prefix="stardis_amd_tables_")
+    table_path = os.path.join(table_dir, "h_minus_bf.dat")
+    with open(table_path, "w") as fh:
+        fh.write("\n".join(f"{x!r},{y!r}" for x, y in zip(cont["hminus_bf_wavelength"].tolist(), cont["hminus_bf_cross_section"].tolist())) + "\n")
+    opacity = NS(
+        file={"Hminus_bf": table_path}, bf={"H_I": {}}, ff={"H_I": {}}, rayleigh=[], disable_electron_scattering=False,
+        line=NS(disable=False, broadening=["linear_stark", "quadratic_stark", "van_der_waals", "radiation"],
+                vald_linelist=NS(use_linelist=True, use_vald_broadening=bool(vald_broadening)), include_molecules=False),
+    )
+    config = NS(opacity=opacity, no_of_thetas=N_THETAS, result_options=NS(return_radiation_field=False))
+    return plasma, model, config, dict(line_nus=dense["line_nus"], alphas=dense["alphas"])

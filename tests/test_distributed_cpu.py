@@ -128,3 +128,67 @@ def test_balanced_shards_partition_and_balance():
         assert max(per) <= 1.02 * np.mean(per) + work.max()
     equal = [work[b : b + c].sum() for b, c in (parallel.shard_bounds(nus.size, 8, r) for r in range(8))]
     assert max(equal) > 1.1 * np.mean(equal)
+
+
+def _worker_overlap(rank, world, port, n_nu, out_dir):
+    """The double-buffered loop of bench.py: the gather of step k is in flight while step k + 1 fills the other buffer."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch
+
+    from stardis_amd import parallel
+
+    parallel.init_from_env("gloo")
+    work = np.linspace(3.0, 1.0, n_nu)
+    shards = parallel.balanced_shards(work, world)  # unequal shards: the shorter ones are padded for the collective
+    begin, count = shards[rank]
+    lanes = [(torch.zeros(count, dtype=torch.float64), parallel.FluxGatherer(n_nu, world, "cpu", shards=shards)) for _ in range(2)]
+    results = []
+    for step in range(5):
+        buf, gatherer = lanes[step % 2]
+        prev = gatherer.finish()  # the gather that last read this buffer (two steps ago)
+        if step >= 2:
+            results.append(prev.clone())
+        buf.copy_(torch.from_numpy((np.arange(n_nu, dtype=np.float64) + 1000.0 * step)[begin : begin + count]))  # "step k" output
+        gatherer.start(buf)
+    for step in (3, 4):
+        results.append(lanes[step % 2][1].finish().clone())
+    np.save(os.path.join(out_dir, f"rank{rank}.npy"), torch.stack(results).numpy())
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_overlapped_gather_double_buffering(tmp_path):
+    import torch.multiprocessing as mp
+
+    n_nu, port = 777, _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_worker_overlap, args=(r, 2, port, n_nu, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    want = np.stack([np.arange(n_nu, dtype=np.float64) + 1000.0 * k for k in range(5)])
+    for r in range(2):
+        assert np.array_equal(np.load(tmp_path / f"rank{r}.npy"), want)
+
+
+def test_bench_starts_its_own_ranks_when_no_rendezvous_is_set(tmp_path):
+    """`python bench.py --gpus 2` with no WORLD_SIZE must launch two ranks itself (torch.distributed.run children) instead of
+    refusing.  Without a GPU the ranks then fail loudly on the missing device — that failure, coming from BOTH ranks, is what
+    shows they were started (on the GPU box tests/test_gpu_multi.py runs the same command to completion)."""
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["SDX_BENCH_BACKEND"] = "gloo"
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-secondary"],
+                          env=env, capture_output=True, text=True, timeout=600)
+    text = proc.stdout + proc.stderr
+    import torch
+
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 1:
+        pytest.skip("a GPU is visible: covered by the GPU test")
+    assert proc.returncode != 0
+    assert "launch with torch.distributed.run" not in text
+    assert text.count("no HIP device") >= 1 or "Found no NVIDIA driver" in text or "HIP" in text, text[-2000:]

@@ -168,6 +168,38 @@ def test_indexed_path_on_a_reused_context_with_a_shorter_list(ctx):
         ctx.set_option("indexed_min_lines", 8192)
 
 
+def test_graph_captured_before_a_workspace_reallocation_is_refused_and_recaptured():
+    """A hipGraph bakes in the context's scratch pointers.  When a larger synthesis on the same context makes the library
+    reallocate its scratch, replaying the old graph would touch freed memory (round-1 advisor finding): the C ABI refuses it
+    (SDX_ERR_STALE) and SpectralSynthesizer.step captures again."""
+    from stardis_amd import _lib
+
+    own = _lib.Context(0)  # a context of its own: the shared one has already grown to the largest test
+    atm, nus, lines, cont, th, w = small_workload(n_lines=100, seed=51)
+    small = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], th, w, lines, cont, ctx=own)
+    small.capture()
+    small.step()
+    want = (small.alpha_line(), small.F_nu())
+    stale_handle = small.graph
+    nus_big = synth.tracing_grid(6500.0, 6600.0, R=2.0e5)
+    big_lines = synth.synth_lines(nus_big, atm, 3000, seed=52)
+    big = SpectralSynthesizer(nus_big, atm["temperatures"], atm["dist"], th, w, big_lines, cont, ctx=own)
+    big.step()  # grows every scratch buffer of the context
+    own.synchronize()
+    with pytest.raises(_lib.StaleGraphError):
+        own.call("sdx_graph_launch", stale_handle)
+    small.step()  # re-captures
+    assert small.graph is not None and small.graph is not stale_handle
+    got = (small.alpha_line(), small.F_nu())
+    for x, y in zip(want, got):
+        assert np.array_equal(x, y)
+    big.step()
+    ref = oracle.calc_alan_entries(56, nus_big, big_lines["line_nus"], big_lines["doppler_widths"], big_lines["gammas"], big_lines["alphas"])
+    assert rel_err(big.alpha_line(), ref) < 1e-12
+    small.close()
+    own.close()
+
+
 def test_long_line_list_on_the_wide_grid(ctx):
     """BASELINE configs[2]/[3] shape: the 3000-10000 A grid at R = 1e5 (120 398 frequencies) with a line list long
     enough (20 000 lines, gamma given as an (N_l, 1) column like the molecular case) to take the indexed wide-window

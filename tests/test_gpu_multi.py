@@ -1,0 +1,65 @@
+"""The N > 1 path on hardware: ranks launched by torch.distributed.run synthesize frequency shards and ONE all-gather
+reassembles the emergent flux, bit for bit the single-GPU spectrum.  On a 1-GPU box both ranks share device 0 and the
+collective is gloo (host-staged); with two or more GPUs the same check runs over RCCL, and bench.py --gpus 2 must start
+its own ranks and print its line."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _torchrun(script_args, extra_env, world=2, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra_env)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), *script_args]
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.parametrize("balanced", [False, True])
+def test_two_ranks_on_one_device_gather_the_single_gpu_spectrum(balanced):
+    args = [os.path.join(ROOT, "scripts", "two_rank_check.py")] + (["--balanced"] if balanced else [])
+    proc = _torchrun(args, {"SDX_BENCH_BACKEND": "gloo", "SDX_BENCH_SINGLE_DEVICE": "1"})
+    assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-3000:]
+    assert "IDENTICAL" in proc.stdout
+
+
+def test_two_ranks_over_rccl_gather_the_single_gpu_spectrum():
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    proc = _torchrun([os.path.join(ROOT, "scripts", "two_rank_check.py"), "--balanced"], {"SDX_BENCH_BACKEND": "nccl"})
+    assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-3000:]
+    assert "IDENTICAL" in proc.stdout and "backend nccl" in proc.stdout
+
+
+def test_bench_self_launches_two_ranks():
+    """`python bench.py --gpus 2` without a rendezvous in the environment: two ranks on two GPUs over RCCL when the box has
+    them, otherwise both on device 0 with the gloo collective."""
+    import torch
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    if torch.cuda.device_count() < 2:
+        env.update(SDX_BENCH_BACKEND="gloo", SDX_BENCH_SINGLE_DEVICE="1")
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--no-cpu-baseline"],
+                          env=env, capture_output=True, text=True, timeout=1200)
+    assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-3000:]
+    line = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["scaling"] == "weak"
+    assert out["strong"]["n_gpus"] == 2 and out["strong"]["ms_per_step"] > 0 and len(out["strong"]["shards"]) == 2
