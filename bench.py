@@ -42,7 +42,7 @@ FP64_VECTOR_PEAK_TFLOPS = 78.6
 # measured = what scripts/fp64_peak.hip sustains on this part (55 TFLOP/s of FMA at 8 waves per SIMD)
 FP64_VALU_SPEC = 256 * 4 * 2.4e9 / 4
 FP64_VALU_MEASURED = 439.0e9
-KERNELS = ("k_dnu_partial", "k_prepass_continuum", "k_line_prepass", "k_count_lists", "k_build_lists", "k_line_all", "k_line_wide",
+KERNELS = ("k_dnu_partial", "k_classify", "k_prepass_continuum", "k_line_prepass", "k_hlist", "k_line_all", "k_line_wide",
            "k_line_narrow", "k_reduce_partials", "k_total_alphas", "k_raytrace")
 
 

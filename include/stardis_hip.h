@@ -54,9 +54,18 @@ void sdx_destroy(sdx_ctx* ctx);
 int sdx_set_stream(sdx_ctx* ctx, void* stream);
 void* sdx_get_stream(sdx_ctx* ctx);
 int sdx_synchronize(sdx_ctx* ctx);
-/* options: "indexed_min_lines" (default 8192): line lists at least this long use the dense-list wide-window path;
- * "mixed_precision" (default 0): 1 evaluates the far-wing (Faddeeva region I) rational of whole-tile windows in fp32
- * (frequency offsets and all sums stay fp64) — a tolerance mode, ~1e-6 relative on opacities instead of 1e-13 */
+/* options:
+ *   "indexed_min_lines" (default 8192): line lists at least this long are not scanned completely by every tile of the wide
+ *       role: lines whose widest window exceeds 4096 grid points are listed once and visited by every tile, all others are
+ *       found by centre range (the list is sorted); frequency shards of such lists also run a culled pre-pass.
+ *   "mixed_precision" (default 0): 1 selects the fp32-mixed TOLERANCE path (BASELINE config 5).  Far-wing evaluations —
+ *       grid tiles wholly inside a line's window and wholly in Faddeeva region I — compute the rational
+ *       y (q + y^2 + 1/2) / ((q - y^2 - 1/2)^2 + 4 q y^2) in fp32: x = (nu_i - nu_l) / doppler from hi + lo fp32 splits of
+ *       both frequencies (relative error ~1e-7 whatever their distance), fp32 constants per (line, depth) written by the
+ *       pre-pass, v_rcp_f32, and an fp32 running sum flushed into the fp64 sum every 64 terms.  Window edges, line cores
+ *       (regions II-IV), the narrow windows, the continuum and the formal solution stay fp64.  Stated tolerance: 1e-4
+ *       relative on the emergent flux (measured ~1e-6 on the line opacity; tests/test_gpu_configs.py).  fp64 remains the
+ *       default and the parity path. */
 int sdx_set_int_option(sdx_ctx* ctx, const char* name, int64_t value);
 
 /* device memory for callers that do not bring their own (numpy-only users) */

@@ -7,7 +7,7 @@ from stardis_amd import synth, _lib
 from stardis_amd.engine import SpectralSynthesizer
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "S-c3"
-n_lines = int(sys.argv[2]) if len(sys.argv) > 2 else None
+n_lines = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else None
 t0 = time.time()
 w = synth.make_workload(tag, n_lines=n_lines)
 atm = w["atm"]
@@ -22,7 +22,7 @@ t0 = time.time()
 for _ in range(3): syn.enqueue()
 ctx.synchronize()
 print(f"wall per step {(time.time()-t0)/3*1e3:.2f} ms")
-for k in ("k_dnu_partial", "k_prepass_continuum", "k_line_prepass", "k_line_all", "k_line_wide", "k_line_narrow", "k_total_alphas", "k_raytrace"):
+for k in ("k_dnu_partial", "k_classify", "k_prepass_continuum", "k_line_prepass", "k_hlist", "k_line_all", "k_line_wide", "k_line_narrow", "k_total_alphas", "k_raytrace"):
     cnt, ms = C.c_int64(), C.c_double()
     _lib.check(ctx.lib.sdx_profile_get(ctx.handle, k.encode(), C.byref(cnt), C.byref(ms)))
     if cnt.value: print(f"  {k:16s} {ms.value/cnt.value*1e3:10.1f} us")

@@ -1,35 +1,51 @@
 """GPU experiment: strong scaling of one workload by frequency sharding, emulated on one GPU — each rank's step is timed
-alone (ranks are independent: no data-path exchange), the projected speed-up is t(1) / max_r t_r(P).
-python scripts/strong_scaling_probe.py [TAG] [WORLD ...] [--balanced]   (--balanced: shards of equal estimated work)"""
-import os, sys, time
+alone (ranks are independent: no data-path exchange; the flux gather overlaps the next step), the projected speed-up is
+t(1) / max_r t_r(P).  Steps are replayed as hipGraphs, like bench.py; the slowest rank's per-kernel times are printed.
+python scripts/strong_scaling_probe.py [TAG] [WORLD ...] [--balanced] [--all-ranks]"""
+import ctypes as C, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from stardis_amd import synth
+from stardis_amd import synth, parallel, _lib
 from stardis_amd.engine import SpectralSynthesizer, shard_bounds
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "S-c3"
 balanced = "--balanced" in sys.argv
 worlds = [int(a) for a in sys.argv[2:] if a.isdigit()] or [1, 2, 4, 8]
 w = synth.make_workload(tag)
-atm, nus = w["atm"], w["nus"]
-from stardis_amd import parallel
-ln = w["lines"]
+atm, nus, ln = w["atm"], w["nus"], w["lines"]
 # per-column cost: window evaluations + the column's share of the formal solution and continuum (~6000 evaluation-equivalents)
 work = parallel.window_work(nus, ln["line_nus"], ln["doppler_widths"], ln["gammas"], ln["alphas"]) if balanced else None
+KERNELS = ("k_dnu_partial", "k_classify", "k_prepass_continuum", "k_line_prepass", "k_hlist", "k_line_all", "k_raytrace")
 
 
-def rank_time(world, rank, reps=5):
-    syn = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], w["thetas"], w["weights"], w["lines"], w["cont"],
-                              shard=parallel.balanced_shards(work, world, 6000.0)[rank] if balanced else shard_bounds(nus.size, world, rank),
-                              track_evaluations=False)
+def rank_time(world, rank, reps=8):
+    shard = parallel.balanced_shards(work, world, 6000.0)[rank] if balanced else shard_bounds(nus.size, world, rank)
+    syn = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], w["thetas"], w["weights"], w["lines"], w["cont"], shard=shard,
+                              track_evaluations=False, keep_line=False)
+    ctx = syn.ctx
+    syn.capture()
     syn.step(); syn.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps): syn.step()
     syn.synchronize()
-    return (time.perf_counter() - t0) / reps
+    t = (time.perf_counter() - t0) / reps
+    ctx.call("sdx_profile_enable", 1); ctx.call("sdx_profile_reset")
+    for _ in range(3): syn.enqueue()
+    ctx.synchronize()
+    kern = {}
+    for k in KERNELS:
+        cnt, ms = C.c_int64(), C.c_double()
+        _lib.check(ctx.lib.sdx_profile_get(ctx.handle, k.encode(), C.byref(cnt), C.byref(ms)))
+        if cnt.value: kern[k] = round(ms.value / 3 * 1e3, 1)
+    ctx.call("sdx_profile_enable", 0); ctx.call("sdx_profile_reset")
+    syn.close()
+    return t, kern, shard
 
 
 t1 = None
 for world in worlds:
-    ts = [rank_time(world, r) for r in (range(world) if balanced else sorted({0, world // 2, world - 1}))]
-    t1 = t1 or max(ts)
-    print(f"{tag} world {world}: slowest of ranks 0/mid/last {max(ts) * 1e3:.3f} ms -> projected speed-up {t1 / max(ts):.2f}x", flush=True)
+    ranks = range(world) if (balanced or "--all-ranks" in sys.argv) else sorted({0, world // 2, world - 1})
+    res = [rank_time(world, r) for r in ranks]
+    slow = max(res, key=lambda x: x[0])
+    t1 = t1 or slow[0]
+    print(f"{tag} world {world}: slowest rank {slow[0] * 1e3:.3f} ms (mean {sum(r[0] for r in res) / len(res) * 1e3:.3f}) -> projected speed-up {t1 / slow[0]:.2f}x; "
+          f"slowest rank's shard {slow[2]} kernels [us] {slow[1]}", flush=True)

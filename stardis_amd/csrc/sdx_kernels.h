@@ -117,12 +117,30 @@ constexpr int kPreBlock = 1024;  // threads per pre-pass block: one (line, depth
 constexpr int kNarrowHalfWidth = 64;    // windows with half-width <= this go to the narrow-window kernel
 constexpr int kMediumHalfWidth = 4096;  // class bound of the indexed wide path: medium lines are found by centre range
 
+// What the pre-pass leaves for the line kernels.  WIDE (line, depth) items (half-width > kNarrowHalfWidth) are depth-major
+// [N_d][N_l] — a (depth, line-range) read is contiguous — and split by use:
+//   wscan   16 B, read by every candidate test: window [lo, hi) and the CORE range [clo, chi), a superset of the grid points
+//           where the Faddeeva region is not I (|x| + y <= 15); lo = hi = 0 for narrow / empty items
+//   wrec    48 B, read once per (item, tile) that overlaps: line frequency, 1 / doppler and the region-I constants
+//   wslow   16 B, read only by tiles that touch a window edge or the core: y and the amplitude (regions II-IV)
+//   wrec32  32 B, the fp32 twin of wrec for the mixed-precision mode (line frequency as a hi + lo pair)
+struct alignas(16) WideScan {
+    int lo, hi, clo, chi;
+};
+struct alignas(16) WideRec {
+    double lnu, inv, yk, c2, c3, c4;
+};
+struct alignas(16) WideSlow {
+    double y, amp;
+};
+struct alignas(32) WideRec32 {  // one s_load_dwordx8
+    float nuh, nul, inv, yk, c2, c3, c4, pad;
+};
 struct LineWork {
-    double* inv_dw;  // [N_d][N_l]
-    double* y;
-    double* amp;
-    int* lo;         // window of WIDE (line, depth) items, 0/0 for narrow ones
-    int* hi;
+    WideScan* wscan;
+    WideRec* wrec;
+    WideSlow* wslow;
+    WideRec32* wrec32;  // nullptr unless the mixed-precision mode is on
     // NARROW items (half-width <= kNarrowHalfWidth), LINE-major [N_l][N_d] so that lane <-> depth reads coalesce
     int* nlo;        // window, 0/0 for wide items
     int* nhi;
@@ -132,23 +150,16 @@ struct LineWork {
     int* cnt_ge;     // [N_nu + 2]: number of lines whose centre index is >= p (lines are a prefix: centres descend)
     int* centre;     // [N_l] centre index of each line
     int* nhw_max;    // [N_l] largest NARROW half-width of the line over all depths (0: no narrow item)
-    // one bit per (depth, line), 16 lines per entry, for non-empty windows of the MEDIUM class (kNarrowHalfWidth < hw <=
-    // kMediumHalfWidth) and of the HUGE class (hw > kMediumHalfWidth); rows of mask_ld entries, a multiple of 4 so that a
-    // 64-line chunk is one aligned 64-bit word
-    unsigned short* wmask_med;
-    unsigned short* wmask_huge;
-    int64_t mask_ld;
-    // dense per-depth lists built from the masks by k_build_lists (large line lists only): row d holds the medium items
-    // at [0, cnt[d]) and the huge items at [cap - cnt[n_depth + d], cap), both in ascending line order
-    int* d_lo;
-    int* d_hi;
-    int* d_centre;
-    double* d_lnu;
-    double* d_inv;
-    double* d_y;
-    double* d_amp;
-    int* d_cnt;  // [2][N_d]
-    int64_t cap;
+    int* whw_max;    // [N_l] largest WIDE half-width of the line over all depths (0: no wide item)
+    // long line lists: ascending indices of the lines whose widest window exceeds kMediumHalfWidth (they may reach any tile and
+    // are scanned completely; all other lines are found by centre range).  nullptr for short lists (every line is scanned).
+    int* hlist;
+    int* hcount;
+    // frequency-sharded runs of long lists: the pre-pass only has to prepare the lines this shard can touch — sel[0..1] = the
+    // index range [la, lb) of the lines whose centre lies within kMediumHalfWidth of the shard's columns (device memory,
+    // written by k_shard_range; nullptr: every line) — plus, in a second launch with gather = 1, the lines of hlist
+    const int* sel;
+    int gather;
     unsigned long long* evals;
 };
 
@@ -186,20 +197,35 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
     }
     constexpr int kStride = kPreDepths + 1;  // odd row stride: conflict-free transposed LDS reads
     constexpr int kPreItems = kPreLines * kPreDepths / kPreBlock;  // items per thread
-    static_assert(kPreLines * kPreDepths == kPreItems * kPreBlock && kPreLines % 16 == 0 && kPreLines <= 32, "whole items per thread; 16-line mask words");
+    static_assert(kPreLines * kPreDepths == kPreItems * kPreBlock && kPreLines <= 32, "whole items per thread");
     constexpr int kMaxWaves = kPreBlock / 64;
     __shared__ double s_dw[kPreLines * kStride], s_g[kPreLines * kStride], s_a[kPreLines * kStride];
     __shared__ int s_lo[kPreLines * kStride], s_hi[kPreLines * kStride];
     __shared__ int64_t s_c[kPreLines];
     __shared__ double s_red[kMaxWaves];
     __shared__ unsigned long long s_ev[kMaxWaves];
-    __shared__ unsigned int s_wmask[2][kPreDepths];
-    __shared__ int s_hwmax[kPreLines];
+    __shared__ int s_hwmax[kPreLines], s_whwmax[kPreLines];
+    __shared__ double s_lnu[kPreLines];
 
     const int nthreads = blockDim.x;
     const int64_t l0 = (int64_t)bx * kPreLines;
     const int d0 = by * kPreDepths;
-    const int nl = (int)min((int64_t)kPreLines, n_lines - l0);
+    // which lines this block prepares: kPreLines consecutive ones, or — gather mode — kPreLines consecutive entries of hlist
+    __shared__ int s_l[kPreLines];
+    int nl = (int)min((int64_t)kPreLines, n_lines - l0);
+    if (w.gather) {
+        const int n_h = *w.hcount;
+        if (l0 >= n_h) return;  // block-uniform
+        nl = min(kPreLines, n_h - (int)l0);
+        if (threadIdx.x < kPreLines) s_l[threadIdx.x] = threadIdx.x < nl ? w.hlist[l0 + threadIdx.x] : 0;
+        __syncthreads();
+    } else {
+        if (w.sel && (l0 + kPreLines <= w.sel[0] || l0 >= w.sel[1])) return;  // no line of this block can reach the shard
+        if (threadIdx.x < kPreLines) s_l[threadIdx.x] = (int)(l0 + threadIdx.x);
+        // (no barrier needed: the non-gather path indexes with l0 + ll directly)
+    }
+    const bool gather = w.gather != 0;
+#define SDX_LINE_OF(ll) (gather ? (int64_t)s_l[ll] : l0 + (ll))
     const int nd = min(kPreDepths, n_depth - d0);
     // The block's dense inputs are requested first (kPreItems per thread), so their latency hides behind the centre search
     // below instead of following it.
@@ -211,7 +237,7 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
             r_dw[it] = r_a[it] = r_g[it] = 0.0;
             if (k < nl * nd) {
                 const int ll = k / nd, dd = k - ll * nd;
-                const int64_t l = l0 + ll;
+                const int64_t l = SDX_LINE_OF(ll);
                 const int d = d0 + dd;
                 r_dw[it] = doppler[l * n_depth + d];
                 r_a[it] = alphas[l * n_depth + d];
@@ -232,7 +258,7 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
     for (int ll = threadIdx.x >> 6; ll < nl; ll += kPreBlock / 64) {
         const int lane = threadIdx.x & 63;
         {
-            const double v = line_nus[l0 + ll];
+            const double v = line_nus[SDX_LINE_OF(ll)];
             int a = 0, b = 128;  // first sample strictly below v
             while (a < b) {
                 const int mid = (a + b) >> 1;
@@ -251,8 +277,10 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
             if (lane == 0) s_c[ll] = m ? lo + __builtin_ctzll(m) : hi;
         }
     }
-    if (threadIdx.x < 2 * kPreDepths) (&s_wmask[0][0])[threadIdx.x] = 0u;
-    if (threadIdx.x < kPreLines) s_hwmax[threadIdx.x] = 0;
+    if (threadIdx.x < kPreLines) {
+        s_hwmax[threadIdx.x] = 0, s_whwmax[threadIdx.x] = 0;
+        s_lnu[threadIdx.x] = threadIdx.x < nl ? line_nus[SDX_LINE_OF(threadIdx.x)] : 0.0;
+    }
     // d_nu (:524-526): from the partial maxima of k_dnu_partial, or — small grids — scanned here directly
     const double d_nu = dnu_partial ? block_dnu(dnu_partial, n_partial, s_red) : block_dnu_scan(nus, n_nu, s_red);
 
@@ -262,11 +290,11 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
         __shared__ GenDepth s_gd[kPreDepths];
         __shared__ GenLine s_gl[kPreLines];
         if (threadIdx.x < nd) s_gd[threadIdx.x] = gen_depth(lp, d0 + threadIdx.x);
-        else if (threadIdx.x >= 64 && threadIdx.x < 64 + nl) s_gl[threadIdx.x - 64] = gen_line(lp, line_nus[l0 + threadIdx.x - 64], l0 + threadIdx.x - 64);
+        else if (threadIdx.x >= 64 && threadIdx.x < 64 + nl) s_gl[threadIdx.x - 64] = gen_line(lp, line_nus[SDX_LINE_OF(threadIdx.x - 64)], SDX_LINE_OF(threadIdx.x - 64));
         __syncthreads();
         for (int k = threadIdx.x; k < nl * nd; k += nthreads) {
             const int ll = k / nd, dd = k - ll * nd;
-            const int64_t l = l0 + ll;
+            const int64_t l = SDX_LINE_OF(ll);
             const GenDepth& D = s_gd[dd];  // fields are read from LDS where they are used: copies would cost ~40 VGPRs
             const GenLine& L = s_gl[ll];
             s_dw[ll * kStride + dd] = gen_doppler(lp, L, D, l);
@@ -304,37 +332,60 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
         s_dw[sidx] = inv;
         s_g[sidx] = yy;
         s_a[sidx] = amp;
-        s_lo[sidx] = lo;
-        s_hi[sidx] = narrow ? hi : -hi - 1;  // sign bit carries the class to the second pass
-        if (w.inv_dw) {
-            const size_t o = (size_t)(d0 + dd) * n_lines + (l0 + ll);  // depth-major (wide kernel)
-            w.lo[o] = narrow ? 0 : lo;
-            w.hi[o] = narrow ? 0 : hi;
-            if (!narrow) {
-                w.inv_dw[o] = inv;
-                w.y[o] = yy;
-                w.amp[o] = amp;
-                if (hi > lo) atomicOr(&s_wmask[hw > kMediumHalfWidth ? 1 : 0][dd], 1u << ll);
-            } else {
+        int core_lo = 0, core_hi = 0;
+        bool delegated = false;
+        if (w.wscan) {
+            const size_t o = (size_t)(d0 + dd) * n_lines + SDX_LINE_OF(ll);  // depth-major (wide kernel)
+            WideScan sc = {0, 0, 0, 0};
+            if (!narrow && hi > lo) {
+                const int64_t c = s_c[ll];
+                // core: grid points with |x| + y <= 15 lie within (15 - y) doppler widths of the line, i.e. within
+                // floor(that / d_nu) + 1 points of the centre (d_nu is the SMALLEST spacing of the grid, :524-526).  A margin
+                // (15.001, + 2 points) covers the rounding of x = delta_nu * (1 / dw); a superset costs nothing but speed.
+                const double reach = mul_rn(15.001 - yy, dw) / d_nu;
+                const int64_t chw = yy < 15.001 ? (reach >= (double)n_nu ? n_nu : (int64_t)reach + 2) : 0;
+                sc.lo = lo;
+                sc.hi = hi;
+                sc.clo = max((int)max(c - chw, (int64_t)0), lo);
+                sc.chi = chw > 0 ? min((int)min(c + chw, n_nu), hi) : sc.clo;
+                // A core no wider than a narrow window is DELEGATED to the narrow role (lanes <-> depth: all depths of a line
+                // sit in the same Faddeeva regions at one frequency, where a 64-point tile holds a few core points of one
+                // depth): the narrow arrays below get [clo, chi) as this item's window and the wide role leaves those points out.
+                core_lo = sc.clo, core_hi = sc.chi;
+                delegated = chw > 0 && chw <= kNarrowHalfWidth && sc.chi > sc.clo;
+                if (delegated) {
+                    atomicMax(&s_hwmax[ll], (int)chw);
+                    sc.clo = -sc.clo - 1;  // the sign marks the delegation
+                }
+                const RegionI k1 = region1_setup(yy, amp);
+                const double lnu = s_lnu[ll];
+                w.wrec[o] = WideRec{lnu, inv, k1.yk, k1.c2, k1.c3, k1.c4};
+                w.wslow[o] = WideSlow{yy, amp};
+                if (w.wrec32) {
+                    const float nuh = (float)lnu;
+                    w.wrec32[o] = WideRec32{nuh, (float)(lnu - (double)nuh), (float)inv, (float)k1.yk, (float)k1.c2, (float)k1.c3, (float)k1.c4, 0.f};
+                }
+                atomicMax(&s_whwmax[ll], (int)hw);
+            } else if (narrow) {
                 atomicMax(&s_hwmax[ll], (int)hw);
             }
+            w.wscan[o] = sc;
         }
+        // the second pass writes the NARROW arrays: a narrow item's window, or the delegated core of a wide item; the sign
+        // bit of the stashed upper bound tells the two apart from "nothing for the narrow role"
+        s_lo[sidx] = delegated ? core_lo : lo;
+        s_hi[sidx] = narrow ? hi : (delegated ? core_hi : -hi - 1);
         if (hi > lo) ev += (unsigned long long)(hi - lo);
     }
     __syncthreads();
-    if (w.wmask_med && threadIdx.x < nd) {  // one 16-bit word per 16 lines
-#pragma unroll
-        for (int h = 0; h < kPreLines / 16; ++h) {
-            const size_t o = (size_t)(d0 + threadIdx.x) * w.mask_ld + (size_t)bx * (kPreLines / 16) + h;
-            w.wmask_med[o] = (unsigned short)(s_wmask[0][threadIdx.x] >> (16 * h));
-            w.wmask_huge[o] = (unsigned short)(s_wmask[1][threadIdx.x] >> (16 * h));
-        }
-    }
     // per-line summary for the narrow kernel's candidate test: centre index and the largest narrow half-width
     if (w.nhw_max && threadIdx.x < nl) {
-        if (gy == 1) w.nhw_max[l0 + threadIdx.x] = s_hwmax[threadIdx.x];
-        else atomicMax(&w.nhw_max[l0 + threadIdx.x], s_hwmax[threadIdx.x]);  // deep models: zeroed by the host first
-        if (by == 0) w.centre[l0 + threadIdx.x] = (int)s_c[threadIdx.x];
+        if (gy == 1) w.nhw_max[SDX_LINE_OF(threadIdx.x)] = s_hwmax[threadIdx.x], w.whw_max[SDX_LINE_OF(threadIdx.x)] = s_whwmax[threadIdx.x];
+        else {  // deep models: several depth blocks per line, both arrays zeroed by the host first
+            atomicMax(&w.nhw_max[SDX_LINE_OF(threadIdx.x)], s_hwmax[threadIdx.x]);
+            atomicMax(&w.whw_max[SDX_LINE_OF(threadIdx.x)], s_whwmax[threadIdx.x]);
+        }
+        if (by == 0) w.centre[SDX_LINE_OF(threadIdx.x)] = (int)s_c[threadIdx.x];
     }
     // line-major outputs: the stashed values, depth fastest so the stores coalesce
     if (w.nlo || out_lo_ref) {
@@ -344,7 +395,7 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
             const int lo = s_lo[sidx], hcode = s_hi[sidx];
             const bool narrow = hcode >= 0;
             const int hi = narrow ? hcode : -hcode - 1;
-            const size_t o = (size_t)(l0 + ll) * n_depth + (d0 + dd);
+            const size_t o = (size_t)SDX_LINE_OF(ll) * n_depth + (d0 + dd);
             if (out_lo_ref) {  // sdx_line_windows_dev
                 out_lo_ref[o] = lo;
                 out_hi_ref[o] = hi;
@@ -369,6 +420,7 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
             if (ev) atomicAdd(w.evals, ev);
         }
     }
+#undef SDX_LINE_OF
 }
 
 template <bool GEN, int LINES>
@@ -393,37 +445,36 @@ __global__ __launch_bounds__(kPreBlock) __attribute__((amdgpu_num_sgpr(80))) voi
 // their depth-column constants, then every lane walks the compacted list.  Splitting the line list over S blocks
 // shortens the serial chain of the deepest (hottest) layers, whose windows are widest; the S partial planes are
 // added in subset order by the consumer (k_reduce_partials / k_total_alphas).  No atomics: bit-stable results.
-// LDS of one wide-role wave: the compacted list of up to 64 lines (8 doubles + 3 ints each), reused at the end of the
-// block for the wave's partial sums (64 R doubles, R <= 8)
-constexpr int kWideLdsDoubles = 8 * 64 + 3 * 32;
-struct WideLds {
-    double *nu, *inv, *y, *amp, *yk, *c2, *c3, *c4;
-    int *lo, *hi, *fast;
-    double* sums;
-};
-__device__ __forceinline__ WideLds wide_lds(double* base)
-{
-    WideLds l;
-    l.nu = base, l.inv = base + 64, l.y = base + 128, l.amp = base + 192, l.yk = base + 256, l.c2 = base + 320, l.c3 = base + 384, l.c4 = base + 448;
-    l.lo = (int*)(base + 512), l.hi = l.lo + 64, l.fast = l.hi + 64;
-    l.sums = base;
-    return l;
-}
+// ------------------------------------------------------------------------------------------------
+// Line opacity, wide windows, gather form.  One wave owns (depth d, a tile of 64 R grid points, one of S line subsets);
+// lane k owns grid points t0 + k + 64 r (r < R) and accumulates in registers.  The wave goes through its candidate lines
+// 64 at a time (chunk q of 64 consecutive candidates belongs to subset q mod S):
+//   scan   each lane tests ONE candidate's window against the tile (16 B per candidate, coalesced) -> two wave masks:
+//          `hit` (window overlaps the tile) and `fast` (the tile lies wholly inside the window and wholly outside the
+//          line's core range, so every point is in Faddeeva region I and inside: no per-point tests);
+//   walk   the hits in ascending order; the 48-byte record of a hit (line frequency, 1 / doppler, region-I constants) is
+//          fetched from ONE address by the whole wave — scalar or broadcast loads, no LDS staging, no cross-lane traffic —
+//          the next hit's record being requested before the current one is evaluated.
+// Candidates: every line of the list (short lists), or — long lists — first the lines whose widest window exceeds
+// kMediumHalfWidth (`hlist`, they may reach any tile) and then the lines whose CENTRE lies within kMediumHalfWidth of the
+// tile, a contiguous index range read from cnt_ge (lines are sorted, so centres descend).  Chunks are counted from the start
+// of the list (hlist position / line index), so the partition into subsets — and with it the summation order of a grid
+// point — does not depend on the tile or on how the grid is sharded.
+// The S subsets of a (depth, tile) are the S waves of one workgroup: their partial sums meet in LDS and wave 0 adds them in
+// subset order and writes the tile — one line-opacity plane, no atomics, bit-stable results.
+constexpr int kWideLdsDoubles = 64 * 8;  // per wave: R <= 8 partial sums per lane
 
-// The S subsets of a (depth, tile) are the S waves of ONE workgroup: every wave accumulates its subset in registers, then the
-// partial sums meet in LDS and wave 0 adds them in subset order and writes the tile — one line-opacity plane instead of
-// S partial planes in HBM (deterministic: the order is fixed, no atomics).
 template <int R>
-__device__ __forceinline__ void wide_reduce_and_store(const int split, const int n_split, double (&acc)[R], const int (&idx)[R], const WideLds& L,
+__device__ __forceinline__ void wide_reduce_and_store(const int split, const int n_split, double (&acc)[R], const int (&idx)[R],
                                                       double* __restrict__ lds_all, int64_t nu_begin, double* __restrict__ plane, int64_t pld,
                                                       const int d)
 {
     const int lane = threadIdx.x & 63;
     if (n_split > 1) {
-        wave_sync();  // this wave's last list reads precede the overwrite
         if (split > 0) {
+            double* mine = lds_all + (size_t)split * kWideLdsDoubles;
 #pragma unroll
-            for (int r = 0; r < R; ++r) L.sums[r * 64 + lane] = acc[r];
+            for (int r = 0; r < R; ++r) mine[r * 64 + lane] = acc[r];
         }
         __syncthreads();
         if (split == 0) {
@@ -441,23 +492,30 @@ __device__ __forceinline__ void wide_reduce_and_store(const int split, const int
     }
 }
 
+// fp32 evaluation of the region-I rational for the mixed-precision mode: x from the hi / lo split of both frequencies
+// (nu_i - nu_l is exact to ~1e-7 relative whatever their distance), everything else plain fp32 (v_rcp_f32 is good to 1 ulp)
+__device__ __forceinline__ float region1_f32(float nuh, float nul, const WideRec32& k)
+{
+    const float x = ((nuh - k.nuh) + (nul - k.nul)) * k.inv;
+    const float q = x * x;
+    const float num = k.yk * (q + k.c2);
+    const float den = fmaf(q, q + k.c3, k.c4);
+    return num * __builtin_amdgcn_rcpf(den);
+}
+
 template <int R, bool MIXED>
-__device__ __forceinline__ void line_wide_block(const int tile_idx, const int split, const int n_split, const int d, int64_t n_nu, const double* __restrict__ nus, int64_t nu_begin,
-                                                  int64_t nu_count, int64_t n_lines, const double* __restrict__ line_nus,
-                                                  LineWork w, double* __restrict__ partial, int64_t pld, int n_depth, double* __restrict__ lds_all)
+__device__ __forceinline__ void line_wide_walk(const int tile_idx, const int split, const int n_split, const int d, int64_t n_nu,
+                                               const double* __restrict__ nus, int64_t nu_begin, int64_t nu_count, int64_t n_lines,
+                                               LineWork w, double* __restrict__ plane, int64_t pld, double* __restrict__ lds_all)
 {
     constexpr int kTile = 64 * R;
-    const WideLds L = wide_lds(lds_all + (size_t)split * kWideLdsDoubles);
-    double *s_nu = L.nu, *s_inv = L.inv, *s_y = L.y, *s_amp = L.amp, *s_yk = L.yk, *s_c2 = L.c2, *s_c3 = L.c3, *s_c4 = L.c4;
-    int *s_lo = L.lo, *s_hi = L.hi, *s_fast = L.fast;
-
-    // grid = (tiles, subsets, depths): depth is the slowest index so the innermost (hottest, widest-window)
-    // layers are dispatched first and the light outer layers fill the tail
     const int64_t t0 = nu_begin + (int64_t)tile_idx * kTile;
     const int64_t t1 = min(t0 + kTile, nu_begin + nu_count);
     const int lane = threadIdx.x & 63;
+    const int it0 = (int)t0, it1 = (int)t1;
 
     double nu_i[R], acc[R];
+    float nu_h[R], nu_l[R], acc32[R];
     int idx[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -465,311 +523,209 @@ __device__ __forceinline__ void line_wide_block(const int tile_idx, const int sp
         idx[r] = i < t1 ? (int)i : -1;
         nu_i[r] = i < t1 ? nus[i] : 0.0;
         acc[r] = 0.0;
-    }
-    const size_t base = (size_t)d * n_lines;
-    const double nu_first = nus[t0], nu_last = nus[t1 - 1];  // tile edges (descending grid)
-    const int64_t cstep = (int64_t)n_split * 64;
-    // the next chunk's windows AND constants are requested behind this chunk's arithmetic (used or not: most chunks hold
-    // a line that reaches the tile), so a chunk costs no dependent round trip to memory
-    int lo_next = 0, hi_next = 0;
-    double y_next = 0.0, inv_next = 0.0, amp_next = 0.0, lnu_next = 0.0;
-    if ((int64_t)split * 64 + lane < n_lines) {
-        const int64_t l = (int64_t)split * 64 + lane;
-        lo_next = w.lo[base + l];
-        hi_next = w.hi[base + l];
-        y_next = w.y[base + l], inv_next = w.inv_dw[base + l], amp_next = w.amp[base + l], lnu_next = line_nus[l];
-    }
-    for (int64_t c0 = (int64_t)split * 64; c0 < n_lines; c0 += cstep) {
-        const int64_t l = c0 + lane;
-        const int lo = lo_next, hi = hi_next;
-        const double y_cur = y_next, inv_cur = inv_next, amp_cur = amp_next, lnu_cur = lnu_next;
-        lo_next = 0;
-        hi_next = 0;
-        if (l + cstep < n_lines) {
-            lo_next = w.lo[base + l + cstep];
-            hi_next = w.hi[base + l + cstep];
-            y_next = w.y[base + l + cstep], inv_next = w.inv_dw[base + l + cstep], amp_next = w.amp[base + l + cstep];
-            lnu_next = line_nus[l + cstep];
+        if (MIXED) {
+            nu_h[r] = (float)nu_i[r];
+            nu_l[r] = (float)(nu_i[r] - (double)nu_h[r]);
+            acc32[r] = 0.f;
         }
-        const bool hit = (l < n_lines) & (lo < t1) & (hi > t0) & (hi > lo);
-        const unsigned long long m = __ballot(hit);
-        if (m == 0) continue;
-        const int total = __popcll(m);
-        if (hit) {
-            const int pos = __popcll(m & ((1ull << lane) - 1ull));
-            const double y = y_cur, inv = inv_cur, lnu = lnu_cur;
-            const RegionI k1 = region1_setup(y, amp_cur);
-            // Whole tile inside the window and every point of it in Faddeeva region I (|x| + y > 15, voigt.py:39)?
-            // The smallest |x| of the tile is at the edge nearer to the line; the 1e-3 margin dwarfs rounding, so
-            // every lane's own test would take the same branch: the per-lane tests can be skipped.
-            const double e_first = nu_first - lnu, e_last = nu_last - lnu;
-            const bool beside = e_last > 0.0 || e_first < 0.0;
-            const double nearest = fmin(fabs(e_first), fabs(e_last));
-            s_fast[pos] = (lo <= t0) & (hi >= t1) & beside & (nearest * inv + y > 15.001);
-            s_nu[pos] = lnu;
-            s_inv[pos] = inv;
-            s_y[pos] = y;
-            s_amp[pos] = amp_cur;
-            s_yk[pos] = k1.yk;
-            s_c2[pos] = k1.c2;
-            s_c3[pos] = k1.c3;
-            s_c4[pos] = k1.c4;
-            s_lo[pos] = lo;
-            s_hi[pos] = hi;
-        }
-        wave_sync();  // orders the LDS writes above before the reads below (the list is this wave's own)
-        for (int j = 0; j < total; ++j) {
-            const double lnu = s_nu[j], inv = s_inv[j];
-            const RegionI k1 = {s_yk[j], s_c2[j], s_c3[j], s_c4[j]};
-            if (__builtin_amdgcn_readfirstlane(s_fast[j])) {
-                // same operations, in the same order, as voigt_term's region-I branch: bit-identical results
-                // (MIXED: the fp32 rational of the optional mixed-precision mode instead)
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const double x = (nu_i[r] - lnu) * inv;
-                    if (MIXED) acc[r] += region1_re_mixed(x, k1);
-                    else acc[r] += region1_re(x * x, k1);
-                }
-            } else {
-                const double y = s_y[j], amp = s_amp[j];
-                const int jlo = s_lo[j], jhi = s_hi[j];
-#pragma unroll
-                for (int r = 0; r < R; ++r)
-                    if (idx[r] >= jlo && idx[r] < jhi) acc[r] += voigt_term(nu_i[r] - lnu, inv, y, amp, k1);
+    }
+    const size_t row = (size_t)d * n_lines;
+    const WideScan* __restrict__ scan_row = w.wscan + row;
+    const WideRec* __restrict__ rec_row = w.wrec + row;
+    const WideSlow* __restrict__ slow_row = w.wslow + row;
+    const WideRec32* __restrict__ rec32_row = MIXED ? w.wrec32 + row : nullptr;
+    const int n_h = w.hlist ? __builtin_amdgcn_readfirstlane(*w.hcount) : 0;
+    int pending32 = 0;  // fp32 terms accumulated since the last flush into the fp64 sums
+
+    for (int pass = w.hlist ? 0 : 1; pass < 2; ++pass) {
+        // candidate positions [ka, kb) of this pass: hlist positions (pass 0) or line indices (pass 1)
+        int ka = 0, kb = n_h;
+        if (pass == 1) {
+            kb = (int)n_lines;
+            if (w.hlist) {  // lines whose centre c satisfies t0 - H < c < t1 + H
+                const int64_t pa = max(t0 - kMediumHalfWidth + 1, (int64_t)0), pb = min(t1 + kMediumHalfWidth - 1, n_nu);
+                ka = __builtin_amdgcn_readfirstlane(w.cnt_ge[pb + 1]);
+                kb = __builtin_amdgcn_readfirstlane(w.cnt_ge[pa]);
             }
         }
-        wave_sync();
-    }
-    wide_reduce_and_store<R>(split, n_split, acc, idx, L, lds_all, nu_begin, partial, pld, d);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Large line lists: dense per-depth lists of the wide items, one per class, in ascending line order.
-// grid = (blocks of kListChunks 64-line chunks, depth, class).  A block first counts the set bits of its row that lie
-// before its chunks (and, for the huge class, in the whole row), then a wave per chunk scatters the flagged lines'
-// constants to prefix + rank: a stable compaction without atomics.
-constexpr int kListChunks = 64;
-static_assert(kListChunks <= 64, "k_count_lists counts one chunk per lane");
-
-// Class-mask word of 64-line chunk c with the bits of lines >= n_lines cleared.  The pre-pass writes one 16-bit entry per
-// 16 lines it owns; the tail entries of the last 64-bit word (and bits beyond the last line) are never written, so on a
-// re-used context they can hold bits of an earlier, longer list: they must not be counted or scattered.
-__device__ __forceinline__ unsigned long long mask_word(const unsigned long long* __restrict__ masks, int64_t c, int64_t n_lines)
-{
-    const int64_t rem = n_lines - c * 64;
-    const unsigned long long valid = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
-    return masks[c] & valid;
-}
-
-// set bits of each block's kListChunks chunks, [class][depth][block]: the scatter kernel then sums a few hundred counts
-// instead of re-reading the whole mask row in every block (which made it quadratic in the number of lines)
-__global__ __launch_bounds__(64) void k_count_lists(int n_depth, int64_t n_lines, LineWork w, int* __restrict__ block_cnt)
-{
-    const int d = blockIdx.y, cls = blockIdx.z;
-    const int64_t n_chunks = (n_lines + 63) >> 6;
-    const int64_t c = (int64_t)blockIdx.x * kListChunks + threadIdx.x;
-    const unsigned long long* masks =
-        reinterpret_cast<const unsigned long long*>((cls ? w.wmask_huge : w.wmask_med) + (size_t)d * w.mask_ld);
-    int n = (threadIdx.x < kListChunks && c < n_chunks) ? __popcll(mask_word(masks, c, n_lines)) : 0;
-    for (int off = 32; off > 0; off >>= 1) n += __shfl_xor(n, off);
-    if (threadIdx.x == 0) block_cnt[((size_t)cls * n_depth + d) * gridDim.x + blockIdx.x] = n;
-}
-
-__global__ __launch_bounds__(kBlock) void k_build_lists(int n_depth, int64_t n_lines, const double* __restrict__ line_nus, LineWork w,
-                                                        const int* __restrict__ block_cnt)
-{
-    __shared__ int s_red[kBlock / 64];
-    __shared__ int s_cnt[kListChunks];
-    const int d = blockIdx.y, cls = blockIdx.z;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t n_chunks = (n_lines + 63) >> 6;
-    const int64_t c_first = (int64_t)blockIdx.x * kListChunks;
-    const unsigned long long* masks =
-        reinterpret_cast<const unsigned long long*>((cls ? w.wmask_huge : w.wmask_med) + (size_t)d * w.mask_ld);
-    // set bits before this block's chunks, and in the whole row
-    int before = 0, all = 0;
-    const int* row_cnt = block_cnt + ((size_t)cls * n_depth + d) * gridDim.x;
-    for (int b = threadIdx.x; b < (int)gridDim.x; b += kBlock) {
-        const int n = row_cnt[b];
-        all += n;
-        before += b < (int)blockIdx.x ? n : 0;
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        before += __shfl_xor(before, off);
-        all += __shfl_xor(all, off);
-    }
-    if (lane == 0) s_red[wave] = before;
-    __syncthreads();
-    before = s_red[0] + s_red[1] + s_red[2] + s_red[3];
-    __syncthreads();
-    if (lane == 0) s_red[wave] = all;
-    __syncthreads();
-    all = s_red[0] + s_red[1] + s_red[2] + s_red[3];
-    if (blockIdx.x == 0 && threadIdx.x == 0) w.d_cnt[cls * n_depth + d] = all;
-    // exclusive scan of this block's chunk counts
-    if (threadIdx.x < kListChunks) {
-        const int64_t c = c_first + threadIdx.x;
-        s_cnt[threadIdx.x] = c < n_chunks ? __popcll(mask_word(masks, c, n_lines)) : 0;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int run = 0;
-        for (int k = 0; k < kListChunks; ++k) {
-            const int n = s_cnt[k];
-            s_cnt[k] = run;
-            run += n;
-        }
-    }
-    __syncthreads();
-    const size_t row = (size_t)d * w.cap;
-    const size_t origin = row + (cls ? (size_t)(w.cap - all) : 0);  // huge items fill the end of the row
-    const size_t src_row = (size_t)d * n_lines;
-    for (int k = wave; k < kListChunks; k += kBlock / 64) {
-        const int64_t c = c_first + k;
-        if (c >= n_chunks) break;
-        const unsigned long long m = mask_word(masks, c, n_lines);
-        const int64_t l = c * 64 + lane;
-        if ((m >> lane) & 1ull) {
-            const size_t dst = origin + before + s_cnt[k] + __popcll(m & ((1ull << lane) - 1ull));
-            const size_t src = src_row + l;
-            w.d_lo[dst] = w.lo[src];
-            w.d_hi[dst] = w.hi[src];
-            w.d_centre[dst] = w.centre[l];
-            w.d_lnu[dst] = line_nus[l];
-            w.d_inv[dst] = w.inv_dw[src];
-            w.d_y[dst] = w.y[src];
-            w.d_amp[dst] = w.amp[src];
-        }
-    }
-}
-
-// first k in [0, n) with key[k] < bound, for keys in DESCENDING order (centre indices of ascending lines)
-__device__ __forceinline__ int first_below(const int* __restrict__ key, int n, int64_t bound)
-{
-    int lo = 0, hi = n;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (key[mid] >= bound) lo = mid + 1; else hi = mid;
-    }
-    return lo;
-}
-
-// Wide windows through the dense lists: the huge class is scanned completely (most of it overlaps any tile), the medium
-// class only over the entries whose centre lies within kMediumHalfWidth of the tile.  List chunk q (64 entries, by
-// absolute list position) belongs to subset q mod S, so the partition — and with it the summation order of a grid
-// point — does not depend on the tile or on how the grid is sharded.
-template <int R, bool MIXED>
-__device__ __forceinline__ void line_wide_block_indexed(const int tile_idx, const int split, const int n_split, const int d,
-                                                        const double* __restrict__ nus, int64_t nu_begin, int64_t nu_count,
-                                                        LineWork w, double* __restrict__ partial, int64_t pld, int n_depth, double* __restrict__ lds_all)
-{
-    constexpr int kTile = 64 * R;
-    const WideLds L = wide_lds(lds_all + (size_t)split * kWideLdsDoubles);
-    double *s_nu = L.nu, *s_inv = L.inv, *s_y = L.y, *s_amp = L.amp, *s_yk = L.yk, *s_c2 = L.c2, *s_c3 = L.c3, *s_c4 = L.c4;
-    int *s_lo = L.lo, *s_hi = L.hi, *s_fast = L.fast;
-    const int64_t t0 = nu_begin + (int64_t)tile_idx * kTile;
-    const int64_t t1 = min(t0 + kTile, nu_begin + nu_count);
-    const int lane = threadIdx.x & 63;
-    double nu_i[R], acc[R];
-    int idx[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int64_t i = t0 + lane + r * 64;
-        idx[r] = i < t1 ? (int)i : -1;
-        nu_i[r] = i < t1 ? nus[i] : 0.0;
-        acc[r] = 0.0;
-    }
-    const double nu_first = nus[t0], nu_last = nus[t1 - 1];
-    const size_t row = (size_t)d * w.cap;
-    const int cnt_med = w.d_cnt[d], cnt_huge = w.d_cnt[n_depth + d];
-    for (int cls = 1; cls >= 0; --cls) {  // huge first, then medium: a fixed order
-        size_t origin;
-        int k_begin, k_end;
-        if (cls) {
-            origin = row + (size_t)(w.cap - cnt_huge);
-            k_begin = 0;
-            k_end = cnt_huge;
-        } else {
-            origin = row;
-            k_begin = first_below(w.d_centre + row, cnt_med, t1 + kMediumHalfWidth);
-            k_end = first_below(w.d_centre + row, cnt_med, t0 - kMediumHalfWidth + 1);
-        }
-        if (k_end <= k_begin) continue;
-        const int q_first = k_begin >> 6, q_last = (k_end - 1) >> 6;
+        if (kb <= ka) continue;
+        const int q_first = ka >> 6, q_last = (kb - 1) >> 6;
         int q = q_first + ((split - q_first % n_split) + n_split) % n_split;  // first chunk >= q_first of this subset
+        // the scan word of the NEXT chunk is requested behind the current chunk's arithmetic
+        auto fetch = [&](int qq, int& line, WideScan& sc) {
+            const int k = qq * 64 + lane;
+            line = -1;
+            sc = WideScan{0, 0, 0, 0};
+            if (qq <= q_last && k >= ka && k < kb) {
+                const int l = pass == 0 ? w.hlist[k] : k;
+                if (pass == 0 || !w.hlist || w.whw_max[l] <= kMediumHalfWidth) {
+                    line = l;
+                    sc = scan_row[l];
+                }
+            }
+        };
+        int line_next;
+        WideScan sc_next;
+        fetch(q, line_next, sc_next);
         for (; q <= q_last; q += n_split) {
-            const int k = q * 64 + lane;
-            int lo = 0, hi = 0;
-            const bool in = k >= k_begin && k < k_end;
-            if (in) {
-                lo = w.d_lo[origin + k];
-                hi = w.d_hi[origin + k];
-            }
-            const bool hit = in & (lo < t1) & (hi > t0);
-            const unsigned long long m = __ballot(hit);
+            const int line = line_next;
+            const WideScan sc = sc_next;
+            fetch(q + n_split, line_next, sc_next);
+            const bool hit = (line >= 0) & (sc.lo < it1) & (sc.hi > it0);  // narrow / empty items have lo = hi = 0
+            const int clo = sc.clo < 0 ? -sc.clo - 1 : sc.clo;                // sign: core delegated to the narrow role
+            const bool fast = hit & (sc.lo <= it0) & (sc.hi >= it1) & ((it1 <= clo) | (it0 >= sc.chi));
+            unsigned long long m = __ballot(hit);
             if (m == 0) continue;
-            const int total = __popcll(m);
-            if (hit) {
-                const int pos = __popcll(m & ((1ull << lane) - 1ull));
-                const double y = w.d_y[origin + k], inv = w.d_inv[origin + k], lnu = w.d_lnu[origin + k];
-                const RegionI k1 = region1_setup(y, w.d_amp[origin + k]);
-                const double e_first = nu_first - lnu, e_last = nu_last - lnu;
-                const bool beside = e_last > 0.0 || e_first < 0.0;
-                const double nearest = fmin(fabs(e_first), fabs(e_last));
-                s_fast[pos] = (lo <= t0) & (hi >= t1) & beside & (nearest * inv + y > 15.001);
-                s_nu[pos] = lnu;
-                s_inv[pos] = inv;
-                s_y[pos] = y;
-                s_amp[pos] = w.d_amp[origin + k];
-                s_yk[pos] = k1.yk;
-                s_c2[pos] = k1.c2;
-                s_c3[pos] = k1.c3;
-                s_c4[pos] = k1.c4;
-                s_lo[pos] = lo;
-                s_hi[pos] = hi;
-            }
-            wave_sync();
-            for (int j = 0; j < total; ++j) {
-                // two consecutive test-free lines share one trip through the loop (their constants are fetched together and
-                // one branch decides for both); the additions keep list order, so the sums are unchanged
-                if (j + 1 < total && __builtin_amdgcn_readfirstlane(s_fast[j] & s_fast[j + 1])) {
-                    const double lnu0 = s_nu[j], inv0 = s_inv[j], lnu1 = s_nu[j + 1], inv1 = s_inv[j + 1];
-                    const RegionI ka = {s_yk[j], s_c2[j], s_c3[j], s_c4[j]}, kb = {s_yk[j + 1], s_c2[j + 1], s_c3[j + 1], s_c4[j + 1]};
+            const unsigned long long mf = __ballot(fast);
+            // walk the hits in ascending order.  The record is fetched with scalar loads straight into SGPRs, which the fp64
+            // instructions take as operands (one each): no copy, no vector registers.  Its latency is not hidden by a
+            // software prefetch — carrying a record across iterations makes the compiler park it in 12 VGPRs and move it
+            // there with six v_mov per hit — but by the other waves of the SIMD.
+            for (;;) {
+                const int b = __builtin_ctzll(m);
+                const int e = __builtin_amdgcn_readlane(line, b);
+                const bool is_fast = (mf >> b) & 1ull;
+                WideRec cur;
+                WideRec32 cur32;
+                if (MIXED && is_fast) cur32 = rec32_row[e];  // the fp64 record is not needed
+                else cur = rec_row[e];
+                m &= m - 1;
+                if (is_fast) {
+                    // every point of the tile is inside the window and in region I: the same operations, in the same order,
+                    // as voigt_term's region-I branch (bit-identical), or the fp32 rational of the mixed-precision mode
+                    if (MIXED) {
 #pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        const double x0 = (nu_i[r] - lnu0) * inv0, x1 = (nu_i[r] - lnu1) * inv1;
-                        if (MIXED) {
-                            acc[r] += region1_re_mixed(x0, ka);
-                            acc[r] += region1_re_mixed(x1, kb);
-                        } else {
-                            acc[r] += region1_re(x0 * x0, ka);
-                            acc[r] += region1_re(x1 * x1, kb);
+                        for (int r = 0; r < R; ++r) acc32[r] += region1_f32(nu_h[r], nu_l[r], cur32);
+                        if (++pending32 >= 64) {
+#pragma unroll
+                            for (int r = 0; r < R; ++r) acc[r] += (double)acc32[r], acc32[r] = 0.f;
+                            pending32 = 0;
+                        }
+                    } else {
+                        const RegionI k1 = {cur.yk, cur.c2, cur.c3, cur.c4};
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            const double x = (nu_i[r] - cur.lnu) * cur.inv;
+                            acc[r] += region1_re(x * x, k1);
                         }
                     }
-                    ++j;
-                    continue;
-                }
-                const double lnu = s_nu[j], inv = s_inv[j];
-                const RegionI k1 = {s_yk[j], s_c2[j], s_c3[j], s_c4[j]};
-                if (__builtin_amdgcn_readfirstlane(s_fast[j])) {
+                } else {
+                    // The tile touches a window edge or the core.  Per 64-point block r (scalar tests): outside the window:
+                    // nothing; clear of the core: the region-I rational for the whole block, added where the point is
+                    // inside the window; over a DELEGATED core: the same, minus the core points (the narrow role adds
+                    // them); over a core kept here (wider than a narrow window): the full Voigt term per point.
+                    const int jlo = __builtin_amdgcn_readlane(sc.lo, b), jhi = __builtin_amdgcn_readlane(sc.hi, b);
+                    const int jc = __builtin_amdgcn_readlane(sc.clo, b), jchi = __builtin_amdgcn_readlane(sc.chi, b);
+                    const bool delegated = jc < 0;
+                    const int jclo = delegated ? -jc - 1 : jc;
+                    const RegionI k1 = {cur.yk, cur.c2, cur.c3, cur.c4};
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
-                        const double x = (nu_i[r] - lnu) * inv;
-                        if (MIXED) acc[r] += region1_re_mixed(x, k1);
-                        else acc[r] += region1_re(x * x, k1);
+                        const int a = it0 + 64 * r, z = min(a + 64, it1);
+                        if (z <= jlo || a >= jhi || a >= it1) continue;
+                        const bool over_core = !(z <= jclo || a >= jchi);
+                        if (!over_core || delegated) {
+                            const double x = (nu_i[r] - cur.lnu) * cur.inv;
+                            const double term = region1_re(x * x, k1);
+                            const bool take = idx[r] >= jlo && idx[r] < jhi && !(over_core && idx[r] >= jclo && idx[r] < jchi);
+                            acc[r] += take ? term : 0.0;
+                        } else {
+                            const WideSlow sl = slow_row[e];
+                            if (idx[r] >= jlo && idx[r] < jhi) acc[r] += voigt_term(nu_i[r] - cur.lnu, cur.inv, sl.y, sl.amp, k1);
+                        }
                     }
-                } else {
-                    const double y = s_y[j], amp = s_amp[j];
-                    const int jlo = s_lo[j], jhi = s_hi[j];
-#pragma unroll
-                    for (int r = 0; r < R; ++r)
-                        if (idx[r] >= jlo && idx[r] < jhi) acc[r] += voigt_term(nu_i[r] - lnu, inv, y, amp, k1);
                 }
+                if (!m) break;
             }
-            wave_sync();
         }
     }
-    wide_reduce_and_store<R>(split, n_split, acc, idx, L, lds_all, nu_begin, partial, pld, d);
+    if (MIXED) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] += (double)acc32[r];
+    }
+    wide_reduce_and_store<R>(split, n_split, acc, idx, lds_all, nu_begin, plane, pld, d);
+}
+
+// Long line lists: ascending indices of the lines whose widest window exceeds kMediumHalfWidth -> hlist, their number ->
+// hcount[0].  A stable compaction in two small launches: per-block counts, then every block sums the counts before it
+// (a few hundred integers) and scatters its own flagged lines.
+constexpr int kHlistBlock = 1024;
+__global__ __launch_bounds__(kHlistBlock) void k_hlist_count(int64_t n_lines, const int* __restrict__ whw_max, int* __restrict__ block_cnt)
+{
+    __shared__ int s_wave[kHlistBlock / 64];
+    const int64_t l = (int64_t)blockIdx.x * kHlistBlock + threadIdx.x;
+    const unsigned long long m = __ballot(l < n_lines && whw_max[l] > kMediumHalfWidth);
+    if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int k = 0; k < kHlistBlock / 64; ++k) tot += s_wave[k];
+        block_cnt[blockIdx.x] = tot;
+    }
+}
+__global__ __launch_bounds__(kHlistBlock) void k_hlist_scatter(int64_t n_lines, const int* __restrict__ whw_max, const int* __restrict__ block_cnt,
+                                                              int* __restrict__ hlist, int* __restrict__ hcount)
+{
+    __shared__ int s_wave[kHlistBlock / 64];
+    __shared__ int s_red[kHlistBlock / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int before = 0;
+    for (int k = threadIdx.x; k < (int)blockIdx.x; k += kHlistBlock) before += block_cnt[k];
+    for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off);
+    const int64_t l = (int64_t)blockIdx.x * kHlistBlock + threadIdx.x;
+    const bool flag = l < n_lines && whw_max[l] > kMediumHalfWidth;
+    const unsigned long long m = __ballot(flag);
+    if (lane == 0) s_red[wave] = before, s_wave[wave] = __popcll(m);
+    __syncthreads();
+    int base = 0;
+    for (int k = 0; k < kHlistBlock / 64; ++k) base += s_red[k];
+    for (int k = 0; k < wave; ++k) base += s_wave[k];
+    if (flag) hlist[base + __popcll(m & ((1ull << lane) - 1ull))] = (int)l;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == kHlistBlock - 1) hcount[0] = base + __popcll(m);  // last thread of the last wave: everything before + its wave
+}
+
+// Frequency-sharded runs of long lists, stage A: the widest window of every line (over all depths), from the window rule
+// alone (:561-575; no centre needed for the half-width) — a streaming pass over the dense inputs that tells which lines can
+// reach any column (whw_max > kMediumHalfWidth -> hlist) before the full pre-pass runs on the lines the shard needs.
+__global__ __launch_bounds__(kBlock) void k_classify(int n_depth, int64_t n_nu, int64_t n_lines, const double* __restrict__ dnu_partial,
+                                                     int n_partial, const double* __restrict__ doppler, const double* __restrict__ gammas,
+                                                     int gamma_cols, const double* __restrict__ alphas, int* __restrict__ whw_max)
+{
+    __shared__ double s_red[kBlock / 64];
+    const double d_nu = block_dnu(dnu_partial, n_partial, s_red);
+    const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (k >= n_lines * n_depth) return;
+    const int64_t l = k / n_depth;
+    const int d = (int)(k - l * n_depth);
+    const double g = gamma_cols > 1 ? gammas[l * gamma_cols + d] : gammas[l];
+    const double pixels = mul_rn(mul_rn(add_rn(g, doppler[k]), alphas[k]) / d_nu, 20.0);
+    const double forced = pixels > 10.0 ? pixels : 10.0;
+    const int64_t hw = forced >= (double)n_nu ? n_nu : (int64_t)forced;
+    if (hw > kNarrowHalfWidth) atomicMax(&whw_max[l], (int)hw);
+}
+
+// sel[0..1] = [la, lb): the lines whose centre c satisfies begin - H < c < end + H for the shard's columns [begin, end)
+// (centre_l = #{i : nus[i] >= line_nu_l}; lines ascend in frequency, so centres descend with the line index)
+__global__ void k_shard_range(int64_t n_nu, const double* __restrict__ nus, int64_t n_lines, const double* __restrict__ line_nus,
+                              int64_t nu_begin, int64_t nu_count, int* __restrict__ sel)
+{
+    if (threadIdx.x >= 2) return;
+    // lines with centre >= p  <=>  line_nu <= nus[p - 1]: their number is cnt_ge[p]
+    const int64_t pa = max(nu_begin - kMediumHalfWidth + 1, (int64_t)0), pb = min(nu_begin + nu_count + kMediumHalfWidth - 1, n_nu);
+    const int64_t p = threadIdx.x == 0 ? pb + 1 : pa;  // sel[0] = cnt_ge[pb + 1], sel[1] = cnt_ge[pa]
+    int64_t cnt;
+    if (p == 0) cnt = n_lines;
+    else if (p >= n_nu + 1) cnt = 0;
+    else {
+        const double v = nus[p - 1];
+        int64_t lo = 0, hi = n_lines;
+        while (lo < hi) {
+            const int64_t mid = lo + ((hi - lo) >> 1);
+            if (line_nus[mid] <= v) lo = mid + 1; else hi = mid;
+        }
+        cnt = lo;
+    }
+    sel[threadIdx.x] = (int)cnt;
 }
 
 // Narrow windows (half-width <= kNarrowHalfWidth, e.g. the reference's 10-pixel floor for weak lines, :565-567):
@@ -841,7 +797,7 @@ __device__ __forceinline__ void line_narrow_wave(const int64_t i, const int dept
 // cross-stream fork/join would cost two ~12 us inter-queue edges per step, one grid costs nothing.
 // roles: bit 0 wide, bit 1 narrow (both by default; one at a time for split-launch profiling, SDX_SPLIT_LAUNCHES=1).
 // Output planes: [0] the wide windows (all subsets summed), [1] the narrow windows.
-template <int R, bool INDEXED, bool MIXED>
+template <int R, bool MIXED>
 __global__ __launch_bounds__(512) void k_line_all(int n_wide, int tiles, int n_split, int n_depth, int64_t n_nu,
                                                    const double* __restrict__ nus, int64_t nu_begin, int64_t nu_count,
                                                    int64_t n_lines, const double* __restrict__ line_nus, LineWork w,
@@ -854,14 +810,11 @@ __global__ __launch_bounds__(512) void k_line_all(int n_wide, int tiles, int n_s
         if (!(roles & 1)) return;
         // XCD-aware tile order: workgroup i runs on XCD i % 8, each with its own L2.  Within a depth the workgroups of one XCD
         // take CONTIGUOUS tiles (position p -> tile prefix(p % 8) + p / 8), so neighbouring tiles, whose line ranges
-        // overlap, hit the same L2 instead of pulling the same constants into all eight.
+        // overlap, hit the same L2 instead of pulling the same records into all eight.
         const int p = b % tiles, d = b / tiles;
         int tile = p >> 3;
         for (int f = 0; f < (p & 7); ++f) tile += (tiles - f + 7) >> 3;
-        if (INDEXED)
-            line_wide_block_indexed<R, MIXED>(tile, wave, n_split, d, nus, nu_begin, nu_count, w, planes, pld, n_depth, s_wide);
-        else
-            line_wide_block<R, MIXED>(tile, wave, n_split, d, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, planes, pld, n_depth, s_wide);
+        line_wide_walk<R, MIXED>(tile, wave, n_split, d, n_nu, nus, nu_begin, nu_count, n_lines, w, planes, pld, s_wide);
     } else {
         if (!(roles & 2)) return;
         const int64_t c = (int64_t)(b - n_wide) * n_split + wave;
@@ -1678,206 +1631,26 @@ __global__ __launch_bounds__(kBlock) void k_raytrace(int n_depth, int64_t n_nu, 
         }
         __syncthreads();
         if (F) {
-            for (int p = lane; p < nb * gpw; p += 64) {
-                const int b = p / gpw, gq = p - b * gpw;
-                const double* c = sX + (b * gpw + gq) * TH;
+            // flux of the nb gaps: lanes <-> (gap, frequency, half of the angles); each half is summed in ascending theta
+            // (the reference's order, :324-338) and the lower half is added to the upper one
+            const int half = (n_theta + 1) >> 1;
+            for (int p = lane; p < 2 * nb * gpw; p += 64) {
+                const int h = p & 1, q = p >> 1;
+                const int b = q / gpw, gq = q - b * gpw;
+                const double* c = sX + (b * gpw + gq) * TH + (h ? half : 0);
+                const int cnt = h ? n_theta - half : half;
                 double sum = 0.0;
-                for (int t = 0; t < n_theta; ++t) sum = add_rn(sum, c[t]);
+                for (int t = 0; t < cnt; ++t) sum = add_rn(sum, c[t]);
+                const double other = __shfl_xor(sum, 1);  // 2 nb gpw is even: the partner lane is in the loop too
                 const int64_t iq = i0 + gq;
-                if (iq < n_nu) {
+                if (h == 0 && iq < n_nu) {
+                    const double tot = add_rn(sum, other);
                     double* dst = F + (size_t)(gap0 + b + 1) * fld + iq;
-                    *dst = accumulate ? add_rn(*dst, sum) : sum;
+                    *dst = accumulate ? add_rn(*dst, tot) : tot;
                 }
             }
         }
         __syncthreads();
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Formal solution, coefficient-parallel (the default for plane-parallel models).
-//
-// The second-order short-characteristic step (:200-266) is AFFINE in the incoming intensity,
-//     I[g+1] = (1 - w0) I[g] + ( w0 S[g+1] + second + third ),
-// and everything but I[g] — exp(-tau), the three weights, the two correction terms: ~55 of the ~60 instructions of a step —
-// depends only on (frequency, gap, angle).  So the N_gap x N_theta coefficient pairs (c, e) of a frequency are independent
-// work items: they are spread over all 64 lanes of a wave (lane <-> item, full lanes), a batch of B gaps at a time, and
-// only the two-instruction recurrence I <- fma(c, I, e) walks the gaps in order (lane <-> (frequency, angle)).
-// What that buys on this chip is WAVES: one SIMD issues one fp64 instruction per ~7.5 cycles for a single wave whatever
-// its instruction-level parallelism and needs ~8 resident waves for its full rate (scripts/issue_cost.hip); the lane <->
-// (frequency, angle) kernel above has 64 / N_theta frequencies per wave, i.e. N_nu N_theta / 64 waves — 2.5 per SIMD at
-// 7 634 frequencies — whereas here a wave owns `fpw` frequencies with fpw = 1 on small grids (7.5 waves per SIMD).
-//
-//   staging   lanes <-> (depth, frequency): total opacity (optionally continuum + line planes, as k_raytrace),
-//             log(alpha) and the Planck source -> LDS; then lanes <-> (gap, frequency): geometric-mean opacity (:121).
-//   batch     a) lanes <-> (gap of the batch, frequency, angle): tau (:123-129, the reference's product), weights
-//                (:22-45), c = 1 - w0, e = (w0 S1 + second) + third with ONE reciprocal for the three divisions of :208-242:
-//                    second = w1 (dS10 tau1^2 - dS21 tau0^2) / D,  third = w2 (dS21 tau0 + dS10 tau1) / D,
-//                    D = tau0 tau1 (tau0 + tau1),  dS10 = S[g] - S[g+1],  dS21 = S[g+2] - S[g+1]
-//                (last gap :256-266: e = w0 S1 + w2 dS10 / tau0^2; tau0 = 0 :203-206: c = 1, e = 0)   -> LDS
-//             b) lanes <-> (frequency, angle): I <- fma(c, I, e) over the B gaps; I w_theta -> LDS (same slot)
-//             c) lanes <-> (gap, frequency, half of the angles): flux sum in ascending theta per half, lower half first
-// The affine form rounds e once more than the reference's left-to-right sum; |dI/I| ~ 1e-16 per step, far inside the
-// 1e-10 flux tolerance (and the 6e-12 of the reference's own conditioning).
-constexpr int kFormalBlock = 512;  // 8 waves share one copy of the ray table: 4 such blocks (32 waves) fit a CU's LDS at MARCS depth
-template <int B>
-__global__ __launch_bounds__(kFormalBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_formal(
-    int n_depth, int64_t n_nu, int n_theta, int theta_stride, const double* __restrict__ nus, const double* __restrict__ temps,
-    const double* __restrict__ ray_dist, const double* __restrict__ wts, const double* __restrict__ alphas, int64_t ald,
-    double* __restrict__ F, int64_t fld, double* __restrict__ I_nus, int accumulate, int fpw, FusedTotal ft)
-{
-    extern __shared__ double smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int n_gap = n_depth - 1;
-    const int col = n_depth + 2;             // padded rows: [g + 1], [g + 2] of the last gap stay inside the row
-    const int FT = fpw * n_theta;            // (frequency, angle) lanes of the recurrence, <= 64
-    const int GPR = 64 / FT;                 // gaps per coefficient round: lane <-> (gap of the round, frequency, angle)
-    const int64_t i0 = ((int64_t)blockIdx.x * (kFormalBlock / 64) + wave) * fpw;  // first frequency of this wave
-    double* sRD = smem;                      // ray_dist [n_gap + 1][n_theta] (last row repeated)
-    double* wbase = sRD + (n_gap + 1) * n_theta + (size_t)wave * (2 * fpw * col + max(2 * B * FT, fpw * col));
-    double* sS = wbase;                      // source function [fpw][col]
-    double* sM = sS + fpw * col;             // mean opacity per gap [fpw][col]
-    double* sC = sM + fpw * col;             // (c, e) [B][FT][2]; c is replaced by I w_theta once the recurrence has used it
-    double* sL = sC;                         // log(alpha) [fpw][col] during staging (the coefficient buffer is idle then)
-
-    for (int k = threadIdx.x; k < (n_gap + 1) * n_theta; k += kFormalBlock) {
-        const int gp = min(k / n_theta, n_gap - 1), t = k - (k / n_theta) * n_theta;
-        sRD[k] = ray_dist[(size_t)gp * theta_stride + t];
-    }
-    // ---- staging: lanes <-> (depth, frequency), frequency fastest (adjacent lanes read adjacent columns)
-    const float inv_fpw = 1.0f / (float)fpw;
-    for (int k = lane; k < fpw * n_depth; k += 64) {
-        const int d = (int)(((float)k + 0.5f) * inv_fpw), f = k - d * fpw;
-        const int64_t i = i0 + f;
-        const bool valid = i < n_nu;
-        const int64_t ic = valid ? i : n_nu - 1;
-        double a;
-        if (ft.cont) {
-            a = ft.cont[(size_t)d * ft.cld + ic];
-            if (ft.planes) {
-                double line = ft.planes[(size_t)d * ft.pld + ic];
-                for (int sp = 1; sp < ft.n_planes; ++sp) line = add_rn(line, ft.planes[((size_t)sp * n_depth + d) * ft.pld + ic]);
-                a = add_rn(a, line);
-                if (valid && ft.line_out) ft.line_out[(size_t)d * ft.out_ld + i] = line;
-            }
-            if (valid && ft.total_out) ft.total_out[(size_t)d * ft.out_ld + i] = a;
-        } else {
-            a = alphas[(size_t)d * ald + ic];
-        }
-        sL[f * col + d] = log(a);
-        const double src = planck(nus[ic], temps[d]);
-        sS[f * col + d] = src;
-        if (d == n_depth - 1) sS[f * col + d + 1] = src;  // pad
-    }
-    __syncthreads();  // sRD is shared by the block; sL / sS are this wave's own
-    for (int k = lane; k < fpw * n_gap; k += 64) {  // lanes <-> (gap, frequency)
-        const int gp = (int)(((float)k + 0.5f) * inv_fpw), f = k - gp * fpw;
-        const double m = exp(mul_rn(add_rn(sL[f * col + gp + 1], sL[f * col + gp]), 0.5));  // :121
-        sM[f * col + gp] = m;
-        if (gp == n_gap - 1) sM[f * col + gp + 1] = m;  // pad
-    }
-    wave_sync();
-
-    // ---- fixed roles of this lane
-    // coefficient rounds: lane <-> (gap of the round bsub, frequency cf, angle ct); q = cf n_theta + ct is the (f, theta) slot
-    const int bsub = (int)(((float)lane + 0.5f) * (1.0f / (float)FT)), q = lane - bsub * FT;
-    const int cf = (int)(((float)q + 0.5f) * (1.0f / (float)n_theta)), ct = q - cf * n_theta;
-    const bool citem = bsub < GPR;
-    const double* pS = sS + cf * col + bsub;        // + gap
-    const double* pM = sM + cf * col + bsub;
-    const double* pR = sRD + bsub * n_theta + ct;   // + gap * n_theta
-    double* pC = sC + 2 * (bsub * FT + q);          // + 2 FT * (gap of the batch)
-    // recurrence: lane <-> (f, theta) slot `lane`
-    const bool rec = lane < FT;
-    const int rf = rec ? cf : 0, rt = rec ? ct : 0;  // bsub = 0 for lane < FT, so (cf, ct) is this lane's own slot
-    const int64_t ri = i0 + rf;
-    const bool rvalid = rec && ri < n_nu;
-    const double wt = rec ? wts[rt] : 0.0;
-    double inten = 0.0;  // np.zeros (:134)
-    if (rvalid && I_nus) I_nus[(size_t)ri * theta_stride + rt] = 0.0;
-    if (rvalid && rt == 0 && F && !accumulate) F[ri] = 0.0;
-    // flux: lane <-> (gap of the batch, frequency, half of the angles)
-    const int half = (n_theta + 1) >> 1;
-    const int fh = lane & 1, fbf = lane >> 1;
-    const int fb = (int)(((float)fbf + 0.5f) * inv_fpw), ff = fbf - fb * fpw;
-    const double* pF = sC + 2 * (fb * FT + ff * n_theta + (fh ? half : 0));
-    const int fcount = fh ? n_theta - half : half;
-    const int64_t fi = i0 + ff;
-
-    for (int gap0 = 0; gap0 < n_gap; gap0 += B) {
-        const int nb = min(B, n_gap - gap0);
-        // a) coefficients
-        if (citem) {
-            const double* S = pS + gap0;
-            const double* M = pM + gap0;
-            const double* R = pR + gap0 * n_theta;
-            double* C = pC;
-            for (int b = bsub; b < nb; b += GPR, S += GPR, M += GPR, R += GPR * n_theta, C += 2 * GPR * FT) {
-                const double s0 = S[0], s1 = S[1], s2 = S[2];
-                const double t0 = mul_rn(M[0], R[0]);
-                const double t1 = mul_rn(M[1], R[n_theta]);
-                const double d10 = s0 - s1, d21 = s2 - s1;
-                const double D = (t0 * t1) * (t0 + t1);
-                double c, e;
-                if (gap0 + b != n_gap - 1 && D > 1e-290 && D < 1e290) {  // :208-249, the common case
-                    double w0, w1, w2;
-                    rt_weights(t0, w0, w1, w2);
-                    const double rD = recip(D);
-                    const double X = w1 * fma(-d21, t0 * t0, d10 * (t1 * t1)) * rD;
-                    const double Y = w2 * fma(d21, t0, d10 * t1) * rD;
-                    c = 1.0 - w0;
-                    e = fma(w0, s1, X) + Y;
-                } else if (t0 == 0.0) {  // no change (:203-206, :253-254)
-                    c = 1.0;
-                    e = 0.0;
-                } else {
-                    double w0, w1, w2;
-                    rt_weights(t0, w0, w1, w2);
-                    c = 1.0 - w0;
-                    if (gap0 + b == n_gap - 1) {  // :256-266
-                        e = fma(w0, s1, w2 * d10 * recip_guarded(t0 * t0));
-                    } else {  // tau1 = 0 or extreme magnitudes: the reference's own divisions, inf / NaN pattern included
-                        const double sum01 = t0 + t1;
-                        const double X = w1 * (d10 * (t1 / t0) - d21 * (t0 / t1)) / sum01;
-                        const double Y = w2 * (d21 / t1 + d10 / t0) / sum01;
-                        e = fma(w0, s1, X) + Y;
-                    }
-                }
-                C[0] = c;
-                C[1] = e;
-            }
-        }
-        wave_sync();
-        // b) recurrence
-        if (rec) {
-            double* slot = sC + 2 * lane;
-            if (I_nus) {
-                for (int b = 0; b < nb; ++b, slot += 2 * FT) {
-                    inten = fma(slot[0], inten, slot[1]);
-                    if (rvalid) I_nus[((size_t)(gap0 + b + 1) * n_nu + ri) * theta_stride + rt] = inten;
-                    slot[0] = inten * wt;
-                }
-            } else {
-#pragma unroll 3
-                for (int b = 0; b < nb; ++b, slot += 2 * FT) {
-                    inten = fma(slot[0], inten, slot[1]);
-                    slot[0] = inten * wt;
-                }
-            }
-        }
-        wave_sync();
-        // c) flux
-        if (F && fb < nb) {  // nb * fpw * 2 <= 64 (host): one item per lane
-            double sum = 0.0;
-            for (int t = 0; t < fcount; ++t) sum = add_rn(sum, pF[2 * t]);
-            const double other = __shfl_xor(sum, 1);  // the upper half sits in the neighbouring lane
-            if (fh == 0 && fi < n_nu) {
-                const double tot = add_rn(sum, other);
-                double* dst = F + (size_t)(gap0 + fb + 1) * fld + fi;
-                *dst = accumulate ? add_rn(*dst, tot) : tot;
-            }
-        }
-        wave_sync();
     }
 }
 

@@ -8,9 +8,13 @@
 //                     faddeeva / voigt_profile entry points.
 //   voigt_term()      what the line-opacity kernel evaluates per (line, depth, nu):
 //                     amp * Re w(z), real part only, FMA, one reciprocal per point.
-//                     Region tests use exactly the reference's predicates on exactly
-//                     its x, y (voigt.py:31-44) so region selection is identical;
-//                     inside a region the arithmetic is re-associated (few-ulp level).
+//                     Region tests are the reference's predicates (voigt.py:31-44) on its y and on
+//                     x = delta_nu * (1 / doppler), which equals the reference's delta_nu / doppler
+//                     to 1 ulp: a point within an ulp of a region boundary (s = 15, s = 5.5,
+//                     y = 0.195 |x| - 0.176) can be evaluated with the neighbouring region's rational,
+//                     a ~1e-5 step of the Humlicek approximation itself.  Inside a region the
+//                     arithmetic is re-associated (few-ulp level; tests/test_gpu_hot_faddeeva.py pins
+//                     the routine point by point against the reference's vectors: <= 2e-13).
 //
 // Everything is IEEE double; nothing here uses fast-math.
 #pragma once
@@ -178,18 +182,6 @@ __device__ __forceinline__ double region1_re(double q, const RegionI& k)
     const double num = k.yk * (q + k.c2);
     const double den = fma(q, q + k.c3, k.c4);
     return num * recip(den);
-}
-
-// Mixed-precision variant of region1_re (the optional "fp32 mixed" tolerance path): x is formed in fp64 — fp32 cannot
-// resolve nu_i - nu_l — and the rational function is evaluated in fp32 (relative error ~3e-7 per term; the terms of a
-// grid point are all positive, so the sum keeps that relative error).  Accumulation stays fp64.
-__device__ __forceinline__ double region1_re_mixed(double x, const RegionI& k)
-{
-    const float xf = (float)x;
-    const float q = xf * xf;
-    const float num = (float)k.yk * (q + (float)k.c2);  // amp folded in: fp32 range is ample for amp * y
-    const float den = fmaf(q, q + (float)k.c3, (float)k.c4);
-    return (double)(num * __builtin_amdgcn_rcpf(den));
 }
 
 // Re w for regions II-IV (real part only).

@@ -62,12 +62,8 @@ struct sdx_ctx {
     void* cnt_ws = nullptr;
     size_t cnt_ws_bytes = 0;
     size_t cnt_ge_len = 0;
-    void* mask_ws = nullptr;  // wide-item bit masks, 2 classes x [n_depth][mask_ld] (uint16)
-    size_t mask_ws_bytes = 0;
-    void* dense_ws = nullptr;  // dense per-depth wide lists of the indexed path
-    size_t dense_ws_bytes = 0;
     // tuning options (sdx_set_int_option)
-    int64_t indexed_min_lines = 8192;  // line lists at least this long go through the dense-list (indexed) wide path
+    int64_t indexed_min_lines = 8192;  // line lists at least this long: wide lines found by centre range / the huge-line list instead of a full scan
     int64_t mixed_precision = 0;       // 1: fp32 rational for far-wing (region I) evaluations of whole-tile windows
     // timing
     hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -108,31 +104,30 @@ int ensure(sdx_ctx* ctx, void** buf, size_t* have, size_t need)
     return SDX_OK;
 }
 
-size_t line_ws_need(int n_depth, int64_t n_lines) { return (size_t)n_depth * (size_t)n_lines * 64 + 256; }
+// per (line, depth) item: wide scan 16 + record 48 + slow 16 + fp32 record 32, narrow windows 8 + constants 24
+size_t line_ws_need(int n_depth, int64_t n_lines) { return (size_t)n_depth * (size_t)n_lines * 144 + 256; }
 
 LineWork carve(sdx_ctx* ctx, int n_depth, int64_t n_lines)
 {
     const size_t n = (size_t)n_depth * (size_t)n_lines;
     char* p = (char*)ctx->line_ws;
     LineWork w;
-    w.inv_dw = (double*)p;
-    w.y = w.inv_dw + n;
-    w.amp = w.y + n;
-    w.n_inv = w.amp + n;
+    w.wrec = (WideRec*)p;                    // 48 n, 16-byte aligned
+    w.wscan = (WideScan*)(w.wrec + n);       // 16 n
+    w.wslow = (WideSlow*)(w.wscan + n);      // 16 n
+    WideRec32* rec32 = (WideRec32*)(w.wslow + n);  // 32 n
+    w.wrec32 = ctx->mixed_precision ? rec32 : nullptr;
+    w.n_inv = (double*)(rec32 + n);
     w.n_y = w.n_inv + n;
     w.n_amp = w.n_y + n;
-    w.lo = (int*)(w.n_amp + n);
-    w.hi = w.lo + n;
-    w.nlo = w.hi + n;
+    w.nlo = (int*)(w.n_amp + n);
     w.nhi = w.nlo + n;
     w.cnt_ge = (int*)ctx->cnt_ws;
     w.centre = w.cnt_ge + ctx->cnt_ge_len;
     w.nhw_max = w.centre + n_lines;
-    w.mask_ld = ((n_lines + 63) / 64) * 4;
-    w.wmask_med = (unsigned short*)ctx->mask_ws;
-    w.wmask_huge = w.wmask_med + (size_t)n_depth * w.mask_ld;
-    w.d_lo = nullptr;
-    w.cap = n_lines;
+    w.whw_max = w.nhw_max + n_lines;
+    w.hlist = nullptr;  // set by line_partials for long lists
+    w.hcount = w.whw_max + n_lines + n_lines;
     w.evals = (unsigned long long*)((char*)ctx->small_ws + 2048);
     return w;
 }
@@ -298,8 +293,6 @@ void sdx_destroy(sdx_ctx* ctx)
     if (ctx->small_ws) hipFree(ctx->small_ws);
     if (ctx->part_ws) hipFree(ctx->part_ws);
     if (ctx->cnt_ws) hipFree(ctx->cnt_ws);
-    if (ctx->mask_ws) hipFree(ctx->mask_ws);
-    if (ctx->dense_ws) hipFree(ctx->dense_ws);
     if (ctx->io_dev) hipFree(ctx->io_dev);
     if (ctx->io_pin) hipHostFree(ctx->io_pin);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
@@ -517,8 +510,9 @@ struct ContinuumJob {  // continuum plane computed by the trailing blocks of the
 static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t n_lines, const double* line_nus,
                         const double* doppler, const double* gammas, int gamma_cols, const double* alphas, bool fill_work,
                         int32_t* lo_ref, int32_t* hi_ref, LineWork* w_out, bool count_evals = true,
-                        const ContinuumJob* job = nullptr, const LineParams* gen = nullptr)
+                        const ContinuumJob* job = nullptr, const LineParams* gen = nullptr, int64_t nu_begin = 0, int64_t nu_count = -1)
 {
+    if (nu_count < 0) nu_count = n_nu;
     const LineParams lp = gen ? *gen : LineParams{};
     int n_partial = 0;
     int rc = ensure(ctx, &ctx->small_ws, &ctx->small_ws_bytes, kSmallHeader);
@@ -534,22 +528,39 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
         rc = ensure(ctx, &ctx->line_ws, &ctx->line_ws_bytes, line_ws_need(n_depth, n_lines));
         if (rc) return rc;
         ctx->cnt_ge_len = (size_t)(n_nu + 2 + 63) / 64 * 64;
-        rc = ensure(ctx, &ctx->cnt_ws, &ctx->cnt_ws_bytes, (ctx->cnt_ge_len + 2 * (size_t)n_lines) * sizeof(int));
+        // cnt_ge, then per line: centre, nhw_max, whw_max, hlist; then hcount
+        rc = ensure(ctx, &ctx->cnt_ws, &ctx->cnt_ws_bytes, (ctx->cnt_ge_len + 4 * (size_t)n_lines + 64 + (size_t)n_lines / 1024 + 8) * sizeof(int));
         if (rc) return rc;
-        {
-            const size_t need = (size_t)2 * n_depth * (((size_t)n_lines + 63) / 64) * 4 * sizeof(unsigned short) + 64;
-            if (ctx->mask_ws_bytes < need) {
-                rc = ensure(ctx, &ctx->mask_ws, &ctx->mask_ws_bytes, need);
-                if (rc) return rc;
-                // padding entries (beyond the last 16-line group) are never written by the pre-pass: zero them once
-                HIP_TRY(hipMemsetAsync(ctx->mask_ws, 0, ctx->mask_ws_bytes, ctx->stream));
-            }
-        }
         w = carve(ctx, n_depth, n_lines);
-        if (n_depth > kPreDepths) HIP_TRY(hipMemsetAsync(w.nhw_max, 0, (size_t)n_lines * sizeof(int), ctx->stream));
+        if (n_depth > kPreDepths) HIP_TRY(hipMemsetAsync(w.nhw_max, 0, (size_t)2 * n_lines * sizeof(int), ctx->stream));  // nhw_max and whw_max
         if (count_evals) HIP_TRY(hipMemsetAsync(w.evals, 0, sizeof(unsigned long long), ctx->stream));
         else w.evals = nullptr;
         n_pixel_blocks = (int)((n_nu + 2 + kPreBlock - 1) / kPreBlock);
+    }
+    w.sel = nullptr;
+    w.gather = 0;
+    // A frequency shard of a long list does not need every line prepared: a streaming classification pass finds the lines
+    // that can reach any column (-> hlist), the full pre-pass then runs on the lines centred near the shard plus those.
+    // Everything is decided on the device (no host round trip, graph-capturable); which lines a shard prepares does not
+    // change what it computes for them.
+    static const bool no_cull = std::getenv("SDX_NO_CULL") != nullptr;
+    const bool cull = fill_work && !no_cull && n_lines >= ctx->indexed_min_lines && !count_evals && !gen && !scan_in_block && nu_count < n_nu;
+    if (cull) {
+        HIP_TRY(hipMemsetAsync(w.whw_max, 0, (size_t)n_lines * sizeof(int), ctx->stream));
+        w.hlist = w.whw_max + n_lines;
+        int* sel = w.hcount + 4;
+        const unsigned hb = (unsigned)((n_lines + kHlistBlock - 1) / kHlistBlock);
+        int* block_cnt = w.hcount + 16;
+        {
+            LaunchScope ls(ctx, "k_classify");
+            hipLaunchKernelGGL(k_classify, dim3(blocks1(n_lines * n_depth)), dim3(kBlock), 0, ctx->stream, n_depth, n_nu, n_lines,
+                               (const double*)ctx->small_ws, n_partial, doppler, gammas, gamma_cols, alphas, w.whw_max);
+            hipLaunchKernelGGL(k_hlist_count, dim3(hb), dim3(kHlistBlock), 0, ctx->stream, n_lines, (const int*)w.whw_max, block_cnt);
+            hipLaunchKernelGGL(k_hlist_scatter, dim3(hb), dim3(kHlistBlock), 0, ctx->stream, n_lines, (const int*)w.whw_max, (const int*)block_cnt,
+                               w.hlist, w.hcount);
+            hipLaunchKernelGGL(k_shard_range, dim3(1), dim3(64), 0, ctx->stream, n_nu, nus, n_lines, line_nus, nu_begin, nu_count, sel);
+        }
+        w.sel = sel;
     }
     const dim3 grid((unsigned)(n_line_blocks + n_pixel_blocks), (unsigned)((n_depth + kPreDepths - 1) / kPreDepths));
     if (job) {
@@ -582,6 +593,16 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
         else if (pre_lines == 16) hipLaunchKernelGGL((k_line_prepass<false, 16>), grid, dim3(kPreBlock), 0, ctx->stream, SDX_PRE_ARGS);
         else hipLaunchKernelGGL((k_line_prepass<false, 32>), grid, dim3(kPreBlock), 0, ctx->stream, SDX_PRE_ARGS);
 #undef SDX_PRE_ARGS
+    }
+    if (cull) {  // second launch: the lines of hlist (gather mode), wherever they are centred
+        LineWork wg = w;
+        wg.gather = 1;
+        wg.sel = nullptr;
+        wg.cnt_ge = nullptr;  // the pixel blocks ran in the first launch
+        LaunchScope ls(ctx, "k_line_prepass");
+        const dim3 ggrid((unsigned)((n_lines + 31) / 32), grid.y);
+        hipLaunchKernelGGL((k_line_prepass<false, 32>), ggrid, dim3(kPreBlock), 0, ctx->stream, n_depth, n_nu, nus, (const double*)ctx->small_ws,
+                           n_partial, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, wg, (int*)nullptr, (int*)nullptr, (int)ggrid.x, lp);
     }
     if (w_out) *w_out = w;
     return check_launch("k_line_prepass");
@@ -627,31 +648,20 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
     constexpr int R = 4;
     LineWork w;
     int rc = line_prepass(ctx, n_depth, n_nu, nus, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, true, nullptr, nullptr, &w,
-                          count_evals, job, gen);
+                          count_evals, job, gen, nu_begin, nu_count);
     if (rc) return rc;
     const int n_split = choose_splits(n_depth, n_nu, n_lines, R);
-    // large line lists: build dense per-depth lists of the medium / huge items so tiles stop scanning the whole list
+    // long line lists: the lines with a window wider than kMediumHalfWidth are listed once (they are scanned by every tile);
+    // all others are found by centre range.  Short lists are scanned completely.
     const int indexed = n_lines >= ctx->indexed_min_lines ? 1 : 0;
-    if (indexed) {
-        const size_t cells = (size_t)n_depth * (size_t)n_lines;
-        const unsigned list_blocks = (unsigned)(((n_lines + 63) / 64 + kListChunks - 1) / kListChunks);
-        rc = ensure(ctx, &ctx->dense_ws, &ctx->dense_ws_bytes,
-                    cells * 44 + (size_t)2 * n_depth * sizeof(int) + 256 + (size_t)2 * n_depth * list_blocks * sizeof(int));
-        if (rc) return rc;
-        w.d_lnu = (double*)ctx->dense_ws;
-        w.d_inv = w.d_lnu + cells;
-        w.d_y = w.d_inv + cells;
-        w.d_amp = w.d_y + cells;
-        w.d_lo = (int*)(w.d_amp + cells);
-        w.d_hi = w.d_lo + cells;
-        w.d_centre = w.d_hi + cells;
-        w.d_cnt = w.d_centre + cells;
-        w.cap = n_lines;
-        LaunchScope ls(ctx, "k_build_lists");
-        const dim3 grid(list_blocks, (unsigned)n_depth, 2u);
-        int* block_cnt = w.d_cnt + 2 * n_depth + 32;
-        hipLaunchKernelGGL(k_count_lists, grid, dim3(64), 0, ctx->stream, n_depth, n_lines, w, block_cnt);
-        hipLaunchKernelGGL(k_build_lists, grid, dim3(kBlock), 0, ctx->stream, n_depth, n_lines, line_nus, w, (const int*)block_cnt);
+    if (indexed && !w.hlist) {  // (a culled pre-pass has built the list already)
+        w.hlist = w.whw_max + n_lines;
+        const unsigned hb = (unsigned)((n_lines + kHlistBlock - 1) / kHlistBlock);
+        int* block_cnt = w.hcount + 16;  // hb ints behind the counter (reserved in cnt_ws)
+        LaunchScope ls(ctx, "k_hlist");
+        hipLaunchKernelGGL(k_hlist_count, dim3(hb), dim3(kHlistBlock), 0, ctx->stream, n_lines, (const int*)w.whw_max, block_cnt);
+        hipLaunchKernelGGL(k_hlist_scatter, dim3(hb), dim3(kHlistBlock), 0, ctx->stream, n_lines, (const int*)w.whw_max, (const int*)block_cnt, w.hlist,
+                           w.hcount);
     }
     // two planes: [0] wide windows (the S subsets are summed inside their workgroup), [1] narrow windows
     rc = ensure(ctx, &ctx->part_ws, &ctx->part_ws_bytes, (size_t)2 * n_depth * nu_count * sizeof(double));
@@ -669,10 +679,8 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
         const int roles = split_launches ? (1 << pass) : 3;
         LaunchScope ls(ctx, split_launches ? (pass ? "k_line_narrow" : "k_line_wide") : "k_line_all");
 #define SDX_LINE_ARGS (int)n_wide, tiles, n_split, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, part, pld, roles
-        if (indexed && ctx->mixed_precision) hipLaunchKernelGGL((k_line_all<R, true, true>), g, blk, shmem, ctx->stream, SDX_LINE_ARGS);
-        else if (indexed) hipLaunchKernelGGL((k_line_all<R, true, false>), g, blk, shmem, ctx->stream, SDX_LINE_ARGS);
-        else if (ctx->mixed_precision) hipLaunchKernelGGL((k_line_all<R, false, true>), g, blk, shmem, ctx->stream, SDX_LINE_ARGS);
-        else hipLaunchKernelGGL((k_line_all<R, false, false>), g, blk, shmem, ctx->stream, SDX_LINE_ARGS);
+        if (ctx->mixed_precision) hipLaunchKernelGGL((k_line_all<R, true>), g, blk, shmem, ctx->stream, SDX_LINE_ARGS);
+        else hipLaunchKernelGGL((k_line_all<R, false>), g, blk, shmem, ctx->stream, SDX_LINE_ARGS);
 #undef SDX_LINE_ARGS
     }
     *partial_out = part;
@@ -1284,54 +1292,12 @@ static int raytrace_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, c
     REQUIRE(!ft.cont || n_theta <= 64, "raytrace: the fused total needs all angles in one launch");
     REQUIRE((F && fld >= n_nu) || I_nus, "raytrace: no output requested");
     constexpr int kMaxChunk = 64;
-    // Default: the coefficient-parallel kernel k_formal (plane-parallel sweep).  The lane <-> (frequency, angle) kernel
-    // k_raytrace remains for the inward sweep of spherical geometry, for models too deep for k_formal's LDS columns, and
-    // for A/B runs (SDX_RT_LEGACY=1).
-    static const bool legacy = std::getenv("SDX_RT_LEGACY") != nullptr;
     for (int th0 = 0; th0 < n_theta; th0 += kMaxChunk) {
         const int nth = std::min(kMaxChunk, n_theta - th0);
         const double* rd = ray_dist + th0;
         const double* w = wts + th0;
         double* inus = I_nus ? I_nus + th0 : nullptr;
         const int acc = (accumulate || th0 > 0) ? 1 : 0;
-        if (!inward && !legacy) {
-            // frequencies per wave: 1 while that still leaves fewer than ~8 waves per SIMD (a SIMD needs that many to issue at
-            // its full rate), more — fewer instructions per frequency in the recurrence and flux phases — on long grids.
-            // B = gaps per batch: a multiple of the gaps one coefficient round covers (64 / (fpw n_theta)) wastes no lanes
-            const int fpw_max = std::max(1, 64 / nth);
-            int fpw = (int)std::max<int64_t>(1, std::min<int64_t>(fpw_max, n_nu / (8 * 4 * (int64_t)ctx->n_cu)));
-            if (const char* e = std::getenv("SDX_RT_FPW")) fpw = std::max(1, std::min(fpw_max, std::atoi(e)));
-            int bsel = 0;
-            if (const char* e = std::getenv("SDX_RT_B")) bsel = std::atoi(e);
-            auto pick_b = [&](int f) {
-                if (bsel == 6 || bsel == 8 || bsel == 9 || bsel == 12) return bsel;
-                const int gpr = 64 / (f * nth);
-                return gpr == 3 ? 9 : 8;
-            };
-            auto lds = [&](int f, int B) {
-                const size_t col = (size_t)n_depth + 2;
-                return ((size_t)n_depth * nth + (size_t)(kFormalBlock / 64) * (2 * f * col + std::max<size_t>((size_t)2 * B * f * nth, f * col))) * sizeof(double);
-            };
-            // one flux item per lane: B fpw 2 <= 64
-            while (fpw > 1 && (lds(fpw, pick_b(fpw)) > 64 * 1024 || 2 * pick_b(fpw) * fpw > 64)) --fpw;
-            const int B = pick_b(fpw);
-            if (nth >= 8 && lds(fpw, B) <= 64 * 1024 && 2 * B * fpw <= 64) {
-                const size_t shmem = lds(fpw, B);
-                const unsigned blocks = (unsigned)((n_nu + (int64_t)fpw * (kFormalBlock / 64) - 1) / ((int64_t)fpw * (kFormalBlock / 64)));
-                {
-                    LaunchScope ls(ctx, "k_raytrace");
-#define SDX_RT_ARGS n_depth, n_nu, nth, n_theta, nus, temps, rd, w, alphas, ald, F, fld, inus, acc, fpw, ft
-                    if (B == 6) hipLaunchKernelGGL(k_formal<6>, dim3(blocks), dim3(kFormalBlock), shmem, ctx->stream, SDX_RT_ARGS);
-                    else if (B == 9) hipLaunchKernelGGL(k_formal<9>, dim3(blocks), dim3(kFormalBlock), shmem, ctx->stream, SDX_RT_ARGS);
-                    else if (B == 12) hipLaunchKernelGGL(k_formal<12>, dim3(blocks), dim3(kFormalBlock), shmem, ctx->stream, SDX_RT_ARGS);
-                    else hipLaunchKernelGGL(k_formal<8>, dim3(blocks), dim3(kFormalBlock), shmem, ctx->stream, SDX_RT_ARGS);
-#undef SDX_RT_ARGS
-                }
-                int rc = check_launch("k_formal");
-                if (rc) return rc;
-                continue;
-            }
-        }
         // Angles per lane P and lanes per frequency G = ceil(n_theta / P).  P = 1 (one lane per (frequency, angle)) is the
         // default at every size measured; SDX_RT_P overrides it for experiments.
         int P = 1;  // measured on MI355X at 7.6e3 and 1.2e5 frequencies: one angle per lane wins (more waves in flight)
@@ -1443,12 +1409,9 @@ static int synthesize_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double
     int rc2 = ensure(ctx, &ctx->cont_ws, &ctx->cont_ws_bytes, (size_t)n_depth * nu_count * sizeof(double));
     if (rc2) return rc2;
     double* cont_plane = (double*)ctx->cont_ws;
-    // the formal solution can form total = continuum + line planes while staging its columns when those fit LDS
-    // (k_formal with one frequency per wave, or k_raytrace's layout)
-    const size_t lds_formal = n_theta >= 8 ? ((size_t)n_depth * n_theta + (size_t)(kFormalBlock / 64) * (2 * ((size_t)n_depth + 2) + std::max<size_t>((size_t)24 * n_theta, (size_t)n_depth + 2))) * sizeof(double)
-                                           : (size_t)-1;
-    const size_t lds_legacy = ((size_t)2 * (n_depth - 1) * n_theta + (size_t)4 * (4 * (size_t)n_depth + 8 * 64)) * sizeof(double);
-    const bool fuse = n_theta <= 64 && std::min(lds_formal, lds_legacy) <= 64 * 1024;
+    // the formal solution forms total = continuum + line planes while staging its columns when those fit LDS
+    const size_t lds_columns = ((size_t)2 * (n_depth - 1) * n_theta + (size_t)4 * (4 * (size_t)n_depth + 8 * 64)) * sizeof(double);
+    const bool fuse = n_theta <= 64 && lds_columns <= 64 * 1024;
     const ContinuumJob job{cont, nu_begin, nu_count, cont_plane};
     const double* part = nullptr;
     int64_t pld = 0;

@@ -200,6 +200,39 @@ def test_graph_captured_before_a_workspace_reallocation_is_refused_and_recapture
     own.close()
 
 
+@pytest.mark.parametrize("world", [2, 5])
+def test_shards_of_a_long_list_prepare_only_the_lines_they_need_and_change_nothing(ctx, world):
+    """Frequency shards of a long list (>= indexed_min_lines lines, grid too long for the in-block d_nu scan) run a culled
+    pre-pass: a classification pass + the lines centred within kMediumHalfWidth of the shard + the lines wide enough to
+    reach any column.  The union of the shards must still be the unsharded answer bit for bit (which lines a shard
+    prepares does not change what it computes), here with windows of every class: 10-point floors, medium windows whose
+    centres lie OUTSIDE the shard they reach into, and lines spanning the whole grid."""
+    atm = synth.solar_atmosphere()
+    nus = synth.tracing_grid(4000.0, 5000.0, R=1.0e5)
+    assert nus.size > 16384
+    lines = synth.synth_lines(nus, atm, 9000, seed=61, mix=(0.7, 0.25, 0.05))
+    cont = synth.synth_continuum_state(atm)
+    th, w = synth.thetas_and_weights(4)
+    full = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], th, w, lines, cont, ctx=ctx, track_evaluations=False)
+    full.step()
+    F_full, line_full = full.F_nu(), full.alpha_line()
+    ref = oracle.calc_alan_entries(56, nus, lines["line_nus"], lines["doppler_widths"], lines["gammas"], lines["alphas"])
+    assert rel_err(line_full, ref) < 1e-12
+    parts_F, parts_l = [], []
+    for rank in range(world):
+        s = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], th, w, lines, cont, ctx=ctx, shard=shard_bounds(nus.size, world, rank),
+                                track_evaluations=False)  # the evaluation counter needs every window: it switches the culling off
+        s.step()
+        parts_F.append(s.F_nu())
+        parts_l.append(s.alpha_line())
+        s.capture()  # the culled pre-pass is decided on the device: it replays as a graph
+        s.step()
+        assert np.array_equal(s.F_nu(), parts_F[-1])
+        s.close()
+    assert np.array_equal(np.concatenate(parts_l, axis=1), line_full)
+    assert np.array_equal(np.concatenate(parts_F, axis=1), F_full)
+
+
 def test_long_line_list_on_the_wide_grid(ctx):
     """BASELINE configs[2]/[3] shape: the 3000-10000 A grid at R = 1e5 (120 398 frequencies) with a line list long
     enough (20 000 lines, gamma given as an (N_l, 1) column like the molecular case) to take the indexed wide-window
