@@ -356,9 +356,7 @@ class Runner:
         self.nd = atm["temperatures"].size
         self.shards = None
         if scaling == "strong" and world > 1 and isinstance(w["lines"], dict):
-            ln_ = w["lines"]
-            work = parallel.window_work(nus, ln_["line_nus"], ln_["doppler_widths"], ln_["gammas"], ln_["alphas"])
-            self.shards = parallel.balanced_shards(work, world, 6000.0)
+            self.shards = parallel.balanced_shards(parallel.column_cost(nus, w["lines"]), world)
         self.begin, self.count = self.shards[rank] if self.shards else shard_bounds(nus.size, world, rank)
         self.world, self.overlap = world, overlap and world > 1
         dev = f"cuda:{local}"
@@ -502,7 +500,7 @@ def main():
         if rank == 0:
             strong = {"workload": synth_desc("S-c3"), "scaling": "strong", "n_gpus": world, "steps": k3, "ms_per_step": e3 / k3 * 1e3,
                       "spectral_points_per_s": w3["nus"].size * nd * k3 / e3, "shards": [[int(b), int(c)] for b, c in (r3.shards or [])],
-                      "note": "shards of equal estimated work (parallel.window_work + balanced_shards); speed-up = the N=1 S-c3 step time in `secondary` / this"}
+                      "note": "shards of equal estimated work (parallel.column_cost + balanced_shards); speed-up = the N=1 S-c3 step time in `secondary` / this"}
         r3.close()
 
     # secondary figure (not `value`): two independent syntheses in flight on two streams — what a parameter grid

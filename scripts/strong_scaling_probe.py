@@ -13,12 +13,12 @@ worlds = [int(a) for a in sys.argv[2:] if a.isdigit()] or [1, 2, 4, 8]
 w = synth.make_workload(tag)
 atm, nus, ln = w["atm"], w["nus"], w["lines"]
 # per-column cost: window evaluations + the column's share of the formal solution and continuum (~6000 evaluation-equivalents)
-work = parallel.window_work(nus, ln["line_nus"], ln["doppler_widths"], ln["gammas"], ln["alphas"]) if balanced else None
+work = parallel.column_cost(nus, ln, scan_weight=float(os.environ.get("SDX_SCAN_WEIGHT", "0.6")), core_weight=float(os.environ.get("SDX_CORE_WEIGHT", "20"))) if balanced else None
 KERNELS = ("k_dnu_partial", "k_classify", "k_prepass_continuum", "k_line_prepass", "k_hlist", "k_line_all", "k_raytrace")
 
 
 def rank_time(world, rank, reps=8):
-    shard = parallel.balanced_shards(work, world, 6000.0)[rank] if balanced else shard_bounds(nus.size, world, rank)
+    shard = parallel.balanced_shards(work, world)[rank] if balanced else shard_bounds(nus.size, world, rank)
     syn = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], w["thetas"], w["weights"], w["lines"], w["cont"], shard=shard,
                               track_evaluations=False, keep_line=False)
     ctx = syn.ctx

@@ -30,7 +30,7 @@ cont = synth.synth_continuum_state(atm)
 th, w = synth.thetas_and_weights(8)
 shards = None
 if balanced:
-    shards = parallel.balanced_shards(parallel.window_work(nus, lines["line_nus"], lines["doppler_widths"], lines["gammas"], lines["alphas"]), world, 6000.0)
+    shards = parallel.balanced_shards(parallel.column_cost(nus, lines), world)
 begin, count = shards[rank] if shards else shard_bounds(nus.size, world, rank)
 lanes = []
 for _ in range(2):

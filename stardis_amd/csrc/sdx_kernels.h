@@ -159,7 +159,9 @@ struct LineWork {
     // index range [la, lb) of the lines whose centre lies within kMediumHalfWidth of the shard's columns (device memory,
     // written by k_shard_range; nullptr: every line) — plus, in a second launch with gather = 1, the lines of hlist
     const int* sel;
-    int gather;
+    int n_pix;      // pixel blocks (cnt_ge) behind the line blocks of the pre-pass grid
+    int gather;     // gather blocks behind those: block g prepares hlist[g kPreLines ...] (0: none)
+    int64_t shard_begin, shard_end;  // the shard's columns (culled runs only need cnt_ge near them)
     unsigned long long* evals;
 };
 
@@ -173,27 +175,36 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
                                                          int* __restrict__ out_lo_ref, int* __restrict__ out_hi_ref,
                                                          int n_line_blocks, const LineParams& lp)
 {
+    int gbx = -1;  // >= 0: a gather block
     if (bx >= n_line_blocks) {
-        // trailing blocks: cnt_ge[p] = #{l : centre_l >= p} = #{l : line_nu_l <= nus[p-1]}  (centre_l = #{i : nus[i] >= line_nu_l})
-        if (by == 0 && w.cnt_ge) {
-            const int64_t pidx = (int64_t)(bx - n_line_blocks) * blockDim.x + threadIdx.x;
-            if (pidx <= n_nu + 1) {
-                int64_t cnt;
-                if (pidx == 0) cnt = n_lines;
-                else if (pidx == n_nu + 1) cnt = 0;
-                else {
-                    const double v = nus[pidx - 1];
-                    int64_t lo = 0, hi = n_lines;  // first l with line_nus[l] > v
-                    while (lo < hi) {
-                        const int64_t mid = lo + ((hi - lo) >> 1);
-                        if (line_nus[mid] <= v) lo = mid + 1; else hi = mid;
+        if (bx >= n_line_blocks + w.n_pix) {
+            if (!w.gather) return;
+            gbx = bx - n_line_blocks - w.n_pix;
+        } else {
+            // pixel blocks: cnt_ge[p] = #{l : centre_l >= p} = #{l : line_nu_l <= nus[p-1]}  (centre_l = #{i : nus[i] >= line_nu_l})
+            if (by == 0 && w.cnt_ge) {
+                const int64_t pidx = (int64_t)(bx - n_line_blocks) * blockDim.x + threadIdx.x;
+                // a shard only reads cnt_ge within kMediumHalfWidth (+ a narrow window) of its columns
+                const bool needed = !w.sel || (pidx >= w.shard_begin - kMediumHalfWidth - 2 * kNarrowHalfWidth &&
+                                               pidx <= w.shard_end + kMediumHalfWidth + 2 * kNarrowHalfWidth);
+                if (pidx <= n_nu + 1 && needed) {
+                    int64_t cnt;
+                    if (pidx == 0) cnt = n_lines;
+                    else if (pidx == n_nu + 1) cnt = 0;
+                    else {
+                        const double v = nus[pidx - 1];
+                        int64_t lo = 0, hi = n_lines;  // first l with line_nus[l] > v
+                        while (lo < hi) {
+                            const int64_t mid = lo + ((hi - lo) >> 1);
+                            if (line_nus[mid] <= v) lo = mid + 1; else hi = mid;
+                        }
+                        cnt = lo;
                     }
-                    cnt = lo;
+                    w.cnt_ge[pidx] = (int)cnt;
                 }
-                w.cnt_ge[pidx] = (int)cnt;
             }
+            return;
         }
-        return;
     }
     constexpr int kStride = kPreDepths + 1;  // odd row stride: conflict-free transposed LDS reads
     constexpr int kPreItems = kPreLines * kPreDepths / kPreBlock;  // items per thread
@@ -208,12 +219,13 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
     __shared__ double s_lnu[kPreLines];
 
     const int nthreads = blockDim.x;
-    const int64_t l0 = (int64_t)bx * kPreLines;
+    const bool gather = gbx >= 0;
+    const int64_t l0 = (int64_t)(gather ? gbx : bx) * kPreLines;
     const int d0 = by * kPreDepths;
-    // which lines this block prepares: kPreLines consecutive ones, or — gather mode — kPreLines consecutive entries of hlist
+    // which lines this block prepares: kPreLines consecutive ones, or — gather blocks — kPreLines consecutive entries of hlist
     __shared__ int s_l[kPreLines];
     int nl = (int)min((int64_t)kPreLines, n_lines - l0);
-    if (w.gather) {
+    if (gather) {
         const int n_h = *w.hcount;
         if (l0 >= n_h) return;  // block-uniform
         nl = min(kPreLines, n_h - (int)l0);
@@ -224,7 +236,6 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
         if (threadIdx.x < kPreLines) s_l[threadIdx.x] = (int)(l0 + threadIdx.x);
         // (no barrier needed: the non-gather path indexes with l0 + ll directly)
     }
-    const bool gather = w.gather != 0;
 #define SDX_LINE_OF(ll) (gather ? (int64_t)s_l[ll] : l0 + (ll))
     const int nd = min(kPreDepths, n_depth - d0);
     // The block's dense inputs are requested first (kPreItems per thread), so their latency hides behind the centre search
@@ -693,15 +704,32 @@ __global__ __launch_bounds__(kBlock) void k_classify(int n_depth, int64_t n_nu, 
 {
     __shared__ double s_red[kBlock / 64];
     const double d_nu = block_dnu(dnu_partial, n_partial, s_red);
-    const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (k >= n_lines * n_depth) return;
-    const int64_t l = k / n_depth;
-    const int d = (int)(k - l * n_depth);
-    const double g = gamma_cols > 1 ? gammas[l * gamma_cols + d] : gammas[l];
-    const double pixels = mul_rn(mul_rn(add_rn(g, doppler[k]), alphas[k]) / d_nu, 20.0);
-    const double forced = pixels > 10.0 ? pixels : 10.0;
-    const int64_t hw = forced >= (double)n_nu ? n_nu : (int64_t)forced;
-    if (hw > kNarrowHalfWidth) atomicMax(&whw_max[l], (int)hw);
+    const int64_t n = n_lines * n_depth;
+    // four items per thread, a block apart: twelve independent loads in flight per lane (the pass is a pure stream)
+    const int64_t k0 = (int64_t)blockIdx.x * (4 * kBlock) + threadIdx.x;
+    double dw[4], al[4], g[4];
+    int64_t ls[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t k = k0 + j * kBlock;
+        ls[j] = -1;
+        dw[j] = al[j] = g[j] = 0.0;
+        if (k < n) {
+            const int64_t l = k / n_depth;
+            ls[j] = l;
+            dw[j] = doppler[k];
+            al[j] = alphas[k];
+            g[j] = gamma_cols > 1 ? gammas[l * gamma_cols + (k - l * n_depth)] : gammas[l];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (ls[j] < 0) continue;
+        const double pixels = mul_rn(mul_rn(add_rn(g[j], dw[j]), al[j]) / d_nu, 20.0);
+        const double forced = pixels > 10.0 ? pixels : 10.0;
+        const int64_t hw = forced >= (double)n_nu ? n_nu : (int64_t)forced;
+        if (hw > kNarrowHalfWidth) atomicMax(&whw_max[ls[j]], (int)hw);
+    }
 }
 
 // sel[0..1] = [la, lb): the lines whose centre c satisfies begin - H < c < end + H for the shard's columns [begin, end)

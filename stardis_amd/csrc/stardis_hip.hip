@@ -521,7 +521,7 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
     if (!scan_in_block && (rc = launch_dnu(ctx, n_nu, nus, &n_partial))) return rc;
     LineWork w{};
     // 16 lines per block while all such blocks are resident at once (two 1024-thread blocks per CU), else 32
-    const int pre_lines = ((n_lines + 15) / 16) * ((n_depth + kPreDepths - 1) / kPreDepths) <= 2 * (int64_t)ctx->n_cu ? 16 : 32;
+    const int pre_lines = ((n_lines + 15) / 16) * ((n_depth + kPreDepths - 1) / kPreDepths) <= 2 * (int64_t)ctx->n_cu ? 16 : 32;  // (culled runs: long lists, 32)
     const int n_line_blocks = (int)((n_lines + pre_lines - 1) / pre_lines);
     int n_pixel_blocks = 0;
     if (fill_work) {
@@ -539,6 +539,9 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
     }
     w.sel = nullptr;
     w.gather = 0;
+    w.n_pix = n_pixel_blocks;
+    w.shard_begin = nu_begin;
+    w.shard_end = nu_begin + nu_count;
     // A frequency shard of a long list does not need every line prepared: a streaming classification pass finds the lines
     // that can reach any column (-> hlist), the full pre-pass then runs on the lines centred near the shard plus those.
     // Everything is decided on the device (no host round trip, graph-capturable); which lines a shard prepares does not
@@ -553,7 +556,7 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
         int* block_cnt = w.hcount + 16;
         {
             LaunchScope ls(ctx, "k_classify");
-            hipLaunchKernelGGL(k_classify, dim3(blocks1(n_lines * n_depth)), dim3(kBlock), 0, ctx->stream, n_depth, n_nu, n_lines,
+            hipLaunchKernelGGL(k_classify, dim3((unsigned)((n_lines * n_depth + 4 * kBlock - 1) / (4 * kBlock))), dim3(kBlock), 0, ctx->stream, n_depth, n_nu, n_lines,
                                (const double*)ctx->small_ws, n_partial, doppler, gammas, gamma_cols, alphas, w.whw_max);
             hipLaunchKernelGGL(k_hlist_count, dim3(hb), dim3(kHlistBlock), 0, ctx->stream, n_lines, (const int*)w.whw_max, block_cnt);
             hipLaunchKernelGGL(k_hlist_scatter, dim3(hb), dim3(kHlistBlock), 0, ctx->stream, n_lines, (const int*)w.whw_max, (const int*)block_cnt,
@@ -561,8 +564,9 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
             hipLaunchKernelGGL(k_shard_range, dim3(1), dim3(64), 0, ctx->stream, n_nu, nus, n_lines, line_nus, nu_begin, nu_count, sel);
         }
         w.sel = sel;
+        w.gather = n_line_blocks;  // worst case: every line in hlist; blocks beyond the list's end return at once
     }
-    const dim3 grid((unsigned)(n_line_blocks + n_pixel_blocks), (unsigned)((n_depth + kPreDepths - 1) / kPreDepths));
+    const dim3 grid((unsigned)(n_line_blocks + n_pixel_blocks + w.gather), (unsigned)((n_depth + kPreDepths - 1) / kPreDepths));
     if (job) {
         ContinuumArgs ca = to_args(job->cont, nullptr);
         ca.bf_level_density = job->cont->bf_level_density;
@@ -594,16 +598,6 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
         else hipLaunchKernelGGL((k_line_prepass<false, 32>), grid, dim3(kPreBlock), 0, ctx->stream, SDX_PRE_ARGS);
 #undef SDX_PRE_ARGS
     }
-    if (cull) {  // second launch: the lines of hlist (gather mode), wherever they are centred
-        LineWork wg = w;
-        wg.gather = 1;
-        wg.sel = nullptr;
-        wg.cnt_ge = nullptr;  // the pixel blocks ran in the first launch
-        LaunchScope ls(ctx, "k_line_prepass");
-        const dim3 ggrid((unsigned)((n_lines + 31) / 32), grid.y);
-        hipLaunchKernelGGL((k_line_prepass<false, 32>), ggrid, dim3(kPreBlock), 0, ctx->stream, n_depth, n_nu, nus, (const double*)ctx->small_ws,
-                           n_partial, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, wg, (int*)nullptr, (int*)nullptr, (int)ggrid.x, lp);
-    }
     if (w_out) *w_out = w;
     return check_launch("k_line_prepass");
 }
@@ -625,15 +619,16 @@ static int check_line_args(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double
 // number of line subsets: enough single-wave blocks to fill the chip when the (tile, depth) grid alone is small
 // (decided from the GLOBAL grid size, not the shard's: the partition fixes the summation order of every grid point,
 // which must not depend on how the grid is sharded)
-static int choose_splits(int n_depth, int64_t n_nu_global, int64_t n_lines, int R)
+static int choose_splits(int n_depth, int64_t n_nu_global, int64_t n_lines, int R, int min_splits)
 {
     const int64_t tiles = (n_nu_global + 64 * R - 1) / (64 * R);
     const int64_t chunks = (n_lines + 63) / 64;
     int64_t target = 2560;  // measured optimum on S-c2: 2 subsets; more planes cost the raytrace staging more than the shorter chains gain
     if (const char* e = std::getenv("SDX_WIDE_BLOCKS")) target = std::max(1, std::atoi(e));  // tuning knob
-    // at least two subsets: the choice must not depend on the shard (it fixes the summation order), and a rank that owns
-    // 1/8 of a large grid still needs enough blocks; on a large unsharded grid the second plane costs ~1 % (S-c3)
-    const int64_t want = std::max<int64_t>(2, (target + tiles * n_depth - 1) / (tiles * n_depth));
+    // at least two subsets (four for long lists): the choice must not depend on the shard (it fixes the summation order), and
+    // a rank that owns 1/8 of a large grid still needs enough, small enough waves — a (tile, depth) of S-c3 is ~2e4
+    // instructions per subset at S = 2, and a shard's last generation of such waves is most of its run time
+    const int64_t want = std::max<int64_t>(min_splits, (target + tiles * n_depth - 1) / (tiles * n_depth));
     return (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(want, chunks), 8));  // the subsets are the waves of one workgroup
 }
 
@@ -650,7 +645,7 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
     int rc = line_prepass(ctx, n_depth, n_nu, nus, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, true, nullptr, nullptr, &w,
                           count_evals, job, gen, nu_begin, nu_count);
     if (rc) return rc;
-    const int n_split = choose_splits(n_depth, n_nu, n_lines, R);
+    const int n_split = choose_splits(n_depth, n_nu, n_lines, R, n_lines >= ctx->indexed_min_lines ? 4 : 2);
     // long line lists: the lines with a window wider than kMediumHalfWidth are listed once (they are scanned by every tile);
     // all others are found by centre range.  Short lists are scanned completely.
     const int indexed = n_lines >= ctx->indexed_min_lines ? 1 : 0;

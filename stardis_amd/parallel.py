@@ -37,10 +37,13 @@ def padded_count(n_nu, world_size):
     return -(-n_nu // world_size)
 
 
-def window_work(nus, line_nus, doppler_widths, gammas, alphas):
+def window_work(nus, line_nus, doppler_widths, gammas, alphas, core_weight=1.0):
     """Voigt evaluations per grid column, sum over (line, depth) of [lo <= i < hi] with the window rule of
     calc_alan_entries (opacities_solvers/base.py:524-575).  A planning estimate on the host (numpy, O(N_l N_d)): it only
-    decides where shard boundaries go, never what is computed."""
+    decides where shard boundaries go, never what is computed.
+    core_weight > 1 counts an evaluation in a line core — a narrow window (half-width <= 64 points) or the points of a wide
+    window within 15 Doppler widths of the centre, Faddeeva regions II-IV — that many times: those cost 100-250
+    instructions where a far-wing evaluation costs 13."""
     nus = np.asarray(nus, dtype=np.float64)
     n = nus.size
     if n < 2 or np.asarray(line_nus).size == 0:
@@ -48,14 +51,48 @@ def window_work(nus, line_nus, doppler_widths, gammas, alphas):
     d_nu = -np.max(np.diff(nus))
     centre = n - np.searchsorted(nus[::-1], np.asarray(line_nus, dtype=np.float64))  # first index with nu < line_nu
     g = np.asarray(gammas, dtype=np.float64).reshape(centre.size, -1)
-    pixels = (g + np.asarray(doppler_widths, dtype=np.float64)) * np.asarray(alphas, dtype=np.float64) / d_nu * 20.0
+    dw = np.asarray(doppler_widths, dtype=np.float64)
+    pixels = (g + dw) * np.asarray(alphas, dtype=np.float64) / d_nu * 20.0
     hw = np.minimum(np.where(pixels > 10.0, pixels, 10.0), float(n)).astype(np.int64)
     lo = np.clip(centre[:, None] - hw, 0, n)
     hi = np.clip(centre[:, None] + hw, 0, n)
     cover = np.zeros(n + 1)
     np.add.at(cover, lo.ravel(), 1.0)
     np.add.at(cover, hi.ravel(), -1.0)
+    if core_weight != 1.0:
+        y = g / (np.sqrt(np.pi) * np.pi) / dw
+        chw = np.minimum(np.where(hw <= 64, hw, np.maximum(15.0 - y, 0.0) * dw / d_nu + 2.0).astype(np.int64), hw)
+        clo = np.clip(centre[:, None] - chw, 0, n)
+        chi = np.clip(centre[:, None] + chw, 0, n)
+        np.add.at(cover, clo.ravel(), core_weight - 1.0)
+        np.add.at(cover, chi.ravel(), -(core_weight - 1.0))
     return np.cumsum(cover)[:n]
+
+
+def scan_work(nus, line_nus, half_width=4096):
+    """Lines whose centre index lies within `half_width` grid points of each column: what a tile of a long line list
+    scans to find the windows that reach it (stardis_amd/csrc: line_wide_walk, candidates by centre range).  On a
+    logarithmic grid the line density per grid point follows the frequency, so this cost is several times higher at the
+    blue end than at the red end while the evaluation count is not."""
+    nus = np.asarray(nus, dtype=np.float64)
+    n = nus.size
+    ln = np.asarray(line_nus, dtype=np.float64)
+    if n == 0 or ln.size == 0:
+        return np.zeros(n)
+    centre = np.sort(n - np.searchsorted(nus[::-1], ln))  # first index with nu < line_nu, ascending
+    i = np.arange(n)
+    return (np.searchsorted(centre, i + half_width, side="left") - np.searchsorted(centre, i - half_width, side="right")).astype(np.float64)
+
+
+def column_cost(nus, lines, indexed_min_lines=8192, scan_weight=0.6, fixed=6000.0, core_weight=20.0):
+    """Estimated cost of every grid column in units of one far-wing Voigt evaluation, for balanced_shards: the window
+    evaluations (line cores weighted by core_weight), the candidate scan of long lists (scan_weight per line in range) and
+    a constant for the continuum and the formal solution — weights measured on MI355X.  A planning estimate on the host: it
+    only decides where shard boundaries go."""
+    cost = window_work(nus, lines["line_nus"], lines["doppler_widths"], lines["gammas"], lines["alphas"], core_weight) + fixed
+    if np.asarray(lines["line_nus"]).size >= indexed_min_lines:
+        cost = cost + scan_weight * scan_work(nus, lines["line_nus"])
+    return cost
 
 
 def window_evaluations(nus, line_nus, doppler_widths, gammas, alphas):
