@@ -206,7 +206,7 @@ def secondary_block(tag, device, steps, check):
     w = build_workload(tag, 1)
     atm, nus = w["atm"], w["nus"]
     ctx = _lib.Context(device)
-    syn = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], w["thetas"], w["weights"], w["lines"], w["cont"], ctx=ctx)
+    syn = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], w["thetas"], w["weights"], w["lines"], w["cont"], ctx=ctx, keep_line=False)
     syn.step()
     ctx.synchronize()
     setup_s = time.perf_counter() - t0
@@ -364,7 +364,7 @@ class Runner:
         for k in range(2 if self.overlap else 1):
             flux = torch.zeros((self.nd, self.count), dtype=torch.float64, device=dev)
             syn = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], w["thetas"], w["weights"], w["lines"], w["cont"], ctx=ctx,
-                                      shard=(self.begin, self.count), flux_out=flux, track_evaluations=(k == 0))
+                                      shard=(self.begin, self.count), flux_out=flux, track_evaluations=(k == 0), keep_line=False)
             self.lanes.append([syn, flux, parallel.FluxGatherer(nus.size, world, flux.device, shards=self.shards)])
         self.syn, self.flux = self.lanes[0][0], self.lanes[0][1]
         self.syn.step()
@@ -511,7 +511,7 @@ def main():
 
         ctx_b = _lib.Context(local)
         syn_b = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], w["thetas"], w["weights"], w["lines"], w["cont"],
-                                    ctx=ctx_b, track_evaluations=False)
+                                    ctx=ctx_b, track_evaluations=False, keep_line=False)
         if not args.no_graph:
             syn_b.capture()
         for _ in range(max(2, args.warmup // 2)):
@@ -564,6 +564,7 @@ def main():
                 "parallelism": f"nu-shard x{world}" + (", 1 all-gather of F_nu[-1] per step" + (" overlapped with the next step" if runner.overlap else "") if world > 1 else ""),
                 "hip_graph": not args.no_graph,
                 "line_inputs": args.inputs,
+                "outputs": "F_nu and total_alphas (N_d, N_nu); the optional alpha_line plane is not written",
                 "untimed_settle_steps_after_warmup": settle,
             },
             "roofline": {

@@ -1,4 +1,5 @@
-"""Run a few fused steps of a workload (for rocprofv3): python scripts/profile_step.py [workload] [steps] [--graph]"""
+"""Run a few fused steps of a workload (for rocprofv3): python scripts/profile_step.py [workload] [steps] [--graph] [--mixed] [--evals]
+The evaluation counter (a memset + a copy per step) is off unless --evals is given, like in bench.py's timed loop."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stardis_amd import synth
@@ -8,7 +9,10 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "S-c2"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 w = synth.make_workload(tag)
 atm = w["atm"]
-syn = SpectralSynthesizer(w["nus"], atm["temperatures"], atm["dist"], w["thetas"], w["weights"], w["lines"], w["cont"])
+syn = SpectralSynthesizer(w["nus"], atm["temperatures"], atm["dist"], w["thetas"], w["weights"], w["lines"], w["cont"],
+                          track_evaluations="--evals" in sys.argv, keep_line=False)
+if "--mixed" in sys.argv:
+    syn.ctx.set_option("mixed_precision", 1)
 if "--graph" in sys.argv:
     syn.capture()
 for _ in range(steps):

@@ -56,9 +56,10 @@ __device__ __forceinline__ double block_dnu(const double* __restrict__ partial, 
     return -m;
 }
 
-__device__ __forceinline__ double block_dnu_scan(const double* __restrict__ nus, int64_t n_nu, double* s_red)
+// this thread's share of max(diff(nus)) — eight independent loads in flight per thread: the scan is latency-, not
+// bandwidth-bound (the grid sits in L2).  Issued EARLY by the pre-pass so that it overlaps the centre search.
+__device__ __forceinline__ double dnu_scan_local(const double* __restrict__ nus, int64_t n_nu)
 {
-    // eight independent loads in flight per thread: the scan is latency-, not bandwidth-bound (the grid sits in L2)
     double m0 = -INFINITY, m1 = -INFINITY, m2 = -INFINITY, m3 = -INFINITY;
     const int64_t step = blockDim.x;
     int64_t i = threadIdx.x;
@@ -71,7 +72,10 @@ __device__ __forceinline__ double block_dnu_scan(const double* __restrict__ nus,
         m3 = fmax(m3, b3 - a3);
     }
     for (; i + 1 < n_nu; i += step) m0 = fmax(m0, nus[i + 1] - nus[i]);
-    double m = fmax(fmax(m0, m1), fmax(m2, m3));
+    return fmax(fmax(m0, m1), fmax(m2, m3));
+}
+__device__ __forceinline__ double block_max_to_dnu(double m, double* s_red)
+{
     for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
     if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = m;
     __syncthreads();
@@ -79,6 +83,10 @@ __device__ __forceinline__ double block_dnu_scan(const double* __restrict__ nus,
     for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = fmax(m, s_red[w]);
     __syncthreads();
     return -m;
+}
+__device__ __forceinline__ double block_dnu_scan(const double* __restrict__ nus, int64_t n_nu, double* s_red)
+{
+    return block_max_to_dnu(dnu_scan_local(nus, n_nu), s_red);
 }
 
 // index of the first grid frequency strictly below line_nu in the DESCENDING grid
@@ -154,7 +162,12 @@ struct LineWork {
     // long line lists: ascending indices of the lines whose widest window exceeds kMediumHalfWidth (they may reach any tile and
     // are scanned completely; all other lines are found by centre range).  nullptr for short lists (every line is scanned).
     int* hlist;
-    int* hcount;
+    int* hcount;     // [0] entries of hlist, [1] entries of wlist
+    // ... and the other lines with a wide window (kNarrowHalfWidth < widest window <= kMediumHalfWidth), ascending, with
+    // wrank[l] = number of wlist entries below line l ([N_l + 1]): the lines centred near a tile are a contiguous range of
+    // line indices (cnt_ge), hence a contiguous range [wrank[la], wrank[lb]) of wlist
+    int* wlist;
+    int* wrank;
     // frequency-sharded runs of long lists: the pre-pass only has to prepare the lines this shard can touch — sel[0..1] = the
     // index range [la, lb) of the lines whose centre lies within kMediumHalfWidth of the shard's columns (device memory,
     // written by k_shard_range; nullptr: every line) — plus, in a second launch with gather = 1, the lines of hlist
@@ -256,6 +269,8 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
             }
         }
     }
+    // small grids: this thread's part of the d_nu scan is requested now, its loads travel while the centres are searched
+    const double dnu_local = dnu_partial ? 0.0 : dnu_scan_local(nus, n_nu);
     // line centres: a 128-entry sample of the grid in LDS brackets the answer; wave ll then narrows the bracket of line
     // ll to 64 points by bisection (none needed when the grid has <= 8192 points) and resolves it with ONE coalesced
     // load and a ballot — a chain of one or two dependent global loads instead of log2(N_nu / 128)
@@ -264,12 +279,15 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
     if (threadIdx.x < 128) {
         const int64_t j = (int64_t)threadIdx.x * cstride;
         s_coarse[threadIdx.x] = j < n_nu ? nus[j] : -INFINITY;
+    } else if (threadIdx.x < 128 + kPreLines) {
+        const int ll = threadIdx.x - 128;
+        s_lnu[ll] = ll < nl ? line_nus[SDX_LINE_OF(ll)] : 0.0;
     }
     __syncthreads();
     for (int ll = threadIdx.x >> 6; ll < nl; ll += kPreBlock / 64) {
         const int lane = threadIdx.x & 63;
         {
-            const double v = line_nus[SDX_LINE_OF(ll)];
+            const double v = s_lnu[ll];
             int a = 0, b = 128;  // first sample strictly below v
             while (a < b) {
                 const int mid = (a + b) >> 1;
@@ -288,12 +306,9 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
             if (lane == 0) s_c[ll] = m ? lo + __builtin_ctzll(m) : hi;
         }
     }
-    if (threadIdx.x < kPreLines) {
-        s_hwmax[threadIdx.x] = 0, s_whwmax[threadIdx.x] = 0;
-        s_lnu[threadIdx.x] = threadIdx.x < nl ? line_nus[SDX_LINE_OF(threadIdx.x)] : 0.0;
-    }
+    if (threadIdx.x < kPreLines) s_hwmax[threadIdx.x] = 0, s_whwmax[threadIdx.x] = 0;
     // d_nu (:524-526): from the partial maxima of k_dnu_partial, or — small grids — scanned here directly
-    const double d_nu = dnu_partial ? block_dnu(dnu_partial, n_partial, s_red) : block_dnu_scan(nus, n_nu, s_red);
+    const double d_nu = dnu_partial ? block_dnu(dnu_partial, n_partial, s_red) : block_max_to_dnu(dnu_local, s_red);
 
     if constexpr (GEN) {
         // line parameters from per-line scalars and per-depth state (f1): nothing dense to read.  The per-depth and the
@@ -503,15 +518,21 @@ __device__ __forceinline__ void wide_reduce_and_store(const int split, const int
     }
 }
 
-// fp32 evaluation of the region-I rational for the mixed-precision mode: x from the hi / lo split of both frequencies
-// (nu_i - nu_l is exact to ~1e-7 relative whatever their distance), everything else plain fp32 (v_rcp_f32 is good to 1 ulp)
-__device__ __forceinline__ float region1_f32(float nuh, float nul, const WideRec32& k)
+// fp32 evaluation of the region-I rational for the mixed-precision mode, TWO grid points per instruction (v_pk_add / mul /
+// fma_f32: a packed instruction issues like one fp64 instruction and does two evaluations; only the reciprocal is per
+// point).  x comes from the hi / lo split of both frequencies (nu_i - nu_l is exact to ~1e-7 relative whatever their
+// distance), everything else is plain fp32 (v_rcp_f32 is good to 1 ulp).
+typedef float float2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2v region1_f32x2(float2v nuh, float2v nul, const WideRec32& k)
 {
-    const float x = ((nuh - k.nuh) + (nul - k.nul)) * k.inv;
-    const float q = x * x;
-    const float num = k.yk * (q + k.c2);
-    const float den = fmaf(q, q + k.c3, k.c4);
-    return num * __builtin_amdgcn_rcpf(den);
+    const float2v x = ((nuh - k.nuh) + (nul - k.nul)) * k.inv;
+    const float2v q = x * x;
+    const float2v num = (q + k.c2) * k.yk;
+    const float2v den = __builtin_elementwise_fma(q, q + k.c3, (float2v)(k.c4));
+    float2v r;
+    r.x = __builtin_amdgcn_rcpf(den.x);
+    r.y = __builtin_amdgcn_rcpf(den.y);
+    return num * r;
 }
 
 template <int R, bool MIXED>
@@ -525,19 +546,24 @@ __device__ __forceinline__ void line_wide_walk(const int tile_idx, const int spl
     const int lane = threadIdx.x & 63;
     const int it0 = (int)t0, it1 = (int)t1;
 
-    double nu_i[R], acc[R];
-    float nu_h[R], nu_l[R], acc32[R];
+    // fp64 mode: the lane's frequencies as doubles.  Mixed mode: as hi + lo fp32 pairs only (the fp64 value is their exact
+    // sum to 2^-48, rebuilt on the rare general path), so that R = 8 points per lane fit the register budget
+    double nu_i[MIXED ? 1 : R], acc[R];
+    float2v nu_h[MIXED ? R / 2 : 1], nu_l[MIXED ? R / 2 : 1], acc32[MIXED ? R / 2 : 1];  // pairs of points (r, r + 1)
     int idx[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int64_t i = t0 + lane + r * 64;
         idx[r] = i < t1 ? (int)i : -1;
-        nu_i[r] = i < t1 ? nus[i] : 0.0;
+        const double nu = i < t1 ? nus[i] : 0.0;
         acc[r] = 0.0;
-        if (MIXED) {
-            nu_h[r] = (float)nu_i[r];
-            nu_l[r] = (float)(nu_i[r] - (double)nu_h[r]);
-            acc32[r] = 0.f;
+        if constexpr (MIXED) {
+            const float h = (float)nu;
+            nu_h[r >> 1][r & 1] = h;
+            nu_l[r >> 1][r & 1] = (float)(nu - (double)h);
+            acc32[r >> 1][r & 1] = 0.f;
+        } else {
+            nu_i[r] = nu;
         }
     }
     const size_t row = (size_t)d * n_lines;
@@ -549,14 +575,14 @@ __device__ __forceinline__ void line_wide_walk(const int tile_idx, const int spl
     int pending32 = 0;  // fp32 terms accumulated since the last flush into the fp64 sums
 
     for (int pass = w.hlist ? 0 : 1; pass < 2; ++pass) {
-        // candidate positions [ka, kb) of this pass: hlist positions (pass 0) or line indices (pass 1)
+        // candidate positions [ka, kb) of this pass: hlist positions (pass 0); wlist positions or — short lists — line indices (pass 1)
         int ka = 0, kb = n_h;
         if (pass == 1) {
             kb = (int)n_lines;
-            if (w.hlist) {  // lines whose centre c satisfies t0 - H < c < t1 + H
+            if (w.hlist) {  // lines whose centre c satisfies t0 - H < c < t1 + H: line indices [la, lb), wlist positions [wrank[la], wrank[lb])
                 const int64_t pa = max(t0 - kMediumHalfWidth + 1, (int64_t)0), pb = min(t1 + kMediumHalfWidth - 1, n_nu);
-                ka = __builtin_amdgcn_readfirstlane(w.cnt_ge[pb + 1]);
-                kb = __builtin_amdgcn_readfirstlane(w.cnt_ge[pa]);
+                ka = __builtin_amdgcn_readfirstlane(w.wrank[w.cnt_ge[pb + 1]]);
+                kb = __builtin_amdgcn_readfirstlane(w.wrank[w.cnt_ge[pa]]);
             }
         }
         if (kb <= ka) continue;
@@ -568,11 +594,8 @@ __device__ __forceinline__ void line_wide_walk(const int tile_idx, const int spl
             line = -1;
             sc = WideScan{0, 0, 0, 0};
             if (qq <= q_last && k >= ka && k < kb) {
-                const int l = pass == 0 ? w.hlist[k] : k;
-                if (pass == 0 || !w.hlist || w.whw_max[l] <= kMediumHalfWidth) {
-                    line = l;
-                    sc = scan_row[l];
-                }
+                line = pass == 0 ? w.hlist[k] : (w.hlist ? w.wlist[k] : k);
+                sc = scan_row[line];
             }
         };
         int line_next;
@@ -596,27 +619,42 @@ __device__ __forceinline__ void line_wide_walk(const int tile_idx, const int spl
                 const int b = __builtin_ctzll(m);
                 const int e = __builtin_amdgcn_readlane(line, b);
                 const bool is_fast = (mf >> b) & 1ull;
+                if constexpr (MIXED) {
+                    // two consecutive test-free hits share one trip: both 32-byte records are requested together (one wait
+                    // instead of two — the fp32 arithmetic is short enough for the record fetch to show), the sums keep
+                    // list order
+                    const unsigned long long m1 = m & (m - 1);
+                    if (is_fast && m1 && ((mf >> __builtin_ctzll(m1)) & 1ull)) {
+                        const int e1 = __builtin_amdgcn_readlane(line, __builtin_ctzll(m1));
+                        const WideRec32 ra = rec32_row[e], rb = rec32_row[e1];
+#pragma unroll
+                        for (int r = 0; r < R / 2; ++r) {
+                            acc32[r] += region1_f32x2(nu_h[r], nu_l[r], ra);
+                            acc32[r] += region1_f32x2(nu_h[r], nu_l[r], rb);
+                        }
+                        pending32 += 2;
+                        m = m1 & (m1 - 1);
+                        if (!m) break;
+                        continue;
+                    }
+                }
                 WideRec cur;
                 WideRec32 cur32;
-                if (MIXED && is_fast) cur32 = rec32_row[e];  // the fp64 record is not needed
-                else cur = rec_row[e];
+                if (MIXED) cur32 = rec32_row[e];
+                if (!MIXED || !is_fast) cur = rec_row[e];  // mixed mode needs the fp64 record only over a core it keeps
                 m &= m - 1;
                 if (is_fast) {
                     // every point of the tile is inside the window and in region I: the same operations, in the same order,
                     // as voigt_term's region-I branch (bit-identical), or the fp32 rational of the mixed-precision mode
-                    if (MIXED) {
+                    if constexpr (MIXED) {
 #pragma unroll
-                        for (int r = 0; r < R; ++r) acc32[r] += region1_f32(nu_h[r], nu_l[r], cur32);
-                        if (++pending32 >= 64) {
-#pragma unroll
-                            for (int r = 0; r < R; ++r) acc[r] += (double)acc32[r], acc32[r] = 0.f;
-                            pending32 = 0;
-                        }
+                        for (int r = 0; r < R / 2; ++r) acc32[r] += region1_f32x2(nu_h[r], nu_l[r], cur32);
+                        ++pending32;
                     } else {
                         const RegionI k1 = {cur.yk, cur.c2, cur.c3, cur.c4};
 #pragma unroll
                         for (int r = 0; r < R; ++r) {
-                            const double x = (nu_i[r] - cur.lnu) * cur.inv;
+                            const double x = (nu_i[MIXED ? 0 : r] - cur.lnu) * cur.inv;
                             acc[r] += region1_re(x * x, k1);
                         }
                     }
@@ -630,69 +668,102 @@ __device__ __forceinline__ void line_wide_walk(const int tile_idx, const int spl
                     const bool delegated = jc < 0;
                     const int jclo = delegated ? -jc - 1 : jc;
                     const RegionI k1 = {cur.yk, cur.c2, cur.c3, cur.c4};
+                    float2v term32[MIXED ? R / 2 : 1];  // mixed mode: the fp32 rational of every point pair, once per hit
+                    if constexpr (MIXED) {
+#pragma unroll
+                        for (int p = 0; p < R / 2; ++p) term32[p] = region1_f32x2(nu_h[p], nu_l[p], cur32);
+                    }
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
                         const int a = it0 + 64 * r, z = min(a + 64, it1);
                         if (z <= jlo || a >= jhi || a >= it1) continue;
                         const bool over_core = !(z <= jclo || a >= jchi);
                         if (!over_core || delegated) {
-                            const double x = (nu_i[r] - cur.lnu) * cur.inv;
-                            const double term = region1_re(x * x, k1);
                             const bool take = idx[r] >= jlo && idx[r] < jhi && !(over_core && idx[r] >= jclo && idx[r] < jchi);
-                            acc[r] += take ? term : 0.0;
+                            if constexpr (MIXED) {  // the tolerance path evaluates window edges in fp32 too (pairs of blocks)
+                                acc32[r >> 1][r & 1] += take ? term32[r >> 1][r & 1] : 0.f;
+                            } else {
+                                const double x = (nu_i[MIXED ? 0 : r] - cur.lnu) * cur.inv;
+                                const double term = region1_re(x * x, k1);
+                                acc[r] += take ? term : 0.0;
+                            }
                         } else {
+                            const double nu_r = MIXED ? (double)nu_h[MIXED ? r >> 1 : 0][r & 1] + (double)nu_l[MIXED ? r >> 1 : 0][r & 1] : nu_i[MIXED ? 0 : r];
                             const WideSlow sl = slow_row[e];
-                            if (idx[r] >= jlo && idx[r] < jhi) acc[r] += voigt_term(nu_i[r] - cur.lnu, cur.inv, sl.y, sl.amp, k1);
+                            if (idx[r] >= jlo && idx[r] < jhi) acc[r] += voigt_term(nu_r - cur.lnu, cur.inv, sl.y, sl.amp, k1);
                         }
                     }
+                    if constexpr (MIXED) ++pending32;
                 }
                 if (!m) break;
             }
+            if constexpr (MIXED) {
+                // the fp32 running sums go into the fp64 sums once ~64 terms have gathered (checked per chunk, not per hit: a
+                // branch around the fp64 accumulators inside the walk costs eight register copies per hit)
+                if (pending32 >= 48) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) acc[r] += (double)acc32[r >> 1][r & 1], acc32[r >> 1][r & 1] = 0.f;
+                    pending32 = 0;
+                }
+            }
         }
     }
-    if (MIXED) {
+    if constexpr (MIXED) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] += (double)acc32[r];
+        for (int r = 0; r < R; ++r) acc[r] += (double)acc32[r >> 1][r & 1];
     }
     wide_reduce_and_store<R>(split, n_split, acc, idx, lds_all, nu_begin, plane, pld, d);
 }
 
-// Long line lists: ascending indices of the lines whose widest window exceeds kMediumHalfWidth -> hlist, their number ->
-// hcount[0].  A stable compaction in two small launches: per-block counts, then every block sums the counts before it
-// (a few hundred integers) and scatters its own flagged lines.
+// Long line lists: two stable compactions of the per-line classes in two small launches (per-block counts, then every
+// block sums the counts before it — a few hundred integers — and scatters its own lines):
+//   hlist  the lines whose widest window exceeds kMediumHalfWidth (they may reach any tile: every tile visits them all)
+//   wlist  the other lines with a wide window at some depth, + wrank[l] = wlist entries below line l
 constexpr int kHlistBlock = 1024;
+__device__ __forceinline__ int line_class(int whw) { return whw > kMediumHalfWidth ? 2 : (whw > kNarrowHalfWidth ? 1 : 0); }
+
 __global__ __launch_bounds__(kHlistBlock) void k_hlist_count(int64_t n_lines, const int* __restrict__ whw_max, int* __restrict__ block_cnt)
 {
-    __shared__ int s_wave[kHlistBlock / 64];
+    __shared__ int s_wave[2][kHlistBlock / 64];
     const int64_t l = (int64_t)blockIdx.x * kHlistBlock + threadIdx.x;
-    const unsigned long long m = __ballot(l < n_lines && whw_max[l] > kMediumHalfWidth);
-    if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = __popcll(m);
+    const int cls = l < n_lines ? line_class(whw_max[l]) : 0;
+    const unsigned long long mh = __ballot(cls == 2), mw = __ballot(cls == 1);
+    if ((threadIdx.x & 63) == 0) s_wave[0][threadIdx.x >> 6] = __popcll(mh), s_wave[1][threadIdx.x >> 6] = __popcll(mw);
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < 2) {
         int tot = 0;
-        for (int k = 0; k < kHlistBlock / 64; ++k) tot += s_wave[k];
-        block_cnt[blockIdx.x] = tot;
+        for (int k = 0; k < kHlistBlock / 64; ++k) tot += s_wave[threadIdx.x][k];
+        block_cnt[2 * blockIdx.x + threadIdx.x] = tot;
     }
 }
 __global__ __launch_bounds__(kHlistBlock) void k_hlist_scatter(int64_t n_lines, const int* __restrict__ whw_max, const int* __restrict__ block_cnt,
-                                                              int* __restrict__ hlist, int* __restrict__ hcount)
+                                                              int* __restrict__ hlist, int* __restrict__ wlist, int* __restrict__ wrank,
+                                                              int* __restrict__ hcount)
 {
-    __shared__ int s_wave[kHlistBlock / 64];
-    __shared__ int s_red[kHlistBlock / 64];
+    __shared__ int s_wave[2][kHlistBlock / 64];
+    __shared__ int s_red[2][kHlistBlock / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int before = 0;
-    for (int k = threadIdx.x; k < (int)blockIdx.x; k += kHlistBlock) before += block_cnt[k];
-    for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off);
+    int bh = 0, bw = 0;
+    for (int k = threadIdx.x; k < (int)blockIdx.x; k += kHlistBlock) bh += block_cnt[2 * k], bw += block_cnt[2 * k + 1];
+    for (int off = 32; off > 0; off >>= 1) bh += __shfl_xor(bh, off), bw += __shfl_xor(bw, off);
     const int64_t l = (int64_t)blockIdx.x * kHlistBlock + threadIdx.x;
-    const bool flag = l < n_lines && whw_max[l] > kMediumHalfWidth;
-    const unsigned long long m = __ballot(flag);
-    if (lane == 0) s_red[wave] = before, s_wave[wave] = __popcll(m);
+    const int cls = l < n_lines ? line_class(whw_max[l]) : 0;
+    const unsigned long long mh = __ballot(cls == 2), mw = __ballot(cls == 1);
+    if (lane == 0) s_red[0][wave] = bh, s_red[1][wave] = bw, s_wave[0][wave] = __popcll(mh), s_wave[1][wave] = __popcll(mw);
     __syncthreads();
-    int base = 0;
-    for (int k = 0; k < kHlistBlock / 64; ++k) base += s_red[k];
-    for (int k = 0; k < wave; ++k) base += s_wave[k];
-    if (flag) hlist[base + __popcll(m & ((1ull << lane) - 1ull))] = (int)l;
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == kHlistBlock - 1) hcount[0] = base + __popcll(m);  // last thread of the last wave: everything before + its wave
+    int base_h = 0, base_w = 0;
+    for (int k = 0; k < kHlistBlock / 64; ++k) base_h += s_red[0][k], base_w += s_red[1][k];
+    for (int k = 0; k < wave; ++k) base_h += s_wave[0][k], base_w += s_wave[1][k];
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int pos_h = base_h + __popcll(mh & below), pos_w = base_w + __popcll(mw & below);
+    if (cls == 2) hlist[pos_h] = (int)l;
+    if (cls == 1) wlist[pos_w] = (int)l;
+    if (l < n_lines) wrank[l] = pos_w;
+    if (l == n_lines - 1) {
+        wrank[n_lines] = pos_w + (cls == 1);
+        hcount[0] = pos_h + (cls == 2);
+        hcount[1] = pos_w + (cls == 1);
+    }
 }
 
 // Frequency-sharded runs of long lists, stage A: the widest window of every line (over all depths), from the window rule
@@ -826,7 +897,7 @@ __device__ __forceinline__ void line_narrow_wave(const int64_t i, const int dept
 // roles: bit 0 wide, bit 1 narrow (both by default; one at a time for split-launch profiling, SDX_SPLIT_LAUNCHES=1).
 // Output planes: [0] the wide windows (all subsets summed), [1] the narrow windows.
 template <int R, bool MIXED>
-__global__ __launch_bounds__(512) void k_line_all(int n_wide, int tiles, int n_split, int n_depth, int64_t n_nu,
+__device__ __forceinline__ void line_all_body(int n_wide, int tiles, int n_split, int n_depth, int64_t n_nu,
                                                    const double* __restrict__ nus, int64_t nu_begin, int64_t nu_count,
                                                    int64_t n_lines, const double* __restrict__ line_nus, LineWork w,
                                                    double* __restrict__ planes, int64_t pld, int roles)
@@ -851,6 +922,24 @@ __global__ __launch_bounds__(512) void k_line_all(int n_wide, int tiles, int n_s
             line_narrow_wave(nu_begin + c % nu_count, (int)(c / nu_count), n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w,
                              planes + (size_t)n_depth * pld, pld);
     }
+}
+
+template <int R>
+__global__ __launch_bounds__(512) void k_line_all(int n_wide, int tiles, int n_split, int n_depth, int64_t n_nu,
+                                                   const double* __restrict__ nus, int64_t nu_begin, int64_t nu_count,
+                                                   int64_t n_lines, const double* __restrict__ line_nus, LineWork w,
+                                                   double* __restrict__ planes, int64_t pld, int roles)
+{
+    line_all_body<R, false>(n_wide, tiles, n_split, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, planes, pld, roles);
+}
+// the mixed-precision variant: 512-point tiles; the register budget is capped at 128 (4 waves per SIMD) — what exceeds it
+// sits in the rarely taken fp64 general path
+template <int R>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_line_all_mixed(
+    int n_wide, int tiles, int n_split, int n_depth, int64_t n_nu, const double* __restrict__ nus, int64_t nu_begin, int64_t nu_count,
+    int64_t n_lines, const double* __restrict__ line_nus, LineWork w, double* __restrict__ planes, int64_t pld, int roles)
+{
+    line_all_body<R, true>(n_wide, tiles, n_split, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, planes, pld, roles);
 }
 
 // out (+)= sum over the S line subsets, in subset order

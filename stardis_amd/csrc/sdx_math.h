@@ -184,6 +184,73 @@ __device__ __forceinline__ double region1_re(double q, const RegionI& k)
     return num * recip(den);
 }
 
+// exp(-tau) for 0 <= tau < 700: the ROCm device library's double-precision exp, operation for operation (same
+// constants, same FMA sequence, hence the same bits as exp(-tau)), written out so that every Horner step is ONE
+// three-address v_fma_f64.  The compiler lowers the library's chain to two-address v_fmac_f64 plus a v_mov_b64 of the
+// coefficient per step — nine extra issue slots in the innermost loop of the formal solution.
+__device__ __forceinline__ double fma3(double a, double b, double c)
+{
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ double exp_neg(double tau)
+{
+    const double n = rint(mul_rn(tau, -0x1.71547652b82fep+0));       // -log2(e)
+    double r = fma(n, -0x1.62e42fefa39efp-1, -tau);                    // -ln2 (high part)
+    r = fma(-0x1.abc9e3b39803fp-56, n, r);                             // -ln2 (low part)
+    // the nine three-address Horner steps as ONE asm block: after every separate asm statement the compiler inserts a
+    // defensive s_nop, which would hand back the issue slots the three-address form saves.  The coefficients sit in SGPR
+    // pairs (one scalar operand per VALU instruction is allowed): as VGPR operands they would pin 20 vector registers
+    // across the caller's whole loop; only the leading coefficient, the second constant of the first step, is a VGPR.
+    double p;
+    asm("v_fma_f64 %0, %2, %1, %3\n\t"
+        "v_fma_f64 %0, %1, %0, %4\n\t"
+        "v_fma_f64 %0, %1, %0, %5\n\t"
+        "v_fma_f64 %0, %1, %0, %6\n\t"
+        "v_fma_f64 %0, %1, %0, %7\n\t"
+        "v_fma_f64 %0, %1, %0, %8\n\t"
+        "v_fma_f64 %0, %1, %0, %9\n\t"
+        "v_fma_f64 %0, %1, %0, %10\n\t"
+        "v_fma_f64 %0, %1, %0, %11"
+        : "=&v"(p)
+        : "v"(r), "v"(0x1.ade156a5dcb37p-26), "s"(0x1.28af3fca7ab0cp-22), "s"(0x1.71dee623fde64p-19), "s"(0x1.a01997c89e6b0p-16),
+          "s"(0x1.a01a014761f6ep-13), "s"(0x1.6c16c1852b7b0p-10), "s"(0x1.1111111122322p-7), "s"(0x1.55555555502a1p-5),
+          "s"(0x1.5555555555511p-3), "s"(0x1.000000000000bp-1));
+    p = fma(r, p, 1.0);
+    p = fma(r, p, 1.0);
+    return ldexp(p, (int)n);
+}
+
+// cos(a) for |a| < ~1e3 (region IV of the Faddeeva function needs |a| = 2 |x| y < 10): two-term Cody-Waite reduction to
+// |r| <= pi/4 and the fdlibm minimax polynomials for sin and cos on that interval (both evaluated: the quadrant differs
+// from lane to lane), < 1 ulp.  The device library's cos carries an argument-reduction path for huge arguments and costs
+// about three times as many instructions.
+__device__ __forceinline__ double cos_small(double a)
+{
+    const double n = rint(a * 0x1.45f306dc9c883p-1);              // 2 / pi
+    double r = fma(n, -0x1.921fb54400000p+0, a);                   // pi/2, leading 33 bits (n * this is exact)
+    r = fma(n, -0x1.0b4611a626331p-34, r);                         // pi/2, next 53 bits
+    const double z = r * r;
+    // sin r
+    double ps = fma(z, 0x1.5d93a5acfd57cp-33, -0x1.ae5e68a2b9cebp-26);
+    ps = fma(z, ps, 0x1.71de357b1fe7dp-19);
+    ps = fma(z, ps, -0x1.a01a019c161d5p-13);
+    ps = fma(z, ps, 0x1.111111110f8a6p-7);
+    const double sn = fma(z * r, fma(z, ps, -0x1.5555555555549p-3), r);
+    // cos r
+    double pc = fma(z, -0x1.8fae9be8838d4p-37, 0x1.1ee9ebdb4b1c4p-29);
+    pc = fma(z, pc, -0x1.27e4f809c52adp-22);
+    pc = fma(z, pc, 0x1.a01a019cb1590p-16);
+    pc = fma(z, pc, -0x1.6c16c16c15177p-10);
+    pc = fma(z, pc, 0x1.555555555554cp-5);
+    const double hz = 0.5 * z, w = 1.0 - hz;
+    const double cs = w + (((1.0 - w) - hz) + z * (z * pc));
+    const int q = (int)n & 3;
+    const double v = (q & 1) ? sn : cs;
+    return (q == 1 || q == 2) ? -v : v;
+}
+
 // Re w for regions II-IV (real part only).
 __device__ __attribute__((noinline)) double faddeeva_re_core(double x, double y, double ax)
 {
@@ -227,7 +294,8 @@ __device__ __attribute__((noinline)) double faddeeva_re_core(double x, double y,
     q = horner_sub(24322.8, u, q);
     q = horner_sub(32066.6, u, q);
     const double frac = fma(n.re, q.re, n.im * q.im) * recip(fma(q.re, q.re, q.im * q.im));
-    return fma(exp(u.re), cos(u.im), -frac);
+    // exp(u.re): -30.3 < u.re < 0.81 here; exp_neg is the device library's exp, operation for operation, on the argument -tau
+    return fma(exp_neg(-u.re), cos_small(u.im), -frac);
 }
 
 // Per-(line, depth) constants the pre-pass stores for the line kernel.
@@ -240,44 +308,6 @@ __device__ __forceinline__ double voigt_term(double delta_nu, double inv_dw, dou
     const double ax = fabs(x);
     if (add_rn(ax, y) > 15.0) return region1_re(x * x, k);  // amp is inside k
     return amp * faddeeva_re_core(x, y, ax);
-}
-
-// exp(-tau) for 0 <= tau < 700: the ROCm device library's double-precision exp, operation for operation (same
-// constants, same FMA sequence, hence the same bits as exp(-tau)), written out so that every Horner step is ONE
-// three-address v_fma_f64.  The compiler lowers the library's chain to two-address v_fmac_f64 plus a v_mov_b64 of the
-// coefficient per step — nine extra issue slots in the innermost loop of the formal solution.
-__device__ __forceinline__ double fma3(double a, double b, double c)
-{
-    double d;
-    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
-__device__ __forceinline__ double exp_neg(double tau)
-{
-    const double n = rint(mul_rn(tau, -0x1.71547652b82fep+0));       // -log2(e)
-    double r = fma(n, -0x1.62e42fefa39efp-1, -tau);                    // -ln2 (high part)
-    r = fma(-0x1.abc9e3b39803fp-56, n, r);                             // -ln2 (low part)
-    // the nine three-address Horner steps as ONE asm block: after every separate asm statement the compiler inserts a
-    // defensive s_nop, which would hand back the issue slots the three-address form saves.  The coefficients sit in SGPR
-    // pairs (one scalar operand per VALU instruction is allowed): as VGPR operands they would pin 20 vector registers
-    // across the caller's whole loop; only the leading coefficient, the second constant of the first step, is a VGPR.
-    double p;
-    asm("v_fma_f64 %0, %2, %1, %3\n\t"
-        "v_fma_f64 %0, %1, %0, %4\n\t"
-        "v_fma_f64 %0, %1, %0, %5\n\t"
-        "v_fma_f64 %0, %1, %0, %6\n\t"
-        "v_fma_f64 %0, %1, %0, %7\n\t"
-        "v_fma_f64 %0, %1, %0, %8\n\t"
-        "v_fma_f64 %0, %1, %0, %9\n\t"
-        "v_fma_f64 %0, %1, %0, %10\n\t"
-        "v_fma_f64 %0, %1, %0, %11"
-        : "=&v"(p)
-        : "v"(r), "v"(0x1.ade156a5dcb37p-26), "s"(0x1.28af3fca7ab0cp-22), "s"(0x1.71dee623fde64p-19), "s"(0x1.a01997c89e6b0p-16),
-          "s"(0x1.a01a014761f6ep-13), "s"(0x1.6c16c1852b7b0p-10), "s"(0x1.1111111122322p-7), "s"(0x1.55555555502a1p-5),
-          "s"(0x1.5555555555511p-3), "s"(0x1.000000000000bp-1));
-    p = fma(r, p, 1.0);
-    p = fma(r, p, 1.0);
-    return ldexp(p, (int)n);
 }
 
 // ---- radiative transfer pieces -------------------------------------------------------------

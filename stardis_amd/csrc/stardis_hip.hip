@@ -126,8 +126,10 @@ LineWork carve(sdx_ctx* ctx, int n_depth, int64_t n_lines)
     w.centre = w.cnt_ge + ctx->cnt_ge_len;
     w.nhw_max = w.centre + n_lines;
     w.whw_max = w.nhw_max + n_lines;
-    w.hlist = nullptr;  // set by line_partials for long lists
-    w.hcount = w.whw_max + n_lines + n_lines;
+    w.hlist = nullptr;  // set for long lists (set_line_lists)
+    w.wlist = nullptr;
+    w.wrank = nullptr;
+    w.hcount = w.whw_max + 4 * n_lines + 8;  // behind hlist [n], wlist [n], wrank [n + 1]
     w.evals = (unsigned long long*)((char*)ctx->small_ws + 2048);
     return w;
 }
@@ -507,6 +509,19 @@ struct ContinuumJob {  // continuum plane computed by the trailing blocks of the
     double* plane;
 };
 
+// long lists: hlist / wlist / wrank from whw_max (two small launches)
+static void launch_line_lists(sdx_ctx* ctx, int64_t n_lines, LineWork& w)
+{
+    w.hlist = w.whw_max + n_lines;
+    w.wlist = w.hlist + n_lines;
+    w.wrank = w.wlist + n_lines;
+    const unsigned hb = (unsigned)((n_lines + kHlistBlock - 1) / kHlistBlock);
+    int* block_cnt = w.hcount + 16;  // 2 hb ints behind the counters and sel (reserved in cnt_ws)
+    hipLaunchKernelGGL(k_hlist_count, dim3(hb), dim3(kHlistBlock), 0, ctx->stream, n_lines, (const int*)w.whw_max, block_cnt);
+    hipLaunchKernelGGL(k_hlist_scatter, dim3(hb), dim3(kHlistBlock), 0, ctx->stream, n_lines, (const int*)w.whw_max, (const int*)block_cnt, w.hlist,
+                       w.wlist, w.wrank, w.hcount);
+}
+
 static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t n_lines, const double* line_nus,
                         const double* doppler, const double* gammas, int gamma_cols, const double* alphas, bool fill_work,
                         int32_t* lo_ref, int32_t* hi_ref, LineWork* w_out, bool count_evals = true,
@@ -528,8 +543,8 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
         rc = ensure(ctx, &ctx->line_ws, &ctx->line_ws_bytes, line_ws_need(n_depth, n_lines));
         if (rc) return rc;
         ctx->cnt_ge_len = (size_t)(n_nu + 2 + 63) / 64 * 64;
-        // cnt_ge, then per line: centre, nhw_max, whw_max, hlist; then hcount
-        rc = ensure(ctx, &ctx->cnt_ws, &ctx->cnt_ws_bytes, (ctx->cnt_ge_len + 4 * (size_t)n_lines + 64 + (size_t)n_lines / 1024 + 8) * sizeof(int));
+        // cnt_ge, then per line: centre, nhw_max, whw_max, hlist, wlist, wrank; then hcount, sel and the per-block counts
+        rc = ensure(ctx, &ctx->cnt_ws, &ctx->cnt_ws_bytes, (ctx->cnt_ge_len + 7 * (size_t)n_lines + 128 + 2 * ((size_t)n_lines / 1024 + 8)) * sizeof(int));
         if (rc) return rc;
         w = carve(ctx, n_depth, n_lines);
         if (n_depth > kPreDepths) HIP_TRY(hipMemsetAsync(w.nhw_max, 0, (size_t)2 * n_lines * sizeof(int), ctx->stream));  // nhw_max and whw_max
@@ -550,17 +565,12 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
     const bool cull = fill_work && !no_cull && n_lines >= ctx->indexed_min_lines && !count_evals && !gen && !scan_in_block && nu_count < n_nu;
     if (cull) {
         HIP_TRY(hipMemsetAsync(w.whw_max, 0, (size_t)n_lines * sizeof(int), ctx->stream));
-        w.hlist = w.whw_max + n_lines;
         int* sel = w.hcount + 4;
-        const unsigned hb = (unsigned)((n_lines + kHlistBlock - 1) / kHlistBlock);
-        int* block_cnt = w.hcount + 16;
         {
             LaunchScope ls(ctx, "k_classify");
             hipLaunchKernelGGL(k_classify, dim3((unsigned)((n_lines * n_depth + 4 * kBlock - 1) / (4 * kBlock))), dim3(kBlock), 0, ctx->stream, n_depth, n_nu, n_lines,
                                (const double*)ctx->small_ws, n_partial, doppler, gammas, gamma_cols, alphas, w.whw_max);
-            hipLaunchKernelGGL(k_hlist_count, dim3(hb), dim3(kHlistBlock), 0, ctx->stream, n_lines, (const int*)w.whw_max, block_cnt);
-            hipLaunchKernelGGL(k_hlist_scatter, dim3(hb), dim3(kHlistBlock), 0, ctx->stream, n_lines, (const int*)w.whw_max, (const int*)block_cnt,
-                               w.hlist, w.hcount);
+            launch_line_lists(ctx, n_lines, w);
             hipLaunchKernelGGL(k_shard_range, dim3(1), dim3(64), 0, ctx->stream, n_nu, nus, n_lines, line_nus, nu_begin, nu_count, sel);
         }
         w.sel = sel;
@@ -640,30 +650,28 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
                          const double* alphas, const double** partial_out, int64_t* pld_out, int* n_planes_out, LineWork* w_out,
                          bool count_evals, const ContinuumJob* job = nullptr, const LineParams* gen = nullptr)
 {
-    constexpr int R = 4;
+    constexpr int R = 4;       // grid points per lane of a wide-role tile (tile = 64 R points)
+    constexpr int R_MIXED = 4;  // fp32 far wings (8 — twice the points per fetched record — measured slower: fewer tiles qualify as far wing)
     LineWork w;
     int rc = line_prepass(ctx, n_depth, n_nu, nus, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, true, nullptr, nullptr, &w,
                           count_evals, job, gen, nu_begin, nu_count);
     if (rc) return rc;
-    const int n_split = choose_splits(n_depth, n_nu, n_lines, R, n_lines >= ctx->indexed_min_lines ? 4 : 2);
+    static const int r_mixed_env = std::getenv("SDX_R_MIXED") ? std::atoi(std::getenv("SDX_R_MIXED")) : R_MIXED;  // experiment knob: 4 or 8
+    const int Rm = ctx->mixed_precision ? (r_mixed_env == 8 ? 8 : R_MIXED) : R;
+    const int n_split = choose_splits(n_depth, n_nu, n_lines, Rm, n_lines >= ctx->indexed_min_lines ? 4 : 2);
     // long line lists: the lines with a window wider than kMediumHalfWidth are listed once (they are scanned by every tile);
     // all others are found by centre range.  Short lists are scanned completely.
     const int indexed = n_lines >= ctx->indexed_min_lines ? 1 : 0;
-    if (indexed && !w.hlist) {  // (a culled pre-pass has built the list already)
-        w.hlist = w.whw_max + n_lines;
-        const unsigned hb = (unsigned)((n_lines + kHlistBlock - 1) / kHlistBlock);
-        int* block_cnt = w.hcount + 16;  // hb ints behind the counter (reserved in cnt_ws)
+    if (indexed && !w.hlist) {  // (a culled pre-pass has built the lists already)
         LaunchScope ls(ctx, "k_hlist");
-        hipLaunchKernelGGL(k_hlist_count, dim3(hb), dim3(kHlistBlock), 0, ctx->stream, n_lines, (const int*)w.whw_max, block_cnt);
-        hipLaunchKernelGGL(k_hlist_scatter, dim3(hb), dim3(kHlistBlock), 0, ctx->stream, n_lines, (const int*)w.whw_max, (const int*)block_cnt, w.hlist,
-                           w.hcount);
+        launch_line_lists(ctx, n_lines, w);
     }
     // two planes: [0] wide windows (the S subsets are summed inside their workgroup), [1] narrow windows
     rc = ensure(ctx, &ctx->part_ws, &ctx->part_ws_bytes, (size_t)2 * n_depth * nu_count * sizeof(double));
     if (rc) return rc;
     double* part = (double*)ctx->part_ws;
     const int64_t pld = nu_count;
-    const int tiles = (int)((nu_count + 64 * R - 1) / (64 * R));
+    const int tiles = (int)((nu_count + 64 * Rm - 1) / (64 * Rm));
     const int64_t n_wide = (int64_t)tiles * n_depth;
     const int64_t n_narrow = (nu_count * ((n_depth + 63) / 64) + n_split - 1) / n_split;  // workgroups of n_split waves
     REQUIRE(n_wide + n_narrow < ((int64_t)1 << 31), "line opacity: grid too large for one launch");
@@ -674,8 +682,9 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
         const int roles = split_launches ? (1 << pass) : 3;
         LaunchScope ls(ctx, split_launches ? (pass ? "k_line_narrow" : "k_line_wide") : "k_line_all");
 #define SDX_LINE_ARGS (int)n_wide, tiles, n_split, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, part, pld, roles
-        if (ctx->mixed_precision) hipLaunchKernelGGL((k_line_all<R, true>), g, blk, shmem, ctx->stream, SDX_LINE_ARGS);
-        else hipLaunchKernelGGL((k_line_all<R, false>), g, blk, shmem, ctx->stream, SDX_LINE_ARGS);
+        if (ctx->mixed_precision && Rm == 8) hipLaunchKernelGGL((k_line_all_mixed<8>), g, blk, shmem, ctx->stream, SDX_LINE_ARGS);
+        else if (ctx->mixed_precision) hipLaunchKernelGGL((k_line_all_mixed<R_MIXED>), g, blk, shmem, ctx->stream, SDX_LINE_ARGS);
+        else hipLaunchKernelGGL((k_line_all<R>), g, blk, shmem, ctx->stream, SDX_LINE_ARGS);
 #undef SDX_LINE_ARGS
     }
     *partial_out = part;
