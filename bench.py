@@ -317,7 +317,8 @@ def profiled_valu(workload, kern):
     committed SQ_INSTS_VALU pass over the kernel time measured live in this run — reported only when the committed pass
     covers exactly the kernels that ran here (same names, same launches per step); otherwise the figure would silently lie."""
     path, rows = _profile_rows(workload, "SQ")
-    rows = [r for r in rows if r["Counter_Name"] == "SQ_INSTS_VALU"]
+    # runtime-internal copy / fill kernels (input uploads of the profiled script) are not part of a step
+    rows = [r for r in rows if r["Counter_Name"] == "SQ_INSTS_VALU" and not r["Kernel_Name"].startswith("__amd_rocclr_")]
     if not rows:
         return None
     by_kernel = {}

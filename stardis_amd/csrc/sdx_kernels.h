@@ -144,17 +144,20 @@ struct alignas(16) WideSlow {
 struct alignas(32) WideRec32 {  // one s_load_dwordx8
     float nuh, nul, inv, yk, c2, c3, c4, pad;
 };
+struct alignas(16) NarrowRec {
+    int lo, hi;      // window, 0/0 when the narrow role has nothing to do for this (line, depth)
+    double inv;      // 1 / doppler
+    double y;
+    double amp;
+};
 struct LineWork {
     WideScan* wscan;
     WideRec* wrec;
     WideSlow* wslow;
     WideRec32* wrec32;  // nullptr unless the mixed-precision mode is on
-    // NARROW items (half-width <= kNarrowHalfWidth), LINE-major [N_l][N_d] so that lane <-> depth reads coalesce
-    int* nlo;        // window, 0/0 for wide items
-    int* nhi;
-    double* n_inv;
-    double* n_y;
-    double* n_amp;
+    // NARROW items (half-width <= kNarrowHalfWidth) and the delegated cores of wide items, LINE-major [N_l][N_d] so that
+    // lane <-> depth reads coalesce: one 32-byte record per item (two 16-byte loads per lane)
+    NarrowRec* nrec;
     int* cnt_ge;     // [N_nu + 2]: number of lines whose centre index is >= p (lines are a prefix: centres descend)
     int* centre;     // [N_l] centre index of each line
     int* nhw_max;    // [N_l] largest NARROW half-width of the line over all depths (0: no narrow item)
@@ -168,6 +171,7 @@ struct LineWork {
     // line indices (cnt_ge), hence a contiguous range [wrank[la], wrank[lb]) of wlist
     int* wlist;
     int* wrank;
+    WideScan* hscan;  // [N_d][N_l] rows, entry k of row d = wscan[d][hlist[k]]: the huge lines' scan words, contiguous
     // frequency-sharded runs of long lists: the pre-pass only has to prepare the lines this shard can touch — sel[0..1] = the
     // index range [la, lb) of the lines whose centre lies within kMediumHalfWidth of the shard's columns (device memory,
     // written by k_shard_range; nullptr: every line) — plus, in a second launch with gather = 1, the lines of hlist
@@ -414,7 +418,7 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
         if (by == 0) w.centre[SDX_LINE_OF(threadIdx.x)] = (int)s_c[threadIdx.x];
     }
     // line-major outputs: the stashed values, depth fastest so the stores coalesce
-    if (w.nlo || out_lo_ref) {
+    if (w.nrec || out_lo_ref) {
         for (int k = threadIdx.x; k < nl * nd; k += nthreads) {
             const int ll = k / nd, dd = k - ll * nd;
             const int sidx = ll * kStride + dd;
@@ -426,15 +430,7 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
                 out_lo_ref[o] = lo;
                 out_hi_ref[o] = hi;
             }
-            if (w.nlo) {
-                w.nlo[o] = narrow ? lo : 0;
-                w.nhi[o] = narrow ? hi : 0;
-                if (narrow) {
-                    w.n_inv[o] = s_dw[sidx];
-                    w.n_y[o] = s_g[sidx];
-                    w.n_amp[o] = s_a[sidx];
-                }
-            }
+            if (w.nrec) w.nrec[o] = narrow ? NarrowRec{lo, hi, s_dw[sidx], s_g[sidx], s_a[sidx]} : NarrowRec{0, 0, 0.0, 0.0, 0.0};
         }
     }
     if (w.evals) {
@@ -568,6 +564,7 @@ __device__ __forceinline__ void line_wide_walk(const int tile_idx, const int spl
     }
     const size_t row = (size_t)d * n_lines;
     const WideScan* __restrict__ scan_row = w.wscan + row;
+    const WideScan* __restrict__ hscan_row = w.hscan + row;
     const WideRec* __restrict__ rec_row = w.wrec + row;
     const WideSlow* __restrict__ slow_row = w.wslow + row;
     const WideRec32* __restrict__ rec32_row = MIXED ? w.wrec32 + row : nullptr;
@@ -594,8 +591,13 @@ __device__ __forceinline__ void line_wide_walk(const int tile_idx, const int spl
             line = -1;
             sc = WideScan{0, 0, 0, 0};
             if (qq <= q_last && k >= ka && k < kb) {
-                line = pass == 0 ? w.hlist[k] : (w.hlist ? w.wlist[k] : k);
-                sc = scan_row[line];
+                if (pass == 0) {
+                    line = w.hlist[k];
+                    sc = w.hscan ? hscan_row[k] : scan_row[line];
+                } else {
+                    line = w.hlist ? w.wlist[k] : k;
+                    sc = scan_row[line];
+                }
             }
         };
         int line_next;
@@ -766,6 +768,18 @@ __global__ __launch_bounds__(kHlistBlock) void k_hlist_scatter(int64_t n_lines, 
     }
 }
 
+// hscan[d][k] = wscan[d][hlist[k]]: every tile scans ALL the huge lines; gathering their 16-byte scan words through the
+// list costs a 64-byte sector each, (tiles x depths) times over — 17 GB per step at 1e6 lines.  Copied once into list
+// order they are read as contiguous kilobytes.
+__global__ __launch_bounds__(kBlock) void k_hscan(int n_depth, int64_t n_lines, const int* __restrict__ hlist, const int* __restrict__ hcount,
+                                                  const WideScan* __restrict__ wscan, WideScan* __restrict__ hscan)
+{
+    const int n_h = hcount[0];
+    const int d = blockIdx.y;
+    for (int k = blockIdx.x * kBlock + threadIdx.x; k < n_h; k += gridDim.x * kBlock)
+        hscan[(size_t)d * n_lines + k] = wscan[(size_t)d * n_lines + hlist[k]];
+}
+
 // Frequency-sharded runs of long lists, stage A: the widest window of every line (over all depths), from the window rule
 // alone (:561-575; no centre needed for the half-width) — a streaming pass over the dense inputs that tells which lines can
 // reach any column (whw_max > kMediumHalfWidth -> hlist) before the full pre-pass runs on the lines the shard needs.
@@ -864,27 +878,27 @@ __device__ __forceinline__ void line_narrow_wave(const int64_t i, const int dept
         unsigned long long m = __ballot(rel);
         // the parameters of the NEXT relevant line are requested before the current one is evaluated (all six loads at
         // once, used or not): one global-memory round trip per line hides behind the previous line's arithmetic
-        int lo = 0, hi = 0;
-        double y = 0.0, amp = 0.0, inv = 0.0, lnu = 0.0;
+        NarrowRec rec = {0, 0, 0.0, 0.0, 0.0};
+        double lnu = 0.0;
         if (m) {
             const int l = base + __builtin_ctzll(m);
-            const size_t o = (size_t)l * n_depth + dc;
-            lo = w.nlo[o], hi = w.nhi[o], y = w.n_y[o], amp = w.n_amp[o], inv = w.n_inv[o], lnu = line_nus[l];
+            rec = w.nrec[(size_t)l * n_depth + dc];
+            lnu = line_nus[l];
         }
         while (m) {
             m &= m - 1;
-            int lo_n = 0, hi_n = 0;
-            double y_n = 0.0, amp_n = 0.0, inv_n = 0.0, lnu_n = 0.0;
+            NarrowRec rec_n = {0, 0, 0.0, 0.0, 0.0};
+            double lnu_n = 0.0;
             if (m) {
                 const int l = base + __builtin_ctzll(m);
-                const size_t o = (size_t)l * n_depth + dc;
-                lo_n = w.nlo[o], hi_n = w.nhi[o], y_n = w.n_y[o], amp_n = w.n_amp[o], inv_n = w.n_inv[o], lnu_n = line_nus[l];
+                rec_n = w.nrec[(size_t)l * n_depth + dc];
+                lnu_n = line_nus[l];
             }
-            if (valid && ii >= lo && ii < hi) {
-                const RegionI k1 = region1_setup(y, amp);
-                acc += voigt_term(nu_i - lnu, inv, y, amp, k1);
+            if (valid && ii >= rec.lo && ii < rec.hi) {
+                const RegionI k1 = region1_setup(rec.y, rec.amp);
+                acc += voigt_term(nu_i - lnu, rec.inv, rec.y, rec.amp, k1);
             }
-            lo = lo_n, hi = hi_n, y = y_n, amp = amp_n, inv = inv_n, lnu = lnu_n;
+            rec = rec_n, lnu = lnu_n;
         }
     }
     if (valid) plane[(size_t)d * pld + (i - nu_begin)] = acc;
@@ -916,8 +930,15 @@ __device__ __forceinline__ void line_all_body(int n_wide, int tiles, int n_split
         line_wide_walk<R, MIXED>(tile, wave, n_split, d, n_nu, nus, nu_begin, nu_count, n_lines, w, planes, pld, s_wide);
     } else {
         if (!(roles & 2)) return;
-        const int64_t c = (int64_t)(b - n_wide) * n_split + wave;
+        // XCD-aware order here too: a wave writes one value into each of the N_d rows of the narrow plane, so the waves that
+        // fill a 64-byte sector of a row (8 consecutive frequencies) should share an L2 — workgroups p, p + 8, ... (one XCD)
+        // take CONSECUTIVE frequencies; otherwise every XCD writes its own fragment of every sector back on its own
         const int64_t n_narrow = nu_count * ((n_depth + 63) / 64);
+        const int64_t n_nb = (n_narrow + n_split - 1) / n_split, per_xcd = (n_nb + 7) / 8;
+        const int64_t p = b - n_wide;
+        const int64_t wg = (p & 7) * per_xcd + (p >> 3);
+        if ((p >> 3) >= per_xcd || wg >= n_nb) return;
+        const int64_t c = wg * n_split + wave;
         if (c < n_narrow)
             line_narrow_wave(nu_begin + c % nu_count, (int)(c / nu_count), n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w,
                              planes + (size_t)n_depth * pld, pld);
@@ -1413,6 +1434,94 @@ __global__ __launch_bounds__(kBlock) void k_total_alphas(int n_depth, int64_t nu
                        total_ld);
 }
 
+// The continuum plane of the fused step, one block per (tile of blockDim frequencies, group of kContDepths depths).  Everything
+// that depends on the frequency alone — the tabulated cross-section (a bisection), nu^-3 (a division), the Rayleigh powers,
+// which bound-free edges lie below nu — is formed ONCE per frequency and everything that depends on the depth alone — the
+// bound-free coefficients (a division and a square root per level), the free-free sum (a division and a square root per
+// species), the Rayleigh and Thomson factors — once per block in LDS; a (depth, frequency) point is then ~25 additions and
+// multiplications, in calc_alphas' order and rounding (:655-700), where evaluating every point from scratch
+// (total_alphas_block) costs ~400 instructions.
+constexpr int kContDepths = 8;  // at most; the host picks 1..8 depths per block so that small grids still fill the chip
+__device__ __forceinline__ void continuum_tile_block(const int tile, const int dg, const int dgs, int n_depth, int64_t nu_begin, int64_t nu_count,
+                                                     const double* __restrict__ nus, ContinuumArgs a, double* __restrict__ cont,
+                                                     int64_t cont_ld, const bool stage_table)
+{
+    extern __shared__ double s_mem[];
+    const int n_levels = a.bf_n_species > 0 ? a.bf_n_levels : 0;
+    double* s_coef = s_mem;                              // [kContDepths][n_levels]
+    double* s_dep = s_coef + kContDepths * n_levels;     // [kContDepths][6]: file density, ff sum, Rayleigh c4 c6 c8, Thomson
+    double* s_xp = s_dep + kContDepths * 6;
+    double* s_fp = s_xp + a.n_table;
+    const int d0 = dg * dgs;
+    const int nd = min(dgs, n_depth - d0);
+    if (stage_table && a.table_sigma)
+        for (int k = threadIdx.x; k < a.n_table; k += blockDim.x) {
+            s_xp[k] = a.table_wavelength[k];
+            s_fp[k] = a.table_sigma[k];
+        }
+    for (int k = threadIdx.x; k < nd * n_levels; k += blockDim.x) {
+        const int dd = k / n_levels, L = k - dd * n_levels;
+        int sp = 0;
+        while (sp + 1 < a.bf_n_species && L >= a.bf_species_offsets[sp + 1]) ++sp;
+        const int zi = a.bf_species_ion_number[sp] + 1;
+        const double r = mul_rn((double)zi, sqrt(kRydFreq / a.bf_cutoff[L]));
+        const double r2 = mul_rn(r, r);
+        const double n5 = mul_rn(mul_rn(r2, r2), r);
+        s_coef[dd * n_levels + L] = mul_rn(mul_rn(kBfConst, (double)(zi * zi * zi * zi)), a.bf_level_density[(size_t)L * n_depth + d0 + dd]) / n5;
+    }
+    if (threadIdx.x < nd) {
+        const int d = d0 + threadIdx.x;
+        double* dep = s_dep + threadIdx.x * 6;
+        dep[0] = a.table_sigma ? a.table_density[d] : 0.0;
+        double ff = 0.0;  // alpha_ff_point's sum (:274-317), the part in front of nu^-3
+        for (int sp = 0; sp < a.ff_n_species; ++sp) {
+            double v = a.ff_number_density[(size_t)sp * n_depth + d] / sqrt(a.temperature[d]);
+            v = mul_rn(v, mul_rn(kFfConst, (double)(a.ff_species_ion_number[sp] * a.ff_species_ion_number[sp])));
+            ff = add_rn(ff, v);
+        }
+        dep[1] = ff;
+        double c4 = 0, c6 = 0, c8 = 0;  // alpha_rayleigh_point's per-depth sums (:74-135)
+        if (a.rayleigh_enabled) {
+            if (a.ray_n_h) { c4 = add_rn(c4, mul_rn(20.24, a.ray_n_h[d])); c6 = add_rn(c6, mul_rn(239.2, a.ray_n_h[d])); c8 = add_rn(c8, mul_rn(2256.0, a.ray_n_h[d])); }
+            if (a.ray_n_he) { c4 = add_rn(c4, mul_rn(1.913, a.ray_n_he[d])); c6 = add_rn(c6, mul_rn(4.52, a.ray_n_he[d])); c8 = add_rn(c8, mul_rn(7.90, a.ray_n_he[d])); }
+            if (a.ray_n_h2) { c4 = add_rn(c4, mul_rn(28.39, a.ray_n_h2[d])); c6 = add_rn(c6, mul_rn(215.0, a.ray_n_h2[d])); c8 = add_rn(c8, mul_rn(1303.0, a.ray_n_h2[d])); }
+        }
+        dep[2] = c4, dep[3] = c6, dep[4] = c8;
+        dep[5] = a.electron_density ? mul_rn(kSigmaT, a.electron_density[d]) : 0.0;
+    }
+    __syncthreads();
+    const int64_t j = (int64_t)tile * blockDim.x + threadIdx.x;
+    if (j >= nu_count) return;
+    const int64_t i = nu_begin + j;
+    const double nu = nus[i];
+    const double sig = a.table_sigma ? (stage_table ? interp1(a.lambdas[i], a.n_table, s_xp, s_fp) : interp1(a.lambdas[i], a.n_table, a.table_wavelength, a.table_sigma)) : 0.0;
+    const double inv3 = (a.bf_n_species > 0 || a.ff_n_species > 0) ? inv_nu3(nu) : 0.0;
+    double r4 = 0, r6 = 0, r8 = 0;
+    if (a.rayleigh_enabled) {
+        const double nuc = nu > 2.3e15 ? 0.0 : nu;
+        const double r = nuc / mul_rn(2.0, mul_rn(kC, kRydCm));
+        const double r2 = mul_rn(r, r);
+        r4 = mul_rn(r2, r2), r6 = mul_rn(r4, r2), r8 = mul_rn(r4, r4);
+    }
+    for (int dd = 0; dd < nd; ++dd) {
+        const double* dep = s_dep + dd * 6;
+        const double* coef = s_coef + dd * n_levels;
+        double t = 0.0;
+        if (a.table_sigma) t = add_rn(t, mul_rn(sig, dep[0]));
+        double bf = 0.0;
+        for (int sp = 0; sp < a.bf_n_species; ++sp) {
+            double spec = 0.0;  // alpha_spec (:214), levels in plasma order (:221-233)
+            for (int L = a.bf_species_offsets[sp]; L < a.bf_species_offsets[sp + 1]; ++L) spec = add_rn(spec, nu >= a.bf_cutoff[L] ? coef[L] : 0.0);
+            bf = add_rn(bf, spec);
+        }
+        t = add_rn(t, a.bf_n_species > 0 ? mul_rn(bf, inv3) : 0.0);
+        t = add_rn(t, a.ff_n_species > 0 ? mul_rn(dep[1], inv3) : 0.0);
+        if (a.rayleigh_enabled) t = add_rn(t, mul_rn(add_rn(add_rn(mul_rn(dep[2], r4), mul_rn(dep[3], r6)), mul_rn(dep[4], r8)), kSigmaT));
+        if (a.electron_density) t = add_rn(t, dep[5]);
+        cont[(size_t)(d0 + dd) * cont_ld + j] = t;
+    }
+}
+
 // Frequencies per thread of a continuum block in the fused pre-pass launch (2 was measured: no gain).
 // The pre-pass kernels cap their SGPRs at 80: a 1024-thread block is 4 waves per SIMD, and at the 94 SGPRs the compiler
 // would use only ONE such block fits a CU (7 waves per SIMD), which ran this launch in three block generations at S-c2
@@ -1438,8 +1547,12 @@ __global__ __launch_bounds__(kPreBlock) __attribute__((amdgpu_num_sgpr(80))) voi
                            gammas, gamma_cols, alphas, w, nullptr, nullptr, n_line_blocks, lp);
     } else {
         const int c = b - n_pre;
-        total_alphas_block<kContPoints>(c % cont_tiles, c / cont_tiles, n_depth, nu_begin, nu_count, nus, ca, nullptr, 0, 1, nullptr, 0,
-                                        cont_plane, cont_ld, stage_table != 0);
+        if (stage_table & 2)  // bit 1: depth-group blocks (the per-depth factors of a group fit LDS); bits 4..7: depths per block
+            continuum_tile_block(c % cont_tiles, c / cont_tiles, (stage_table >> 4) & 15, n_depth, nu_begin, nu_count, nus, ca, cont_plane, cont_ld,
+                                 (stage_table & 1) != 0);
+        else
+            total_alphas_block<kContPoints>(c % cont_tiles, c / cont_tiles, n_depth, nu_begin, nu_count, nus, ca, nullptr, 0, 1, nullptr, 0,
+                                            cont_plane, cont_ld, (stage_table & 1) != 0);
     }
 }
 

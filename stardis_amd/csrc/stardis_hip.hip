@@ -104,8 +104,8 @@ int ensure(sdx_ctx* ctx, void** buf, size_t* have, size_t need)
     return SDX_OK;
 }
 
-// per (line, depth) item: wide scan 16 + record 48 + slow 16 + fp32 record 32, narrow windows 8 + constants 24
-size_t line_ws_need(int n_depth, int64_t n_lines) { return (size_t)n_depth * (size_t)n_lines * 144 + 256; }
+// per (line, depth) item: wide scan 16 + record 48 + slow 16 + fp32 record 32, narrow record 32, huge-line scan copy 16
+size_t line_ws_need(int n_depth, int64_t n_lines) { return (size_t)n_depth * (size_t)n_lines * 160 + 256; }
 
 LineWork carve(sdx_ctx* ctx, int n_depth, int64_t n_lines)
 {
@@ -117,11 +117,8 @@ LineWork carve(sdx_ctx* ctx, int n_depth, int64_t n_lines)
     w.wslow = (WideSlow*)(w.wscan + n);      // 16 n
     WideRec32* rec32 = (WideRec32*)(w.wslow + n);  // 32 n
     w.wrec32 = ctx->mixed_precision ? rec32 : nullptr;
-    w.n_inv = (double*)(rec32 + n);
-    w.n_y = w.n_inv + n;
-    w.n_amp = w.n_y + n;
-    w.nlo = (int*)(w.n_amp + n);
-    w.nhi = w.nlo + n;
+    w.nrec = (NarrowRec*)(rec32 + n);  // 32 n
+    w.hscan = (WideScan*)(w.nrec + n);  // 16 n (only the first hcount[0] entries of a row are used)
     w.cnt_ge = (int*)ctx->cnt_ws;
     w.centre = w.cnt_ge + ctx->cnt_ge_len;
     w.nhw_max = w.centre + n_lines;
@@ -585,10 +582,22 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
             REQUIRE(job->cont->bf_n_levels > 0 && job->cont->bf_n_levels <= 4096, "synthesize: bf_n_levels must be set (1..4096)");
             shmem = (size_t)job->cont->bf_n_levels * sizeof(double);
         }
-        const int stage_table = ca.table_sigma && ca.n_table > 0 && ca.n_table <= 1024;  // 1-D cross-section table searched from LDS
+        int stage_table = ca.table_sigma && ca.n_table > 0 && ca.n_table <= 1024;  // 1-D cross-section table searched from LDS
         if (stage_table) shmem = ((ca.bf_n_species > 0 ? (size_t)job->cont->bf_n_levels : 0) + 2 * (size_t)ca.n_table) * sizeof(double);
         const int cont_tiles = (int)((job->nu_count + kPreBlock * kContPoints - 1) / (kPreBlock * kContPoints));
-        const unsigned total_blocks = grid.x * grid.y + (unsigned)cont_tiles * (unsigned)n_depth;
+        // continuum blocks: one per (frequency tile, group of kContDepths depths) when the per-depth factors of a group fit LDS
+        // (always, for a handful of bound-free levels), else one per (tile, depth) evaluating every point from scratch
+        const size_t n_lev = ca.bf_n_species > 0 ? (size_t)job->cont->bf_n_levels : 0;
+        const size_t tile_shmem = ((size_t)kContDepths * (n_lev + 6) + (stage_table ? 2 * (size_t)ca.n_table : 0)) * sizeof(double);
+        unsigned cont_rows = (unsigned)n_depth;
+        if (tile_shmem <= 48 * 1024) {
+            // depths per block: as many as leave ~2 blocks per CU (one depth per block on small grids)
+            const int dgs = (int)std::max<int64_t>(1, std::min<int64_t>(kContDepths, ((int64_t)cont_tiles * n_depth) / (2 * (int64_t)ctx->n_cu)));
+            stage_table |= 2 | (dgs << 4);
+            shmem = tile_shmem;
+            cont_rows = (unsigned)((n_depth + dgs - 1) / dgs);
+        }
+        const unsigned total_blocks = grid.x * grid.y + (unsigned)cont_tiles * cont_rows;
         LaunchScope ls(ctx, "k_prepass_continuum");
 #define SDX_PRE_ARGS (int)grid.x, (int)grid.y, cont_tiles, n_depth, n_nu, nus, scan_in_block ? (const double*)nullptr : (const double*)ctx->small_ws, \
                      n_partial, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, w, n_line_blocks, job->nu_begin, job->nu_count, ca,          \
@@ -666,6 +675,13 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
         LaunchScope ls(ctx, "k_hlist");
         launch_line_lists(ctx, n_lines, w);
     }
+    static const bool no_hscan = std::getenv("SDX_NO_HSCAN") != nullptr;  // A/B knob
+    if (no_hscan) w.hscan = nullptr;
+    if (indexed && !no_hscan) {  // the huge lines' scan words in list order (the pre-pass has written them by now)
+        LaunchScope ls(ctx, "k_hlist");
+        hipLaunchKernelGGL(k_hscan, dim3(64, (unsigned)n_depth), dim3(kBlock), 0, ctx->stream, n_depth, n_lines, (const int*)w.hlist, (const int*)w.hcount,
+                           (const WideScan*)w.wscan, w.hscan);
+    }
     // two planes: [0] wide windows (the S subsets are summed inside their workgroup), [1] narrow windows
     rc = ensure(ctx, &ctx->part_ws, &ctx->part_ws_bytes, (size_t)2 * n_depth * nu_count * sizeof(double));
     if (rc) return rc;
@@ -673,7 +689,8 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
     const int64_t pld = nu_count;
     const int tiles = (int)((nu_count + 64 * Rm - 1) / (64 * Rm));
     const int64_t n_wide = (int64_t)tiles * n_depth;
-    const int64_t n_narrow = (nu_count * ((n_depth + 63) / 64) + n_split - 1) / n_split;  // workgroups of n_split waves
+    // workgroups of n_split waves, rounded up to 8 per row of the XCD-aware order (surplus workgroups return at once)
+    const int64_t n_narrow = (((nu_count * ((n_depth + 63) / 64) + n_split - 1) / n_split + 7) / 8) * 8;
     REQUIRE(n_wide + n_narrow < ((int64_t)1 << 31), "line opacity: grid too large for one launch");
     static const bool split_launches = std::getenv("SDX_SPLIT_LAUNCHES") != nullptr;  // analysis knob: time the two roles apart
     const size_t shmem = (size_t)n_split * kWideLdsDoubles * sizeof(double);

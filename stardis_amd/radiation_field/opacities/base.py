@@ -28,7 +28,8 @@ class Opacities:
 
     def calc_total_alphas(self):
         ctx = default_context()
-        total = ctx.upload(self.total_alphas)
+        # += into total_alphas (idempotence is NOT guaranteed, like the reference); the usual all-zero start needs no upload
+        total = ctx.upload(self.total_alphas) if np.any(self.total_alphas) else ctx.zeros(self.total_alphas.shape)
         for key, value in self.opacities_dict.items():
             if "gammas" in key or "doppler" in key:
                 continue

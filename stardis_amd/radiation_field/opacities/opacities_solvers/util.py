@@ -15,8 +15,28 @@ from stardis_amd.util import species_string_to_tuple
 logger = logging.getLogger(__name__)
 
 
+_TABLE_CACHE = {}
+
+
 def read_table(fpath, opacity_source):
-    """-> ("1d", wavelength_AA, sigma) or ("2d", wavelength_AA, second_axis, values, scale_kind)"""
+    """-> ("1d", wavelength_AA, sigma) or ("2d", wavelength_AA, second_axis, values, scale_kind).  Parsed once per
+    (file, modification time): the reference re-reads the file on every call, which is a millisecond of pandas per source
+    next to a synthesis that takes a tenth of that."""
+    import os
+
+    try:
+        stamp = (str(fpath), opacity_source, os.stat(fpath).st_mtime_ns)
+    except OSError:
+        stamp = None
+    if stamp is not None and stamp in _TABLE_CACHE:
+        return _TABLE_CACHE[stamp]
+    table = _read_table(fpath, opacity_source)
+    if stamp is not None:
+        _TABLE_CACHE[stamp] = table
+    return table
+
+
+def _read_table(fpath, opacity_source):
     import pandas as pd
 
     if opacity_source == "Hminus_bf":

@@ -70,8 +70,10 @@ def raytrace(stellar_model, stellar_radiation_field):
     opac = field.opacities
     alphas = opac.total_alphas_device(ctx) if hasattr(opac, "total_alphas_device") else opac.total_alphas
     track = bool(getattr(field, "track_individual_intensities", False))
+    # F_nu is accumulated into (:336); a freshly created field holds zeros, which need no upload
+    f_in = field.F_nu if np.any(field.F_nu) else None
     F, I = ops.raytrace_arrays(
-        field.frequencies, plain(stellar_model.temperatures), ray_distances, field.I_nus_weights, alphas, F_nu=field.F_nu,
+        field.frequencies, plain(stellar_model.temperatures), ray_distances, field.I_nus_weights, alphas, F_nu=f_in,
         track=track, ctx=ctx, inward_rays=bool(stellar_model.spherical), photospheric_correction=correction,
     )
     field.F_nu[...] = F
