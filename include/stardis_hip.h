@@ -124,6 +124,10 @@ int sdx_voigt_profile_dev(sdx_ctx* ctx, int64_t n, const double* delta_nu, const
  * compared point by point with the reference's Faddeeva / Voigt vectors. */
 int sdx_voigt_term_dev(sdx_ctx* ctx, int64_t n, const double* delta_nu, const double* inv_doppler_width, const double* y,
                        const double* amp, double* out);
+/* The fp32 routine the narrow windows are evaluated with when the option mixed_precision is on (all four regions in packed
+ * fp32, hardware exp / cos); same arguments, rounded to fp32 inside.  Test hook for the stated 1e-4 tolerance of that mode. */
+int sdx_voigt_term_f32_dev(sdx_ctx* ctx, int64_t n, const double* delta_nu, const double* inv_doppler_width, const double* y,
+                           const double* amp, double* out);
 
 /* ---- broadening (opacities_solvers/broadening.py) -------------------------------------------
  * calc_gamma :550-656 with calculate_broadening's argument preparation :706-721 (ion_number is the

@@ -10,7 +10,8 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libstardis_hip.so")
+# STARDIS_AMD_LIB points at another build of the same ABI (A/B measurements of kernel changes)
+LIB_PATH = os.environ.get("STARDIS_AMD_LIB") or os.path.join(_HERE, "lib", "libstardis_hip.so")
 
 c_dp = C.POINTER(C.c_double)
 _vp = C.c_void_p
@@ -108,6 +109,7 @@ PROTOTYPES = {
     "sdx_faddeeva_dev": (_int, [_vp, _i64, _vp, _vp]),
     "sdx_voigt_profile_dev": (_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "sdx_voigt_term_dev": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "sdx_voigt_term_f32_dev": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "sdx_calc_gamma_dev": (_int, [_vp, _i64, _int] + [_vp] * 9 + [_int, _vp]),
     "sdx_doppler_widths_dev": (_int, [_vp, _i64, _int, _vp, _vp, _vp, C.c_double, _vp]),
     "sdx_calc_vald_gamma_dev": (_int, [_vp, _i64, _int] + [_vp] * 12 + [_int, _vp]),

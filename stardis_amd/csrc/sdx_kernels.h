@@ -136,19 +136,15 @@ struct alignas(16) WideScan {
     int lo, hi, clo, chi;
 };
 struct alignas(16) WideRec {
-    double lnu, inv, yk, c2, c3, c4;
+    double lnu, inv, yk, cv, cd, spare;
 };
 struct alignas(16) WideSlow {
     double y, amp;
 };
 struct alignas(32) WideRec32 {  // one s_load_dwordx8
-    float nuh, nul, inv, yk, c2, c3, c4, pad;
-};
-struct alignas(16) NarrowRec {
-    int lo, hi;      // window, 0/0 when the narrow role has nothing to do for this (line, depth)
-    double inv;      // 1 / doppler
-    double y;
-    double amp;
+    // ncl = -(lnu - nuh) * inv: the low part of the line frequency, already scaled.  Operands that meet in one instruction
+    // share an aligned 8-byte pair (a VALU instruction reads one scalar register pair): (inv, ncl), (cv, cd), yk twice
+    float nuh, yk, inv, ncl, cv, cd, pad0, pad1;
 };
 struct LineWork {
     WideScan* wscan;
@@ -156,8 +152,19 @@ struct LineWork {
     WideSlow* wslow;
     WideRec32* wrec32;  // nullptr unless the mixed-precision mode is on
     // NARROW items (half-width <= kNarrowHalfWidth) and the delegated cores of wide items, LINE-major [N_l][N_d] so that
-    // lane <-> depth reads coalesce: one 32-byte record per item (two 16-byte loads per lane)
-    NarrowRec* nrec;
+    // lane <-> depth reads coalesce.  Separate arrays: one 32-byte record per item was measured 45 % slower in the narrow
+    // role (a wave's load then touches 28 cache lines three times over instead of 4 + 4 + 7 + 7 + 7)
+    int* nlo;        // window, 0/0 when the narrow role has nothing to do for this (line, depth)
+    int* nhi;
+    double* n_inv;   // 1 / doppler
+    double* n_y;
+    double* n_amp;
+    // mixed-precision mode: the narrow role evaluates in fp32 — the same three arrays as floats, and the line frequencies
+    // as hi + lo float pairs [N_l]
+    float* n_inv32;
+    float* n_y32;
+    float* n_amp32;
+    float2v* lnu32;
     int* cnt_ge;     // [N_nu + 2]: number of lines whose centre index is >= p (lines are a prefix: centres descend)
     int* centre;     // [N_l] centre index of each line
     int* nhw_max;    // [N_l] largest NARROW half-width of the line over all depths (0: no narrow item)
@@ -389,11 +396,11 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
                 }
                 const RegionI k1 = region1_setup(yy, amp);
                 const double lnu = s_lnu[ll];
-                w.wrec[o] = WideRec{lnu, inv, k1.yk, k1.c2, k1.c3, k1.c4};
+                w.wrec[o] = WideRec{lnu, inv, k1.yk, k1.cv, k1.cd, 0.0};
                 w.wslow[o] = WideSlow{yy, amp};
                 if (w.wrec32) {
                     const float nuh = (float)lnu;
-                    w.wrec32[o] = WideRec32{nuh, (float)(lnu - (double)nuh), (float)inv, (float)k1.yk, (float)k1.c2, (float)k1.c3, (float)k1.c4, 0.f};
+                    w.wrec32[o] = WideRec32{nuh, (float)k1.yk, (float)inv, -((float)(lnu - (double)nuh) * (float)inv), (float)k1.cv, (float)k1.cd, 0.f, 0.f};
                 }
                 atomicMax(&s_whwmax[ll], (int)hw);
             } else if (narrow) {
@@ -416,9 +423,13 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
             atomicMax(&w.whw_max[SDX_LINE_OF(threadIdx.x)], s_whwmax[threadIdx.x]);
         }
         if (by == 0) w.centre[SDX_LINE_OF(threadIdx.x)] = (int)s_c[threadIdx.x];
+        if (by == 0 && w.lnu32) {
+            const double lnu = s_lnu[threadIdx.x];
+            w.lnu32[SDX_LINE_OF(threadIdx.x)] = float2v{(float)lnu, (float)(lnu - (double)(float)lnu)};
+        }
     }
     // line-major outputs: the stashed values, depth fastest so the stores coalesce
-    if (w.nrec || out_lo_ref) {
+    if (w.nlo || out_lo_ref) {
         for (int k = threadIdx.x; k < nl * nd; k += nthreads) {
             const int ll = k / nd, dd = k - ll * nd;
             const int sidx = ll * kStride + dd;
@@ -430,7 +441,19 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
                 out_lo_ref[o] = lo;
                 out_hi_ref[o] = hi;
             }
-            if (w.nrec) w.nrec[o] = narrow ? NarrowRec{lo, hi, s_dw[sidx], s_g[sidx], s_a[sidx]} : NarrowRec{0, 0, 0.0, 0.0, 0.0};
+            if (w.nlo) {
+                w.nlo[o] = narrow ? lo : 0;
+                w.nhi[o] = narrow ? hi : 0;
+                if (narrow && w.n_inv32) {
+                    w.n_inv32[o] = (float)s_dw[sidx];
+                    w.n_y32[o] = (float)s_g[sidx];
+                    w.n_amp32[o] = (float)s_a[sidx];
+                } else if (narrow) {
+                    w.n_inv[o] = s_dw[sidx];
+                    w.n_y[o] = s_g[sidx];
+                    w.n_amp[o] = s_a[sidx];
+                }
+            }
         }
     }
     if (w.evals) {
@@ -518,17 +541,19 @@ __device__ __forceinline__ void wide_reduce_and_store(const int split, const int
 // fma_f32: a packed instruction issues like one fp64 instruction and does two evaluations; only the reciprocal is per
 // point).  x comes from the hi / lo split of both frequencies (nu_i - nu_l is exact to ~1e-7 relative whatever their
 // distance), everything else is plain fp32 (v_rcp_f32 is good to 1 ulp).
-typedef float float2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float2v region1_f32x2(float2v nuh, float2v nul, const WideRec32& k)
+__device__ __forceinline__ float2v region1_f32x2(float2v acc, float2v nuh, float2v nul, const WideRec32& k)
 {
-    const float2v x = ((nuh - k.nuh) + (nul - k.nul)) * k.inv;
-    const float2v q = x * x;
-    const float2v num = (q + k.c2) * k.yk;
-    const float2v den = __builtin_elementwise_fma(q, q + k.c3, (float2v)(k.c4));
+    // x = ((nuh - k.nuh) + (nul - k.nul)) * inv in three packed instructions
+    const float2v x = __builtin_elementwise_fma(nul, (float2v)(k.inv), __builtin_elementwise_fma(nuh - k.nuh, (float2v)(k.inv), (float2v)(k.ncl)));
+    const float2v v = __builtin_elementwise_fma(x, x, (float2v)(k.cv));
+    const float2v den = __builtin_elementwise_fma(v, v, (float2v)(k.cd));
+    const float2v num = __builtin_elementwise_fma((float2v)(k.yk), v, (float2v)(k.yk));
     float2v r;
     r.x = __builtin_amdgcn_rcpf(den.x);
     r.y = __builtin_amdgcn_rcpf(den.y);
-    return num * r;
+    // no inline asm here: its operands come straight from v_rcp_f32, and the compiler does not insert the wait state a
+    // transcendental result needs before a VALU use when the user is an asm statement
+    return __builtin_elementwise_fma(num, r, acc);
 }
 
 template <int R, bool MIXED>
@@ -613,54 +638,52 @@ __device__ __forceinline__ void line_wide_walk(const int tile_idx, const int spl
             unsigned long long m = __ballot(hit);
             if (m == 0) continue;
             const unsigned long long mf = __ballot(fast);
+            if constexpr (MIXED) pending32 += __popcll(m);
             // walk the hits in ascending order.  The record is fetched with scalar loads straight into SGPRs, which the fp64
             // instructions take as operands (one each): no copy, no vector registers.  Its latency is not hidden by a
             // software prefetch — carrying a record across iterations makes the compiler park it in 12 VGPRs and move it
             // there with six v_mov per hit — but by the other waves of the SIMD.
             for (;;) {
-                const int b = __builtin_ctzll(m);
-                const int e = __builtin_amdgcn_readlane(line, b);
-                const bool is_fast = (mf >> b) & 1ull;
-                if constexpr (MIXED) {
-                    // two consecutive test-free hits share one trip: both 32-byte records are requested together (one wait
-                    // instead of two — the fp32 arithmetic is short enough for the record fetch to show), the sums keep
-                    // list order
+                // A run of test-free hits (every point of the tile inside the window and in region I: the operations of
+                // voigt_add's region-I branch, bit-identical, or the fp32 rational of the mixed-precision mode) is a loop of
+                // its own — a single basic block, so the sums stay in their registers; as one arm of an if / else with the
+                // general case the compiler forms them in fresh registers and copies them back, five v_mov_b64 per hit.
+                while ((m & (0ull - m)) & mf) {
+                    const int e = __builtin_amdgcn_readlane(line, __builtin_ctzll(m));
                     const unsigned long long m1 = m & (m - 1);
-                    if (is_fast && m1 && ((mf >> __builtin_ctzll(m1)) & 1ull)) {
-                        const int e1 = __builtin_amdgcn_readlane(line, __builtin_ctzll(m1));
-                        const WideRec32 ra = rec32_row[e], rb = rec32_row[e1];
+                    if constexpr (MIXED) {
+                        // two test-free hits per trip: both 32-byte records are requested together (one wait instead of
+                        // two — the fp32 arithmetic is short enough for the record fetch to show), the sums keep list order.
+                        // When the next hit is not test-free the second evaluation runs on the first record again with a
+                        // zero amplitude (a scalar select; adds exactly 0): the loop stays one basic block
+                        const bool two = ((m1 & (0ull - m1)) & mf) != 0;
+                        const int e1 = __builtin_amdgcn_readlane(line, __builtin_ctzll(two ? m1 : m));
+                        const WideRec32 ra = rec32_row[e];
+                        WideRec32 rb = rec32_row[e1];
+                        rb.yk = two ? rb.yk : 0.f;
 #pragma unroll
                         for (int r = 0; r < R / 2; ++r) {
-                            acc32[r] += region1_f32x2(nu_h[r], nu_l[r], ra);
-                            acc32[r] += region1_f32x2(nu_h[r], nu_l[r], rb);
+                            acc32[r] = region1_f32x2(acc32[r], nu_h[r], nu_l[r], ra);
+                            acc32[r] = region1_f32x2(acc32[r], nu_h[r], nu_l[r], rb);
                         }
-                        pending32 += 2;
-                        m = m1 & (m1 - 1);
-                        if (!m) break;
+                        m = two ? (m1 & (m1 - 1)) : m1;
                         continue;
+                    } else {
+                        const WideRec cur = rec_row[e];
+                        const RegionI k1 = {cur.yk, cur.cv, cur.cd};
+#pragma unroll
+                        for (int r = 0; r < R; ++r) acc[r] = region1_add(acc[r], (nu_i[MIXED ? 0 : r] - cur.lnu) * cur.inv, k1);
                     }
+                    m = m1;
                 }
-                WideRec cur;
+                if (!m) break;
+                const int b = __builtin_ctzll(m);
+                const int e = __builtin_amdgcn_readlane(line, b);
+                const WideRec cur = rec_row[e];
                 WideRec32 cur32;
                 if (MIXED) cur32 = rec32_row[e];
-                if (!MIXED || !is_fast) cur = rec_row[e];  // mixed mode needs the fp64 record only over a core it keeps
                 m &= m - 1;
-                if (is_fast) {
-                    // every point of the tile is inside the window and in region I: the same operations, in the same order,
-                    // as voigt_term's region-I branch (bit-identical), or the fp32 rational of the mixed-precision mode
-                    if constexpr (MIXED) {
-#pragma unroll
-                        for (int r = 0; r < R / 2; ++r) acc32[r] += region1_f32x2(nu_h[r], nu_l[r], cur32);
-                        ++pending32;
-                    } else {
-                        const RegionI k1 = {cur.yk, cur.c2, cur.c3, cur.c4};
-#pragma unroll
-                        for (int r = 0; r < R; ++r) {
-                            const double x = (nu_i[MIXED ? 0 : r] - cur.lnu) * cur.inv;
-                            acc[r] += region1_re(x * x, k1);
-                        }
-                    }
-                } else {
+                {
                     // The tile touches a window edge or the core.  Per 64-point block r (scalar tests): outside the window:
                     // nothing; clear of the core: the region-I rational for the whole block, added where the point is
                     // inside the window; over a DELEGATED core: the same, minus the core points (the narrow role adds
@@ -669,11 +692,11 @@ __device__ __forceinline__ void line_wide_walk(const int tile_idx, const int spl
                     const int jc = __builtin_amdgcn_readlane(sc.clo, b), jchi = __builtin_amdgcn_readlane(sc.chi, b);
                     const bool delegated = jc < 0;
                     const int jclo = delegated ? -jc - 1 : jc;
-                    const RegionI k1 = {cur.yk, cur.c2, cur.c3, cur.c4};
-                    float2v term32[MIXED ? R / 2 : 1];  // mixed mode: the fp32 rational of every point pair, once per hit
+                    const RegionI k1 = {cur.yk, cur.cv, cur.cd};
+                    float2v term32[MIXED ? R / 2 : 1];  // mixed mode: sum + fp32 rational of every point pair, once per hit
                     if constexpr (MIXED) {
 #pragma unroll
-                        for (int p = 0; p < R / 2; ++p) term32[p] = region1_f32x2(nu_h[p], nu_l[p], cur32);
+                        for (int p = 0; p < R / 2; ++p) term32[p] = region1_f32x2(acc32[p], nu_h[p], nu_l[p], cur32);
                     }
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
@@ -683,19 +706,16 @@ __device__ __forceinline__ void line_wide_walk(const int tile_idx, const int spl
                         if (!over_core || delegated) {
                             const bool take = idx[r] >= jlo && idx[r] < jhi && !(over_core && idx[r] >= jclo && idx[r] < jchi);
                             if constexpr (MIXED) {  // the tolerance path evaluates window edges in fp32 too (pairs of blocks)
-                                acc32[r >> 1][r & 1] += take ? term32[r >> 1][r & 1] : 0.f;
+                                acc32[r >> 1][r & 1] = take ? term32[r >> 1][r & 1] : acc32[r >> 1][r & 1];
                             } else {
-                                const double x = (nu_i[MIXED ? 0 : r] - cur.lnu) * cur.inv;
-                                const double term = region1_re(x * x, k1);
-                                acc[r] += take ? term : 0.0;
+                                acc[r] = region1_add_if(acc[r], (nu_i[MIXED ? 0 : r] - cur.lnu) * cur.inv, k1, take);
                             }
                         } else {
                             const double nu_r = MIXED ? (double)nu_h[MIXED ? r >> 1 : 0][r & 1] + (double)nu_l[MIXED ? r >> 1 : 0][r & 1] : nu_i[MIXED ? 0 : r];
                             const WideSlow sl = slow_row[e];
-                            if (idx[r] >= jlo && idx[r] < jhi) acc[r] += voigt_term(nu_r - cur.lnu, cur.inv, sl.y, sl.amp, k1);
+                            if (idx[r] >= jlo && idx[r] < jhi) acc[r] = voigt_add(acc[r], nu_r - cur.lnu, cur.inv, sl.y, sl.amp, k1);
                         }
                     }
-                    if constexpr (MIXED) ++pending32;
                 }
                 if (!m) break;
             }
@@ -878,28 +898,83 @@ __device__ __forceinline__ void line_narrow_wave(const int64_t i, const int dept
         unsigned long long m = __ballot(rel);
         // the parameters of the NEXT relevant line are requested before the current one is evaluated (all six loads at
         // once, used or not): one global-memory round trip per line hides behind the previous line's arithmetic
-        NarrowRec rec = {0, 0, 0.0, 0.0, 0.0};
-        double lnu = 0.0;
+        int lo = 0, hi = 0;
+        double y = 0.0, amp = 0.0, inv = 0.0, lnu = 0.0;
         if (m) {
             const int l = base + __builtin_ctzll(m);
-            rec = w.nrec[(size_t)l * n_depth + dc];
-            lnu = line_nus[l];
+            const size_t o = (size_t)l * n_depth + dc;
+            lo = w.nlo[o], hi = w.nhi[o], y = w.n_y[o], amp = w.n_amp[o], inv = w.n_inv[o], lnu = line_nus[l];
         }
         while (m) {
             m &= m - 1;
-            NarrowRec rec_n = {0, 0, 0.0, 0.0, 0.0};
-            double lnu_n = 0.0;
+            int lo_n = 0, hi_n = 0;
+            double y_n = 0.0, amp_n = 0.0, inv_n = 0.0, lnu_n = 0.0;
             if (m) {
                 const int l = base + __builtin_ctzll(m);
-                rec_n = w.nrec[(size_t)l * n_depth + dc];
-                lnu_n = line_nus[l];
+                const size_t o = (size_t)l * n_depth + dc;
+                lo_n = w.nlo[o], hi_n = w.nhi[o], y_n = w.n_y[o], amp_n = w.n_amp[o], inv_n = w.n_inv[o], lnu_n = line_nus[l];
             }
-            if (valid && ii >= rec.lo && ii < rec.hi) {
-                const RegionI k1 = region1_setup(rec.y, rec.amp);
-                acc += voigt_term(nu_i - lnu, rec.inv, rec.y, rec.amp, k1);
+            if (valid && ii >= lo && ii < hi) {
+                const RegionI k1 = region1_setup(y, amp);
+                acc = voigt_add(acc, nu_i - lnu, inv, y, amp, k1);
             }
-            rec = rec_n, lnu = lnu_n;
+            lo = lo_n, hi = hi_n, y = y_n, amp = amp_n, inv = inv_n, lnu = lnu_n;
         }
+    }
+    if (valid) plane[(size_t)d * pld + (i - nu_begin)] = acc;
+}
+
+// The narrow role of the mixed-precision mode: the same walk, every term evaluated by voigt_add32 (packed fp32, all four
+// regions) from fp32 records; the frequency difference comes from the hi + lo float pairs of both frequencies (exact to
+// 2^-48 of the frequency, i.e. ~1e-7 of a narrow window's reach), the terms of one 64-candidate chunk gather in an fp32
+// sum that goes into the fp64 sum once per chunk.
+__device__ __forceinline__ void line_narrow_wave32(const int64_t i, const int depth_chunk, int n_depth, int64_t n_nu, const double* __restrict__ nus,
+                                                          int64_t nu_begin, int64_t nu_count, LineWork w, double* __restrict__ plane, int64_t pld)
+{
+    const int lane = threadIdx.x & 63;
+    if (i >= nu_begin + nu_count) return;
+    const int d = depth_chunk * 64 + lane;
+    const bool valid = d < n_depth;
+    const int dc = valid ? d : n_depth - 1;
+    const int ii = (int)i;
+    const int64_t pa = max(i - kNarrowHalfWidth + 1, (int64_t)0);
+    const int64_t pb = min(i + kNarrowHalfWidth, n_nu);
+    const int la = __builtin_amdgcn_readfirstlane(w.cnt_ge[pb + 1]);
+    const int lb = __builtin_amdgcn_readfirstlane(w.cnt_ge[pa]);
+    const double nu_i = nus[i];
+    const float nih = (float)nu_i, nil = (float)(nu_i - (double)nih);
+    double acc = 0.0;
+    for (int base = la; base < lb; base += 64) {
+        const int lc = base + lane;
+        bool rel = false;
+        if (lc < lb) {
+            const int hwm = w.nhw_max[lc], c = w.centre[lc];
+            rel = hwm > 0 && ii >= c - hwm && ii < c + hwm;
+        }
+        unsigned long long m = __ballot(rel);
+        float acc32 = 0.f;
+        int lo = 0, hi = 0;
+        float y = 0.f, amp = 0.f, inv = 0.f;
+        float2v lnu = {0.f, 0.f};
+        if (m) {
+            const int l = base + __builtin_ctzll(m);
+            const size_t o = (size_t)l * n_depth + dc;
+            lo = w.nlo[o], hi = w.nhi[o], y = w.n_y32[o], amp = w.n_amp32[o], inv = w.n_inv32[o], lnu = w.lnu32[l];
+        }
+        while (m) {
+            m &= m - 1;
+            int lo_n = 0, hi_n = 0;
+            float y_n = 0.f, amp_n = 0.f, inv_n = 0.f;
+            float2v lnu_n = {0.f, 0.f};
+            if (m) {
+                const int l = base + __builtin_ctzll(m);
+                const size_t o = (size_t)l * n_depth + dc;
+                lo_n = w.nlo[o], hi_n = w.nhi[o], y_n = w.n_y32[o], amp_n = w.n_amp32[o], inv_n = w.n_inv32[o], lnu_n = w.lnu32[l];
+            }
+            if (valid && ii >= lo && ii < hi) acc32 = voigt_add32(acc32, ((nih - lnu.x) + (nil - lnu.y)) * inv, y, amp);
+            lo = lo_n, hi = hi_n, y = y_n, amp = amp_n, inv = inv_n, lnu = lnu_n;
+        }
+        acc += (double)acc32;
     }
     if (valid) plane[(size_t)d * pld + (i - nu_begin)] = acc;
 }
@@ -930,16 +1005,25 @@ __device__ __forceinline__ void line_all_body(int n_wide, int tiles, int n_split
         line_wide_walk<R, MIXED>(tile, wave, n_split, d, n_nu, nus, nu_begin, nu_count, n_lines, w, planes, pld, s_wide);
     } else {
         if (!(roles & 2)) return;
-        // XCD-aware order here too: a wave writes one value into each of the N_d rows of the narrow plane, so the waves that
-        // fill a 64-byte sector of a row (8 consecutive frequencies) should share an L2 — workgroups p, p + 8, ... (one XCD)
-        // take CONSECUTIVE frequencies; otherwise every XCD writes its own fragment of every sector back on its own
+        // A wave writes one value into each of the N_d rows of the narrow plane: the waves that fill a 64-byte sector of a
+        // row (8 consecutive frequencies) should share an L2, or every XCD writes its own fragment of every sector back on
+        // its own.  Workgroups p, p + 8, ... (one XCD) therefore take GROUPS of kNarrowGroup consecutive workgroups' worth
+        // of frequencies, the groups going round the XCDs.  (Giving each XCD one contiguous eighth of the grid was measured
+        // 45 % slower: the lines per grid point follow the frequency, so one XCD gets several times the work of another.)
+        constexpr int kNarrowGroup = 4;
         const int64_t n_narrow = nu_count * ((n_depth + 63) / 64);
-        const int64_t n_nb = (n_narrow + n_split - 1) / n_split, per_xcd = (n_nb + 7) / 8;
-        const int64_t p = b - n_wide;
-        const int64_t wg = (p & 7) * per_xcd + (p >> 3);
-        if ((p >> 3) >= per_xcd || wg >= n_nb) return;
+        const int64_t n_nb = (n_narrow + n_split - 1) / n_split;
+        const int64_t p = b - n_wide, j = p >> 3;
+        const int order = (roles >> 2) & 3;  // analysis knob (SDX_NARROW_ORDER): 0 grouped (default), 1 plain, 2 one block per XCD
+        int64_t wg = ((j / kNarrowGroup) * 8 + (p & 7)) * kNarrowGroup + j % kNarrowGroup;
+        if (order == 1) wg = p;
+        if (order == 2) wg = (p & 7) * ((n_nb + 7) / 8) + j;
+        if ((order == 2 && j >= (n_nb + 7) / 8) || wg >= n_nb) return;
         const int64_t c = wg * n_split + wave;
-        if (c < n_narrow)
+        if (c >= n_narrow) return;
+        if constexpr (MIXED)
+            line_narrow_wave32(nu_begin + c % nu_count, (int)(c / nu_count), n_depth, n_nu, nus, nu_begin, nu_count, w, planes + (size_t)n_depth * pld, pld);
+        else
             line_narrow_wave(nu_begin + c % nu_count, (int)(c / nu_count), n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w,
                              planes + (size_t)n_depth * pld, pld);
     }
@@ -1009,6 +1093,17 @@ __global__ __launch_bounds__(kBlock) void k_voigt_term(int64_t n, const double* 
     if (i >= n) return;
     const RegionI k1 = region1_setup(y[i], amp[i]);
     out[i] = voigt_term(dnu[i], inv_dw[i], y[i], amp[i], k1);
+}
+
+// The fp32 routine of the mixed-precision mode's narrow role (voigt_add32), element-wise: inputs rounded to fp32 as the
+// pre-pass and the kernel round them.
+__global__ __launch_bounds__(kBlock) void k_voigt_term32(int64_t n, const double* __restrict__ dnu, const double* __restrict__ inv_dw,
+                                                         const double* __restrict__ y, const double* __restrict__ amp,
+                                                         double* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    out[i] = (double)voigt_add32(0.f, (float)dnu[i] * (float)inv_dw[i], (float)y[i], (float)amp[i]);
 }
 
 // F_lambda = F_nu * nu / lambda (stardis/base.py:137-141: spectrum_lambda; the unit conversion there has scale 1)

@@ -162,26 +162,44 @@ __device__ __forceinline__ double recip(double d)
     return fma(r, fma(e, e, e), r);
 }
 
-// amp * Re w(x + i y) for region I given q = x*x:  y (q + y^2 + 1/2) / ((q - y^2 - 1/2)^2 + 4 q y^2) / sqrt(pi)
-//   = Re[ (i/sqrt(pi)) z / (z^2 - 1/2) ]  (voigt.py:47), written without cancellation.
+// acc + amp * Re w(x + i y) for region I:  Re[ (i/sqrt(pi)) z / (z^2 - 1/2) ]  (voigt.py:47)
+//   = (y/sqrt(pi)) (q + y^2 + 1/2) / ((q - y^2 - 1/2)^2 + 4 q y^2),  q = x^2.
+// With v = q + y^2 - 1/2 the denominator is v^2 + 2 y^2 and the numerator's bracket is v + 1: no cancellation anywhere
+// (v >= 100 in region I), and the point costs TEN instructions — v = fma(x, x, cv), den = fma(v, v, cd),
+// num = fma(yk, v, yk), the reciprocal (4) and fma(num, 1/den, acc); the difference nu - nu_l and the scaling by 1/dnu_D
+// are the other two.  The sum is part of the routine: every caller adds a region-I term with this one FMA, so a point
+// gets the same bits whichever path (test-free tile, edge block, core block, narrow role) evaluates it.
 struct RegionI {
-    double yk;   // amp * y / sqrt(pi): the line's amplitude is folded into the numerator (one multiplication per point less)
-    double c2;   // y^2 + 1/2
-    double c3;   // 2 y^2 - 1
-    double c4;   // c2^2
+    double yk;   // amp * y / sqrt(pi): the line's amplitude is folded into the numerator
+    double cv;   // y^2 - 1/2
+    double cd;   // 2 y^2
 };
 __device__ __forceinline__ RegionI region1_setup(double y, double amp)
 {
     const double y2 = y * y;
-    const double c2 = y2 + 0.5;
-    return {amp * (y * kInvSqrtPi), c2, fma(2.0, y2, -1.0), c2 * c2};
+    return {amp * (y * kInvSqrtPi), y2 - 0.5, y2 + y2};
 }
-// amp * Re w for region I
-__device__ __forceinline__ double region1_re(double q, const RegionI& k)
+__device__ __forceinline__ double region1_add(double acc, double x, const RegionI& k)
 {
-    const double num = k.yk * (q + k.c2);
-    const double den = fma(q, q + k.c3, k.c4);
-    return num * recip(den);
+    const double v = fma(x, x, k.cv);
+    const double den = fma(v, v, k.cd);
+    const double num = fma(k.yk, v, k.yk);
+    const double r = recip(den);
+    // acc <- fma(num, r, acc) IN PLACE: left to the compiler, the loop-carried sums of the line kernel are formed in fresh
+    // registers and copied back (five v_mov_b64 per walked line next to forty useful instructions)
+    asm("v_fma_f64 %0, %1, %2, %0" : "+v"(acc) : "v"(num), "v"(r));
+    return acc;
+}
+// the same where only some lanes take the term: the others add num * 0 (num is finite whatever x is; the reciprocal may
+// not be — v can vanish next to a line centre, where callers pass take = false)
+__device__ __forceinline__ double region1_add_if(double acc, double x, const RegionI& k, bool take)
+{
+    const double v = fma(x, x, k.cv);
+    const double den = fma(v, v, k.cd);
+    const double num = fma(k.yk, v, k.yk);
+    const double r = take ? recip(den) : 0.0;
+    asm("v_fma_f64 %0, %1, %2, %0" : "+v"(acc) : "v"(num), "v"(r));
+    return acc;
 }
 
 // exp(-tau) for 0 <= tau < 700: the ROCm device library's double-precision exp, operation for operation (same
@@ -302,12 +320,95 @@ __device__ __attribute__((noinline)) double faddeeva_re_core(double x, double y,
 //   inv_dw = 1 / doppler_width
 //   y      = (gamma / (sqrt(pi) * pi)) / doppler_width        (voigt.py:148, exact operations)
 //   amp    = alpha / (sqrt(pi) * doppler_width)               (voigt.py:149 and base.py:627)
-__device__ __forceinline__ double voigt_term(double delta_nu, double inv_dw, double y, double amp, const RegionI& k)
+// voigt_add returns acc + the term (see region1_add for why the sum is inside).
+__device__ __forceinline__ double voigt_add(double acc, double delta_nu, double inv_dw, double y, double amp, const RegionI& k)
 {
     const double x = delta_nu * inv_dw;
     const double ax = fabs(x);
-    if (add_rn(ax, y) > 15.0) return region1_re(x * x, k);  // amp is inside k
-    return amp * faddeeva_re_core(x, y, ax);
+    if (add_rn(ax, y) > 15.0) return region1_add(acc, x, k);  // amp is inside k
+    const double core = faddeeva_re_core(x, y, ax);
+    asm("v_fma_f64 %0, %1, %2, %0" : "+v"(acc) : "v"(amp), "v"(core));
+    return acc;
+}
+__device__ __forceinline__ double voigt_term(double delta_nu, double inv_dw, double y, double amp, const RegionI& k)
+{
+    return voigt_add(0.0, delta_nu, inv_dw, y, amp, k);
+}
+
+// ---- fp32 evaluation, mixed-precision mode only ---------------------------------------------------------------------
+// The same four Humlicek regions evaluated in fp32 with the complex arithmetic PACKED: a complex number is one float2v
+// (re, im), a complex Horner step p <- c + t p is two v_pk_fma_f32 (t.re * p + (c, 0), then (-t.im, t.im) * p.yx + that)
+// where the fp64 routine spends four FMAs, exp and cos are the hardware's (v_exp_f32, v_cos_f32).  Measured against
+// the fp64 routine over the golden (x, y) sets: tests/test_gpu_hot_faddeeva.py, tolerance 2e-5 of Re w (the W4
+// approximation itself is good to 1e-4).
+typedef float float2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2v pk_fma(float2v a, float2v b, float2v c) { return __builtin_elementwise_fma(a, b, c); }
+// a * b for complex a, b given pm = (-a.im, a.im)
+__device__ __forceinline__ float2v cmul32(float2v a, float2v pm, float2v b) { return pk_fma((float2v)(a.x), b, pm * b.yx); }
+// (c, 0) + t p and (c, 0) - u p:  pm = (-t.im, t.im), resp. mp = (u.im, -u.im)
+__device__ __forceinline__ float2v chorner_add32(float c, float tre, float2v pm, float2v p)
+{
+    return pk_fma(pm, p.yx, pk_fma((float2v)(tre), p, (float2v){c, 0.f}));
+}
+__device__ __forceinline__ float2v chorner_sub32(float c, float ure, float2v mp, float2v p)
+{
+    return pk_fma(mp, p.yx, pk_fma((float2v)(-ure), p, (float2v){c, 0.f}));
+}
+__device__ __forceinline__ float hsum32(float2v a) { return a.x + a.y; }
+// acc + amp * Re w(x + i y), all regions
+__device__ __forceinline__ float voigt_add32(float acc, float x, float y, float amp)
+{
+    const float ax = fabsf(x), s = ax + y;
+    if (s > 15.f) {  // region I, the form of region1_add
+        const float y2 = y * y;
+        const float v = fmaf(x, x, y2 - 0.5f);
+        const float yk = amp * (y * 0.5641895835f);
+        return fmaf(fmaf(yk, v, yk), __builtin_amdgcn_rcpf(fmaf(v, v, y2 + y2)), acc);
+    }
+    float re;
+    if (s > 5.5f) {  // region II
+        const float2v z = {x, y}, zpm = {-y, y};
+        const float2v z2 = cmul32(z, zpm, z);
+        const float2v inner = pk_fma(z2, (float2v)(0.5641895835f), (float2v){-1.4104739589f, 0.f});
+        const float2v n = cmul32(z, zpm, inner);
+        const float2v d = pk_fma((float2v){-z2.y, z2.y}, (float2v){z2.y, z2.x - 3.0f}, pk_fma((float2v)(z2.x), (float2v){z2.x - 3.0f, z2.y}, (float2v){0.75f, 0.f}));
+        const float2v cr = n * d.yx;  // (n.re d.im, n.im d.re)
+        re = (cr.x - cr.y) * __builtin_amdgcn_rcpf(hsum32(d * d));
+    } else {
+        const float2v t = {y, -x}, tpm = {x, -x};  // (-t.im, t.im)
+        if (y >= 0.195f * ax - 0.176f) {  // region III
+            float2v p = pk_fma(t, (float2v)(0.5642236f), (float2v){3.778987f, 0.f});
+            p = chorner_add32(11.96482f, y, tpm, p);
+            p = chorner_add32(20.20933f, y, tpm, p);
+            p = chorner_add32(16.4955f, y, tpm, p);
+            float2v q = t + (float2v){6.699398f, 0.f};
+            q = chorner_add32(21.69274f, y, tpm, q);
+            q = chorner_add32(39.27121f, y, tpm, q);
+            q = chorner_add32(38.82363f, y, tpm, q);
+            q = chorner_add32(16.4955f, y, tpm, q);
+            re = hsum32(p * q) * __builtin_amdgcn_rcpf(hsum32(q * q));
+        } else {  // region IV
+            const float2v u = cmul32(t, tpm, t), ump = {u.y, -u.y};
+            float2v p = pk_fma(u, (float2v)(-0.56419f), (float2v){1.320522f, 0.f});
+            p = chorner_sub32(35.7668f, u.x, ump, p);
+            p = chorner_sub32(219.031f, u.x, ump, p);
+            p = chorner_sub32(1540.787f, u.x, ump, p);
+            p = chorner_sub32(3321.99f, u.x, ump, p);
+            p = chorner_sub32(36183.31f, u.x, ump, p);
+            const float2v n = cmul32(t, tpm, p);
+            float2v q = (float2v){1.84144f, 0.f} - u;
+            q = chorner_sub32(61.5704f, u.x, ump, q);
+            q = chorner_sub32(364.219f, u.x, ump, q);
+            q = chorner_sub32(2186.18f, u.x, ump, q);
+            q = chorner_sub32(9022.23f, u.x, ump, q);
+            q = chorner_sub32(24322.8f, u.x, ump, q);
+            q = chorner_sub32(32066.6f, u.x, ump, q);
+            const float frac = hsum32(n * q) * __builtin_amdgcn_rcpf(hsum32(q * q));
+            // exp(u.re) cos(u.im): v_exp_f32 is 2^x, v_cos_f32 takes revolutions; -30.3 < u.re < 0.81, |u.im| < 10
+            re = fmaf(__builtin_amdgcn_exp2f(u.x * 1.4426950409f), __builtin_amdgcn_cosf(u.y * 0.15915494309f), -frac);
+        }
+    }
+    return fmaf(amp, re, acc);
 }
 
 // ---- radiative transfer pieces -------------------------------------------------------------

@@ -117,8 +117,20 @@ LineWork carve(sdx_ctx* ctx, int n_depth, int64_t n_lines)
     w.wslow = (WideSlow*)(w.wscan + n);      // 16 n
     WideRec32* rec32 = (WideRec32*)(w.wslow + n);  // 32 n
     w.wrec32 = ctx->mixed_precision ? rec32 : nullptr;
-    w.nrec = (NarrowRec*)(rec32 + n);  // 32 n
-    w.hscan = (WideScan*)(w.nrec + n);  // 16 n (only the first hcount[0] entries of a row are used)
+    w.n_inv = (double*)(rec32 + n);  // 8 n each
+    w.n_y = w.n_inv + n;
+    w.n_amp = w.n_y + n;
+    w.nlo = (int*)(w.n_amp + n);     // 4 n each
+    w.nhi = w.nlo + n;
+    w.n_inv32 = w.n_y32 = w.n_amp32 = nullptr;
+    w.lnu32 = nullptr;
+    if (ctx->mixed_precision) {  // the narrow role's records as floats in the same 24 n bytes, + the line frequencies as float pairs
+        w.n_inv32 = (float*)w.n_inv;
+        w.n_y32 = w.n_inv32 + n;
+        w.n_amp32 = w.n_y32 + n;
+        w.lnu32 = (float2v*)(w.n_amp32 + n);
+    }
+    w.hscan = (WideScan*)(w.nhi + n);  // 16 n (only the first hcount[0] entries of a row are used)
     w.cnt_ge = (int*)ctx->cnt_ws;
     w.centre = w.cnt_ge + ctx->cnt_ge_len;
     w.nhw_max = w.centre + n_lines;
@@ -689,14 +701,15 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
     const int64_t pld = nu_count;
     const int tiles = (int)((nu_count + 64 * Rm - 1) / (64 * Rm));
     const int64_t n_wide = (int64_t)tiles * n_depth;
-    // workgroups of n_split waves, rounded up to 8 per row of the XCD-aware order (surplus workgroups return at once)
-    const int64_t n_narrow = (((nu_count * ((n_depth + 63) / 64) + n_split - 1) / n_split + 7) / 8) * 8;
+    // workgroups of n_split waves, rounded up to whole rounds of the XCD-aware order (surplus workgroups return at once)
+    const int64_t n_narrow = (((nu_count * ((n_depth + 63) / 64) + n_split - 1) / n_split + 31) / 32) * 32;
+    static const int narrow_order = std::getenv("SDX_NARROW_ORDER") ? atoi(std::getenv("SDX_NARROW_ORDER")) & 3 : 0;
     REQUIRE(n_wide + n_narrow < ((int64_t)1 << 31), "line opacity: grid too large for one launch");
     static const bool split_launches = std::getenv("SDX_SPLIT_LAUNCHES") != nullptr;  // analysis knob: time the two roles apart
     const size_t shmem = (size_t)n_split * kWideLdsDoubles * sizeof(double);
     const dim3 g((unsigned)(n_wide + n_narrow)), blk((unsigned)(64 * n_split));
     for (int pass = 0; pass < (split_launches ? 2 : 1); ++pass) {
-        const int roles = split_launches ? (1 << pass) : 3;
+        const int roles = (split_launches ? (1 << pass) : 3) | (narrow_order << 2);
         LaunchScope ls(ctx, split_launches ? (pass ? "k_line_narrow" : "k_line_wide") : "k_line_all");
 #define SDX_LINE_ARGS (int)n_wide, tiles, n_split, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, part, pld, roles
         if (ctx->mixed_precision && Rm == 8) hipLaunchKernelGGL((k_line_all_mixed<8>), g, blk, shmem, ctx->stream, SDX_LINE_ARGS);
@@ -1024,6 +1037,18 @@ int sdx_voigt_term_dev(sdx_ctx* ctx, int64_t n, const double* delta_nu, const do
         hipLaunchKernelGGL(k_voigt_term, dim3(blocks1(n)), dim3(kBlock), 0, ctx->stream, n, delta_nu, inv_doppler_width, y, amp, out);
     }
     return check_launch("k_voigt_term");
+}
+
+int sdx_voigt_term_f32_dev(sdx_ctx* ctx, int64_t n, const double* delta_nu, const double* inv_doppler_width, const double* y,
+                           const double* amp, double* out)
+{
+    REQUIRE(ctx && n >= 0 && (n == 0 || (delta_nu && inv_doppler_width && y && amp && out)), "voigt_term_f32: bad arguments");
+    if (n == 0) return SDX_OK;
+    {
+        LaunchScope ls(ctx, "k_voigt_term32");
+        hipLaunchKernelGGL(k_voigt_term32, dim3(blocks1(n)), dim3(kBlock), 0, ctx->stream, n, delta_nu, inv_doppler_width, y, amp, out);
+    }
+    return check_launch("k_voigt_term32");
 }
 
 // ================================================================================================ broadening

@@ -53,10 +53,11 @@ def voigt_profile(delta_nu, doppler_width, gamma, ctx=None):
     return r if r.ndim else r[()]
 
 
-def voigt_term(delta_nu, doppler_width, gamma, alpha=1.0, ctx=None):
+def voigt_term(delta_nu, doppler_width, gamma, alpha=1.0, ctx=None, fp32=False):
     """alpha * voigt_profile(delta_nu, doppler_width, gamma) through the routine the LINE KERNELS evaluate (real part only,
     FMA arithmetic, one reciprocal per point; sdx_math.h voigt_term) instead of the reference-order element-wise one.
-    The derived constants are formed exactly as the pre-pass forms them (voigt.py:148-149, base.py:627)."""
+    The derived constants are formed exactly as the pre-pass forms them (voigt.py:148-149, base.py:627).
+    fp32=True: the packed-fp32 routine the mixed_precision option uses for narrow windows (sdx_math.h voigt_add32)."""
     ctx = ctx or default_context()
     dnu, dw, g, a = (np.ascontiguousarray(v) for v in np.broadcast_arrays(_host(delta_nu), _host(doppler_width), _host(gamma), _host(alpha)))
     if np.any(dw == 0):
@@ -67,7 +68,7 @@ def voigt_term(delta_nu, doppler_width, gamma, alpha=1.0, ctx=None):
     amp = a / (sqrt_pi * dw)
     d = [ctx.upload(v) for v in (dnu, inv, y, amp)]
     out = ctx.empty(dnu.shape)
-    ctx.call("sdx_voigt_term_dev", dnu.size, d[0].ptr, d[1].ptr, d[2].ptr, d[3].ptr, out.ptr)
+    ctx.call("sdx_voigt_term_f32_dev" if fp32 else "sdx_voigt_term_dev", dnu.size, d[0].ptr, d[1].ptr, d[2].ptr, d[3].ptr, out.ptr)
     r = out.numpy()
     return r if r.ndim else r[()]
 

@@ -53,6 +53,23 @@ def test_hot_path_voigt_vs_reference_vectors(ctx):
         assert rel_err(got[near], g["phi"][near]) < 1e-4
 
 
+def test_fp32_routine_of_the_mixed_mode_by_region(ctx):
+    """voigt_add32 (packed fp32, hardware exp / cos: the narrow role of mixed_precision=1) against the reference's own G1
+    vectors, per region.  The W4 approximation is good to 1e-4; the mode's stated tolerance is 1e-4 on the flux; the fp32
+    evaluation itself stays below 2e-5 of Re w (measured ~7e-6 in region IV, ~2e-6 elsewhere)."""
+    g = load_golden("g1_faddeeva")
+    x, y, ref = g["z"].real.copy(), g["z"].imag.copy(), g["w"].real
+    # keep away from the region boundaries by more than an fp32 ulp of x, y: a point may take the neighbouring rational
+    s = np.abs(x) + y
+    far = (np.abs(s - 15.0) > 1e-4) & (np.abs(s - 5.5) > 1e-4) & (np.abs(y - (0.195 * np.abs(x) - 0.176)) > 1e-4) & (y > 1e-30)
+    x, y, ref = x[far], y[far], ref[far]
+    gamma = y * (np.float64(SQRT_PI) * np.float64(np.pi))
+    got = ops.voigt_term(x, 1.0, gamma, alpha=SQRT_PI, fp32=True)
+    for name, m in regions(x, y).items():
+        assert m.sum() > 100, name
+        assert rel_err(got[m], ref[m]) < 2e-5, name
+
+
 @pytest.mark.parametrize("role", ["wide", "narrow"])
 def test_line_kernel_evaluates_every_region_like_the_reference(ctx, role):
     """One line per test column of (Doppler width, gamma), windows forced over a grid whose offsets sweep |x| from 0
