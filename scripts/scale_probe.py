@@ -43,7 +43,9 @@ if "--mixed" in sys.argv:
     ctx.call("sdx_profile_enable", 1); ctx.call("sdx_profile_reset")
     for _ in range(3): syn.enqueue()
     ctx.synchronize()
-    cnt, ms = C.c_int64(), C.c_double()
-    _lib.check(ctx.lib.sdx_profile_get(ctx.handle, b"k_line_all", C.byref(cnt), C.byref(ms)))
-    print(f"mixed precision: k_line_all {ms.value/cnt.value*1e3:.1f} us; line opacity rel diff vs fp64 {float(np.max(np.abs(syn.alpha_line()-line)/np.maximum(np.abs(line),1e-300))):.2e}")
+    for k in ("k_line_all", "k_line_wide", "k_line_narrow", "k_prepass_continuum"):
+        cnt, ms = C.c_int64(), C.c_double()
+        _lib.check(ctx.lib.sdx_profile_get(ctx.handle, k.encode(), C.byref(cnt), C.byref(ms)))
+        if cnt.value: print(f"mixed precision: {k} {ms.value/cnt.value*1e3:.1f} us")
+    print(f"mixed precision: line opacity rel diff vs fp64 {float(np.max(np.abs(syn.alpha_line()-line)/np.maximum(np.abs(line),1e-300))):.2e}")
     ctx.call("sdx_profile_enable", 0); ctx.set_option("mixed_precision", 0)

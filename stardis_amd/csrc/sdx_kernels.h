@@ -810,30 +810,42 @@ __global__ __launch_bounds__(kBlock) void k_classify(int n_depth, int64_t n_nu, 
     __shared__ double s_red[kBlock / 64];
     const double d_nu = block_dnu(dnu_partial, n_partial, s_red);
     const int64_t n = n_lines * n_depth;
-    // four items per thread, a block apart: twelve independent loads in flight per lane (the pass is a pure stream)
-    const int64_t k0 = (int64_t)blockIdx.x * (4 * kBlock) + threadIdx.x;
-    double dw[4], al[4], g[4];
-    int64_t ls[4];
+    const double scale = 20.0 / d_nu;
+    // a fixed number of blocks strides over the items (the grid-spacing reduction above is paid once per block, not once per
+    // 1024 items); four items per thread and trip, a block apart: twelve independent loads in flight per lane
+    for (int64_t base = (int64_t)blockIdx.x * (4 * kBlock); base < n; base += (int64_t)gridDim.x * (4 * kBlock)) {
+        const int64_t k0 = base + threadIdx.x;
+        const int64_t l_first = base / n_depth;  // the line of the trip's first item
+        double dw[4], al[4], g[4];
+        int64_t ls[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int64_t k = k0 + j * kBlock;
-        ls[j] = -1;
-        dw[j] = al[j] = g[j] = 0.0;
-        if (k < n) {
-            const int64_t l = k / n_depth;
-            ls[j] = l;
-            dw[j] = doppler[k];
-            al[j] = alphas[k];
-            g[j] = gamma_cols > 1 ? gammas[l * gamma_cols + (k - l * n_depth)] : gammas[l];
+        for (int j = 0; j < 4; ++j) {
+            const int64_t k = k0 + j * kBlock;
+            ls[j] = -1;
+            dw[j] = al[j] = g[j] = 0.0;
+            if (k < n) {
+                // line index: one 64-bit division per trip (uniform), a 32-bit one per item (a 64-bit division per item is
+                // ~100 instructions)
+                const unsigned r = (unsigned)(k - l_first * n_depth);
+                const unsigned q = r / (unsigned)n_depth;
+                const int64_t l = l_first + q;
+                ls[j] = l;
+                dw[j] = doppler[k];
+                al[j] = alphas[k];
+                g[j] = gamma_cols > 1 ? gammas[l * gamma_cols + (r - q * (unsigned)n_depth)] : gammas[l];
+            }
         }
-    }
+        // almost every item is a narrow window: the product with the rounded 20 / d_nu is within 1e-15 of the window rule's
+        // value, so anything below 64.99 needs no exact evaluation (an IEEE division per item)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        if (ls[j] < 0) continue;
-        const double pixels = mul_rn(mul_rn(add_rn(g[j], dw[j]), al[j]) / d_nu, 20.0);
-        const double forced = pixels > 10.0 ? pixels : 10.0;
-        const int64_t hw = forced >= (double)n_nu ? n_nu : (int64_t)forced;
-        if (hw > kNarrowHalfWidth) atomicMax(&whw_max[ls[j]], (int)hw);
+        for (int j = 0; j < 4; ++j) {
+            if (ls[j] < 0) continue;
+            if (mul_rn(mul_rn(add_rn(g[j], dw[j]), al[j]), scale) < (double)kNarrowHalfWidth + 0.99) continue;
+            const double pixels = mul_rn(mul_rn(add_rn(g[j], dw[j]), al[j]) / d_nu, 20.0);
+            const double forced = pixels > 10.0 ? pixels : 10.0;
+            const int64_t hw = forced >= (double)n_nu ? n_nu : (int64_t)forced;
+            if (hw > kNarrowHalfWidth) atomicMax(&whw_max[ls[j]], (int)hw);
+        }
     }
 }
 
@@ -878,6 +890,7 @@ __device__ __forceinline__ void line_narrow_wave(const int64_t i, const int dept
     const int d = depth_chunk * 64 + lane;
     const bool valid = d < n_depth;
     const int dc = valid ? d : n_depth - 1;
+    const unsigned dcu = (unsigned)dc;
     const int ii = (int)i;
     // lines with centre c in [i - H + 1, i + H]
     const int64_t pa = max(i - kNarrowHalfWidth + 1, (int64_t)0);
@@ -900,10 +913,11 @@ __device__ __forceinline__ void line_narrow_wave(const int64_t i, const int dept
         // once, used or not): one global-memory round trip per line hides behind the previous line's arithmetic
         int lo = 0, hi = 0;
         double y = 0.0, amp = 0.0, inv = 0.0, lnu = 0.0;
+        // addresses: a per-line base (uniform: scalar arithmetic) + the lane's depth as an unsigned 32-bit offset
         if (m) {
             const int l = base + __builtin_ctzll(m);
-            const size_t o = (size_t)l * n_depth + dc;
-            lo = w.nlo[o], hi = w.nhi[o], y = w.n_y[o], amp = w.n_amp[o], inv = w.n_inv[o], lnu = line_nus[l];
+            const size_t ob = (size_t)l * n_depth;
+            lo = (w.nlo + ob)[dcu], hi = (w.nhi + ob)[dcu], y = (w.n_y + ob)[dcu], amp = (w.n_amp + ob)[dcu], inv = (w.n_inv + ob)[dcu], lnu = line_nus[l];
         }
         while (m) {
             m &= m - 1;
@@ -911,8 +925,8 @@ __device__ __forceinline__ void line_narrow_wave(const int64_t i, const int dept
             double y_n = 0.0, amp_n = 0.0, inv_n = 0.0, lnu_n = 0.0;
             if (m) {
                 const int l = base + __builtin_ctzll(m);
-                const size_t o = (size_t)l * n_depth + dc;
-                lo_n = w.nlo[o], hi_n = w.nhi[o], y_n = w.n_y[o], amp_n = w.n_amp[o], inv_n = w.n_inv[o], lnu_n = line_nus[l];
+                const size_t ob = (size_t)l * n_depth;
+                lo_n = (w.nlo + ob)[dcu], hi_n = (w.nhi + ob)[dcu], y_n = (w.n_y + ob)[dcu], amp_n = (w.n_amp + ob)[dcu], inv_n = (w.n_inv + ob)[dcu], lnu_n = line_nus[l];
             }
             if (valid && ii >= lo && ii < hi) {
                 const RegionI k1 = region1_setup(y, amp);
@@ -1030,7 +1044,7 @@ __device__ __forceinline__ void line_all_body(int n_wide, int tiles, int n_split
 }
 
 template <int R>
-__global__ __launch_bounds__(512) void k_line_all(int n_wide, int tiles, int n_split, int n_depth, int64_t n_nu,
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_line_all(int n_wide, int tiles, int n_split, int n_depth, int64_t n_nu,
                                                    const double* __restrict__ nus, int64_t nu_begin, int64_t nu_count,
                                                    int64_t n_lines, const double* __restrict__ line_nus, LineWork w,
                                                    double* __restrict__ planes, int64_t pld, int roles)
@@ -1040,7 +1054,7 @@ __global__ __launch_bounds__(512) void k_line_all(int n_wide, int tiles, int n_s
 // the mixed-precision variant: 512-point tiles; the register budget is capped at 128 (4 waves per SIMD) — what exceeds it
 // sits in the rarely taken fp64 general path
 template <int R>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_line_all_mixed(
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(R == 4 ? 6 : 4, 8))) void k_line_all_mixed(
     int n_wide, int tiles, int n_split, int n_depth, int64_t n_nu, const double* __restrict__ nus, int64_t nu_begin, int64_t nu_count,
     int64_t n_lines, const double* __restrict__ line_nus, LineWork w, double* __restrict__ planes, int64_t pld, int roles)
 {
@@ -1302,6 +1316,10 @@ struct ContinuumArgs {
     int rayleigh_enabled;
     const double* electron_density;
     const double* temperature;
+    // fused step only: 1 / ray_dist for the segmented formal solution, formed by the first continuum block
+    const double* ray_dist;
+    double* inv_ray;
+    int n_ray;
 };
 
 __device__ inline double alpha_bf_point(int n_depth, int d, double nu, int n_species, const int* __restrict__ offs,
@@ -1642,6 +1660,8 @@ __global__ __launch_bounds__(kPreBlock) __attribute__((amdgpu_num_sgpr(80))) voi
                            gammas, gamma_cols, alphas, w, nullptr, nullptr, n_line_blocks, lp);
     } else {
         const int c = b - n_pre;
+        if (c == 0 && ca.inv_ray)
+            for (int k = threadIdx.x; k < ca.n_ray; k += blockDim.x) ca.inv_ray[k] = 1.0 / ca.ray_dist[k];
         if (stage_table & 2)  // bit 1: depth-group blocks (the per-depth factors of a group fit LDS); bits 4..7: depths per block
             continuum_tile_block(c % cont_tiles, c / cont_tiles, (stage_table >> 4) & 15, n_depth, nu_begin, nu_count, nus, ca, cont_plane, cont_ld,
                                  (stage_table & 1) != 0);
@@ -1976,6 +1996,174 @@ __global__ __launch_bounds__(kBlock) void k_raytrace(int n_depth, int64_t n_nu, 
             }
         }
         __syncthreads();
+    }
+}
+
+// Formal solution with the GAPS OF A RAY SPLIT OVER THE WAVES OF A WORKGROUP (plane-parallel geometry, one angle per lane).
+// k_raytrace above is bounded by latency, not throughput: a wave walks all N_d - 1 gaps of its rays one after the other —
+// ~5000 dependent-issue instructions — and a grid of a few thousand frequencies offers only 2-3 such waves per SIMD.  But a
+// step of the recurrence is AFFINE in the incoming intensity, I' = c I + e with c = 1 - w0, and everything expensive
+// (exp(-tau), the weights, the second-order source terms: ~55 of ~60 instructions) is in c and e, which do not depend on I.
+// So the NS waves of a workgroup take the same rays (lane <-> (frequency, angle), as above) and one SEGMENT of L = ceil
+// (n_gap / NS) gaps each:
+//   1  every wave forms (c, e) of its gaps — kept in registers — and composes them, (A, B) <- (c A, c B + e);
+//   2  the segment maps meet in LDS; wave s folds the maps of the segments below it: its incoming intensity;
+//   3  it replays its gaps, I <- c I + e (one FMA each), and writes I w_theta to LDS; the flux of its own gaps is summed
+//      over theta by the wave itself, in the order of k_raytrace (two ascending halves).
+// Eight times the waves, each an eighth as long.  Staging (ray table, log alpha, Planck source, geometric means) is done once
+// per workgroup by all its threads; the flux terms reuse that LDS after the barrier of step 2.
+// The intensity differs from k_raytrace's by the rounding of the composition (a few ulp; the tolerance is 1e-10).
+// 1 / ray_dist, once per launch (an IEEE division per table entry in every workgroup would cost the segmented kernel a
+// fifth of its instructions)
+__global__ __launch_bounds__(kBlock) void k_ray_recip(int n, const double* __restrict__ ray_dist, double* __restrict__ inv)
+{
+    const int k = blockIdx.x * kBlock + threadIdx.x;
+    if (k < n) inv[k] = 1.0 / ray_dist[k];
+}
+
+template <int NS, int LMAX>
+__global__ __launch_bounds__(64 * NS) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_raytrace_seg(
+    int n_depth, int64_t n_nu, int n_theta, int theta_stride, const double* __restrict__ nus, const double* __restrict__ temps,
+    const double* __restrict__ ray_dist, const double* __restrict__ inv_ray_dist, const double* __restrict__ wts, const double* __restrict__ alphas,
+    int64_t ald, double* __restrict__ F, int64_t fld, double* __restrict__ I_nus, int gpw, FusedTotal ft)
+{
+    extern __shared__ double smem[];
+    const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
+    const int G = n_theta;
+    const int grp = lane / G, g = lane - grp * G;
+    const int64_t i0 = (int64_t)blockIdx.x * gpw;
+    const int64_t i = i0 + grp;
+    const bool active = grp < gpw;
+    const bool valid = active && i < n_nu;
+    const int n_gap = n_depth - 1, col = n_depth;
+    double* sAB = smem;                        // [NS][64][2] segment maps
+    double* sRD = sAB + NS * 128;              // ray_dist [n_gap][n_theta]
+    double* sIRD = sRD + n_gap * n_theta;      // 1 / ray_dist
+    double* sS = sIRD + n_gap * n_theta;       // source function [gpw][col]
+    double* sM = sS + gpw * col;               // mean opacity
+    double* sIM = sM + gpw * col;              // 1 / mean opacity
+    double* sX = sIM + gpw * col;              // log(alpha)
+    double* sFx = sRD;                         // after the barrier of step 2: flux terms [NS][LMAX][gpw][G]
+
+    for (int k = threadIdx.x; k < n_gap * n_theta; k += 64 * NS) {
+        const int gp = k / n_theta, t = k - gp * n_theta;
+        sRD[k] = ray_dist[(size_t)gp * theta_stride + t];
+        sIRD[k] = inv_ray_dist[(size_t)gp * theta_stride + t];
+    }
+    // the columns of the workgroup's frequencies: log(alpha) by the first gpw * n_depth threads, the Planck source by the next
+    for (int k = threadIdx.x; k < 2 * gpw * n_depth; k += 64 * NS) {
+        const bool source = k >= gpw * n_depth;
+        const int kk = source ? k - gpw * n_depth : k;
+        const int gq = kk / n_depth, d = kk - gq * n_depth;
+        const int64_t iq = i0 + gq;
+        const bool vq = iq < n_nu;
+        const int64_t ic = vq ? iq : n_nu - 1;
+        if (source) {
+            sS[gq * col + d] = planck(nus[ic], temps[d]);
+            continue;
+        }
+        double a;
+        if (ft.cont) {
+            a = ft.cont[(size_t)d * ft.cld + ic];
+            if (ft.planes) {
+                double line = ft.planes[(size_t)d * ft.pld + ic];
+                for (int sp = 1; sp < ft.n_planes; ++sp) line = add_rn(line, ft.planes[((size_t)sp * n_depth + d) * ft.pld + ic]);
+                a = add_rn(a, line);
+                if (vq && ft.line_out) ft.line_out[(size_t)d * ft.out_ld + iq] = line;
+            }
+            if (vq && ft.total_out) ft.total_out[(size_t)d * ft.out_ld + iq] = a;
+        } else {
+            a = alphas[(size_t)d * ald + ic];
+        }
+        sX[gq * col + d] = log(a);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < gpw * n_gap; k += 64 * NS) {
+        const int gq = k / n_gap, gp = k - gq * n_gap;
+        const double m = exp(mul_rn(add_rn(sX[gq * col + gp + 1], sX[gq * col + gp]), 0.5));
+        sM[gq * col + gp] = m;
+        sIM[gq * col + gp] = 1.0 / m;
+    }
+    __syncthreads();
+
+    // step 1: the coefficients of this wave's gaps [g_lo, g_lo + count)
+    const int L = (n_gap + NS - 1) / NS;
+    const int g_lo = min(seg * L, n_gap - 1);
+    const int count = max(0, min(L, n_gap - seg * L));
+    const int gi = (active ? grp : 0) * col;  // idle lanes shadow group 0 and never store
+    const int th = min(g, n_theta - 1);
+    const double wt = wts[th];
+    double c[LMAX], e[LMAX];
+    double A = 1.0, B = 0.0;
+    {
+        double t0 = mul_rn(sM[gi + g_lo], sRD[g_lo * n_theta + th]);
+        double r0 = sIM[gi + g_lo] * sIRD[g_lo * n_theta + th];
+        double s0 = sS[gi + g_lo], s1 = sS[gi + g_lo + 1];
+#pragma unroll
+        for (int j = 0; j < LMAX; ++j) {
+            c[j] = 1.0, e[j] = 0.0;
+            if (j < count) {
+                const int gap = g_lo + j;
+                const bool last = gap == n_gap - 1;
+                const int nx = last ? gap : gap + 1;  // clamp LDS reads of the step that has no successor
+                const double s2 = sS[gi + nx + 1];
+                const double t1 = mul_rn(sM[gi + nx], sRD[nx * n_theta + th]);
+                const double r1 = sIM[gi + nx] * sIRD[nx * n_theta + th];
+                if (t0 != 0.0) {  // tau == 0: no change (:203-206, :253-254)
+                    double w0, w1, w2;
+                    rt_weights(t0, w0, w1, w2);
+                    const double bb = (s0 - s1) * r0;
+                    double rest;
+                    if (!last) {  // :208-249
+                        const double rs = recip_guarded(t0 + t1);
+                        const double aa = (s2 - s1) * r1;
+                        rest = fma(w1 * (bb * t1 - aa * t0), rs, w2 * (aa + bb) * rs);
+                    } else {  // :256-266
+                        rest = w2 * bb * r0;
+                    }
+                    c[j] = 1.0 - w0;
+                    e[j] = fma(w0, s1, rest);
+                    A *= c[j];
+                    B = fma(c[j], B, e[j]);
+                }
+                t0 = t1, r0 = r1, s0 = s1, s1 = s2;
+            }
+        }
+    }
+    sAB[(seg * 64 + lane) * 2] = A;
+    sAB[(seg * 64 + lane) * 2 + 1] = B;
+    __syncthreads();
+    // step 2: the intensity entering this segment (0 at the innermost point, np.zeros :134)
+    double inten = 0.0;
+    for (int k = 0; k < seg; ++k) inten = fma(sAB[(k * 64 + lane) * 2], inten, sAB[(k * 64 + lane) * 2 + 1]);
+    if (seg == 0) {
+        if (valid && I_nus) I_nus[(size_t)i * theta_stride + th] = 0.0;
+        if (valid && g == 0 && F) F[i] = 0.0;
+    }
+    // step 3: replay, flux terms to LDS (the staging arrays are dead since the barrier)
+    double* fx = sFx + (size_t)seg * LMAX * gpw * G;
+#pragma unroll
+    for (int j = 0; j < LMAX; ++j) {
+        if (j < count) {
+            inten = fma(c[j], inten, e[j]);
+            if (valid && I_nus) I_nus[((size_t)(g_lo + j + 1) * n_nu + i) * theta_stride + th] = inten;
+            if (active) fx[(j * gpw + grp) * G + g] = inten * wt;
+        }
+    }
+    wave_sync();
+    if (F) {
+        const int half = (n_theta + 1) >> 1;
+        for (int p = lane; p < 2 * count * gpw; p += 64) {
+            const int h = p & 1, q = p >> 1;  // q = b * gpw + gq
+            const int b = (int)(((float)q + 0.5f) * (1.0f / (float)gpw)), gq = q - b * gpw;  // q < 64 LMAX: exact
+            const double* cc = fx + q * G + (h ? half : 0);
+            const int cnt = h ? n_theta - half : half;
+            double sum = 0.0;
+            for (int t = 0; t < cnt; ++t) sum = add_rn(sum, cc[t]);
+            const double other = __shfl_xor(sum, 1);
+            const int64_t iq = i0 + gq;
+            if (h == 0 && iq < n_nu) F[(size_t)(g_lo + b + 1) * fld + iq] = add_rn(sum, other);
+        }
     }
 }
 

@@ -55,6 +55,8 @@ struct sdx_ctx {
     // small scratch: d_nu partials, evaluation counter, bf coefficients
     void* small_ws = nullptr;
     size_t small_ws_bytes = 0;
+    void* rt_ws = nullptr;  // 1 / ray_dist for the segmented formal solution
+    size_t rt_ws_bytes = 0;
     // partial line-opacity planes [n_split + 1][n_depth][nu_count] (last plane: narrow windows)
     void* part_ws = nullptr;
     size_t part_ws_bytes = 0;
@@ -302,6 +304,7 @@ void sdx_destroy(sdx_ctx* ctx)
     if (ctx->t1) hipEventDestroy(ctx->t1);
     if (ctx->line_ws) hipFree(ctx->line_ws);
     if (ctx->small_ws) hipFree(ctx->small_ws);
+    if (ctx->rt_ws) hipFree(ctx->rt_ws);
     if (ctx->part_ws) hipFree(ctx->part_ws);
     if (ctx->cnt_ws) hipFree(ctx->cnt_ws);
     if (ctx->io_dev) hipFree(ctx->io_dev);
@@ -516,7 +519,27 @@ struct ContinuumJob {  // continuum plane computed by the trailing blocks of the
     const sdx_continuum* cont;
     int64_t nu_begin, nu_count;
     double* plane;
+    const double* ray_dist = nullptr;  // + the reciprocals of the ray table [n_ray] into ctx->rt_ws (segmented formal solution)
+    int n_ray = 0;
 };
+
+// The segmented formal solution (k_raytrace_seg: the gaps of a ray over the 8 waves of a workgroup) pays ~40 % more
+// instructions for eight times the waves: it wins where k_raytrace would leave the chip under three waves per SIMD.
+constexpr int kSegWaves = 8, kSegMax = 7;
+static size_t seg_lds_doubles(int n_depth, int nth)
+{
+    const int gpw = 64 / nth;
+    return (size_t)kSegWaves * 128 + std::max((size_t)2 * (n_depth - 1) * nth + (size_t)4 * gpw * n_depth, (size_t)kSegWaves * kSegMax * gpw * nth);
+}
+static bool use_segmented_raytrace(const sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, bool plain)
+{
+    static const int mode = std::getenv("SDX_RT_SEG") ? std::atoi(std::getenv("SDX_RT_SEG")) : -1;  // A/B knob: 0 never, 1 whenever possible
+    if (mode == 0 || !plain || n_theta > 64) return false;
+    if ((n_depth - 1 + kSegWaves - 1) / kSegWaves > kSegMax || seg_lds_doubles(n_depth, n_theta) * sizeof(double) > 64 * 1024) return false;
+    if (mode == 1) return true;
+    const int64_t legacy_waves = (n_nu + 64 / n_theta - 1) / (64 / n_theta);
+    return legacy_waves < (int64_t)3 * 4 * ctx->n_cu;
+}
 
 // long lists: hlist / wlist / wrank from whw_max (two small launches)
 static void launch_line_lists(sdx_ctx* ctx, int64_t n_lines, LineWork& w)
@@ -577,7 +600,7 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
         int* sel = w.hcount + 4;
         {
             LaunchScope ls(ctx, "k_classify");
-            hipLaunchKernelGGL(k_classify, dim3((unsigned)((n_lines * n_depth + 4 * kBlock - 1) / (4 * kBlock))), dim3(kBlock), 0, ctx->stream, n_depth, n_nu, n_lines,
+            hipLaunchKernelGGL(k_classify, dim3((unsigned)std::min<int64_t>((n_lines * n_depth + 4 * kBlock - 1) / (4 * kBlock), (int64_t)8 * ctx->n_cu)), dim3(kBlock), 0, ctx->stream, n_depth, n_nu, n_lines,
                                (const double*)ctx->small_ws, n_partial, doppler, gammas, gamma_cols, alphas, w.whw_max);
             launch_line_lists(ctx, n_lines, w);
             hipLaunchKernelGGL(k_shard_range, dim3(1), dim3(64), 0, ctx->stream, n_nu, nus, n_lines, line_nus, nu_begin, nu_count, sel);
@@ -588,6 +611,7 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
     const dim3 grid((unsigned)(n_line_blocks + n_pixel_blocks + w.gather), (unsigned)((n_depth + kPreDepths - 1) / kPreDepths));
     if (job) {
         ContinuumArgs ca = to_args(job->cont, nullptr);
+        if (job->ray_dist) ca.ray_dist = job->ray_dist, ca.inv_ray = (double*)ctx->rt_ws, ca.n_ray = job->n_ray;
         ca.bf_level_density = job->cont->bf_level_density;
         size_t shmem = 8;
         if (ca.bf_n_species > 0) {
@@ -654,7 +678,7 @@ static int choose_splits(int n_depth, int64_t n_nu_global, int64_t n_lines, int 
 {
     const int64_t tiles = (n_nu_global + 64 * R - 1) / (64 * R);
     const int64_t chunks = (n_lines + 63) / 64;
-    int64_t target = 2560;  // measured optimum on S-c2: 2 subsets; more planes cost the raytrace staging more than the shorter chains gain
+    int64_t target = 2560;  // S-c2: 2 subsets (4 measured the same, 8 slower: 40.4 / 40.7 / 50.1 us — the narrow role shares the workgroup size)
     if (const char* e = std::getenv("SDX_WIDE_BLOCKS")) target = std::max(1, std::atoi(e));  // tuning knob
     // at least two subsets (four for long lists): the choice must not depend on the shard (it fixes the summation order), and
     // a rank that owns 1/8 of a large grid still needs enough, small enough waves — a (tile, depth) of S-c3 is ~2e4
@@ -1304,7 +1328,7 @@ int sdx_calc_weights_dev(sdx_ctx* ctx, int64_t n, const double* tau, double* w0,
 
 static int raytrace_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, const double* nus, const double* temps,
                          const double* ray_dist, const double* wts, const double* alphas, int64_t ald, double* F, int64_t fld,
-                         double* I_nus, int accumulate, int inward, const FusedTotal* fused = nullptr);
+                         double* I_nus, int accumulate, int inward, const FusedTotal* fused = nullptr, bool inv_ray_ready = false);
 
 int sdx_raytrace_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, const double* nus, const double* temps,
                      const double* ray_dist, const double* wts, const double* alphas, int64_t ald, double* F, int64_t fld,
@@ -1328,7 +1352,7 @@ int sdx_raytrace_spherical_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_th
 
 static int raytrace_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, const double* nus, const double* temps,
                          const double* ray_dist, const double* wts, const double* alphas, int64_t ald, double* F, int64_t fld,
-                         double* I_nus, int accumulate, int inward, const FusedTotal* fused)
+                         double* I_nus, int accumulate, int inward, const FusedTotal* fused, bool inv_ray_ready)
 {
     FusedTotal ft{};
     if (fused) ft = *fused;
@@ -1363,6 +1387,28 @@ static int raytrace_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, c
         const size_t shmem = lds_bytes(gpw);
         const unsigned blocks = (unsigned)((n_nu + (int64_t)gpw * (kBlock / 64) - 1) / ((int64_t)gpw * (kBlock / 64)));
         const unsigned blocks_basic = (unsigned)((n_nu + (int64_t)(64 / G) * (kBlock / 64) - 1) / ((int64_t)(64 / G) * (kBlock / 64)));
+        // plane-parallel, one angle per lane, nothing to add to, a small grid: the gaps of a ray split over the 8 waves of a
+        // workgroup (k_raytrace_seg)
+        const int seg_gpw = 64 / nth;
+        const size_t seg_doubles = seg_lds_doubles(n_depth, nth);
+        if (use_segmented_raytrace(ctx, n_depth, n_nu, n_theta, P == 1 && !inward && !acc)) {
+            if (!inv_ray_ready) {
+                int rc = ensure(ctx, &ctx->rt_ws, &ctx->rt_ws_bytes, (size_t)(n_depth - 1) * n_theta * sizeof(double));
+                if (rc) return rc;
+            }
+            {
+                LaunchScope ls(ctx, "k_raytrace");
+                const unsigned seg_blocks = (unsigned)((n_nu + seg_gpw - 1) / seg_gpw);
+                const int n_tab = (n_depth - 1) * n_theta;  // the whole table (n_theta <= 64: one chunk)
+                if (!inv_ray_ready)
+                    hipLaunchKernelGGL(k_ray_recip, dim3((unsigned)((n_tab + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, n_tab, ray_dist, (double*)ctx->rt_ws);
+                hipLaunchKernelGGL((k_raytrace_seg<kSegWaves, kSegMax>), dim3(seg_blocks), dim3(64 * kSegWaves), seg_doubles * sizeof(double), ctx->stream,
+                                   n_depth, n_nu, nth, n_theta, nus, temps, rd, (const double*)ctx->rt_ws + th0, w, alphas, ald, F, fld, inus, seg_gpw, ft);
+            }
+            int rc = check_launch("k_raytrace_seg");
+            if (rc) return rc;
+            continue;
+        }
         {
             LaunchScope ls(ctx, "k_raytrace");
 #define SDX_RT_ARGS n_depth, n_nu, nth, n_theta, G, nus, temps, rd, w, alphas, ald, F, fld, inus, acc
@@ -1458,7 +1504,15 @@ static int synthesize_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double
     // the formal solution forms total = continuum + line planes while staging its columns when those fit LDS
     const size_t lds_columns = ((size_t)2 * (n_depth - 1) * n_theta + (size_t)4 * (4 * (size_t)n_depth + 8 * 64)) * sizeof(double);
     const bool fuse = n_theta <= 64 && lds_columns <= 64 * 1024;
-    const ContinuumJob job{cont, nu_begin, nu_count, cont_plane};
+    ContinuumJob job{cont, nu_begin, nu_count, cont_plane};
+    // the segmented formal solution wants 1 / ray_dist: the first continuum block of the pre-pass launch forms it
+    const bool seg_recip = n_lines > 0 && fuse && use_segmented_raytrace(ctx, n_depth, nu_count, n_theta, true);
+    if (seg_recip) {
+        rc2 = ensure(ctx, &ctx->rt_ws, &ctx->rt_ws_bytes, (size_t)(n_depth - 1) * n_theta * sizeof(double));
+        if (rc2) return rc2;
+        job.ray_dist = ray_dist;
+        job.n_ray = (n_depth - 1) * n_theta;
+    }
     const double* part = nullptr;
     int64_t pld = 0;
     int n_planes = 0;
@@ -1505,7 +1559,7 @@ static int synthesize_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double
     ft.total_out = total_alphas;
     ft.line_out = part ? alpha_line_out : nullptr;
     ft.out_ld = ld;
-    return raytrace_impl(ctx, n_depth, nu_count, n_theta, nus + nu_begin, temps, ray_dist, wts, nullptr, 0, F_nu, ld, nullptr, 0, 0, &ft);
+    return raytrace_impl(ctx, n_depth, nu_count, n_theta, nus + nu_begin, temps, ray_dist, wts, nullptr, 0, F_nu, ld, nullptr, 0, 0, &ft, seg_recip);
 }
 
 int sdx_synthesize_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin, int64_t nu_count,
