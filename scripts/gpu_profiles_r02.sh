@@ -1,5 +1,6 @@
 #!/bin/bash
-# round-2 rocprofv3 evidence: kernel stats + SQ / FETCH_SIZE / WRITE_SIZE passes (separate runs) for S-c2, S-c3, S-c4m
+# round-2 rocprofv3 evidence: kernel stats + SQ / FETCH_SIZE / WRITE_SIZE passes (separate runs) for S-c2, S-c3, S-c4m,
+# kernel stats of the fp32-mixed mode at S-c3 / S-c4m and of one rank of an 8-way frequency split of S-c3
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/prof_r02; mkdir -p $O
@@ -10,6 +11,9 @@ for T in S-c2 S-c3 S-c4m; do
   timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${T}_FETCH_SIZE -- python3 scripts/profile_step.py $T 3 > $O/${T}_FETCH.log 2>&1
   timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${T}_WRITE_SIZE -- python3 scripts/profile_step.py $T 3 > $O/${T}_WRITE.log 2>&1
 done
-# the mixed-precision line kernel at S-c3 (BASELINE config 5)
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/S-c5_stats -- python3 scripts/profile_step.py S-c3 5 --mixed > $O/S-c5_stats.log 2>&1
+for T in S-c3 S-c4m; do
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}mixed_stats -- python3 scripts/profile_step.py $T 5 --mixed > $O/${T}mixed_stats.log 2>&1
+  timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d $O/${T}mixed_SQ -- python3 scripts/profile_step.py $T 3 --mixed > $O/${T}mixed_SQ.log 2>&1
+done
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/S-c3shard8_stats -- python3 scripts/profile_shard.py S-c3 8 5 20 > $O/S-c3shard8_stats.log 2>&1
 find $O -name "*.csv" | wc -l

@@ -28,8 +28,10 @@ __device__ __forceinline__ void wave_sync()
 constexpr int kDnuPartials = 256;
 
 __global__ __launch_bounds__(kBlock) void k_dnu_partial(int64_t n_nu, const double* __restrict__ nus,
-                                                        double* __restrict__ partial)
+                                                        double* __restrict__ partial, int* __restrict__ zero, int64_t n_zero)
 {
+    // (culled pre-pass: the per-line maxima the classification pass accumulates into are cleared here, not by a memset node)
+    for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < n_zero; k += (int64_t)gridDim.x * kBlock) zero[k] = 0;
     double m = -INFINITY;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i + 1 < n_nu; i += (int64_t)gridDim.x * kBlock)
         m = fmax(m, nus[i + 1] - nus[i]);
@@ -800,14 +802,43 @@ __global__ __launch_bounds__(kBlock) void k_hscan(int n_depth, int64_t n_lines, 
         hscan[(size_t)d * n_lines + k] = wscan[(size_t)d * n_lines + hlist[k]];
 }
 
+// sel[0..1] = [la, lb): the lines whose centre c satisfies begin - H < c < end + H for the shard's columns [begin, end)
+// (centre_l = #{i : nus[i] >= line_nu_l}; lines ascend in frequency, so centres descend with the line index)
+__device__ __forceinline__ void shard_range(int64_t n_nu, const double* __restrict__ nus, int64_t n_lines, const double* __restrict__ line_nus,
+                                            int64_t nu_begin, int64_t nu_count, int* __restrict__ sel)
+{
+    if (threadIdx.x >= 2) return;
+    // lines with centre >= p  <=>  line_nu <= nus[p - 1]: their number is cnt_ge[p]
+    const int64_t pa = max(nu_begin - kMediumHalfWidth + 1, (int64_t)0), pb = min(nu_begin + nu_count + kMediumHalfWidth - 1, n_nu);
+    const int64_t p = threadIdx.x == 0 ? pb + 1 : pa;  // sel[0] = cnt_ge[pb + 1], sel[1] = cnt_ge[pa]
+    int64_t cnt;
+    if (p == 0) cnt = n_lines;
+    else if (p >= n_nu + 1) cnt = 0;
+    else {
+        const double v = nus[p - 1];
+        int64_t lo = 0, hi = n_lines;
+        while (lo < hi) {
+            const int64_t mid = lo + ((hi - lo) >> 1);
+            if (line_nus[mid] <= v) lo = mid + 1; else hi = mid;
+        }
+        cnt = lo;
+    }
+    sel[threadIdx.x] = (int)cnt;
+}
+
 // Frequency-sharded runs of long lists, stage A: the widest window of every line (over all depths), from the window rule
 // alone (:561-575; no centre needed for the half-width) — a streaming pass over the dense inputs that tells which lines can
 // reach any column (whw_max > kMediumHalfWidth -> hlist) before the full pre-pass runs on the lines the shard needs.
 __global__ __launch_bounds__(kBlock) void k_classify(int n_depth, int64_t n_nu, int64_t n_lines, const double* __restrict__ dnu_partial,
                                                      int n_partial, const double* __restrict__ doppler, const double* __restrict__ gammas,
-                                                     int gamma_cols, const double* __restrict__ alphas, int* __restrict__ whw_max)
+                                                     int gamma_cols, const double* __restrict__ alphas, int* __restrict__ whw_max,
+                                                     const double* __restrict__ nus, const double* __restrict__ line_nus, int64_t nu_begin,
+                                                     int64_t nu_count, int* __restrict__ sel)
 {
     __shared__ double s_red[kBlock / 64];
+    // two threads of the first block find the shard's line range on the side (two binary searches: a chain of dependent loads
+    // that a launch of its own would spend 7 us on)
+    if (blockIdx.x == 0 && sel) shard_range(n_nu, nus, n_lines, line_nus, nu_begin, nu_count, sel);
     const double d_nu = block_dnu(dnu_partial, n_partial, s_red);
     const int64_t n = n_lines * n_depth;
     const double scale = 20.0 / d_nu;
@@ -849,29 +880,6 @@ __global__ __launch_bounds__(kBlock) void k_classify(int n_depth, int64_t n_nu, 
     }
 }
 
-// sel[0..1] = [la, lb): the lines whose centre c satisfies begin - H < c < end + H for the shard's columns [begin, end)
-// (centre_l = #{i : nus[i] >= line_nu_l}; lines ascend in frequency, so centres descend with the line index)
-__global__ void k_shard_range(int64_t n_nu, const double* __restrict__ nus, int64_t n_lines, const double* __restrict__ line_nus,
-                              int64_t nu_begin, int64_t nu_count, int* __restrict__ sel)
-{
-    if (threadIdx.x >= 2) return;
-    // lines with centre >= p  <=>  line_nu <= nus[p - 1]: their number is cnt_ge[p]
-    const int64_t pa = max(nu_begin - kMediumHalfWidth + 1, (int64_t)0), pb = min(nu_begin + nu_count + kMediumHalfWidth - 1, n_nu);
-    const int64_t p = threadIdx.x == 0 ? pb + 1 : pa;  // sel[0] = cnt_ge[pb + 1], sel[1] = cnt_ge[pa]
-    int64_t cnt;
-    if (p == 0) cnt = n_lines;
-    else if (p >= n_nu + 1) cnt = 0;
-    else {
-        const double v = nus[p - 1];
-        int64_t lo = 0, hi = n_lines;
-        while (lo < hi) {
-            const int64_t mid = lo + ((hi - lo) >> 1);
-            if (line_nus[mid] <= v) lo = mid + 1; else hi = mid;
-        }
-        cnt = lo;
-    }
-    sel[threadIdx.x] = (int)cnt;
-}
 
 // Narrow windows (half-width <= kNarrowHalfWidth, e.g. the reference's 10-pixel floor for weak lines, :565-567):
 // a 256-point tile would be almost empty for them.  Here a wave owns ONE frequency and its lanes are the depth
@@ -2022,7 +2030,7 @@ __global__ __launch_bounds__(kBlock) void k_ray_recip(int n, const double* __res
 }
 
 template <int NS, int LMAX>
-__global__ __launch_bounds__(64 * NS) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_raytrace_seg(
+__global__ __launch_bounds__(64 * NS) __attribute__((amdgpu_waves_per_eu(NS >= 8 ? 6 : 4, 8))) void k_raytrace_seg(
     int n_depth, int64_t n_nu, int n_theta, int theta_stride, const double* __restrict__ nus, const double* __restrict__ temps,
     const double* __restrict__ ray_dist, const double* __restrict__ inv_ray_dist, const double* __restrict__ wts, const double* __restrict__ alphas,
     int64_t ald, double* __restrict__ F, int64_t fld, double* __restrict__ I_nus, int gpw, FusedTotal ft)

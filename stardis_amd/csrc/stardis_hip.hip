@@ -190,14 +190,14 @@ inline dim3 grid2(int64_t n, int rows) { return dim3((unsigned)((n + kBlock - 1)
 inline unsigned blocks1(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 
 // d_nu partial maxima into small_ws
-int launch_dnu(sdx_ctx* ctx, int64_t n_nu, const double* nus, int* n_partial)
+int launch_dnu(sdx_ctx* ctx, int64_t n_nu, const double* nus, int* n_partial, int* zero = nullptr, int64_t n_zero = 0)
 {
     int rc = ensure(ctx, &ctx->small_ws, &ctx->small_ws_bytes, kSmallHeader);
     if (rc) return rc;
     const int nb = (int)std::min<int64_t>(kDnuPartials, std::max<int64_t>(1, (n_nu + kBlock * 8 - 1) / (kBlock * 8)));
     {
         LaunchScope ls(ctx, "k_dnu_partial");
-        hipLaunchKernelGGL(k_dnu_partial, dim3(nb), dim3(kBlock), 0, ctx->stream, n_nu, nus, (double*)ctx->small_ws);
+        hipLaunchKernelGGL(k_dnu_partial, dim3(nb), dim3(kBlock), 0, ctx->stream, n_nu, nus, (double*)ctx->small_ws, zero, n_zero);
     }
     *n_partial = nb;
     return check_launch("k_dnu_partial");
@@ -525,7 +525,8 @@ struct ContinuumJob {  // continuum plane computed by the trailing blocks of the
 
 // The segmented formal solution (k_raytrace_seg: the gaps of a ray over the 8 waves of a workgroup) pays ~40 % more
 // instructions for eight times the waves: it wins where k_raytrace would leave the chip under three waves per SIMD.
-constexpr int kSegWaves = 8, kSegMax = 7;
+static const int kSegWaves = std::getenv("SDX_RT_NS") && std::atoi(std::getenv("SDX_RT_NS")) == 4 ? 4 : 8;  // experiment knob: 4 waves x 14 gaps
+static const int kSegMax = kSegWaves == 4 ? 14 : 7;
 static size_t seg_lds_doubles(int n_depth, int nth)
 {
     const int gpw = 64 / nth;
@@ -565,7 +566,6 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
     int rc = ensure(ctx, &ctx->small_ws, &ctx->small_ws_bytes, kSmallHeader);
     if (rc) return rc;
     const bool scan_in_block = n_nu <= 16384;  // every pre-pass block re-scans a small grid instead of a separate launch
-    if (!scan_in_block && (rc = launch_dnu(ctx, n_nu, nus, &n_partial))) return rc;
     LineWork w{};
     // 16 lines per block while all such blocks are resident at once (two 1024-thread blocks per CU), else 32
     const int pre_lines = ((n_lines + 15) / 16) * ((n_depth + kPreDepths - 1) / kPreDepths) <= 2 * (int64_t)ctx->n_cu ? 16 : 32;  // (culled runs: long lists, 32)
@@ -595,15 +595,15 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
     // change what it computes for them.
     static const bool no_cull = std::getenv("SDX_NO_CULL") != nullptr;
     const bool cull = fill_work && !no_cull && n_lines >= ctx->indexed_min_lines && !count_evals && !gen && !scan_in_block && nu_count < n_nu;
+    // the grid-spacing reduction (it also clears whw_max for the classification pass of a culled run)
+    if (!scan_in_block && (rc = launch_dnu(ctx, n_nu, nus, &n_partial, cull ? w.whw_max : nullptr, cull ? n_lines : 0))) return rc;
     if (cull) {
-        HIP_TRY(hipMemsetAsync(w.whw_max, 0, (size_t)n_lines * sizeof(int), ctx->stream));
         int* sel = w.hcount + 4;
         {
             LaunchScope ls(ctx, "k_classify");
             hipLaunchKernelGGL(k_classify, dim3((unsigned)std::min<int64_t>((n_lines * n_depth + 4 * kBlock - 1) / (4 * kBlock), (int64_t)8 * ctx->n_cu)), dim3(kBlock), 0, ctx->stream, n_depth, n_nu, n_lines,
-                               (const double*)ctx->small_ws, n_partial, doppler, gammas, gamma_cols, alphas, w.whw_max);
+                               (const double*)ctx->small_ws, n_partial, doppler, gammas, gamma_cols, alphas, w.whw_max, nus, line_nus, nu_begin, nu_count, sel);
             launch_line_lists(ctx, n_lines, w);
-            hipLaunchKernelGGL(k_shard_range, dim3(1), dim3(64), 0, ctx->stream, n_nu, nus, n_lines, line_nus, nu_begin, nu_count, sel);
         }
         w.sel = sel;
         w.gather = n_line_blocks;  // worst case: every line in hlist; blocks beyond the list's end return at once
@@ -1402,8 +1402,10 @@ static int raytrace_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, c
                 const int n_tab = (n_depth - 1) * n_theta;  // the whole table (n_theta <= 64: one chunk)
                 if (!inv_ray_ready)
                     hipLaunchKernelGGL(k_ray_recip, dim3((unsigned)((n_tab + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, n_tab, ray_dist, (double*)ctx->rt_ws);
-                hipLaunchKernelGGL((k_raytrace_seg<kSegWaves, kSegMax>), dim3(seg_blocks), dim3(64 * kSegWaves), seg_doubles * sizeof(double), ctx->stream,
-                                   n_depth, n_nu, nth, n_theta, nus, temps, rd, (const double*)ctx->rt_ws + th0, w, alphas, ald, F, fld, inus, seg_gpw, ft);
+#define SDX_SEG_ARGS n_depth, n_nu, nth, n_theta, nus, temps, rd, (const double*)ctx->rt_ws + th0, w, alphas, ald, F, fld, inus, seg_gpw, ft
+                if (kSegWaves == 4) hipLaunchKernelGGL((k_raytrace_seg<4, 14>), dim3(seg_blocks), dim3(256), seg_doubles * sizeof(double), ctx->stream, SDX_SEG_ARGS);
+                else hipLaunchKernelGGL((k_raytrace_seg<8, 7>), dim3(seg_blocks), dim3(512), seg_doubles * sizeof(double), ctx->stream, SDX_SEG_ARGS);
+#undef SDX_SEG_ARGS
             }
             int rc = check_launch("k_raytrace_seg");
             if (rc) return rc;
