@@ -14,7 +14,7 @@ for d in sorted(os.listdir(src)):
     pattern, name = ("*kernel_stats.csv", f"{rnd}_{tag}_kernel_stats.csv") if kind == "stats" else ("*counter_collection.csv", f"{rnd}_{tag}_pmc_{kind}.csv")
     files = glob.glob(os.path.join(path, "*", pattern))
     if files:
-        shutil.copy(files[0], os.path.join(root, "profiles", name))
+        shutil.copy(max(files, key=os.path.getmtime), os.path.join(root, "profiles", name))
         n += 1
         print(name)
 print(n, "files")

@@ -125,6 +125,9 @@ constexpr int kPreDepths = 64;
 constexpr int kPreBlock = 1024;  // threads per pre-pass block: one (line, depth) item per thread, 16 waves to hide latency
 
 constexpr int kNarrowHalfWidth = 64;    // windows with half-width <= this go to the narrow-window kernel
+constexpr int kNarrowReach = 128;       // ... which looks for its lines within this many points of a frequency: line CORES up to this
+                                        // half-width are delegated to it (lane <-> depth: one Faddeeva region per wave, where a
+                                        // 64-point block of the wide role holds all four)
 constexpr int kMediumHalfWidth = 4096;  // class bound of the indexed wide path: medium lines are found by centre range
 
 // What the pre-pass leaves for the line kernels.  WIDE (line, depth) items (half-width > kNarrowHalfWidth) are depth-major
@@ -211,8 +214,8 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
             if (by == 0 && w.cnt_ge) {
                 const int64_t pidx = (int64_t)(bx - n_line_blocks) * blockDim.x + threadIdx.x;
                 // a shard only reads cnt_ge within kMediumHalfWidth (+ a narrow window) of its columns
-                const bool needed = !w.sel || (pidx >= w.shard_begin - kMediumHalfWidth - 2 * kNarrowHalfWidth &&
-                                               pidx <= w.shard_end + kMediumHalfWidth + 2 * kNarrowHalfWidth);
+                const bool needed = !w.sel || (pidx >= w.shard_begin - kMediumHalfWidth - 2 * kNarrowReach &&
+                                               pidx <= w.shard_end + kMediumHalfWidth + 2 * kNarrowReach);
                 if (pidx <= n_nu + 1 && needed) {
                     int64_t cnt;
                     if (pidx == 0) cnt = n_lines;
@@ -391,7 +394,7 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
                 // sit in the same Faddeeva regions at one frequency, where a 64-point tile holds a few core points of one
                 // depth): the narrow arrays below get [clo, chi) as this item's window and the wide role leaves those points out.
                 core_lo = sc.clo, core_hi = sc.chi;
-                delegated = chw > 0 && chw <= kNarrowHalfWidth && sc.chi > sc.clo;
+                delegated = chw > 0 && chw <= kNarrowReach && sc.chi > sc.clo;
                 if (delegated) {
                     atomicMax(&s_hwmax[ll], (int)chw);
                     sc.clo = -sc.clo - 1;  // the sign marks the delegation
@@ -901,8 +904,8 @@ __device__ __forceinline__ void line_narrow_wave(const int64_t i, const int dept
     const unsigned dcu = (unsigned)dc;
     const int ii = (int)i;
     // lines with centre c in [i - H + 1, i + H]
-    const int64_t pa = max(i - kNarrowHalfWidth + 1, (int64_t)0);
-    const int64_t pb = min(i + kNarrowHalfWidth, n_nu);
+    const int64_t pa = max(i - kNarrowReach + 1, (int64_t)0);
+    const int64_t pb = min(i + kNarrowReach, n_nu);
     const int la = __builtin_amdgcn_readfirstlane(w.cnt_ge[pb + 1]);
     const int lb = __builtin_amdgcn_readfirstlane(w.cnt_ge[pa]);
     const double nu_i = nus[i];
@@ -959,8 +962,8 @@ __device__ __forceinline__ void line_narrow_wave32(const int64_t i, const int de
     const bool valid = d < n_depth;
     const int dc = valid ? d : n_depth - 1;
     const int ii = (int)i;
-    const int64_t pa = max(i - kNarrowHalfWidth + 1, (int64_t)0);
-    const int64_t pb = min(i + kNarrowHalfWidth, n_nu);
+    const int64_t pa = max(i - kNarrowReach + 1, (int64_t)0);
+    const int64_t pb = min(i + kNarrowReach, n_nu);
     const int la = __builtin_amdgcn_readfirstlane(w.cnt_ge[pb + 1]);
     const int lb = __builtin_amdgcn_readfirstlane(w.cnt_ge[pa]);
     const double nu_i = nus[i];
@@ -1015,7 +1018,7 @@ __device__ __forceinline__ void line_all_body(int n_wide, int tiles, int n_split
 {
     extern __shared__ double s_wide[];  // n_split x kWideLdsDoubles
     const int b = blockIdx.x;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform, which the compiler cannot see: chunk and frequency indices stay scalar
     if (b < n_wide) {
         if (!(roles & 1)) return;
         // XCD-aware tile order: workgroup i runs on XCD i % 8, each with its own L2.  Within a depth the workgroups of one XCD
@@ -1668,8 +1671,9 @@ __global__ __launch_bounds__(kPreBlock) __attribute__((amdgpu_num_sgpr(80))) voi
                            gammas, gamma_cols, alphas, w, nullptr, nullptr, n_line_blocks, lp);
     } else {
         const int c = b - n_pre;
-        if (c == 0 && ca.inv_ray)
-            for (int k = threadIdx.x; k < ca.n_ray; k += blockDim.x) ca.inv_ray[k] = 1.0 / ca.ray_dist[k];
+        if (ca.inv_ray)  // one table entry per thread of the first few continuum blocks
+            for (int k = c * (int)blockDim.x + (int)threadIdx.x; k < ca.n_ray; k += ((int)gridDim.x - n_pre) * (int)blockDim.x)
+                ca.inv_ray[k] = 1.0 / ca.ray_dist[k];
         if (stage_table & 2)  // bit 1: depth-group blocks (the per-depth factors of a group fit LDS); bits 4..7: depths per block
             continuum_tile_block(c % cont_tiles, c / cont_tiles, (stage_table >> 4) & 15, n_depth, nu_begin, nu_count, nus, ca, cont_plane, cont_ld,
                                  (stage_table & 1) != 0);
@@ -1836,7 +1840,7 @@ __global__ __launch_bounds__(kBlock) void k_raytrace(int n_depth, int64_t n_nu, 
 {
     constexpr int kBatch = P == 1 ? 8 : (P == 2 ? 4 : 2);
     extern __shared__ double smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // gpw = groups (frequencies) per wave, <= 64 / G; the host lowers it when the LDS columns would not fit
     const int grp = lane / G, g = lane - grp * G;
     const int TH = P * G;  // theta slots per group, ascending theta = k*G + g
@@ -2030,16 +2034,24 @@ __global__ __launch_bounds__(kBlock) void k_ray_recip(int n, const double* __res
 }
 
 template <int NS, int LMAX>
-__global__ __launch_bounds__(64 * NS) __attribute__((amdgpu_waves_per_eu(NS >= 8 ? 6 : 4, 8))) void k_raytrace_seg(
+__global__ __launch_bounds__(64 * NS) __attribute__((amdgpu_waves_per_eu(NS >= 8 ? 7 : 4, 8))) void k_raytrace_seg(
     int n_depth, int64_t n_nu, int n_theta, int theta_stride, const double* __restrict__ nus, const double* __restrict__ temps,
     const double* __restrict__ ray_dist, const double* __restrict__ inv_ray_dist, const double* __restrict__ wts, const double* __restrict__ alphas,
     int64_t ald, double* __restrict__ F, int64_t fld, double* __restrict__ I_nus, int gpw, FusedTotal ft)
 {
     extern __shared__ double smem[];
-    const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int seg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: gap indices and their branches stay scalar
     const int G = n_theta;
     const int grp = lane / G, g = lane - grp * G;
-    const int64_t i0 = (int64_t)blockIdx.x * gpw;
+    // XCD-aware order: a workgroup reads and writes only gpw (= 3) adjacent columns of every plane row, less than half a 64-byte
+    // sector — the workgroups that share a sector must share an L2, or every XCD fetches and writes back its own copy of it
+    // (measured: 30 MB fetched, 13 MB written for 10 + 7 MB).  Workgroups b, b + 8, ... run on one XCD: they take one
+    // contiguous eighth of the frequencies (the work per frequency is uniform here).
+    const int64_t n_wg = (n_nu + gpw - 1) / gpw, per_xcd = (n_wg + 7) / 8;
+    const int64_t wg = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if ((int64_t)(blockIdx.x >> 3) >= per_xcd || wg >= n_wg) return;  // (the whole workgroup: no barrier is left waiting)
+    const int64_t i0 = wg * gpw;
     const int64_t i = i0 + grp;
     const bool active = grp < gpw;
     const bool valid = active && i < n_nu;
@@ -2053,45 +2065,52 @@ __global__ __launch_bounds__(64 * NS) __attribute__((amdgpu_waves_per_eu(NS >= 8
     double* sX = sIM + gpw * col;              // log(alpha)
     double* sFx = sRD;                         // after the barrier of step 2: flux terms [NS][LMAX][gpw][G]
 
-    for (int k = threadIdx.x; k < n_gap * n_theta; k += 64 * NS) {
-        const int gp = k / n_theta, t = k - gp * n_theta;
-        sRD[k] = ray_dist[(size_t)gp * theta_stride + t];
-        sIRD[k] = inv_ray_dist[(size_t)gp * theta_stride + t];
+    // staging without a division per item: the ray table is copied linearly when its rows are dense; a wave takes one
+    // frequency's column (lane <-> depth) — waves 0 .. gpw-1 log(alpha), the next gpw the Planck source
+    if (theta_stride == n_theta) {
+        for (int k = threadIdx.x; k < n_gap * n_theta; k += 64 * NS) sRD[k] = ray_dist[k], sIRD[k] = inv_ray_dist[k];
+    } else {
+        for (int k = threadIdx.x; k < n_gap * n_theta; k += 64 * NS) {
+            const int gp = k / n_theta, t = k - gp * n_theta;
+            sRD[k] = ray_dist[(size_t)gp * theta_stride + t];
+            sIRD[k] = inv_ray_dist[(size_t)gp * theta_stride + t];
+        }
     }
-    // the columns of the workgroup's frequencies: log(alpha) by the first gpw * n_depth threads, the Planck source by the next
-    for (int k = threadIdx.x; k < 2 * gpw * n_depth; k += 64 * NS) {
-        const bool source = k >= gpw * n_depth;
-        const int kk = source ? k - gpw * n_depth : k;
-        const int gq = kk / n_depth, d = kk - gq * n_depth;
+    for (int part = seg; part < 2 * gpw; part += NS) {
+        const bool source = part >= gpw;
+        const int gq = source ? part - gpw : part;
         const int64_t iq = i0 + gq;
         const bool vq = iq < n_nu;
         const int64_t ic = vq ? iq : n_nu - 1;
         if (source) {
-            sS[gq * col + d] = planck(nus[ic], temps[d]);
+            const double nu = nus[ic];
+            for (int d = lane; d < n_depth; d += 64) sS[gq * col + d] = planck(nu, temps[d]);
             continue;
         }
-        double a;
-        if (ft.cont) {
-            a = ft.cont[(size_t)d * ft.cld + ic];
-            if (ft.planes) {
-                double line = ft.planes[(size_t)d * ft.pld + ic];
-                for (int sp = 1; sp < ft.n_planes; ++sp) line = add_rn(line, ft.planes[((size_t)sp * n_depth + d) * ft.pld + ic]);
-                a = add_rn(a, line);
-                if (vq && ft.line_out) ft.line_out[(size_t)d * ft.out_ld + iq] = line;
+        for (int d = lane; d < n_depth; d += 64) {
+            double a;
+            if (ft.cont) {
+                a = ft.cont[(size_t)d * ft.cld + ic];
+                if (ft.planes) {
+                    double line = ft.planes[(size_t)d * ft.pld + ic];
+                    for (int sp = 1; sp < ft.n_planes; ++sp) line = add_rn(line, ft.planes[((size_t)sp * n_depth + d) * ft.pld + ic]);
+                    a = add_rn(a, line);
+                    if (vq && ft.line_out) ft.line_out[(size_t)d * ft.out_ld + iq] = line;
+                }
+                if (vq && ft.total_out) ft.total_out[(size_t)d * ft.out_ld + iq] = a;
+            } else {
+                a = alphas[(size_t)d * ald + ic];
             }
-            if (vq && ft.total_out) ft.total_out[(size_t)d * ft.out_ld + iq] = a;
-        } else {
-            a = alphas[(size_t)d * ald + ic];
+            sX[gq * col + d] = log(a);
         }
-        sX[gq * col + d] = log(a);
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < gpw * n_gap; k += 64 * NS) {
-        const int gq = k / n_gap, gp = k - gq * n_gap;
-        const double m = exp(mul_rn(add_rn(sX[gq * col + gp + 1], sX[gq * col + gp]), 0.5));
-        sM[gq * col + gp] = m;
-        sIM[gq * col + gp] = 1.0 / m;
-    }
+    for (int gq = seg; gq < gpw; gq += NS)
+        for (int gp = lane; gp < n_gap; gp += 64) {
+            const double m = exp(mul_rn(add_rn(sX[gq * col + gp + 1], sX[gq * col + gp]), 0.5));
+            sM[gq * col + gp] = m;
+            sIM[gq * col + gp] = 1.0 / m;
+        }
     __syncthreads();
 
     // step 1: the coefficients of this wave's gaps [g_lo, g_lo + count)
@@ -2149,15 +2168,20 @@ __global__ __launch_bounds__(64 * NS) __attribute__((amdgpu_waves_per_eu(NS >= 8
         if (valid && g == 0 && F) F[i] = 0.0;
     }
     // step 3: replay, flux terms to LDS (the staging arrays are dead since the barrier)
-    double* fx = sFx + (size_t)seg * LMAX * gpw * G;
+    double* fx = sFx + (size_t)seg * LMAX * gpw * G + (active ? grp * G + g : 0);
+    // (one pointer stepped per gap: left as an index expression, the 64-bit address of the optional intensity output is
+    // formed for every gap whether or not it is requested — ten instructions next to one FMA)
+    double* ip = valid && I_nus ? I_nus + ((size_t)(g_lo + 1) * n_nu + i) * theta_stride + th : nullptr;
+    const size_t istep = (size_t)n_nu * theta_stride;
 #pragma unroll
     for (int j = 0; j < LMAX; ++j) {
         if (j < count) {
             inten = fma(c[j], inten, e[j]);
-            if (valid && I_nus) I_nus[((size_t)(g_lo + j + 1) * n_nu + i) * theta_stride + th] = inten;
-            if (active) fx[(j * gpw + grp) * G + g] = inten * wt;
+            if (ip) *ip = inten, ip += istep;
+            if (active) fx[j * gpw * G] = inten * wt;
         }
     }
+    fx = sFx + (size_t)seg * LMAX * gpw * G;
     wave_sync();
     if (F) {
         const int half = (n_theta + 1) >> 1;

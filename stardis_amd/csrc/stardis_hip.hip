@@ -1398,7 +1398,7 @@ static int raytrace_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, c
             }
             {
                 LaunchScope ls(ctx, "k_raytrace");
-                const unsigned seg_blocks = (unsigned)((n_nu + seg_gpw - 1) / seg_gpw);
+                const unsigned seg_blocks = (unsigned)(((n_nu + seg_gpw - 1) / seg_gpw + 7) / 8 * 8);  // whole rounds of the XCD-aware order
                 const int n_tab = (n_depth - 1) * n_theta;  // the whole table (n_theta <= 64: one chunk)
                 if (!inv_ray_ready)
                     hipLaunchKernelGGL(k_ray_recip, dim3((unsigned)((n_tab + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, n_tab, ray_dist, (double*)ctx->rt_ws);
@@ -1508,7 +1508,8 @@ static int synthesize_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double
     const bool fuse = n_theta <= 64 && lds_columns <= 64 * 1024;
     ContinuumJob job{cont, nu_begin, nu_count, cont_plane};
     // the segmented formal solution wants 1 / ray_dist: the first continuum block of the pre-pass launch forms it
-    const bool seg_recip = n_lines > 0 && fuse && use_segmented_raytrace(ctx, n_depth, nu_count, n_theta, true);
+    static const bool recip_kernel = std::getenv("SDX_RT_RECIP_KERNEL") != nullptr;  // A/B knob: a launch of its own instead
+    const bool seg_recip = !recip_kernel && n_lines > 0 && fuse && use_segmented_raytrace(ctx, n_depth, nu_count, n_theta, true);
     if (seg_recip) {
         rc2 = ensure(ctx, &ctx->rt_ws, &ctx->rt_ws_bytes, (size_t)(n_depth - 1) * n_theta * sizeof(double));
         if (rc2) return rc2;

@@ -325,8 +325,10 @@ def raytrace_arrays(tracing_nus, temperatures, ray_distances, theta_weights, tot
     if want_flux:
         d_F = ctx.zeros((t.size, nus.size)) if F_nu is None else ctx.upload(_host(F_nu))
     d_I = ctx.empty((t.size, nus.size, n_theta)) if track else None
+    # accumulate only into a flux the caller handed over (base.py:336 adds to F_nu); a fresh one is written — the entry point
+    # then picks its kernel freely (the segmented formal solution needs nothing to add to)
     args = (t.size, nus.size, n_theta, d[0].ptr, d[1].ptr, d[2].ptr, d[3].ptr, ptr_of(d_alpha), nus.size, ptr_of(d_F), nus.size,
-            ptr_of(d_I), 1)
+            ptr_of(d_I), 0 if F_nu is None else 1)
     if inward_rays:
         ctx.call("sdx_raytrace_spherical_dev", *args, float(photospheric_correction))
     else:

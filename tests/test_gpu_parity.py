@@ -234,6 +234,32 @@ def test_raytrace_many_angles_chunks(ctx):
     assert rel_err(F, ref) < FLUX_RTOL
 
 
+@pytest.mark.parametrize("n_depth,n_theta,n_nu", [(2, 3, 5), (3, 1, 70), (9, 7, 33), (30, 20, 200), (57, 20, 100), (57, 64, 9),
+                                                  (58, 20, 50), (12, 33, 17), (56, 20, 3000)])
+def test_raytrace_fresh_flux_shapes(ctx, n_depth, n_theta, n_nu):
+    """A flux that is written, not added to, on grids of every shape: small plane-parallel grids take the segmented formal
+    solution (the gaps of a ray over the 8 waves of a workgroup: segments of 1..7 gaps, idle trailing waves, angle counts
+    that do not divide 64, one frequency in the last workgroup), the rest the one-wave-per-ray kernel — both against the oracle,
+    intensities included (radiation_field_solvers/base.py:85-268)."""
+    rng = np.random.default_rng(100 * n_depth + n_theta)
+    temps = np.linspace(3900.0, 9500.0, n_depth)
+    dist = rng.uniform(2e5, 4e6, n_depth - 1)
+    nus = np.linspace(6.5e14, 4.2e14, n_nu)
+    alphas = 10.0 ** rng.uniform(-9.5, -4.5, (n_depth, n_nu)) * np.linspace(0.05, 30.0, n_depth).reshape(-1, 1)
+    if n_nu > 4:
+        alphas[:, 3] = 0.0  # a transparent column (:203-206)
+    th, w = synth.thetas_and_weights(n_theta)
+    rd = dist.reshape(-1, 1) / np.cos(th)
+    F, I = ops.raytrace_arrays(nus, temps, rd, w, alphas, track=True)
+    ref, Iref = oracle.raytrace(nus, temps, dist, th, w, alphas, track=True)
+    # random columns are far rougher than an atmosphere: where the intensity passes through ~1e-6 of its scale the
+    # reference's own formulas lose six digits (both kernels and the oracle differ there by the same 1e-9), so the error is
+    # measured against the scale of the ray / column
+    assert np.max(np.abs(I - Iref) / np.maximum(np.abs(Iref).max(axis=0, keepdims=True), 1e-300)) < FLUX_RTOL
+    assert np.max(np.abs(F - ref) / np.maximum(np.abs(ref).max(axis=0, keepdims=True), 1e-300)) < FLUX_RTOL
+    assert np.all(F[0] == 0)
+
+
 # ------------------------------------------------------------------------------------------------ post-processing
 def test_rotation_broadening_golden(ctx):
     """reference rotation_broadening (broadening.py:824-877) incl. scipy's reflect boundary and summation order"""
