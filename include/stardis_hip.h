@@ -58,14 +58,17 @@ int sdx_synchronize(sdx_ctx* ctx);
  *   "indexed_min_lines" (default 8192): line lists at least this long are not scanned completely by every tile of the wide
  *       role: lines whose widest window exceeds 4096 grid points are listed once and visited by every tile, all others are
  *       found by centre range (the list is sorted); frequency shards of such lists also run a culled pre-pass.
- *   "mixed_precision" (default 0): 1 selects the fp32-mixed TOLERANCE path (BASELINE config 5).  Far-wing evaluations —
- *       grid tiles wholly inside a line's window and wholly in Faddeeva region I — compute the rational
- *       y (q + y^2 + 1/2) / ((q - y^2 - 1/2)^2 + 4 q y^2) in fp32: x = (nu_i - nu_l) / doppler from hi + lo fp32 splits of
- *       both frequencies (relative error ~1e-7 whatever their distance), fp32 constants per (line, depth) written by the
- *       pre-pass, v_rcp_f32, and an fp32 running sum flushed into the fp64 sum every 64 terms.  Window edges, line cores
- *       (regions II-IV), the narrow windows, the continuum and the formal solution stay fp64.  Stated tolerance: 1e-4
- *       relative on the emergent flux (measured ~1e-6 on the line opacity; tests/test_gpu_configs.py).  fp64 remains the
- *       default and the parity path. */
+ *   "mixed_precision" (default 0): 1 selects the fp32-mixed TOLERANCE path (BASELINE config 5).  Wide windows: far-wing
+ *       evaluations — grid tiles wholly inside a line's window and wholly in Faddeeva region I, and window edges — compute
+ *       the rational y (q + y^2 + 1/2) / ((q - y^2 - 1/2)^2 + 4 q y^2) in packed fp32, two grid points per instruction:
+ *       x = (nu_i - nu_l) / doppler from hi + lo fp32 splits of both frequencies (relative error ~1e-7 whatever their
+ *       distance), fp32 constants per (line, depth) written by the pre-pass, v_rcp_f32, fp32 running sums flushed into the
+ *       fp64 sums every >= 48 terms.  Narrow windows (half-width <= 64 grid points) and the line cores delegated to them:
+ *       all four Humlicek regions in fp32 with packed complex arithmetic and the hardware exp / cos
+ *       (sdx_voigt_term_f32_dev exposes that routine).  Line cores kept by the wide windows, the continuum and the formal
+ *       solution stay fp64.  Stated tolerance: 1e-4 relative on the emergent flux (measured: 7e-6 on the line opacity, 7e-6
+ *       of Re w per evaluation; tests/test_gpu_configs.py, tests/test_gpu_hot_faddeeva.py).  fp64 remains the default and
+ *       the parity path. */
 int sdx_set_int_option(sdx_ctx* ctx, const char* name, int64_t value);
 
 /* device memory for callers that do not bring their own (numpy-only users) */

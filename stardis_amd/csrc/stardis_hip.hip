@@ -713,7 +713,7 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
     }
     static const bool no_hscan = std::getenv("SDX_NO_HSCAN") != nullptr;  // A/B knob
     if (no_hscan) w.hscan = nullptr;
-    if (indexed && !no_hscan) {  // the huge lines' scan words in list order (the pre-pass has written them by now)
+    if (indexed && !no_hscan && !w.sel) {  // the huge lines' scan words in list order (a culled pre-pass has written them itself)
         LaunchScope ls(ctx, "k_hlist");
         hipLaunchKernelGGL(k_hscan, dim3(64, (unsigned)n_depth), dim3(kBlock), 0, ctx->stream, n_depth, n_lines, (const int*)w.hlist, (const int*)w.hcount,
                            (const WideScan*)w.wscan, w.hscan);
