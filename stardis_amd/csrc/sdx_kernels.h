@@ -1331,10 +1331,6 @@ struct ContinuumArgs {
     int rayleigh_enabled;
     const double* electron_density;
     const double* temperature;
-    // fused step only: 1 / ray_dist for the segmented formal solution, formed by the first continuum block
-    const double* ray_dist;
-    double* inv_ray;
-    int n_ray;
 };
 
 __device__ inline double alpha_bf_point(int n_depth, int d, double nu, int n_species, const int* __restrict__ offs,
@@ -1675,9 +1671,6 @@ __global__ __launch_bounds__(kPreBlock) __attribute__((amdgpu_num_sgpr(80))) voi
                            gammas, gamma_cols, alphas, w, nullptr, nullptr, n_line_blocks, lp);
     } else {
         const int c = b - n_pre;
-        if (ca.inv_ray)  // one table entry per thread of the first few continuum blocks
-            for (int k = c * (int)blockDim.x + (int)threadIdx.x; k < ca.n_ray; k += ((int)gridDim.x - n_pre) * (int)blockDim.x)
-                ca.inv_ray[k] = 1.0 / ca.ray_dist[k];
         if (stage_table & 2)  // bit 1: depth-group blocks (the per-depth factors of a group fit LDS); bits 4..7: depths per block
             continuum_tile_block(c % cont_tiles, c / cont_tiles, (stage_table >> 4) & 15, n_depth, nu_begin, nu_count, nus, ca, cont_plane, cont_ld,
                                  (stage_table & 1) != 0);
@@ -2026,21 +2019,13 @@ __global__ __launch_bounds__(kBlock) void k_raytrace(int n_depth, int64_t n_nu, 
 //   2  the segment maps meet in LDS; wave s folds the maps of the segments below it: its incoming intensity;
 //   3  it replays its gaps, I <- c I + e (one FMA each), and writes I w_theta to LDS; the flux of its own gaps is summed
 //      over theta by the wave itself, in the order of k_raytrace (two ascending halves).
-// Eight times the waves, each an eighth as long.  Staging (ray table, log alpha, Planck source, geometric means) is done once
+// Eight times the waves, each an eighth as long.  Staging (ray table and its reciprocals, log alpha, Planck source, geometric means) is done once
 // per workgroup by all its threads; the flux terms reuse that LDS after the barrier of step 2.
 // The intensity differs from k_raytrace's by the rounding of the composition (a few ulp; the tolerance is 1e-10).
-// 1 / ray_dist, once per launch (an IEEE division per table entry in every workgroup would cost the segmented kernel a
-// fifth of its instructions)
-__global__ __launch_bounds__(kBlock) void k_ray_recip(int n, const double* __restrict__ ray_dist, double* __restrict__ inv)
-{
-    const int k = blockIdx.x * kBlock + threadIdx.x;
-    if (k < n) inv[k] = 1.0 / ray_dist[k];
-}
-
 template <int NS, int LMAX>
 __global__ __launch_bounds__(64 * NS) __attribute__((amdgpu_waves_per_eu(NS >= 8 ? 7 : 4, 8))) void k_raytrace_seg(
     int n_depth, int64_t n_nu, int n_theta, int theta_stride, const double* __restrict__ nus, const double* __restrict__ temps,
-    const double* __restrict__ ray_dist, const double* __restrict__ inv_ray_dist, const double* __restrict__ wts, const double* __restrict__ alphas,
+    const double* __restrict__ ray_dist, const double* __restrict__ wts, const double* __restrict__ alphas,
     int64_t ald, double* __restrict__ F, int64_t fld, double* __restrict__ I_nus, int gpw, FusedTotal ft)
 {
     extern __shared__ double smem[];
@@ -2071,13 +2056,19 @@ __global__ __launch_bounds__(64 * NS) __attribute__((amdgpu_waves_per_eu(NS >= 8
 
     // staging without a division per item: the ray table is copied linearly when its rows are dense; a wave takes one
     // frequency's column (lane <-> depth) — waves 0 .. gpw-1 log(alpha), the next gpw the Planck source
+    // (the reciprocals by the refined hardware reciprocal — four instructions, the neighbouring double in ~1 of 1e8 cases: every
+    // workgroup forms the table again, and an IEEE division per entry was a fifth of this kernel's instructions; a table
+    // made once by another launch cost that launch more than it saved here)
     if (theta_stride == n_theta) {
-        for (int k = threadIdx.x; k < n_gap * n_theta; k += 64 * NS) sRD[k] = ray_dist[k], sIRD[k] = inv_ray_dist[k];
+        for (int k = threadIdx.x; k < n_gap * n_theta; k += 64 * NS) {
+            const double rd = ray_dist[k];
+            sRD[k] = rd, sIRD[k] = recip_guarded(rd);
+        }
     } else {
         for (int k = threadIdx.x; k < n_gap * n_theta; k += 64 * NS) {
             const int gp = k / n_theta, t = k - gp * n_theta;
-            sRD[k] = ray_dist[(size_t)gp * theta_stride + t];
-            sIRD[k] = inv_ray_dist[(size_t)gp * theta_stride + t];
+            const double rd = ray_dist[(size_t)gp * theta_stride + t];
+            sRD[k] = rd, sIRD[k] = recip_guarded(rd);
         }
     }
     for (int part = seg; part < 2 * gpw; part += NS) {

@@ -55,8 +55,6 @@ struct sdx_ctx {
     // small scratch: d_nu partials, evaluation counter, bf coefficients
     void* small_ws = nullptr;
     size_t small_ws_bytes = 0;
-    void* rt_ws = nullptr;  // 1 / ray_dist for the segmented formal solution
-    size_t rt_ws_bytes = 0;
     // partial line-opacity planes [n_split + 1][n_depth][nu_count] (last plane: narrow windows)
     void* part_ws = nullptr;
     size_t part_ws_bytes = 0;
@@ -304,7 +302,6 @@ void sdx_destroy(sdx_ctx* ctx)
     if (ctx->t1) hipEventDestroy(ctx->t1);
     if (ctx->line_ws) hipFree(ctx->line_ws);
     if (ctx->small_ws) hipFree(ctx->small_ws);
-    if (ctx->rt_ws) hipFree(ctx->rt_ws);
     if (ctx->part_ws) hipFree(ctx->part_ws);
     if (ctx->cnt_ws) hipFree(ctx->cnt_ws);
     if (ctx->io_dev) hipFree(ctx->io_dev);
@@ -519,8 +516,6 @@ struct ContinuumJob {  // continuum plane computed by the trailing blocks of the
     const sdx_continuum* cont;
     int64_t nu_begin, nu_count;
     double* plane;
-    const double* ray_dist = nullptr;  // + the reciprocals of the ray table [n_ray] into ctx->rt_ws (segmented formal solution)
-    int n_ray = 0;
 };
 
 // The segmented formal solution (k_raytrace_seg: the gaps of a ray over the 8 waves of a workgroup) pays ~40 % more
@@ -611,7 +606,6 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
     const dim3 grid((unsigned)(n_line_blocks + n_pixel_blocks + w.gather), (unsigned)((n_depth + kPreDepths - 1) / kPreDepths));
     if (job) {
         ContinuumArgs ca = to_args(job->cont, nullptr);
-        if (job->ray_dist) ca.ray_dist = job->ray_dist, ca.inv_ray = (double*)ctx->rt_ws, ca.n_ray = job->n_ray;
         ca.bf_level_density = job->cont->bf_level_density;
         size_t shmem = 8;
         if (ca.bf_n_species > 0) {
@@ -626,9 +620,11 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
         const size_t n_lev = ca.bf_n_species > 0 ? (size_t)job->cont->bf_n_levels : 0;
         const size_t tile_shmem = ((size_t)kContDepths * (n_lev + 6) + (stage_table ? 2 * (size_t)ca.n_table : 0)) * sizeof(double);
         unsigned cont_rows = (unsigned)n_depth;
-        if (tile_shmem <= 48 * 1024) {
+        static const int cont_dgs_env = std::getenv("SDX_CONT_DGS") ? std::atoi(std::getenv("SDX_CONT_DGS")) : -1;  // experiment knob: 0 = per-point blocks
+        if (tile_shmem <= 48 * 1024 && cont_dgs_env != 0) {
             // depths per block: as many as leave ~2 blocks per CU (one depth per block on small grids)
-            const int dgs = (int)std::max<int64_t>(1, std::min<int64_t>(kContDepths, ((int64_t)cont_tiles * n_depth) / (2 * (int64_t)ctx->n_cu)));
+            int dgs = (int)std::max<int64_t>(1, std::min<int64_t>(kContDepths, ((int64_t)cont_tiles * n_depth) / (2 * (int64_t)ctx->n_cu)));
+            if (cont_dgs_env > 0) dgs = std::min(cont_dgs_env, kContDepths);
             stage_table |= 2 | (dgs << 4);
             shmem = tile_shmem;
             cont_rows = (unsigned)((n_depth + dgs - 1) / dgs);
@@ -1328,7 +1324,7 @@ int sdx_calc_weights_dev(sdx_ctx* ctx, int64_t n, const double* tau, double* w0,
 
 static int raytrace_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, const double* nus, const double* temps,
                          const double* ray_dist, const double* wts, const double* alphas, int64_t ald, double* F, int64_t fld,
-                         double* I_nus, int accumulate, int inward, const FusedTotal* fused = nullptr, bool inv_ray_ready = false);
+                         double* I_nus, int accumulate, int inward, const FusedTotal* fused = nullptr);
 
 int sdx_raytrace_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, const double* nus, const double* temps,
                      const double* ray_dist, const double* wts, const double* alphas, int64_t ald, double* F, int64_t fld,
@@ -1352,7 +1348,7 @@ int sdx_raytrace_spherical_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_th
 
 static int raytrace_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, const double* nus, const double* temps,
                          const double* ray_dist, const double* wts, const double* alphas, int64_t ald, double* F, int64_t fld,
-                         double* I_nus, int accumulate, int inward, const FusedTotal* fused, bool inv_ray_ready)
+                         double* I_nus, int accumulate, int inward, const FusedTotal* fused)
 {
     FusedTotal ft{};
     if (fused) ft = *fused;
@@ -1392,17 +1388,10 @@ static int raytrace_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, c
         const int seg_gpw = 64 / nth;
         const size_t seg_doubles = seg_lds_doubles(n_depth, nth);
         if (use_segmented_raytrace(ctx, n_depth, n_nu, n_theta, P == 1 && !inward && !acc)) {
-            if (!inv_ray_ready) {
-                int rc = ensure(ctx, &ctx->rt_ws, &ctx->rt_ws_bytes, (size_t)(n_depth - 1) * n_theta * sizeof(double));
-                if (rc) return rc;
-            }
             {
                 LaunchScope ls(ctx, "k_raytrace");
                 const unsigned seg_blocks = (unsigned)(((n_nu + seg_gpw - 1) / seg_gpw + 7) / 8 * 8);  // whole rounds of the XCD-aware order
-                const int n_tab = (n_depth - 1) * n_theta;  // the whole table (n_theta <= 64: one chunk)
-                if (!inv_ray_ready)
-                    hipLaunchKernelGGL(k_ray_recip, dim3((unsigned)((n_tab + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, n_tab, ray_dist, (double*)ctx->rt_ws);
-#define SDX_SEG_ARGS n_depth, n_nu, nth, n_theta, nus, temps, rd, (const double*)ctx->rt_ws + th0, w, alphas, ald, F, fld, inus, seg_gpw, ft
+#define SDX_SEG_ARGS n_depth, n_nu, nth, n_theta, nus, temps, rd, w, alphas, ald, F, fld, inus, seg_gpw, ft
                 if (kSegWaves == 4) hipLaunchKernelGGL((k_raytrace_seg<4, 14>), dim3(seg_blocks), dim3(256), seg_doubles * sizeof(double), ctx->stream, SDX_SEG_ARGS);
                 else hipLaunchKernelGGL((k_raytrace_seg<8, 7>), dim3(seg_blocks), dim3(512), seg_doubles * sizeof(double), ctx->stream, SDX_SEG_ARGS);
 #undef SDX_SEG_ARGS
@@ -1506,16 +1495,7 @@ static int synthesize_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double
     // the formal solution forms total = continuum + line planes while staging its columns when those fit LDS
     const size_t lds_columns = ((size_t)2 * (n_depth - 1) * n_theta + (size_t)4 * (4 * (size_t)n_depth + 8 * 64)) * sizeof(double);
     const bool fuse = n_theta <= 64 && lds_columns <= 64 * 1024;
-    ContinuumJob job{cont, nu_begin, nu_count, cont_plane};
-    // the segmented formal solution wants 1 / ray_dist: the first continuum block of the pre-pass launch forms it
-    static const bool recip_kernel = std::getenv("SDX_RT_RECIP_KERNEL") != nullptr;  // A/B knob: a launch of its own instead
-    const bool seg_recip = !recip_kernel && n_lines > 0 && fuse && use_segmented_raytrace(ctx, n_depth, nu_count, n_theta, true);
-    if (seg_recip) {
-        rc2 = ensure(ctx, &ctx->rt_ws, &ctx->rt_ws_bytes, (size_t)(n_depth - 1) * n_theta * sizeof(double));
-        if (rc2) return rc2;
-        job.ray_dist = ray_dist;
-        job.n_ray = (n_depth - 1) * n_theta;
-    }
+    const ContinuumJob job{cont, nu_begin, nu_count, cont_plane};
     const double* part = nullptr;
     int64_t pld = 0;
     int n_planes = 0;
@@ -1562,7 +1542,7 @@ static int synthesize_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double
     ft.total_out = total_alphas;
     ft.line_out = part ? alpha_line_out : nullptr;
     ft.out_ld = ld;
-    return raytrace_impl(ctx, n_depth, nu_count, n_theta, nus + nu_begin, temps, ray_dist, wts, nullptr, 0, F_nu, ld, nullptr, 0, 0, &ft, seg_recip);
+    return raytrace_impl(ctx, n_depth, nu_count, n_theta, nus + nu_begin, temps, ray_dist, wts, nullptr, 0, F_nu, ld, nullptr, 0, 0, &ft);
 }
 
 int sdx_synthesize_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin, int64_t nu_count,
