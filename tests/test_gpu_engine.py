@@ -296,9 +296,10 @@ def test_deep_models_and_many_angles(ctx, n_depth, n_theta):
 
 
 def test_mixed_precision_mode_is_a_tolerance_path(ctx):
-    """BASELINE config 5's tolerance path: far-wing (region I) evaluations of whole-tile windows in fp32, frequency
-    offsets and sums in fp64.  Stated tolerance 1e-5 relative on opacity and flux (observed ~1e-7); fp64 remains the
-    default and the parity path."""
+    """BASELINE config 5's tolerance path: far-wing evaluations and window edges in packed fp32, narrow windows through the
+    fp32 Faddeeva routine (all four regions), cores kept by wide windows, continuum and formal solution in fp64.  The mode's
+    stated tolerance is 1e-4 on the flux; on this workload opacity and flux stay within 1e-5 (observed ~7e-6 / ~1e-6).
+    fp64 remains the default and the parity path."""
     atm, nus, lines, cont, th, w = small_workload(n_lines=400, step=0.005, seed=23)
     ref = oracle.calc_alan_entries(56, nus, lines["line_nus"], lines["doppler_widths"], lines["gammas"], lines["alphas"])
     syn64 = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], th, w, lines, cont, ctx=ctx)
