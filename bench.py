@@ -429,12 +429,18 @@ def timed(runner, steps, warmup, world, local, settle_s=0.5):
         runner.step()
     runner.drain()
     fence()
+    import gc
+
+    gc_was_on = gc.isenabled()
+    gc.disable()  # a collection pause between two enqueues leaves the device idle for longer than a step takes
     t0 = time.perf_counter()
     for _ in range(steps):
         runner.step()
     runner.drain()
     fence()
     elapsed = time.perf_counter() - t0
+    if gc_was_on:
+        gc.enable()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
