@@ -72,6 +72,8 @@ int sdx_synchronize(sdx_ctx* ctx);
 int sdx_set_int_option(sdx_ctx* ctx, const char* name, int64_t value);
 
 /* device memory for callers that do not bring their own (numpy-only users) */
+/* (freed blocks are kept by the context — up to 4 GiB — and handed out again: all uses are ordered on the context's stream, so the
+ * Python mirror's ~30 small uploads per drop-in call cost no hipMalloc / hipFree after the first call) */
 void* sdx_malloc(sdx_ctx* ctx, size_t bytes);
 int sdx_free(sdx_ctx* ctx, void* ptr);
 int sdx_memcpy_h2d(sdx_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes); /* async on ctx stream */
