@@ -5,14 +5,15 @@ cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/prof_r02; mkdir -p $O
 for T in S-c2 S-c3 S-c4m; do
-  N=5; G=""; if [ $T = S-c2 ]; then N=200; G="--graph"; fi
+  N=40; G="--graph"; if [ $T = S-c2 ]; then N=200; fi; if [ $T = S-c4m ]; then N=20; fi  # enough replays for warm clocks
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_stats -- python3 scripts/profile_step.py $T $N $G > $O/${T}_stats.log 2>&1
   timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d $O/${T}_SQ -- python3 scripts/profile_step.py $T 3 > $O/${T}_SQ.log 2>&1
   timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${T}_FETCH_SIZE -- python3 scripts/profile_step.py $T 3 > $O/${T}_FETCH.log 2>&1
   timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${T}_WRITE_SIZE -- python3 scripts/profile_step.py $T 3 > $O/${T}_WRITE.log 2>&1
 done
 for T in S-c3 S-c4m; do
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}mixed_stats -- python3 scripts/profile_step.py $T 5 --mixed > $O/${T}mixed_stats.log 2>&1
+  N=40; if [ $T = S-c4m ]; then N=20; fi
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}mixed_stats -- python3 scripts/profile_step.py $T $N --mixed --graph > $O/${T}mixed_stats.log 2>&1
   timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d $O/${T}mixed_SQ -- python3 scripts/profile_step.py $T 3 --mixed > $O/${T}mixed_SQ.log 2>&1
 done
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/S-c3shard8_stats -- python3 scripts/profile_shard.py S-c3 8 5 20 > $O/S-c3shard8_stats.log 2>&1
