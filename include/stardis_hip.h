@@ -30,7 +30,7 @@ extern "C" {
 #define SDX_OK 0
 #define SDX_ERR_ARG (-1)  /* bad argument: null pointer, non-monotone grid, zero Doppler width ... */
 #define SDX_ERR_HIP (-2)  /* HIP runtime error (no device, launch failure, ...) */
-#define SDX_ERR_COMM (-3) /* reserved for collective errors (the flux gather lives in torch.distributed) */
+#define SDX_ERR_COMM (-3) /* RCCL error: library not loadable, communicator set-up or the collective itself (sdx_group_*) */
 #define SDX_ERR_OOM (-4)  /* device or host allocation failed */
 #define SDX_ERR_STALE (-5) /* sdx_graph_launch: the context's scratch was reallocated after the graph was captured; capture again */
 
@@ -45,6 +45,7 @@ typedef struct sdx_ctx sdx_ctx;
 /* ---- runtime -------------------------------------------------------------------------------- */
 const char* sdx_version(void);
 const char* sdx_last_error_string(void);
+int sdx_last_error_code(void); /* the SDX_ERR_* behind the last message (for entry points that return a pointer) */
 int sdx_device_count(void); /* number of visible HIP devices, 0 when none (never an error) */
 
 /* One context per device.  stream = NULL: the context creates its own non-blocking stream;
@@ -68,7 +69,12 @@ int sdx_synchronize(sdx_ctx* ctx);
  *       (sdx_voigt_term_f32_dev exposes that routine).  Line cores kept by the wide windows, the continuum and the formal
  *       solution stay fp64.  Stated tolerance: 1e-4 relative on the emergent flux (measured: 7e-6 on the line opacity, 7e-6
  *       of Re w per evaluation; tests/test_gpu_configs.py, tests/test_gpu_hot_faddeeva.py).  fp64 remains the default and
- *       the parity path. */
+ *       the parity path.
+ *   "segmented_raytrace" (default -1): which formal-solution kernel runs.  -1: decided from the size of the GLOBAL grid against
+ *       a fixed constant (grids under 3 x 4 x 256 k_raytrace waves take the segmented kernel) — never from the shard's own
+ *       width or the device's CU count, so that a frequency shard and the unsharded grid run the same arithmetic and stay
+ *       bit-identical; 0: never the segmented kernel; 1: whenever it supports the shape.  The fp32-mixed twins (*_f32mix) that
+ *       SURVEY §8b proposed are this library's "mixed_precision" option instead: one set of entry points, two modes. */
 int sdx_set_int_option(sdx_ctx* ctx, const char* name, int64_t value);
 
 /* device memory for callers that do not bring their own (numpy-only users) */
@@ -221,6 +227,15 @@ int sdx_raytrace_spherical_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_th
                                const double* temperature, const double* ray_dist, const double* theta_weights,
                                const double* total_alphas, int64_t alpha_ld, double* F_nu, int64_t F_ld, double* I_nus,
                                int accumulate, double photospheric_correction);
+/* raytrace with the source function handed over as a plane [n_depth][source_ld] instead of the Planck function the other
+ * entry points evaluate in the kernel: RadiationField.source_function is any callable (nu, T[:, None]) -> (N_d, N_nu)
+ * (radiation_field/base.py:12-68, used at radiation_field_solvers/base.py:133); the host evaluates a foreign one and uploads
+ * the result.  source = NULL: Planck.  inward != 0: spherical geometry (as sdx_raytrace_spherical_dev, with the correction). */
+int sdx_raytrace_source_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, const double* nus,
+                            const double* temperature, const double* ray_dist, const double* theta_weights,
+                            const double* total_alphas, int64_t alpha_ld, const double* source, int64_t source_ld,
+                            double* F_nu, int64_t F_ld, double* I_nus, int accumulate, int inward,
+                            double photospheric_correction);
 int sdx_raytrace_f64(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, const double* nus,
                      const double* temperature, const double* ray_dist, const double* theta_weights,
                      const double* total_alphas, double* F_nu, double* I_nus);
@@ -291,6 +306,38 @@ int sdx_synthesize_f64(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nu
                        const sdx_continuum* cont, int n_theta, const double* temperature, const double* ray_dist,
                        const double* theta_weights, double* alpha_line_out, double* total_alphas, double* F_nu,
                        int64_t* n_evaluations);
+
+/* ---- one process, several GPUs ---------------------------------------------------
+ * The frequency axis shards with no data-path exchange: every output column depends only on its own frequency
+ * (radiation_field_solvers/base.py:200 is a prange over nu; calc_alan_entries :548-590 is a pure gather per (depth, nu)).
+ * A group is one context + one stream per device and ONE RCCL communicator over them (ncclCommInitAll).
+ * sdx_synthesize_sharded_f64 = sdx_synthesize_f64 with the columns split over the group's devices: the line list is
+ * replicated, every device applies the window rule on the GLOBAL grid (global d_nu, centres, clamp — results equal the
+ * single-GPU call bit for bit), and ONE ncclAllGather of the zero-padded F_nu[-1] shards (8 * max shard width bytes per
+ * rank, over xGMI) leaves the emergent spectrum on every device; it is returned from device 0.
+ *   devices      NULL = devices 0 .. n_gpus-1; each device at most once.
+ *   shard_begin  NULL = equal blocks of ceil(n_nu / n_gpus) columns; else [n_gpus + 1] ascending column indices from 0 to n_nu
+ *                (e.g. shards of equal estimated work).
+ *   outputs      all host, all optional except that one of F_nu / emergent_flux must be given: alpha_line_out, total_alphas,
+ *                F_nu are [n_depth][n_nu] (each device fills the columns it owns), emergent_flux [n_nu] = the gathered F_nu[-1].
+ * RCCL is opened at run time (librccl.so.1; env SDX_RCCL_LIB overrides the path); any RCCL failure returns SDX_ERR_COMM.
+ * Test hook: with SDX_GROUP_LOOPBACK=1 in the environment a group may list one device several times and the gather is done
+ * with plain device copies instead of RCCL (RCCL refuses two ranks on one GPU) — for exercising the sharding logic on a
+ * one-GPU box, never a product mode. */
+typedef struct sdx_group sdx_group;
+sdx_group* sdx_group_create(int n_gpus, const int* devices); /* NULL on error: sdx_last_error_code / _string */
+void sdx_group_destroy(sdx_group* group);
+int sdx_group_size(const sdx_group* group);
+sdx_ctx* sdx_group_context(sdx_group* group, int rank); /* the rank's context (options, profiling); owned by the group */
+/* what the last sharded call's collective was: ranks in the communicator, bytes each rank contributed, RCCL's version code
+ * (0 in loop-back mode) */
+int sdx_group_last_gather(const sdx_group* group, int* ranks, int64_t* bytes_per_rank, int* rccl_version);
+int sdx_synthesize_sharded_f64(sdx_group* group, int n_depth, int64_t n_nu, const double* nus, int64_t n_lines,
+                               const double* line_nus, const double* doppler_widths, const double* gammas, int gamma_cols,
+                               const double* alphas, const sdx_continuum* cont, int n_theta, const double* temperature,
+                               const double* ray_dist, const double* theta_weights, const int64_t* shard_begin,
+                               double* alpha_line_out, double* total_alphas, double* F_nu, double* emergent_flux,
+                               int64_t* n_evaluations);
 
 /* ---- line parameters generated on the device ---------------------------------------
  * Instead of the three dense (N_l, N_d) tables the reference builds on the host before calc_alan_entries —

@@ -81,6 +81,14 @@ class LineListStruct(C.Structure):
 PROTOTYPES = {
     "sdx_version": (C.c_char_p, []),
     "sdx_last_error_string": (C.c_char_p, []),
+    "sdx_last_error_code": (_int, []),
+    "sdx_group_create": (_vp, [_int, C.POINTER(_int)]),
+    "sdx_group_destroy": (None, [_vp]),
+    "sdx_group_size": (_int, [_vp]),
+    "sdx_group_context": (_vp, [_vp, _int]),
+    "sdx_group_last_gather": (_int, [_vp, C.POINTER(_int), C.POINTER(_i64), C.POINTER(_int)]),
+    "sdx_synthesize_sharded_f64": (_int, [_vp, _int, _i64, _vp, _i64, _vp, _vp, _vp, _int, _vp, C.POINTER(Continuum), _int, _vp, _vp, _vp, _vp,
+                                          _vp, _vp, _vp, _vp, _vp]),
     "sdx_device_count": (_int, []),
     "sdx_create": (_vp, [_int, _vp]),
     "sdx_destroy": (None, [_vp]),
@@ -126,6 +134,7 @@ PROTOTYPES = {
     "sdx_calc_weights_dev": (_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "sdx_raytrace_dev": (_int, [_vp, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _int]),
     "sdx_raytrace_spherical_dev": (_int, [_vp, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _int, C.c_double]),
+    "sdx_raytrace_source_dev": (_int, [_vp, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _int, _int, C.c_double]),
     "sdx_raytrace_f64": (_int, [_vp, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sdx_total_alphas_dev": (_int, [_vp, _int, _i64, _vp, _i64, _i64, C.POINTER(Continuum), _vp, _i64, _vp, _i64]),
     "sdx_convolve1d_reflect_dev": (_int, [_vp, _i64, _vp, _int, _vp, _int, _vp]),
@@ -170,6 +179,10 @@ class StaleGraphError(RuntimeError):
     """sdx_graph_launch refused a graph captured before the context's scratch was reallocated (SDX_ERR_STALE)."""
 
 
+class CommError(RuntimeError):
+    """An RCCL failure inside the library (SDX_ERR_COMM): library not loadable, communicator set-up, the collective."""
+
+
 def check(rc):
     if rc == 0:
         return
@@ -178,6 +191,8 @@ def check(rc):
         raise ValueError(msg)
     if rc == -4:
         raise MemoryError(msg)
+    if rc == -3:
+        raise CommError(msg)
     if rc == -5:
         raise StaleGraphError(msg)
     raise RuntimeError(f"stardis_hip error {rc}: {msg}")

@@ -1816,6 +1816,10 @@ struct FusedTotal {
     double* total_out;     // [n_depth][out_ld], optional
     double* line_out;      // optional
     int64_t out_ld;
+    // source function given by the caller as a plane [n_depth][sld] (RadiationField.source_function is any callable
+    // (nu, T) -> (N_d, N_nu), radiation_field_solvers/base.py:133); nullptr: the Planck function, evaluated here
+    const double* source;
+    int64_t sld;
 };
 
 // One short-characteristic step (:208-249 outward, :150-198 inward): from a point with intensity `inten` and source
@@ -1883,7 +1887,7 @@ __global__ __launch_bounds__(kBlock) void k_raytrace(int n_depth, int64_t n_nu, 
                 a = alphas[(size_t)d * ald + ic];
             }
             sX[grp * col + d] = log(a);
-            sS[grp * col + d] = planck(nu, temps[d]);
+            sS[grp * col + d] = ft.source ? ft.source[(size_t)d * ft.sld + ic] : planck(nu, temps[d]);
         }
     }
     __syncthreads();
@@ -2082,7 +2086,7 @@ __global__ __launch_bounds__(64 * NS) __attribute__((amdgpu_waves_per_eu(NS >= 8
         const int64_t ic = vq ? iq : n_nu - 1;
         if (source) {
             const double nu = nus[ic];
-            for (int d = lane; d < n_depth; d += 64) sS[gq * col + d] = planck(nu, temps[d]);
+            for (int d = lane; d < n_depth; d += 64) sS[gq * col + d] = ft.source ? ft.source[(size_t)d * ft.sld + ic] : planck(nu, temps[d]);
             continue;
         }
         for (int d = lane; d < n_depth; d += 64) {

@@ -8,9 +8,16 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and enums only: the library is opened at run time (RcclApi below)
+
+#include <memory>
+#include <thread>
 
 #include "../../include/stardis_hip.h"
 #include "sdx_kernels.h"
@@ -20,10 +27,12 @@ using namespace sdx;
 namespace {
 
 thread_local std::string g_error;
+thread_local int g_error_code = 0;
 
 int fail(int code, const std::string& msg)
 {
     g_error = msg;
+    g_error_code = code;
     return code;
 }
 
@@ -68,6 +77,7 @@ struct sdx_ctx {
     // tuning options (sdx_set_int_option)
     int64_t indexed_min_lines = 8192;  // line lists at least this long: wide lines found by centre range / the huge-line list instead of a full scan
     int64_t mixed_precision = 0;       // 1: fp32 rational for far-wing (region I) evaluations of whole-tile windows
+    int64_t segmented_raytrace = -1;   // -1: by the size of the GLOBAL grid; 0 never; 1 whenever the kernel supports the shape
     // timing
     hipEvent_t t0 = nullptr, t1 = nullptr;
     void* cont_ws = nullptr;  // continuum plane [n_depth][nu_count] of the fused step
@@ -81,6 +91,7 @@ struct sdx_ctx {
     size_t xfer_pin_bytes = 0;
     // sdx_malloc / sdx_free: freed blocks are kept (by capacity) and handed out again — every use is ordered on this context's
     // stream, so a block can be reused the moment it is freed; a drop-in call of the Python mirror uploads ~30 small arrays
+    std::mutex pool_mutex;  // guards the block pool and the bounce buffer (DeviceArray.__del__ may run on any thread)
     std::unordered_map<void*, size_t> live_blocks;  // handed out: pointer -> capacity
     std::multimap<size_t, void*> free_blocks;       // kept: capacity -> pointer
     size_t free_block_bytes = 0;
@@ -108,7 +119,22 @@ int ensure(sdx_ctx* ctx, void** buf, size_t* have, size_t need)
         *buf = nullptr;
         *have = 0;
     }
-    HIP_TRY(hipMalloc(buf, need));
+    hipError_t e = hipMalloc(buf, need);
+    if (e == hipErrorOutOfMemory) {  // blocks kept by sdx_free are reclaimable: release them and try once more
+        (void)hipGetLastError();
+        std::lock_guard<std::mutex> lock(ctx->pool_mutex);
+        if (!ctx->free_blocks.empty()) {
+            hipStreamSynchronize(ctx->stream);
+            for (auto& b : ctx->free_blocks) hipFree(b.second);
+            ctx->free_blocks.clear();
+            ctx->free_block_bytes = 0;
+            e = hipMalloc(buf, need);
+        }
+    }
+    if (e != hipSuccess) {
+        *buf = nullptr;
+        return fail(e == hipErrorOutOfMemory ? SDX_ERR_OOM : SDX_ERR_HIP, std::string("hipMalloc(workspace): ") + hipGetErrorString(e));
+    }
     *have = need;
     ++ctx->ws_generation;
     return SDX_OK;
@@ -261,6 +287,7 @@ extern "C" {
 
 const char* sdx_version(void) { return "stardis_hip 0.1 (gfx950, fp64)"; }
 const char* sdx_last_error_string(void) { return g_error.c_str(); }
+int sdx_last_error_code(void) { return g_error_code; }
 
 int sdx_device_count(void)
 {
@@ -352,6 +379,10 @@ int sdx_set_int_option(sdx_ctx* ctx, const char* name, int64_t value)
         ctx->mixed_precision = value ? 1 : 0;
         return SDX_OK;
     }
+    if (std::strcmp(name, "segmented_raytrace") == 0) {
+        ctx->segmented_raytrace = value < 0 ? -1 : (value ? 1 : 0);
+        return SDX_OK;
+    }
     return fail(SDX_ERR_ARG, std::string("unknown option ") + name);
 }
 
@@ -377,6 +408,7 @@ void* sdx_malloc(sdx_ctx* ctx, size_t bytes)
     if (!ctx) return nullptr;
     hipSetDevice(ctx->device);
     const size_t cap = block_capacity(bytes);
+    std::lock_guard<std::mutex> lock(ctx->pool_mutex);
     auto it = ctx->free_blocks.lower_bound(cap);
     if (it != ctx->free_blocks.end() && it->first <= 2 * cap) {  // a kept block of (nearly) this size
         void* p = it->second;
@@ -406,8 +438,13 @@ int sdx_free(sdx_ctx* ctx, void* ptr)
 {
     REQUIRE(ctx, "null context");
     if (!ptr) return SDX_OK;
-    auto it = ctx->live_blocks.find(ptr);
-    if (it != ctx->live_blocks.end()) {
+    {
+        std::lock_guard<std::mutex> lock(ctx->pool_mutex);
+        auto it = ctx->live_blocks.find(ptr);
+        if (it == ctx->live_blocks.end()) {
+            // not handed out by sdx_malloc of this context (or freed already: the block may be pooled or reused by now)
+            return fail(SDX_ERR_ARG, "sdx_free: pointer is not a live block of this context (double free?)");
+        }
         const size_t cap = it->second;
         ctx->live_blocks.erase(it);
         if (ctx->free_block_bytes + cap <= kBlockPoolLimit) {
@@ -448,6 +485,7 @@ int sdx_memcpy_h2d(sdx_ctx* ctx, void* dst, const void* src, size_t bytes)
         HIP_TRY(hipStreamSynchronize(ctx->stream));  // pageable source: safe to reuse on return
         return SDX_OK;
     }
+    std::lock_guard<std::mutex> lock(ctx->pool_mutex);  // one bounce buffer per context
     int rc = xfer_buffer(ctx, bytes);
     if (rc) return rc;
     for (size_t off = 0; off < bytes; off += ctx->xfer_pin_bytes) {
@@ -469,6 +507,7 @@ int sdx_memcpy_d2h(sdx_ctx* ctx, void* dst, const void* src, size_t bytes)
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         return SDX_OK;
     }
+    std::lock_guard<std::mutex> lock(ctx->pool_mutex);
     int rc = xfer_buffer(ctx, bytes);
     if (rc) return rc;
     for (size_t off = 0; off < bytes; off += ctx->xfer_pin_bytes) {
@@ -617,14 +656,20 @@ static size_t seg_lds_doubles(int n_depth, int nth)
     const int gpw = 64 / nth;
     return (size_t)kSegWaves * 128 + std::max((size_t)2 * (n_depth - 1) * nth + (size_t)4 * gpw * n_depth, (size_t)kSegWaves * kSegMax * gpw * nth);
 }
-static bool use_segmented_raytrace(const sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, bool plain)
+// Which kernel runs must not depend on how the grid is sharded or on the device (the two differ by the rounding of the affine
+// composition, a few ulp: a shard below the threshold next to an unsharded run above it would break the bit-identity of
+// sharded and unsharded spectra): the choice is made from the GLOBAL grid size against a fixed constant — three k_raytrace
+// waves per SIMD of a 256-CU part — or set explicitly (context option "segmented_raytrace").
+constexpr int64_t kSegLegacyWaves = (int64_t)3 * 4 * 256;
+static bool use_segmented_raytrace(const sdx_ctx* ctx, int n_depth, int64_t n_nu_global, int n_theta, bool plain)
 {
-    static const int mode = std::getenv("SDX_RT_SEG") ? std::atoi(std::getenv("SDX_RT_SEG")) : -1;  // A/B knob: 0 never, 1 whenever possible
+    static const int env_mode = std::getenv("SDX_RT_SEG") ? std::atoi(std::getenv("SDX_RT_SEG")) : -1;  // A/B knob: 0 never, 1 whenever possible
+    const int mode = ctx->segmented_raytrace >= 0 ? (int)ctx->segmented_raytrace : env_mode;
     if (mode == 0 || !plain || n_theta > 64) return false;
     if ((n_depth - 1 + kSegWaves - 1) / kSegWaves > kSegMax || seg_lds_doubles(n_depth, n_theta) * sizeof(double) > 64 * 1024) return false;
     if (mode == 1) return true;
-    const int64_t legacy_waves = (n_nu + 64 / n_theta - 1) / (64 / n_theta);
-    return legacy_waves < (int64_t)3 * 4 * ctx->n_cu;
+    const int64_t legacy_waves = (n_nu_global + 64 / n_theta - 1) / (64 / n_theta);
+    return legacy_waves < kSegLegacyWaves;
 }
 
 // long lists: hlist / wlist / wrank from whw_max (two small launches)
@@ -989,9 +1034,22 @@ struct HostIo {
     struct Pending {
         void* dst;
         const void* src_pin;
-        size_t bytes;
+        size_t bytes;      // bytes per row
+        size_t rows = 1;   // rows of `bytes`, packed in the pinned buffer, dst_pitch apart in the destination
+        size_t dst_pitch = 0;
     };
     std::vector<Pending> pending;
+    bool finished = false;
+
+    explicit HostIo(sdx_ctx* c) : ctx(c) {}
+    HostIo(const HostIo&) = delete;
+    HostIo& operator=(const HostIo&) = delete;
+    // error exits return before finish(): DMAs out of / into the context's pinned buffer may still be in flight, and the next
+    // call would memcpy new data over them
+    ~HostIo()
+    {
+        if (!finished) hipStreamSynchronize(ctx->stream);
+    }
 
     static size_t pad(size_t b) { return (b + 255) & ~(size_t)255; }
 
@@ -1048,16 +1106,33 @@ struct HostIo {
             void* h = (char*)ctx->io_pin + pin_off;
             pin_off += pad(bytes);
             HIP_TRY(hipMemcpyAsync(h, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
-            pending.push_back({dst, h, bytes});
+            pending.push_back({dst, h, bytes, 1, 0});
         } else {
             HIP_TRY(hipMemcpyAsync(dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        return SDX_OK;
+    }
+    // rows x row_bytes, contiguous on the device, into a host array whose rows are dst_pitch bytes apart
+    int download2d(void* dst, size_t dst_pitch, const void* dev_src, size_t row_bytes, size_t rows)
+    {
+        if (dst_pitch == row_bytes || rows <= 1) return download(dst, dev_src, row_bytes * rows);
+        if (!row_bytes) return SDX_OK;
+        if (pinned) {
+            void* h = (char*)ctx->io_pin + pin_off;
+            pin_off += pad(row_bytes * rows);
+            HIP_TRY(hipMemcpyAsync(h, dev_src, row_bytes * rows, hipMemcpyDeviceToHost, ctx->stream));
+            pending.push_back({dst, h, row_bytes, rows, dst_pitch});
+        } else {
+            HIP_TRY(hipMemcpy2DAsync(dst, dst_pitch, dev_src, row_bytes, row_bytes, rows, hipMemcpyDeviceToHost, ctx->stream));
         }
         return SDX_OK;
     }
     int finish()
     {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
-        for (auto& p : pending) std::memcpy(p.dst, p.src_pin, p.bytes);
+        finished = true;
+        for (auto& p : pending)
+            for (size_t r = 0; r < p.rows; ++r) std::memcpy((char*)p.dst + r * p.dst_pitch, (const char*)p.src_pin + r * p.bytes, p.bytes);
         pending.clear();
         return SDX_OK;
     }
@@ -1414,13 +1489,32 @@ int sdx_calc_weights_dev(sdx_ctx* ctx, int64_t n, const double* tau, double* w0,
 
 static int raytrace_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, const double* nus, const double* temps,
                          const double* ray_dist, const double* wts, const double* alphas, int64_t ald, double* F, int64_t fld,
-                         double* I_nus, int accumulate, int inward, const FusedTotal* fused = nullptr);
+                         double* I_nus, int accumulate, int inward, const FusedTotal* fused = nullptr, int64_t nu_global = -1);
 
 int sdx_raytrace_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, const double* nus, const double* temps,
                      const double* ray_dist, const double* wts, const double* alphas, int64_t ald, double* F, int64_t fld,
                      double* I_nus, int accumulate)
 {
     return raytrace_impl(ctx, n_depth, n_nu, n_theta, nus, temps, ray_dist, wts, alphas, ald, F, fld, I_nus, accumulate, 0);
+}
+
+int sdx_raytrace_source_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, const double* nus, const double* temps,
+                            const double* ray_dist, const double* wts, const double* alphas, int64_t ald, const double* source,
+                            int64_t source_ld, double* F, int64_t fld, double* I_nus, int accumulate, int inward,
+                            double photospheric_correction)
+{
+    REQUIRE(ctx && (n_nu == 0 || !source || source_ld >= n_nu), "raytrace: bad source plane");
+    FusedTotal ft{};
+    ft.source = source;
+    ft.sld = source_ld;
+    int rc = raytrace_impl(ctx, n_depth, n_nu, n_theta, nus, temps, ray_dist, wts, alphas, ald, F, fld, I_nus, accumulate, inward ? 1 : 0,
+                           source ? &ft : nullptr);
+    if (rc || !inward || !F || n_nu == 0) return rc;
+    {
+        LaunchScope ls(ctx, "k_scale");
+        hipLaunchKernelGGL(k_scale, grid2(n_nu, n_depth), dim3(kBlock), 0, ctx->stream, n_depth, n_nu, F, fld, photospheric_correction);
+    }
+    return check_launch("k_scale");
 }
 
 int sdx_raytrace_spherical_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, const double* nus, const double* temps,
@@ -1438,14 +1532,16 @@ int sdx_raytrace_spherical_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_th
 
 static int raytrace_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, const double* nus, const double* temps,
                          const double* ray_dist, const double* wts, const double* alphas, int64_t ald, double* F, int64_t fld,
-                         double* I_nus, int accumulate, int inward, const FusedTotal* fused)
+                         double* I_nus, int accumulate, int inward, const FusedTotal* fused, int64_t nu_global)
 {
+    if (nu_global < n_nu) nu_global = n_nu;  // stand-alone calls: the grid handed over is the whole grid
     FusedTotal ft{};
     if (fused) ft = *fused;
     REQUIRE(ctx && n_depth >= 2 && n_nu >= 0 && n_theta > 0, "raytrace: need n_depth >= 2, n_theta > 0");
     if (n_nu == 0) return SDX_OK;
     REQUIRE(nus && temps && ray_dist && wts && ((alphas && ald >= n_nu) || ft.cont), "raytrace: null pointer");
     REQUIRE(!ft.cont || n_theta <= 64, "raytrace: the fused total needs all angles in one launch");
+    REQUIRE(!ft.source || n_theta <= 64, "raytrace: a caller-provided source plane needs all angles in one launch");
     REQUIRE((F && fld >= n_nu) || I_nus, "raytrace: no output requested");
     constexpr int kMaxChunk = 64;
     for (int th0 = 0; th0 < n_theta; th0 += kMaxChunk) {
@@ -1477,7 +1573,7 @@ static int raytrace_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, c
         // workgroup (k_raytrace_seg)
         const int seg_gpw = 64 / nth;
         const size_t seg_doubles = seg_lds_doubles(n_depth, nth);
-        if (use_segmented_raytrace(ctx, n_depth, n_nu, n_theta, P == 1 && !inward && !acc)) {
+        if (use_segmented_raytrace(ctx, n_depth, nu_global, n_theta, P == 1 && !inward && !acc)) {
             {
                 LaunchScope ls(ctx, "k_raytrace");
                 const unsigned seg_blocks = (unsigned)(((n_nu + seg_gpw - 1) / seg_gpw + 7) / 8 * 8);  // whole rounds of the XCD-aware order
@@ -1498,7 +1594,7 @@ static int raytrace_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, c
                 else if (P == 2) hipLaunchKernelGGL(k_raytrace<2>, dim3(blocks), dim3(kBlock), shmem, ctx->stream, SDX_RT_ARGS, inward, gpw, ft);
                 else hipLaunchKernelGGL(k_raytrace<4>, dim3(blocks), dim3(kBlock), shmem, ctx->stream, SDX_RT_ARGS, inward, gpw, ft);
             } else {  // very deep models: the column does not fit LDS, recompute per lane instead
-                REQUIRE(!ft.cont, "raytrace: fused total not available for models this deep");
+                REQUIRE(!ft.cont && !ft.source, "raytrace: fused total / caller's source plane not available for models this deep");
                 REQUIRE(!inward, "raytrace: spherical geometry needs (3*n_depth*64/n_theta + 2*n_depth*n_theta) doubles of LDS per wave; model too deep");
                 if (P == 1) hipLaunchKernelGGL(k_raytrace_basic<1>, dim3(blocks_basic), dim3(kBlock), 0, ctx->stream, SDX_RT_ARGS);
                 else if (P == 2) hipLaunchKernelGGL(k_raytrace_basic<2>, dim3(blocks_basic), dim3(kBlock), 0, ctx->stream, SDX_RT_ARGS);
@@ -1621,7 +1717,7 @@ static int synthesize_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double
         }
         rc = check_launch("k_reduce_partials");
         if (rc) return rc;
-        return sdx_raytrace_dev(ctx, n_depth, nu_count, n_theta, nus + nu_begin, temps, ray_dist, wts, total, tld, F_nu, ld, nullptr, 0);
+        return raytrace_impl(ctx, n_depth, nu_count, n_theta, nus + nu_begin, temps, ray_dist, wts, total, tld, F_nu, ld, nullptr, 0, 0, nullptr, n_nu);
     }
     FusedTotal ft{};
     ft.cont = cont_plane;
@@ -1632,7 +1728,7 @@ static int synthesize_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double
     ft.total_out = total_alphas;
     ft.line_out = part ? alpha_line_out : nullptr;
     ft.out_ld = ld;
-    return raytrace_impl(ctx, n_depth, nu_count, n_theta, nus + nu_begin, temps, ray_dist, wts, nullptr, 0, F_nu, ld, nullptr, 0, 0, &ft);
+    return raytrace_impl(ctx, n_depth, nu_count, n_theta, nus + nu_begin, temps, ray_dist, wts, nullptr, 0, F_nu, ld, nullptr, 0, 0, &ft, n_nu);
 }
 
 int sdx_synthesize_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin, int64_t nu_count,
@@ -1665,25 +1761,35 @@ int sdx_synthesize_linelist_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const d
 
 // The fused synthesis for a caller that holds everything in host memory (C, or numpy through ctypes): uploads, runs
 // sdx_synthesize_dev, downloads.  `cont` carries HOST pointers here; array lengths follow from the sizes in the struct.
-int sdx_synthesize_f64(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t n_lines, const double* line_nus,
-                       const double* doppler, const double* gammas, int gamma_cols, const double* alphas, const sdx_continuum* cont,
-                       int n_theta, const double* temps, const double* ray_dist, const double* wts, double* alpha_line_out,
-                       double* total_alphas, double* F_nu, int64_t* n_evaluations)
+static int synthesize_host_check(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t n_lines, const double* line_nus,
+                                 const double* doppler, const double* gammas, int gamma_cols, const double* alphas, const sdx_continuum* cont,
+                                 int n_theta, const double* temps, const double* ray_dist, const double* wts)
 {
     int rc = check_line_args(ctx, n_depth, n_nu, nus, n_lines, line_nus, doppler, gammas, gamma_cols, alphas);
     if (rc) return rc;
     REQUIRE(cont && temps && ray_dist && wts && n_theta > 0 && n_depth >= 2, "synthesize: bad arguments");
-    REQUIRE(n_nu == 0 || F_nu, "synthesize: null output");
-    if (n_nu == 0) return SDX_OK;
     if ((rc = host_grid_check(n_nu, nus))) return rc;
     if ((rc = host_lines_check(n_lines, line_nus))) return rc;
     for (int64_t k = 0; k < n_lines * n_depth; ++k)
         if (doppler[k] == 0.0) return fail(SDX_ERR_ARG, "doppler_width == 0 (ZeroDivisionError in the reference, voigt.py:148)");
+    REQUIRE(cont->bf_n_species == 0 || !cont->bf_cutoff || cont->bf_n_levels > 0, "synthesize: bf_n_levels must be set");
+    return SDX_OK;
+}
+
+// Uploads everything to ctx's device, enqueues the synthesis of columns [nu_begin, nu_begin + nu_count) and the downloads of the
+// requested planes into the caller's [n_depth][n_nu] host arrays (the shard's columns only).  `io` stays alive until the caller
+// has called io.finish(); *d_F_out is the shard's device flux plane [n_depth][nu_count] (valid until the next call on ctx).
+static int synthesize_host_shard(sdx_ctx* ctx, HostIo& io, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin, int64_t nu_count,
+                                 int64_t n_lines, const double* line_nus, const double* doppler, const double* gammas, int gamma_cols,
+                                 const double* alphas, const sdx_continuum* cont, int n_theta, const double* temps, const double* ray_dist,
+                                 const double* wts, double* alpha_line_out, double* total_alphas, double* F_nu, int64_t* n_evaluations,
+                                 double** d_F_out, size_t extra_dev_bytes = 0)
+{
+    int rc;
     HIP_TRY(hipSetDevice(ctx->device));
-    const size_t f8 = sizeof(double), plane = (size_t)n_depth * n_nu * f8, ld = (size_t)n_lines * n_depth * f8;
+    const size_t f8 = sizeof(double), plane = (size_t)n_depth * nu_count * f8, ld = (size_t)n_lines * n_depth * f8;
     sdx_continuum c = *cont;
     const int n_levels = c.bf_n_species > 0 ? c.bf_n_levels : 0;
-    REQUIRE(c.bf_n_species == 0 || !c.bf_cutoff || n_levels > 0, "synthesize: bf_n_levels must be set");
     // every non-null host array goes up; lengths follow from the sizes in the struct
     struct In {
         const void* src;
@@ -1716,10 +1822,10 @@ int sdx_synthesize_f64(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nu
         {cont->electron_density, (size_t)n_depth * f8, (const void**)&c.electron_density},
     };
     const int n_out = 1 + (alpha_line_out ? 1 : 0) + (total_alphas ? 1 : 0);
-    size_t dev_need = (size_t)n_out * HostIo::pad(plane) + 512, pin_need = (size_t)n_out * HostIo::pad(plane) + 512;
+    size_t dev_need = (size_t)n_out * HostIo::pad(plane) + 512 + HostIo::pad(extra_dev_bytes);
+    size_t pin_need = (size_t)(F_nu ? n_out : n_out - 1) * HostIo::pad(plane) + 512 + HostIo::pad(extra_dev_bytes);
     for (const In& in : ins)
         if (in.src) dev_need += HostIo::pad(in.bytes ? in.bytes : 8), pin_need += HostIo::pad(in.bytes);
-    HostIo io{ctx};
     if ((rc = io.begin(dev_need, pin_need))) return rc;
     for (const In& in : ins)
         if (in.src && (rc = io.upload(in.src, in.bytes, in.dst))) return rc;
@@ -1728,15 +1834,320 @@ int sdx_synthesize_f64(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nu
     double* d_total = total_alphas ? (double*)io.alloc(plane) : nullptr;
     double* d_F = (double*)io.alloc(plane);
     int64_t* d_ev = (int64_t*)io.alloc(sizeof(int64_t));
-    rc = sdx_synthesize_dev(ctx, n_depth, n_nu, d_nus, 0, n_nu, n_lines, d_ln, d_dw, d_g, gamma_cols, d_a, &c, n_theta, d_t, d_rd, d_w, d_line,
-                            d_total, d_F, n_nu, n_evaluations ? d_ev : nullptr);
+    rc = sdx_synthesize_dev(ctx, n_depth, n_nu, d_nus, nu_begin, nu_count, n_lines, d_ln, d_dw, d_g, gamma_cols, d_a, &c, n_theta, d_t, d_rd, d_w,
+                            d_line, d_total, d_F, nu_count, n_evaluations ? d_ev : nullptr);
     if (rc) return rc;
-    if (alpha_line_out && (rc = io.download(alpha_line_out, d_line, plane))) return rc;
-    if (total_alphas && (rc = io.download(total_alphas, d_total, plane))) return rc;
-    if ((rc = io.download(F_nu, d_F, plane))) return rc;
+    const size_t pitch = (size_t)n_nu * f8, row = (size_t)nu_count * f8;
+    if (alpha_line_out && (rc = io.download2d(alpha_line_out + nu_begin, pitch, d_line, row, n_depth))) return rc;
+    if (total_alphas && (rc = io.download2d(total_alphas + nu_begin, pitch, d_total, row, n_depth))) return rc;
+    if (F_nu && (rc = io.download2d(F_nu + nu_begin, pitch, d_F, row, n_depth))) return rc;
+    if (n_evaluations) HIP_TRY(hipMemcpyAsync(n_evaluations, d_ev, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (d_F_out) *d_F_out = d_F;
+    return SDX_OK;
+}
+
+int sdx_synthesize_f64(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t n_lines, const double* line_nus,
+                       const double* doppler, const double* gammas, int gamma_cols, const double* alphas, const sdx_continuum* cont,
+                       int n_theta, const double* temps, const double* ray_dist, const double* wts, double* alpha_line_out,
+                       double* total_alphas, double* F_nu, int64_t* n_evaluations)
+{
+    int rc = synthesize_host_check(ctx, n_depth, n_nu, nus, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, cont, n_theta, temps, ray_dist, wts);
+    if (rc) return rc;
+    REQUIRE(n_nu == 0 || F_nu, "synthesize: null output");
+    if (n_nu == 0) return SDX_OK;
+    HostIo io{ctx};
     int64_t ev = 0;
-    if (n_evaluations) HIP_TRY(hipMemcpyAsync(&ev, d_ev, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    rc = synthesize_host_shard(ctx, io, n_depth, n_nu, nus, 0, n_nu, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, cont, n_theta, temps,
+                               ray_dist, wts, alpha_line_out, total_alphas, F_nu, n_evaluations ? &ev : nullptr, nullptr);
+    if (rc) return rc;
     if ((rc = io.finish())) return rc;
+    if (n_evaluations) *n_evaluations = ev;
+    return SDX_OK;
+}
+
+}  // extern "C"
+
+// ================================================================================================ one process, several GPUs
+// the frequency axis shards with no data-path exchange (radiation_field_solvers/base.py:200 is a prange over
+// nu); one process drives one context + stream per device, the line list is replicated, every device keeps the GLOBAL window
+// rule, and ONE ncclAllGather (RCCL over xGMI) of the padded F_nu[-1] shards leaves the whole emergent spectrum on every device.
+//
+// RCCL is opened at run time (dlopen of librccl.so.1, RTLD_LOCAL), not linked: a process that has imported torch already holds
+// torch's own copy under the same SONAME and the loader hands that one back — two RCCL builds never meet in one process — and a
+// single-GPU user of this library does not map RCCL's half gigabyte of device code.  Every RCCL failure (library missing,
+// communicator set-up, the collective itself) is SDX_ERR_COMM.
+namespace {
+struct RcclApi {
+    void* handle = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclGetVersion) GetVersion = nullptr;
+    std::string error;
+};
+
+RcclApi* rccl_api()
+{
+    static std::mutex m;
+    static RcclApi api;
+    std::lock_guard<std::mutex> lock(m);
+    if (api.handle) return &api;
+    const char* path = std::getenv("SDX_RCCL_LIB");  // another build of RCCL (or, in tests, a path that does not exist)
+    if (!path || !*path) path = "librccl.so.1";
+    void* h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    if (!h && !std::getenv("SDX_RCCL_LIB")) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) {
+        const char* e = dlerror();
+        api.error = std::string("RCCL not available: ") + (e ? e : "dlopen failed");
+        return &api;
+    }
+    bool ok = true;
+    auto sym = [&](const char* name) {
+        void* p = dlsym(h, name);
+        if (!p) ok = false, api.error = std::string("RCCL symbol missing: ") + name;
+        return p;
+    };
+    api.CommInitAll = (decltype(api.CommInitAll))sym("ncclCommInitAll");
+    api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+    api.AllGather = (decltype(api.AllGather))sym("ncclAllGather");
+    api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
+    api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
+    api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+    api.GetVersion = (decltype(api.GetVersion))sym("ncclGetVersion");
+    if (!ok) {
+        dlclose(h);
+        return &api;
+    }
+    api.handle = h;
+    api.error.clear();
+    return &api;
+}
+}  // namespace
+
+struct sdx_group {
+    int n = 0;
+    std::vector<int> devices;
+    std::vector<sdx_ctx*> ctx;
+    std::vector<ncclComm_t> comm;  // empty: loop-back test mode (SDX_GROUP_LOOPBACK=1, duplicate devices allowed, no RCCL)
+    std::vector<double*> send, recv;  // per device: [per], [per * n]
+    size_t per_cap = 0;
+    // what the last sdx_synthesize_sharded_f64 did (sdx_group_last_gather)
+    int64_t last_bytes_per_rank = 0;
+    int last_ranks = 0;
+};
+
+#define NCCL_TRY(api, expr)                                                                                     \
+    do {                                                                                                        \
+        ncclResult_t r_ = (expr);                                                                               \
+        if (r_ != ncclSuccess) return fail(SDX_ERR_COMM, std::string(#expr) + ": " + (api)->GetErrorString(r_)); \
+    } while (0)
+
+static int group_buffers(sdx_group* g, size_t per)
+{
+    if (g->per_cap >= per) return SDX_OK;
+    for (int r = 0; r < g->n; ++r) {
+        HIP_TRY(hipSetDevice(g->devices[r]));
+        HIP_TRY(hipStreamSynchronize(g->ctx[r]->stream));
+        if (g->send[r]) HIP_TRY(hipFree(g->send[r]));
+        if (g->recv[r]) HIP_TRY(hipFree(g->recv[r]));
+        g->send[r] = g->recv[r] = nullptr;
+        HIP_TRY(hipMalloc((void**)&g->send[r], per * sizeof(double)));
+        HIP_TRY(hipMalloc((void**)&g->recv[r], per * g->n * sizeof(double)));
+    }
+    g->per_cap = per;
+    return SDX_OK;
+}
+
+extern "C" {
+
+void sdx_group_destroy(sdx_group* g)
+{
+    if (!g) return;
+    RcclApi* api = g->comm.empty() ? nullptr : rccl_api();
+    for (int r = 0; r < (int)g->ctx.size(); ++r) {
+        if (!g->ctx[r]) continue;
+        hipSetDevice(g->devices[r]);
+        hipStreamSynchronize(g->ctx[r]->stream);
+        if (r < (int)g->send.size() && g->send[r]) hipFree(g->send[r]);
+        if (r < (int)g->recv.size() && g->recv[r]) hipFree(g->recv[r]);
+    }
+    if (api && api->handle)
+        for (ncclComm_t c : g->comm)
+            if (c) api->CommDestroy(c);
+    for (sdx_ctx* c : g->ctx) sdx_destroy(c);
+    delete g;
+}
+
+sdx_group* sdx_group_create(int n_gpus, const int* devices)
+{
+    if (n_gpus <= 0 || n_gpus > 64) {
+        fail(SDX_ERR_ARG, "sdx_group_create: n_gpus must be 1..64");
+        return nullptr;
+    }
+    const bool loopback = std::getenv("SDX_GROUP_LOOPBACK") && std::atoi(std::getenv("SDX_GROUP_LOOPBACK")) == 1;  // test hook, see header
+    // RCCL first: without it there is no group, whatever the devices
+    RcclApi* api = loopback ? nullptr : rccl_api();
+    if (api && !api->handle) {
+        fail(SDX_ERR_COMM, api->error);
+        return nullptr;
+    }
+    const int visible = sdx_device_count();
+    std::unique_ptr<sdx_group> g(new sdx_group());
+    g->n = n_gpus;
+    for (int r = 0; r < n_gpus; ++r) {
+        const int dev = devices ? devices[r] : r;
+        if (dev < 0 || dev >= visible) {
+            fail(SDX_ERR_ARG, "sdx_group_create: device " + std::to_string(dev) + " is not visible (sdx_device_count() = " + std::to_string(visible) + ")");
+            return nullptr;
+        }
+        if (!loopback)
+            for (int q = 0; q < r; ++q)
+                if (g->devices[q] == dev) {
+                    fail(SDX_ERR_ARG, "sdx_group_create: device " + std::to_string(dev) + " listed twice (one RCCL rank per GPU)");
+                    return nullptr;
+                }
+        g->devices.push_back(dev);
+    }
+    g->send.assign(n_gpus, nullptr);
+    g->recv.assign(n_gpus, nullptr);
+    for (int r = 0; r < n_gpus; ++r) {
+        sdx_ctx* c = sdx_create(g->devices[r], nullptr);
+        if (!c) {
+            sdx_group_destroy(g.release());
+            return nullptr;
+        }
+        g->ctx.push_back(c);
+    }
+    if (!loopback) {
+        g->comm.assign(n_gpus, nullptr);
+        const ncclResult_t r = api->CommInitAll(g->comm.data(), n_gpus, g->devices.data());
+        if (r != ncclSuccess) {
+            const std::string msg = std::string("ncclCommInitAll: ") + api->GetErrorString(r);
+            for (auto& c : g->comm) c = nullptr;
+            sdx_group_destroy(g.release());
+            fail(SDX_ERR_COMM, msg);
+            return nullptr;
+        }
+    }
+    return g.release();
+}
+
+int sdx_group_size(const sdx_group* g) { return g ? g->n : 0; }
+sdx_ctx* sdx_group_context(sdx_group* g, int rank) { return g && rank >= 0 && rank < g->n ? g->ctx[rank] : nullptr; }
+
+int sdx_group_last_gather(const sdx_group* g, int* ranks, int64_t* bytes_per_rank, int* rccl_version)
+{
+    REQUIRE(g, "null group");
+    if (ranks) *ranks = g->last_ranks;
+    if (bytes_per_rank) *bytes_per_rank = g->last_bytes_per_rank;
+    if (rccl_version) {
+        *rccl_version = 0;
+        if (!g->comm.empty()) {
+            RcclApi* api = rccl_api();
+            if (api->handle) api->GetVersion(rccl_version);
+        }
+    }
+    return SDX_OK;
+}
+
+int sdx_synthesize_sharded_f64(sdx_group* g, int n_depth, int64_t n_nu, const double* nus, int64_t n_lines, const double* line_nus,
+                               const double* doppler, const double* gammas, int gamma_cols, const double* alphas, const sdx_continuum* cont,
+                               int n_theta, const double* temps, const double* ray_dist, const double* wts, const int64_t* shard_begin,
+                               double* alpha_line_out, double* total_alphas, double* F_nu, double* emergent_flux, int64_t* n_evaluations)
+{
+    REQUIRE(g, "null group");
+    const int P = g->n;
+    int rc = synthesize_host_check(g->ctx[0], n_depth, n_nu, nus, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, cont, n_theta, temps, ray_dist, wts);
+    if (rc) return rc;
+    REQUIRE(n_nu == 0 || F_nu || emergent_flux, "synthesize_sharded: no output requested");
+    if (n_nu == 0) return SDX_OK;
+    // shards: contiguous blocks of the GLOBAL frequency index, equal by default
+    std::vector<int64_t> begin(P + 1);
+    const int64_t per_equal = (n_nu + P - 1) / P;
+    for (int r = 0; r <= P; ++r) begin[r] = shard_begin ? shard_begin[r] : std::min<int64_t>((int64_t)r * per_equal, n_nu);
+    REQUIRE(begin[0] == 0 && begin[P] == n_nu, "synthesize_sharded: shard_begin must run from 0 to n_nu");
+    int64_t per = 0;
+    for (int r = 0; r < P; ++r) {
+        REQUIRE(begin[r + 1] >= begin[r], "synthesize_sharded: shard_begin must not descend");
+        per = std::max(per, begin[r + 1] - begin[r]);
+    }
+    if ((rc = group_buffers(g, (size_t)per))) return rc;
+
+    // per device, in parallel host threads (the staging memcpy of a replicated 10^6-line list is the slow part): upload,
+    // enqueue the shard's synthesis, pack its F_nu[-1] columns into the (zero-padded) send buffer, enqueue the plane downloads
+    std::vector<std::unique_ptr<HostIo>> io(P);
+    std::vector<int> rcs(P, SDX_OK), codes(P, 0);
+    std::vector<std::string> errs(P);
+    int64_t ev = 0;
+    auto work = [&](int r) {
+        sdx_ctx* ctx = g->ctx[r];
+        io[r].reset(new HostIo(ctx));
+        const int64_t b = begin[r], cnt = begin[r + 1] - begin[r];
+        double* d_F = nullptr;
+        int rr = SDX_OK;
+        if (hipSetDevice(ctx->device) != hipSuccess) rr = fail(SDX_ERR_HIP, "hipSetDevice failed");
+        if (!rr && cnt > 0)
+            rr = synthesize_host_shard(ctx, *io[r], n_depth, n_nu, nus, b, cnt, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, cont, n_theta,
+                                       temps, ray_dist, wts, alpha_line_out, total_alphas, F_nu, (r == 0 && n_evaluations) ? &ev : nullptr, &d_F);
+        if (!rr && hipMemsetAsync(g->send[r], 0, (size_t)per * sizeof(double), ctx->stream) != hipSuccess) rr = fail(SDX_ERR_HIP, "hipMemsetAsync(send) failed");
+        if (!rr && cnt > 0 &&
+            hipMemcpyAsync(g->send[r], d_F + (size_t)(n_depth - 1) * cnt, (size_t)cnt * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
+            rr = fail(SDX_ERR_HIP, "hipMemcpyAsync(pack flux shard) failed");
+        rcs[r] = rr;
+        if (rr) errs[r] = g_error, codes[r] = g_error_code;
+    };
+    if (P == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> th;
+        for (int r = 0; r < P; ++r) th.emplace_back(work, r);
+        for (auto& t : th) t.join();
+    }
+    for (int r = 0; r < P; ++r)
+        if (rcs[r]) return fail(rcs[r], "device " + std::to_string(g->devices[r]) + ": " + errs[r]);
+
+    // the one collective: all-gather of the padded emergent-flux shards, stream-ordered behind each device's kernels
+    if (!g->comm.empty()) {
+        RcclApi* api = rccl_api();
+        NCCL_TRY(api, api->GroupStart());
+        for (int r = 0; r < P; ++r) {
+            const ncclResult_t res = api->AllGather(g->send[r], g->recv[r], (size_t)per, ncclDouble, g->comm[r], g->ctx[r]->stream);
+            if (res != ncclSuccess) {
+                api->GroupEnd();
+                return fail(SDX_ERR_COMM, std::string("ncclAllGather: ") + api->GetErrorString(res));
+            }
+        }
+        NCCL_TRY(api, api->GroupEnd());
+    } else {  // loop-back test mode: the same data movement as plain copies after a full synchronisation
+        for (int r = 0; r < P; ++r) {
+            HIP_TRY(hipSetDevice(g->devices[r]));
+            HIP_TRY(hipStreamSynchronize(g->ctx[r]->stream));
+        }
+        for (int r = 0; r < P; ++r) {
+            HIP_TRY(hipSetDevice(g->devices[r]));
+            for (int q = 0; q < P; ++q)
+                HIP_TRY(hipMemcpyAsync(g->recv[r] + (size_t)q * per, g->send[q], (size_t)per * sizeof(double), hipMemcpyDeviceToDevice, g->ctx[r]->stream));
+        }
+    }
+    g->last_ranks = P;
+    g->last_bytes_per_rank = per * (int64_t)sizeof(double);
+
+    // the gathered spectrum comes back from device 0 (every device holds it), padding trimmed
+    HIP_TRY(hipSetDevice(g->devices[0]));
+    std::vector<double> gathered;
+    if (emergent_flux) {
+        gathered.resize((size_t)per * P);
+        HIP_TRY(hipMemcpyAsync(gathered.data(), g->recv[0], gathered.size() * sizeof(double), hipMemcpyDeviceToHost, g->ctx[0]->stream));
+    }
+    for (int r = 0; r < P; ++r) {
+        HIP_TRY(hipSetDevice(g->devices[r]));
+        if ((rc = io[r]->finish())) return rc;
+    }
+    if (emergent_flux)
+        for (int r = 0; r < P; ++r) std::memcpy(emergent_flux + begin[r], gathered.data() + (size_t)r * per, (size_t)(begin[r + 1] - begin[r]) * sizeof(double));
     if (n_evaluations) *n_evaluations = ev;
     return SDX_OK;
 }

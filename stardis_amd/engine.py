@@ -80,13 +80,14 @@ class SpectralSynthesizer:
         self._keep = []
         self.cont = self._build_continuum(continuum, nus, t)
 
-        self.d_line = c.empty((self.n_depth, self.count))
-        self.d_total = c.empty((self.n_depth, self.count))
+        # optional output planes: allocated only when asked for (0.5 GB each at 1.2e6 frequencies)
+        self.d_line = c.empty((self.n_depth, self.count)) if keep_line else None
+        self.d_total = c.empty((self.n_depth, self.count)) if keep_total else None
         self._flux_tensor = flux_out
         self.d_F = None if flux_out is not None else c.empty((self.n_depth, self.count))
         self.d_evals = c.zeros((1,), np.int64) if track_evaluations else None
-        self.keep_line = keep_line  # also write the summed line opacity plane (alpha_line())
-        self.keep_total = keep_total  # also write total_alphas (the reference keeps it on Opacities; the flux does not need it in HBM)
+        self._keep_line = keep_line  # also write the summed line opacity plane (alpha_line())
+        self._keep_total = keep_total  # also write total_alphas (the reference keeps it on Opacities; the flux does not need it in HBM)
         self.count_evaluations = track_evaluations  # sum(hi - lo) per step costs a memset + copy: switch off when timing
         self.graph = None
         c.call("sdx_reserve_line_workspace", self.n_depth, self.n_lines)
@@ -119,6 +120,26 @@ class SpectralSynthesizer:
         s.electron_density = up(cont["n_e"])
         return s
 
+    @property
+    def keep_line(self):
+        return self._keep_line
+
+    @keep_line.setter
+    def keep_line(self, on):
+        if on and self.d_line is None:
+            self.d_line = self.ctx.empty((self.n_depth, self.count))
+        self._keep_line = bool(on)
+
+    @property
+    def keep_total(self):
+        return self._keep_total
+
+    @keep_total.setter
+    def keep_total(self, on):
+        if on and self.d_total is None:
+            self.d_total = self.ctx.empty((self.n_depth, self.count))
+        self._keep_total = bool(on)
+
     def _hold(self, dev):
         self._keep.append(dev)
         return dev.ptr
@@ -146,6 +167,7 @@ class SpectralSynthesizer:
         """The same step through the individual entry points (what calc_alphas + raytrace issue)."""
         c = self.ctx
         nd, cnt = self.n_depth, self.count
+        self.keep_line = self.keep_total = True  # this path materialises both planes
         if self.linelist is not None:
             c.call("sdx_line_opacity_linelist_dev", nd, self.n_nu, self.d_nus.ptr, self.begin, cnt, self.linelist.byref(),
                    self.d_line.ptr, cnt, 0, ptr_of(self.d_evals))
@@ -196,9 +218,13 @@ class SpectralSynthesizer:
         return self.d_F.numpy()
 
     def total_alphas(self):
+        if not self.keep_total:
+            raise RuntimeError("total_alphas was not kept: construct the synthesizer with keep_total=True")
         return self.d_total.numpy()
 
     def alpha_line(self):
+        if not self.keep_line:
+            raise RuntimeError("alpha_line was not kept: construct the synthesizer with keep_line=True")
         return self.d_line.numpy()
 
     def evaluations(self):

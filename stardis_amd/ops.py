@@ -74,7 +74,9 @@ def voigt_term(delta_nu, doppler_width, gamma, alpha=1.0, ctx=None, fp32=False):
 
 
 # ------------------------------------------------------------------------------------------------ line opacity
-def _line_inputs(no_of_depth_points, line_nus, doppler_widths, gammas, alphas_array):
+def _line_inputs(no_of_depth_points, line_nus, doppler_widths, gammas, alphas_array, sort=True):
+    """The four line arrays as contiguous float64 in the kernels' shapes.  sort=True: stably sorted by frequency when they
+    are not (the line-opacity kernels want an ascending list); sort=False leaves the caller's order alone (per-line outputs)."""
     ln = _host(line_nus).reshape(-1)
     nd = int(no_of_depth_points)
     dw = _host(doppler_widths).reshape(ln.size, nd)  # may arrive F-ordered from DataFrame.to_numpy() (base.py:403-407)
@@ -83,7 +85,7 @@ def _line_inputs(no_of_depth_points, line_nus, doppler_widths, gammas, alphas_ar
     g = g.reshape(ln.size, -1) if ln.size else g.reshape(0, 1)
     if g.shape[1] not in (1, nd):
         raise ValueError(f"gammas must have shape (n_lines, {nd}) or (n_lines, 1), got {g.shape}")
-    if ln.size > 1 and np.any(ln[1:] < ln[:-1]):
+    if sort and ln.size > 1 and np.any(ln[1:] < ln[:-1]):
         # The reference treats every line independently (base.py:548-590), so any order is legal there; the kernels want
         # ascending frequency (what calc_alpha_line_at_nu hands over, :392-397).  A stable sort changes only the order of
         # the per-point sum, which differs from the reference's per-thread slabs anyway.
@@ -111,10 +113,11 @@ def calc_alan_entries(no_of_depth_points, tracing_nus_values, line_nus, doppler_
 
 
 def line_windows(no_of_depth_points, tracing_nus_values, line_nus, doppler_widths, gammas, alphas_array, ctx=None):
-    """Window bounds [lower, upper) per (line, depth): opacities/opacities_solvers/base.py:556-575."""
+    """Window bounds [lower, upper) per (line, depth): opacities/opacities_solvers/base.py:556-575.  Row k belongs to line k
+    of the caller's list whatever its order (the window rule is per line; sdx_line_windows_dev does not need a sorted list)."""
     ctx = ctx or default_context()
     nus = _host(tracing_nus_values).reshape(-1)
-    ln, dw, g, al = _line_inputs(no_of_depth_points, line_nus, doppler_widths, gammas, alphas_array)
+    ln, dw, g, al = _line_inputs(no_of_depth_points, line_nus, doppler_widths, gammas, alphas_array, sort=False)
     nd = int(no_of_depth_points)
     d = [ctx.upload(x) for x in (nus, ln, dw, g, al)]
     lo = ctx.empty((ln.size, nd), np.int32)
@@ -307,12 +310,14 @@ def calc_weights_parallel(delta_tau, ctx=None):
 
 
 def raytrace_arrays(tracing_nus, temperatures, ray_distances, theta_weights, total_alphas, F_nu=None, track=False, ctx=None,
-                    inward_rays=False, photospheric_correction=1.0, want_flux=True):
+                    inward_rays=False, photospheric_correction=1.0, want_flux=True, source=None):
     """radiation_field_solvers/base.py:271-346 on arrays.
 
     ray_distances is the (N_d-1, N_theta) table of :302-305 (plane-parallel) or of calculate_spherical_ray
     (:296-300; pass inward_rays=True and the photospheric correction of :340-344).  total_alphas may be a host
-    array or a device array.  Returns (F_nu host array — accumulated into when given —, I_nus or None)."""
+    array or a device array.  source: optional (N_d, N_nu) source-function plane (a foreign RadiationField.source_function
+    evaluated by the caller, :133); default: the Planck function in the kernel.
+    Returns (F_nu host array — accumulated into when given —, I_nus or None)."""
     ctx = ctx or default_context()
     nus = _host(tracing_nus).reshape(-1)
     t = _host(temperatures).reshape(-1)
@@ -329,7 +334,13 @@ def raytrace_arrays(tracing_nus, temperatures, ray_distances, theta_weights, tot
     # then picks its kernel freely (the segmented formal solution needs nothing to add to)
     args = (t.size, nus.size, n_theta, d[0].ptr, d[1].ptr, d[2].ptr, d[3].ptr, ptr_of(d_alpha), nus.size, ptr_of(d_F), nus.size,
             ptr_of(d_I), 0 if F_nu is None else 1)
-    if inward_rays:
+    if source is not None:
+        src = _host(source)
+        if src.shape != (t.size, nus.size):
+            raise ValueError(f"source function must return shape {(t.size, nus.size)}, got {src.shape}")
+        d_S = ctx.upload(src)
+        ctx.call("sdx_raytrace_source_dev", *args[:9], d_S.ptr, nus.size, *args[9:], 1 if inward_rays else 0, float(photospheric_correction))
+    elif inward_rays:
         ctx.call("sdx_raytrace_spherical_dev", *args, float(photospheric_correction))
     else:
         ctx.call("sdx_raytrace_dev", *args)

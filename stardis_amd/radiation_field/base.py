@@ -1,5 +1,6 @@
 """Radiation field container and driver, call-compatible with stardis/radiation_field/base.py."""
 import logging
+import os
 
 import numpy as np
 
@@ -37,8 +38,20 @@ class RadiationField(_Base):
             self.I_nus = np.zeros((n_depth, len(frequencies), len(self.thetas)))
 
 
+FUSED = os.environ.get("STARDIS_AMD_FUSED", "1") != "0"  # one fused device pass when the configuration allows it
+
+
 def create_stellar_radiation_field(tracing_nus, stellar_model, stellar_plasma, config):
-    """Opacities then formal solution, as the reference's driver (:71-117)."""
+    """Opacities then formal solution, as the reference's driver (:71-117).  Configurations the fused synthesis covers run
+    as ONE device pass with lazily materialised dictionary entries (stardis_amd/radiation_field/fused.py); everything else —
+    and STARDIS_AMD_FUSED=0 — takes the source-by-source path below.  Both produce the same numbers."""
+    if FUSED:
+        from stardis_amd.radiation_field.fused import try_fused
+
+        field = try_fused(RadiationField, tracing_nus, stellar_model, stellar_plasma, config, blackbody_flux_at_nu)
+        if field is not None:
+            logger.info("Radiation field computed by the fused synthesis")
+            return field
     field = RadiationField(
         tracing_nus,
         blackbody_flux_at_nu,

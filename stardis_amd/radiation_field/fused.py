@@ -1,0 +1,369 @@
+"""create_stellar_radiation_field in ONE device pass: what stardis/radiation_field/base.py:71-117 computes, through
+sdx_synthesize_dev instead of one kernel + one (N_d, N_nu) download per opacity source.
+
+The general mirror (calc_alphas, raytrace) forms every entry of `opacities_dict` as a host array because the reference does;
+a caller of run_stardis reads `F_nu` and, now and then, one of those entries.  Here the fused step (pre-pass + continuum +
+line opacity + formal solution, stardis_amd/csrc) runs on inputs uploaded in ONE staging copy, only `F_nu` comes back, and the
+dictionary entries are produced the first time somebody reads them — from the device twins the step left behind
+(`alpha_line_at_nu`, `total_alphas`, the broadening tables) or by the per-source entry point the general mirror would have
+called (`alpha_bf`, `alpha_ff`, ...: same device functions, bit-identical planes).  Keys, insertion order, shapes, the scalar 0
+of disabled sources and `F_nu` accumulation semantics are the reference's (opacities_solvers/base.py:655-738,
+radiation_field_solvers/base.py:324-338).
+
+`try_fused` returns None for configurations the fused step does not cover (2-D tabulated cross-sections, molecules,
+spherical geometry, tracked intensities, a foreign source function, frequencies the Rayleigh cut-off would clip, line lists
+without a dense alpha table); the caller then takes the general path.
+"""
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+from stardis_amd import _lib
+from stardis_amd import constants as K
+from stardis_amd._lib import Continuum, default_context, plain
+from stardis_amd.radiation_field.opacities import Opacities
+from stardis_amd.radiation_field.opacities.opacities_solvers import base as B
+from stardis_amd.radiation_field.opacities.opacities_solvers.broadening import _microturbulence_cgs, _switches
+from stardis_amd.radiation_field.opacities.opacities_solvers.util import get_number_density, read_table
+
+F8 = np.float64
+RAYLEIGH_CUTOFF = 2.3e15  # opacities_solvers/base.py:99
+
+
+class _Thunk:
+    """A dictionary entry that has not been asked for yet."""
+
+    __slots__ = ("make",)
+
+    def __init__(self, make):
+        self.make = make
+
+
+class LazyOpacitiesDict(dict):
+    """`opacities_dict` whose array entries materialise on first read.  Every read path goes through __getitem__ (a
+    trivially overridden __iter__ keeps dict(d) / d.copy() off CPython's raw-value fast path)."""
+
+    def __getitem__(self, key):
+        value = dict.__getitem__(self, key)
+        if isinstance(value, _Thunk):
+            value = value.make()
+            dict.__setitem__(self, key, value)
+        return value
+
+    def __iter__(self):
+        return dict.__iter__(self)
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def _all(self):
+        for key in dict.keys(self):
+            self[key]
+
+    def items(self):
+        self._all()
+        return dict.items(self)
+
+    def values(self):
+        self._all()
+        return dict.values(self)
+
+    def copy(self):
+        self._all()
+        return dict(dict.items(self))
+
+    def pop(self, key, *default):
+        if key in self:
+            self[key]
+        return dict.pop(self, key, *default)
+
+
+class FusedOpacities(Opacities):
+    """Opacities whose `total_alphas` lives on the device until read (opacities/base.py:4-28 keeps a host array)."""
+
+    def __init__(self, shape):
+        self.opacities_dict = LazyOpacitiesDict()
+        self._resident = {}
+        self._total_dev = None
+        self._total_host = None
+        self._total_twin = None  # device plane written by the fused step
+        self._shape = shape
+
+    @property
+    def total_alphas(self):
+        if self._total_host is None:
+            self._total_host = self._total_twin.numpy() if self._total_twin is not None else np.zeros(self._shape)
+            if self._total_twin is not None:
+                self._total_dev = (self._total_host.copy(), self._total_twin)
+        return self._total_host
+
+    @total_alphas.setter
+    def total_alphas(self, value):
+        self._total_host = value
+
+    def total_alphas_device(self, ctx):
+        if self._total_host is None and self._total_twin is not None:
+            return self._total_twin
+        return super().total_alphas_device(ctx)
+
+
+def _packed_upload(ctx, arrays):
+    """One staging copy for many small arrays: -> (DeviceArray holding them all, [device address of each])."""
+    offs, total = [], 0
+    for a in arrays:
+        offs.append(total)
+        total += (a.nbytes + 255) & ~255
+    blob = np.empty(max(total, 256), dtype=np.uint8)
+    for a, o in zip(arrays, offs):
+        blob[o:o + a.nbytes] = a.reshape(-1).view(np.uint8)
+    dev = ctx.upload(blob, np.uint8)
+    return dev, [dev.ptr + o for o in offs]
+
+
+def _sorted_in_grid(nu, lo, hi):
+    """Row order of `_in_grid` (opacities_solvers/base.py:392-397): table.sort_values("nu") then nu.between(min, max).
+    pandas sorts a single float column with ndarray.argsort(kind="quicksort"); None when NaNs would need its special casing."""
+    if np.isnan(nu).any():
+        return None
+    order = np.argsort(nu, kind="quicksort")
+    s = nu[order]
+    return order[(s >= lo) & (s <= hi)]
+
+
+def _mass_of(nuclide_masses, atomic_number):
+    idx = nuclide_masses.index.get_indexer(atomic_number)
+    if (idx < 0).any():
+        raise KeyError(f"no nuclide mass for atomic numbers {sorted(set(np.asarray(atomic_number)[idx < 0].tolist()))}")
+    return np.asarray(nuclide_masses.to_numpy(), dtype=F8)[idx]
+
+
+def _bf_arrays(stellar_plasma, species):
+    """_bf_levels of the general mirror without a pandas look-up per level: levels of each species in plasma order."""
+    levels = stellar_plasma.levels
+    z_all = np.asarray(levels.get_level_values(0))
+    ion_all = np.asarray(levels.get_level_values(1))
+    exc, dens = stellar_plasma.excitation_energy, stellar_plasma.level_number_density
+    if not (exc.index.equals(levels) and dens.index.equals(levels)):
+        return None  # label look-ups needed: general path
+    exc_v, dens_v = np.asarray(exc.to_numpy(), dtype=F8), np.asarray(dens.to_numpy(), dtype=F8)
+    offsets, ions, cutoffs, densities = [0], [], [], []
+    for spec in species:
+        _, atomic_number, ion_number = get_number_density(stellar_plasma, spec + "_bf")
+        e_ion = float(stellar_plasma.ionization_data.loc[(atomic_number, ion_number + 1)])
+        sel = np.flatnonzero((z_all == atomic_number) & (ion_all == ion_number))
+        cutoffs.append((e_ion - exc_v[sel]) / K.H_CGS)
+        densities.append(dens_v[sel])
+        offsets.append(offsets[-1] + sel.size)
+        ions.append(ion_number)
+    n_depth = dens_v.shape[1] if dens_v.ndim == 2 else 0
+    return (np.asarray(offsets, dtype=np.int32), np.asarray(ions, dtype=np.int32),
+            np.concatenate(cutoffs) if cutoffs else np.zeros(0), np.vstack(densities) if densities else np.zeros((0, n_depth)))
+
+
+def _line_arrays(stellar_plasma, stellar_model, nus, cfg):
+    """calc_alpha_line_at_nu's host preparation (:362-421) as flat arrays: the selected lines in ascending frequency with
+    their dense alphas and per-line broadening scalars.  None when this path does not cover the configuration."""
+    vald = cfg.vald_linelist
+    if vald.use_linelist:
+        lines, alpha_table = stellar_plasma.lines_from_linelist, getattr(stellar_plasma, "alpha_line_from_linelist", None)
+        if alpha_table is None:
+            return None  # parameters generated on the device (f1): general path
+    else:
+        lines, alpha_table = B._atomic_line_table(stellar_plasma), stellar_plasma.alpha_line
+    lo, hi = nus.min(), nus.max()
+    nu_l = np.asarray(lines["nu"].to_numpy(), dtype=F8)
+    nu_a = np.asarray(alpha_table["nu"].to_numpy(), dtype=F8)
+    sel_l, sel_a = _sorted_in_grid(nu_l, lo, hi), _sorted_in_grid(nu_a, lo, hi)
+    if sel_l is None or sel_a is None or sel_l.size != sel_a.size:
+        return None
+    col = lambda name, dt=F8: np.asarray(lines[name].to_numpy(), dtype=dt)[sel_l]  # noqa: E731  (pd.to_numeric of :411)
+    out = dict(nu=nu_l[sel_l], z=col("atomic_number", np.int64), ion=col("ion_number", np.int64), e_ion=col("ionization_energy"),
+               e_up=col("level_energy_upper"), e_lo=col("level_energy_lower"), a_ul=col("A_ul"))
+    vald_broadening = bool(vald.use_vald_broadening and vald.use_linelist)
+    if vald_broadening:
+        out["stark"], out["waals"] = col("stark"), col("waals")
+    alpha_cols = [c for c in alpha_table.columns if c != "nu"]
+    alphas = np.asarray(alpha_table[alpha_cols].to_numpy(), dtype=F8)[sel_a]
+    if not vald.use_vald_broadening:  # auto-ionising lines are dropped unless VALD broadening is used (:413-421)
+        keep = ~(out["e_up"] > out["e_ion"])
+        if not keep.all():
+            out = {k: v[keep] for k, v in out.items()}
+            alphas = alphas[keep]
+    out["alphas"] = np.ascontiguousarray(alphas)
+    out["mass"] = _mass_of(stellar_model.composition.nuclide_masses, out["z"])
+    out["vald_broadening"] = vald_broadening
+    return out
+
+
+def try_fused(field_cls, tracing_nus, stellar_model, stellar_plasma, config, source_function):
+    """-> RadiationField computed by one fused device pass, or None when the configuration needs the general path."""
+    opacity = config.opacity
+    if getattr(stellar_model, "spherical", False) or config.result_options.return_radiation_field:
+        return None
+    if getattr(source_function, "__name__", "") != "blackbody_flux_at_nu" or opacity.line.include_molecules:
+        return None
+    if int(config.no_of_thetas) > 64 or len(opacity.file) > 1:
+        return None
+    nus = np.ascontiguousarray(plain(tracing_nus), dtype=F8).reshape(-1)
+    nd = int(stellar_model.no_of_depth_points)
+    if nus.size < 2 or nd < 2 or np.any(np.diff(nus) >= 0):
+        return None
+    rayleigh_species = list(opacity.rayleigh)
+    if rayleigh_species and nus.max() > RAYLEIGH_CUTOFF:
+        return None  # the reference clips the caller's frequencies in place there (:99): general path reproduces it
+    table = None
+    for source, fpath in opacity.file.items():
+        table = read_table(Path(fpath), source)
+        if table[0] != "1d":
+            return None
+    bf_species = list(opacity.bf.keys()) if hasattr(opacity.bf, "keys") else list(opacity.bf)
+    bf = _bf_arrays(stellar_plasma, bf_species)
+    if bf is None or bf[2].size > 4096:
+        return None
+    line = None
+    if not opacity.line.disable:
+        line = _line_arrays(stellar_plasma, stellar_model, nus, opacity.line)
+        if line is None:
+            return None
+        if line["nu"].size and np.any(np.diff(line["nu"]) < 0):
+            return None
+        # a zero Doppler width (nu = 0, or T = 0 without microturbulence) raises in the general path (voigt.py:148): leave it to it
+        if np.any(line["nu"] == 0) or np.any(line["mass"] <= 0) or not np.all(np.asarray(plain(stellar_model.temperatures), dtype=F8) > 0):
+            return None
+    ctx = default_context()
+    temps = np.ascontiguousarray(plain(stellar_model.temperatures), dtype=F8).reshape(-1)
+    n_e = np.ascontiguousarray(plain(stellar_plasma.electron_densities), dtype=F8).reshape(-1)
+
+    field = field_cls.__new__(field_cls)  # the attributes of RadiationField.__init__ (:38-68) without its zero-filled planes
+    field.frequencies = tracing_nus
+    field.source_function = source_function
+    nodes, weights = np.polynomial.legendre.leggauss(int(config.no_of_thetas))
+    field.thetas = (nodes / 2) + 0.5 * np.pi / 2
+    field.I_nus_weights = weights * np.pi / 2
+    field.track_individual_intensities = False
+    opac = FusedOpacities((nd, nus.size))
+    field.opacities = opac
+
+    # ---- everything the step reads, in one staging copy
+    host, slot = [], {}
+
+    def add(name, a, dt=F8):
+        slot[name] = len(host)
+        host.append(np.ascontiguousarray(a, dtype=dt).reshape(-1))
+
+    dist = np.asarray(plain(stellar_model.geometry.dist_to_next_depth_point), dtype=F8)
+    add("nus", nus)
+    add("temps", temps)
+    add("ray", dist.reshape(-1, 1) / np.cos(field.thetas))  # radiation_field_solvers/base.py:302-305
+    add("wts", field.I_nus_weights)
+    add("lambdas", K.nu_to_angstrom(nus))
+    file_source = None
+    if table is not None:
+        file_source = next(iter(opacity.file))
+        density, _, _ = get_number_density(stellar_plasma, file_source)
+        add("tab_x", table[1]), add("tab_y", table[2]), add("tab_n", plain(density))
+    add("bf_off", bf[0], np.int32), add("bf_ion", bf[1], np.int32), add("bf_cut", bf[2]), add("bf_den", bf[3])
+    ff_ions, ff_dens = [], []
+    for spec in (opacity.ff.keys() if hasattr(opacity.ff, "keys") else opacity.ff):
+        number_density, _, ion_number = get_number_density(stellar_plasma, spec + "_ff")
+        ff_ions.append(ion_number), ff_dens.append(np.asarray(plain(number_density), dtype=F8))
+    add("ff_ion", ff_ions, np.int32), add("ff_den", np.vstack(ff_dens) if ff_dens else np.zeros((0, nd)))
+    ions = stellar_plasma.ion_number_density
+    if "H" in rayleigh_species:
+        add("ray_h", plain(ions.loc[1, 0]))
+    if "He" in rayleigh_species:
+        add("ray_he", plain(ions.loc[2, 0]))
+    if "H2" in rayleigh_species:
+        add("ray_h2", plain(stellar_plasma.h2_density))
+    if not opacity.disable_electron_scattering:
+        add("n_e", n_e)
+    n_lines = 0
+    if line is not None:
+        n_lines = line["nu"].size
+        n_h = np.asarray(plain(ions.loc[1, 0]), dtype=F8)
+        add("l_nu", line["nu"]), add("l_alpha", line["alphas"]), add("l_z", line["z"], np.int32), add("l_ion", line["ion"] + 1, np.int32)
+        for k in ("e_ion", "e_up", "e_lo", "a_ul", "mass"):
+            add("l_" + k, line[k])
+        if line["vald_broadening"]:
+            add("l_stark", line["stark"]), add("l_waals", line["waals"])
+        add("b_ne", n_e), add("b_nh", n_h)
+        if n_lines and np.any(line["alphas"].shape != (n_lines, nd)):
+            return None
+    blob, ptrs = _packed_upload(ctx, host)
+    P = lambda name: ptrs[slot[name]] if name in slot else None  # noqa: E731
+
+    c = Continuum()
+    c.temperature = P("temps")
+    c.lambdas = P("lambdas")
+    if table is not None:
+        c.n_table, c.table_wavelength, c.table_sigma, c.table_density = int(np.size(table[1])), P("tab_x"), P("tab_y"), P("tab_n")
+    if bf[1].size:
+        c.bf_n_species, c.bf_n_levels = int(bf[1].size), int(bf[2].size)
+        c.bf_species_offsets, c.bf_species_ion_number, c.bf_cutoff, c.bf_level_density = P("bf_off"), P("bf_ion"), P("bf_cut"), P("bf_den")
+        if c.bf_n_levels == 0:
+            c.bf_n_species = 0
+    if ff_ions:
+        c.ff_n_species, c.ff_species_ion_number, c.ff_number_density = len(ff_ions), P("ff_ion"), P("ff_den")
+    c.ray_n_h, c.ray_n_he, c.ray_n_h2 = P("ray_h"), P("ray_he"), P("ray_h2")
+    c.rayleigh_enabled = 1 if rayleigh_species else 0
+    c.electron_density = P("n_e")
+
+    d_gamma = d_doppler = None
+    if n_lines:
+        lin, quad, vdw, rad = _switches(opacity.line.broadening)
+        flags = (1 if lin else 0) | (2 if quad else 0) | (4 if vdw else 0) | (8 if rad else 0)
+        d_gamma, d_doppler = ctx.empty((n_lines, nd)), ctx.empty((n_lines, nd))
+        common = (n_lines, nd, P("l_z"), P("l_ion"), P("l_e_ion"), P("l_e_up"), P("l_e_lo"), P("l_a_ul"))
+        if line["vald_broadening"]:  # broadening.py:1009-1085
+            ctx.call("sdx_calc_vald_gamma_dev", *common, P("l_stark"), P("l_waals"), P("l_mass"), P("b_ne"), P("temps"), P("b_nh"), flags, d_gamma.ptr)
+        else:  # broadening.py:550-656 with the argument preparation of :706-721
+            ctx.call("sdx_calc_gamma_dev", *common, P("b_ne"), P("temps"), P("b_nh"), flags, d_gamma.ptr)
+        ctx.call("sdx_doppler_widths_dev", n_lines, nd, P("l_nu"), P("l_mass"), P("temps"), _microturbulence_cgs(stellar_model), d_doppler.ptr)
+    d_F, d_total = ctx.empty((nd, nus.size)), ctx.empty((nd, nus.size))
+    d_line = ctx.empty((nd, nus.size)) if n_lines else None
+    ctx.call("sdx_synthesize_dev", nd, nus.size, P("nus"), 0, nus.size, n_lines, P("l_nu"), d_doppler.ptr if n_lines else None,
+             d_gamma.ptr if n_lines else None, nd, P("l_alpha"), C.byref(c), int(config.no_of_thetas), P("temps"), P("ray"), P("wts"),
+             d_line.ptr if n_lines else None, d_total.ptr, d_F.ptr, nus.size, None)
+    field.F_nu = np.empty((nd, nus.size))
+    _lib.check(ctx.lib.sdx_memcpy_d2h(ctx.handle, field.F_nu.ctypes.data, d_F.ptr, field.F_nu.nbytes))
+    opac._total_twin = d_total
+    field._device_blob = blob  # keeps the staged inputs alive as long as the lazy entries may need them
+
+    # ---- dictionary entries, the reference's keys in the reference's order (:655-738); planes on first read
+    entries = opac.opacities_dict
+    put = lambda key, value: dict.__setitem__(entries, key, value)  # noqa: E731
+
+    def twin(dev):
+        def make():
+            host_array = B._download(dev)
+            return host_array
+        return _Thunk(make)
+
+    def remembered(key, make):
+        def run():
+            value = make()
+            t = B.device_twin(value)
+            if t is not None:
+                opac._remember(key, value, t)
+            return value
+        return _Thunk(run)
+
+    fnus = field.frequencies
+    for source, fpath in opacity.file.items():
+        put(f"alpha_file_{source}", remembered(f"alpha_file_{source}", lambda s=source, f=fpath: B.calc_alpha_file(stellar_plasma, stellar_model, fnus, s, f)))
+    put("alpha_bf", remembered("alpha_bf", lambda: B.calc_alpha_bf(stellar_plasma, stellar_model, fnus, opacity.bf)))
+    put("alpha_ff", remembered("alpha_ff", lambda: B.calc_alpha_ff(stellar_plasma, stellar_model, fnus, opacity.ff)))
+    put("alpha_rayleigh", remembered("alpha_rayleigh", lambda: B.calc_alpha_rayleigh(stellar_plasma, stellar_model, fnus, opacity.rayleigh)))
+    put("alpha_electron", 0 if opacity.disable_electron_scattering else remembered(
+        "alpha_electron", lambda: B.calc_alpha_electron(stellar_plasma, stellar_model, fnus, False)))
+    if opacity.line.disable:
+        put("alpha_line_at_nu", 0), put("alpha_line_at_nu_gammas", 0), put("alpha_line_at_nu_doppler_widths", 0)
+    elif n_lines:
+        put("alpha_line_at_nu", twin(d_line))
+        put("alpha_line_at_nu_gammas", _Thunk(d_gamma.numpy))
+        put("alpha_line_at_nu_doppler_widths", _Thunk(d_doppler.numpy))
+    else:  # no line on the grid: what the general path returns for an empty selection
+        put("alpha_line_at_nu", np.zeros((nd, nus.size)))
+        put("alpha_line_at_nu_gammas", np.zeros((0, nd))), put("alpha_line_at_nu_doppler_widths", np.zeros((0, nd)))
+    return field

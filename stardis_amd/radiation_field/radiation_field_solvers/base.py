@@ -17,22 +17,25 @@ def calc_weights_parallel(delta_tau):
 calc_weights = calc_weights_parallel  # the reference keeps an unused numpy twin (:50-82) with the same contract
 
 
-def _check_source_function(source_function):
-    name = getattr(source_function, "__name__", "")
-    if source_function is not None and name != "blackbody_flux_at_nu":
-        raise NotImplementedError(
-            "the GPU formal solver evaluates the Planck source function in-kernel; "
-            f"source_function={name!r} is not supported (the reference only ever passes blackbody_flux_at_nu)"
-        )
+def _source_plane(source_function, tracing_nus, temps):
+    """None for the Planck function (evaluated inside the kernel), else the caller's source function evaluated on the host
+    the way the reference calls it — source_function(tracing_nus, temps) with temps shaped (N_d, 1), :133 — as a plain
+    (N_d, N_nu) array for the kernel to read."""
+    if source_function is None or getattr(source_function, "__name__", "") == "blackbody_flux_at_nu":
+        return None
+    nus = np.asarray(plain(tracing_nus), dtype=np.float64).reshape(-1)
+    t = np.asarray(plain(temps), dtype=np.float64).reshape(-1, 1)
+    plane = np.asarray(plain(source_function(nus, t)), dtype=np.float64)
+    return np.ascontiguousarray(np.broadcast_to(plane, (t.size, nus.size)))
 
 
 def single_theta_trace_parallel(ray_dist_to_next_depth_point, temps, alphas, tracing_nus, source_function=None,
                                 inward_rays=False):
     """Specific intensity (N_d, N_nu) along one ray direction.  Reference :85-268; inward_rays adds the
     surface-to-centre sweep of spherical geometry (:141-198) before the outward pass."""
-    _check_source_function(source_function)
     rd = np.asarray(plain(ray_dist_to_next_depth_point), dtype=np.float64).reshape(-1, 1)
-    _, I = ops.raytrace_arrays(tracing_nus, temps, rd, np.ones(1), alphas, track=True, inward_rays=bool(inward_rays), want_flux=False)
+    _, I = ops.raytrace_arrays(tracing_nus, temps, rd, np.ones(1), alphas, track=True, inward_rays=bool(inward_rays), want_flux=False,
+                               source=_source_plane(source_function, tracing_nus, temps))
     return I[:, :, 0]
 
 
@@ -56,7 +59,6 @@ def raytrace(stellar_model, stellar_radiation_field):
     """Trace every angle and accumulate the Gauss-Legendre flux sum into stellar_radiation_field.F_nu
     (in place, like the reference :324-338).  Fills I_nus when track_individual_intensities is set."""
     field = stellar_radiation_field
-    _check_source_function(getattr(field, "source_function", None))
     thetas = np.asarray(field.thetas, dtype=np.float64)
     correction = 1.0
     if stellar_model.spherical:  # :296-300, :340-344
@@ -75,6 +77,7 @@ def raytrace(stellar_model, stellar_radiation_field):
     F, I = ops.raytrace_arrays(
         field.frequencies, plain(stellar_model.temperatures), ray_distances, field.I_nus_weights, alphas, F_nu=f_in,
         track=track, ctx=ctx, inward_rays=bool(stellar_model.spherical), photospheric_correction=correction,
+        source=_source_plane(getattr(field, "source_function", None), field.frequencies, stellar_model.temperatures),
     )
     field.F_nu[...] = F
     if track:

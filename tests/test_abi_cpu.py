@@ -109,3 +109,20 @@ def test_host_side_tables_match_reference():
         tab = json.load(fh)
     sig = np.interp(g["opt_lambdas"], tab["wavelength"], tab["cross_section"])
     assert np.array_equal(sig * g["n_hminus"][:, None], g["opt_alpha_file_Hminus_bf"])
+
+
+def test_group_entry_fails_loudly_without_rccl_or_devices():
+    """sdx_group_create on a box without GPUs: RCCL is opened first (a missing library is SDX_ERR_COMM = -3), then the devices
+    are checked (SDX_ERR_ARG = -1).  Nothing falls back to one device or to the CPU."""
+    import subprocess
+    import sys
+
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from stardis_amd import _lib\nlib = _lib.load()\n"
+            "h = lib.sdx_group_create(1, None)\nprint('HANDLE', h, 'CODE', lib.sdx_last_error_code(), lib.sdx_last_error_string().decode())\n" % ROOT)
+    proc = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SDX_RCCL_LIB="/nonexistent/librccl.so.1"), capture_output=True, text=True,
+                          timeout=300)
+    assert "HANDLE None CODE -3" in proc.stdout and "RCCL not available" in proc.stdout, proc.stdout + proc.stderr
+    if _lib.load().sdx_device_count() == 0:
+        proc = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+        assert "HANDLE None CODE -1" in proc.stdout and "not visible" in proc.stdout, proc.stdout + proc.stderr

@@ -120,8 +120,8 @@ def test_full_size_properties(ctx):
 
 
 def test_indexed_wide_path_matches_direct_path_and_oracle(ctx):
-    """Long line lists go through dense per-depth lists (medium lines found by centre range, huge ones scanned);
-    forced here on a small list: same windows, same evaluations, results equal to the direct path up to the summation
+    """Long line lists go through the compact line lists (`wlist`: medium lines found by centre range through `wrank`;
+    `hlist`: huge ones scanned by every tile); forced here on a small list: same windows, same evaluations, results equal to the direct path up to the summation
     order (huge before medium instead of pure line order) and to the oracle within the opacity tolerance."""
     atm, nus, lines, cont, th, w = small_workload(n_lines=700, step=0.005, seed=21)
     ref = oracle.calc_alan_entries(56, nus, lines["line_nus"], lines["doppler_widths"], lines["gammas"], lines["alphas"])
