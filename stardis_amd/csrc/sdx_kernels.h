@@ -521,7 +521,7 @@ __global__ __launch_bounds__(kPreBlock) __attribute__((amdgpu_num_sgpr(80))) voi
 constexpr int kWideLdsDoubles = 64 * 8;  // per wave: R <= 8 partial sums per lane
 
 template <int R>
-__device__ __forceinline__ void wide_reduce_and_store(const int split, const int n_split, double (&acc)[R], const int (&idx)[R],
+__device__ __forceinline__ void wide_reduce_and_store(const int split, const int n_split, double (&acc)[R], const int (&idx)[R], const bool (&keep)[R],
                                                       double* __restrict__ lds_all, int64_t nu_begin, double* __restrict__ plane, int64_t pld,
                                                       const int d)
 {
@@ -544,7 +544,7 @@ __device__ __forceinline__ void wide_reduce_and_store(const int split, const int
     if (split == 0) {
 #pragma unroll
         for (int r = 0; r < R; ++r)
-            if (idx[r] >= 0) plane[(size_t)d * pld + (idx[r] - nu_begin)] = acc[r];
+            if (keep[r]) plane[(size_t)d * pld + (idx[r] - nu_begin)] = acc[r];
     }
 }
 
@@ -573,21 +573,38 @@ __device__ __forceinline__ void line_wide_walk(const int tile_idx, const int spl
                                                LineWork w, double* __restrict__ plane, int64_t pld, double* __restrict__ lds_all)
 {
     constexpr int kTile = 64 * R;
-    const int64_t t0 = nu_begin + (int64_t)tile_idx * kTile;
-    const int64_t t1 = min(t0 + kTile, nu_begin + nu_count);
+    // GLOBAL tiles: tile boundaries are multiples of kTile from grid index 0 whatever the shard, and a tile cut by a shard
+    // boundary is classified and evaluated whole (only the stores are masked).  How a (line, depth, tile) is treated — test-free,
+    // edge, core — and which four points of a lane share one reciprocal is then a property of the grid alone: a frequency shard
+    // produces the bits of the unsharded run.
+    const int64_t t0 = (nu_begin / kTile + (int64_t)tile_idx) * kTile;
+    const int64_t t1 = min(t0 + kTile, n_nu);
+    const int64_t s0 = nu_begin, s1 = nu_begin + nu_count;  // columns stored by this launch
     const int lane = threadIdx.x & 63;
     const int it0 = (int)t0, it1 = (int)t1;
 
-    // fp64 mode: the lane's frequencies as doubles.  Mixed mode: as hi + lo fp32 pairs only (the fp64 value is their exact
-    // sum to 2^-48, rebuilt on the rare general path), so that R = 8 points per lane fit the register budget
-    double nu_i[MIXED ? 1 : R], acc[R];
+    // fp64 mode: the lane's frequencies as offsets from the tile's first frequency (exact: neighbouring grid frequencies are
+    // within a factor of two), so that x = (nu_i - nu_l) / doppler is ONE instruction per point,
+    // x = fma(dnu_i, inv, c0) with c0 = (nu_base - nu_l) * inv formed once per (line, tile).  Mixed mode: hi + lo fp32 pairs only
+    // (the fp64 value is their exact sum to 2^-48, rebuilt on the rare general path), so that R = 8 points per lane fit the
+    // register budget
+    double dnu[MIXED ? 1 : R], acc[R];
     float2v nu_h[MIXED ? R / 2 : 1], nu_l[MIXED ? R / 2 : 1], acc32[MIXED ? R / 2 : 1];  // pairs of points (r, r + 1)
     int idx[R];
+    bool keep[R];
+    // (both halves through readfirstlane: the base is wave-uniform and ends up in an SGPR pair)
+    const double nu_base_v = nus[t0];
+    const double nu_base = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(nu_base_v)), __builtin_amdgcn_readfirstlane(__double2loint(nu_base_v)));
+    // ... and a copy pinned in a VGPR pair: c0 = (nu_base - nu_l) * inv takes the record's nu_l as its scalar operand (a VALU
+    // instruction reads one SGPR pair), otherwise the compiler moves nu_l into vector registers for every line it walks
+    double nu_base_vec = nu_base;
+    asm("" : "+v"(nu_base_vec));
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int64_t i = t0 + lane + r * 64;
         idx[r] = i < t1 ? (int)i : -1;
-        const double nu = i < t1 ? nus[i] : 0.0;
+        keep[r] = i >= s0 && i < s1;
+        const double nu = i < t1 ? nus[i] : nu_base;
         acc[r] = 0.0;
         if constexpr (MIXED) {
             const float h = (float)nu;
@@ -595,7 +612,7 @@ __device__ __forceinline__ void line_wide_walk(const int tile_idx, const int spl
             nu_l[r >> 1][r & 1] = (float)(nu - (double)h);
             acc32[r >> 1][r & 1] = 0.f;
         } else {
-            nu_i[r] = nu;
+            dnu[r] = nu - nu_base;
         }
     }
     const size_t row = (size_t)d * n_lines;
@@ -682,8 +699,8 @@ __device__ __forceinline__ void line_wide_walk(const int tile_idx, const int spl
                     } else {
                         const WideRec cur = rec_row[e];
                         const RegionI k1 = {cur.yk, cur.cv, cur.cd};
-#pragma unroll
-                        for (int r = 0; r < R; ++r) acc[r] = region1_add(acc[r], (nu_i[MIXED ? 0 : r] - cur.lnu) * cur.inv, k1);
+                        const double c0 = (nu_base_vec - cur.lnu) * cur.inv;
+                        region1_add_shared<R>(acc, dnu, cur.inv, c0, k1);
                     }
                     m = m1;
                 }
@@ -704,6 +721,7 @@ __device__ __forceinline__ void line_wide_walk(const int tile_idx, const int spl
                     const bool delegated = jc < 0;
                     const int jclo = delegated ? -jc - 1 : jc;
                     const RegionI k1 = {cur.yk, cur.cv, cur.cd};
+                    const double c0 = (nu_base_vec - cur.lnu) * cur.inv;
                     float2v term32[MIXED ? R / 2 : 1];  // mixed mode: sum + fp32 rational of every point pair, once per hit
                     if constexpr (MIXED) {
 #pragma unroll
@@ -719,10 +737,10 @@ __device__ __forceinline__ void line_wide_walk(const int tile_idx, const int spl
                             if constexpr (MIXED) {  // the tolerance path evaluates window edges in fp32 too (pairs of blocks)
                                 acc32[r >> 1][r & 1] = take ? term32[r >> 1][r & 1] : acc32[r >> 1][r & 1];
                             } else {
-                                acc[r] = region1_add_if(acc[r], (nu_i[MIXED ? 0 : r] - cur.lnu) * cur.inv, k1, take);
+                                acc[r] = region1_add_if(acc[r], fma(dnu[MIXED ? 0 : r], cur.inv, c0), k1, take);
                             }
                         } else {
-                            const double nu_r = MIXED ? (double)nu_h[MIXED ? r >> 1 : 0][r & 1] + (double)nu_l[MIXED ? r >> 1 : 0][r & 1] : nu_i[MIXED ? 0 : r];
+                            const double nu_r = MIXED ? (double)nu_h[MIXED ? r >> 1 : 0][r & 1] + (double)nu_l[MIXED ? r >> 1 : 0][r & 1] : dnu[MIXED ? 0 : r] + nu_base;  // exact
                             const WideSlow sl = slow_row[e];
                             if (idx[r] >= jlo && idx[r] < jhi) acc[r] = voigt_add(acc[r], nu_r - cur.lnu, cur.inv, sl.y, sl.amp, k1);
                         }
@@ -745,7 +763,7 @@ __device__ __forceinline__ void line_wide_walk(const int tile_idx, const int spl
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] += (double)acc32[r >> 1][r & 1];
     }
-    wide_reduce_and_store<R>(split, n_split, acc, idx, lds_all, nu_begin, plane, pld, d);
+    wide_reduce_and_store<R>(split, n_split, acc, idx, keep, lds_all, nu_begin, plane, pld, d);
 }
 
 // Long line lists: two stable compactions of the per-line classes in two small launches (per-block counts, then every

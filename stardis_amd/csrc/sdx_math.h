@@ -190,6 +190,38 @@ __device__ __forceinline__ double region1_add(double acc, double x, const Region
     asm("v_fma_f64 %0, %1, %2, %0" : "+v"(acc) : "v"(num), "v"(r));
     return acc;
 }
+// R region-I terms of ONE line at the R grid points of a lane (a test-free tile of the wide role) with ONE refined reciprocal
+// between them: r = 1 / (d0 d1 d2 d3), then 1/d0 = (r d2 d3) d1 ... — three products, the reciprocal (a quarter-rate
+// instruction and its three refinement FMAs) and six more products where four separate reciprocals cost sixteen instructions,
+// four of them quarter-rate.  x comes from the lane's frequency OFFSETS within the tile, x = fma(dnu, inv, c0) with
+// c0 = (nu_base - nu_l) * inv formed once per (line, tile): one instruction per point instead of two.  The denominators are
+// >= 1e4 (|x| + y > 15) and <= ~1e24 (a window spanning the whole optical grid): their product stays far inside the exponent
+// range.  Each factor is within 1 ulp, the terms within ~3 ulp of region1_add's; which points share a reciprocal is fixed by
+// the grid (global tiles), so the bits do not depend on sharding.
+template <int R>
+__device__ __forceinline__ void region1_add_shared(double (&acc)[R], const double (&dnu)[R], double inv, double c0, const RegionI& k)
+{
+    static_assert(R == 4 || R == 8, "four points share a reciprocal");
+#pragma unroll
+    for (int q = 0; q < R; q += 4) {
+        double den[4], num[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double x = fma(dnu[q + j], inv, c0);
+            const double v = fma(x, x, k.cv);
+            den[j] = fma(v, v, k.cd);
+            num[j] = fma(k.yk, v, k.yk);
+        }
+        const double p01 = den[0] * den[1], p23 = den[2] * den[3];
+        const double r = recip(p01 * p23);
+        const double r01 = r * p23, r23 = r * p01;  // 1 / (d0 d1), 1 / (d2 d3)
+        const double i0 = r01 * den[1], i1 = r01 * den[0], i2 = r23 * den[3], i3 = r23 * den[2];
+        asm("v_fma_f64 %0, %1, %2, %0" : "+v"(acc[q + 0]) : "v"(num[0]), "v"(i0));
+        asm("v_fma_f64 %0, %1, %2, %0" : "+v"(acc[q + 1]) : "v"(num[1]), "v"(i1));
+        asm("v_fma_f64 %0, %1, %2, %0" : "+v"(acc[q + 2]) : "v"(num[2]), "v"(i2));
+        asm("v_fma_f64 %0, %1, %2, %0" : "+v"(acc[q + 3]) : "v"(num[3]), "v"(i3));
+    }
+}
 // the same where only some lanes take the term: the others add num * 0 (num is finite whatever x is; the reciprocal may
 // not be — v can vanish next to a line centre, where callers pass take = false)
 __device__ __forceinline__ double region1_add_if(double acc, double x, const RegionI& k, bool take)

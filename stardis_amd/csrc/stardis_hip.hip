@@ -854,7 +854,9 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
     if (rc) return rc;
     double* part = (double*)ctx->part_ws;
     const int64_t pld = nu_count;
-    const int tiles = (int)((nu_count + 64 * Rm - 1) / (64 * Rm));
+    // tiles are aligned to the GLOBAL grid (multiples of 64 Rm points from index 0), whatever the shard: which points share a
+    // tile — and with it how a (line, depth, tile) is classified and which points share a reciprocal — is a property of the grid
+    const int tiles = (int)((nu_begin + nu_count + 64 * Rm - 1) / (64 * Rm) - nu_begin / (64 * Rm));
     const int64_t n_wide = (int64_t)tiles * n_depth;
     // workgroups of n_split waves, rounded up to whole rounds of the XCD-aware order (surplus workgroups return at once)
     const int64_t n_narrow = (((nu_count * ((n_depth + 63) / 64) + n_split - 1) / n_split + 31) / 32) * 32;
