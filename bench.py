@@ -10,8 +10,11 @@ through torch.distributed.run, before anything in this process touches the GPU) 
 One "step" = one full pass of the hot path over inputs already resident in HBM: window pre-pass + line opacity
 (Voigt/Faddeeva over the whole line list) + continuum (H- bf table, H I bf/ff, Thomson) + total + LTE formal solution
 over N_theta angles -> F_nu (N_d, N_nu).  Metric: spectral points per second = N_nu * N_depth * steps / time
-(BASELINE.json).  `value` is measured on BASELINE configs[1] (S-c2) — weak scaling at N GPUs: fixed points per GPU, the
-window's resolving power grows with N; every step ends with ONE all-gather of the emergent flux (RCCL).
+(BASELINE.json).  At N = 1 `value` is measured on BASELINE configs[1] (S-c2, the 1-GPU config).  At N > 1 it is BASELINE
+configs[2] — S-c3, the fixed 3000-10000 A grid (120 398 frequencies, 1.5e5 lines) split N ways in shards of equal estimated
+work, `scaling: "strong"`; every step ends with ONE all-gather of the emergent flux (RCCL); `n1_same_workload` carries the
+one-GPU step of the same workload measured in the same run, `collective` what torch.distributed actually ran, `per_rank` every
+rank's shard and kernel times.  (--workload / --scaling override both, e.g. --workload S-c2 --scaling weak.)
 
 Besides `value` the JSON line carries
   roofline              HBM roofline of the dominant kernel (live HIP-event durations), traffic from profiles/
@@ -19,7 +22,7 @@ Besides `value` the JSON line carries
   cpu_baseline          the oracle (reference algorithm restated in C) on this box's host cores: one_core / best / all_cores
   secondary             BASELINE configs[2] and [3] at full size (S-c3: 1.5e5 lines, S-c4m: 1e6 lines): step time, per-kernel
                         times, Voigt evaluations/s, strided-column parity against the oracle
-  strong                (N > 1) BASELINE configs[2] split N ways in shards of equal estimated work
+  secondary also holds  S-c5 (configs[4]: fp32-mixed synthesis + LSF + rotation on the device) and S-c4m-linelist (f1 inputs)
   dropin                wall time of the reference-shaped call path (RadiationField + calc_alphas + raytrace) at configs[0] and S-c2
 
 Prints ONE JSON line on rank 0.
@@ -42,7 +45,7 @@ FP64_VECTOR_PEAK_TFLOPS = 78.6
 # measured = what scripts/fp64_peak.hip sustains on this part (55 TFLOP/s of FMA at 8 waves per SIMD)
 FP64_VALU_SPEC = 256 * 4 * 2.4e9 / 4
 FP64_VALU_MEASURED = 439.0e9
-KERNELS = ("k_dnu_partial", "k_classify", "k_prepass_continuum", "k_line_prepass", "k_hlist", "k_line_all", "k_line_wide",
+KERNELS = ("k_dnu_partial", "k_classify", "k_prepass_continuum", "k_line_prepass", "k_hlist", "k_gather", "k_line_all", "k_line_wide",
            "k_line_narrow", "k_reduce_partials", "k_total_alphas", "k_raytrace")
 
 
@@ -235,19 +238,21 @@ def secondary_block(tag, device, steps, check):
     }
     if parity is not None:
         out["parity_vs_cpu_oracle"] = parity
+    valu = profiled_valu(tag, kern)
+    if valu is not None:
+        out["roofline_fp64_valu"] = valu
     syn.close()
     ctx.close()
     return out
 
 
 def dropin_block(device, check):
-    """Wall time of the reference-shaped call path on a pandas stand-in for the plasma (synth.fake_plasma): what a user of
-    create_stellar_radiation_field pays, host buffers in and out through the C ABI, beside the oracle on the same arrays."""
+    """Wall time of the reference-shaped call on a pandas stand-in for the plasma (synth.fake_plasma): what a user of
+    create_stellar_radiation_field (stardis/radiation_field/base.py:71-117) pays, host objects in, F_nu on the host out —
+    as one fused device pass with lazily materialised dictionary entries (the default), and source by source with every
+    dictionary entry downloaded (`general_path_ms`: RadiationField + calc_alphas + raytrace), beside the oracle on the same arrays."""
+    import stardis_amd.radiation_field.base as rf
     from stardis_amd import synth
-    from stardis_amd.radiation_field import RadiationField
-    from stardis_amd.radiation_field.opacities.opacities_solvers import calc_alphas
-    from stardis_amd.radiation_field.radiation_field_solvers import raytrace
-    from stardis_amd.radiation_field.source_functions.blackbody import blackbody_flux_at_nu
 
     out = {}
     for label, tag, n_lines in (("configs[0] (1000-point grid)", "S-c1", 2000), ("S-c2", "S-c2", 2000)):
@@ -256,19 +261,27 @@ def dropin_block(device, check):
         nus = synth.tracing_grid(cfg["lam0"], cfg["lam1"], cfg.get("R"), cfg.get("step"))
         plasma, model, config, arrays = synth.fake_plasma(nus, atm, n_lines, synth.SEED)
 
-        def one():
-            field = RadiationField(nus.copy(), blackbody_flux_at_nu, model, synth.N_THETAS)
-            calc_alphas(plasma, model, field, config.opacity)
-            raytrace(model, field)
-            return field
+        def bench_path(fused, n=6):
+            was = rf.FUSED
+            rf.FUSED = fused
+            try:
+                times = []
+                for _ in range(n):
+                    t0 = time.perf_counter()
+                    field = rf.create_stellar_radiation_field(nus.copy(), model, plasma, config)
+                    times.append(time.perf_counter() - t0)
+            finally:
+                rf.FUSED = was
+            return times, field
 
-        times = []
-        for _ in range(4):
-            t0 = time.perf_counter()
-            field = one()
-            times.append(time.perf_counter() - t0)
+        times, field = bench_path(True)
+        gen_times, gen_field = bench_path(False, 4)
         entry = {"n_nu": int(nus.size), "n_lines": int(n_lines), "first_call_ms": times[0] * 1e3, "steady_ms": min(times[1:]) * 1e3,
-                 "spectral_points_per_s": nus.size * 56 / min(times[1:])}
+                 "spectral_points_per_s": nus.size * 56 / min(times[1:]), "path": type(field.opacities).__name__,
+                 "general_path_ms": min(gen_times[1:]) * 1e3, "fused_equals_general_bit_for_bit": bool(np.array_equal(field.F_nu, gen_field.F_nu))}
+        t0 = time.perf_counter()
+        _ = field.opacities.total_alphas, [v for v in field.opacities.opacities_dict.values()]
+        entry["materialise_every_dictionary_entry_ms"] = (time.perf_counter() - t0) * 1e3
         if check:
             import oracle
 
@@ -308,14 +321,15 @@ def profiled_traffic(workload, kernel):
 
 
 def kernel_matches(short, full):
-    alias = {"k_raytrace": ("k_raytrace", "k_formal")}
+    alias = {"k_raytrace": ("k_raytrace", "k_formal"), "k_hlist": ("k_hlist", "k_hscan"), "k_gather": ("k_line_prepass",)}
     return any(a in full for a in alias.get(short, (short,)))
 
 
 def profiled_valu(workload, kern):
     """The bound that actually limits this path: fp64 VALU issue.  Wave-level VALU instructions per step from the newest
     committed SQ_INSTS_VALU pass over the kernel time measured live in this run — reported only when the committed pass
-    covers exactly the kernels that ran here (same names, same launches per step); otherwise the figure would silently lie."""
+    covers exactly the kernels that ran here (same names, same launches per step); otherwise the figure would silently lie.
+    `per_kernel` gives the same ratio kernel by kernel."""
     path, rows = _profile_rows(workload, "SQ")
     # runtime-internal copy / fill kernels (input uploads of the profiled script) are not part of a step
     rows = [r for r in rows if r["Counter_Name"] == "SQ_INSTS_VALU" and not r["Kernel_Name"].startswith("__amd_rocclr_")]
@@ -324,22 +338,24 @@ def profiled_valu(workload, kern):
     by_kernel = {}
     for r in rows:
         by_kernel.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
-    insts, t_ms = 0.0, 0.0
+    insts, t_ms, per_kernel = 0.0, 0.0, {}
     for name, ms in kern.items():
         matches = [v for k, v in by_kernel.items() if kernel_matches(name, k)]
-        if len(matches) != 1:
-            return {"skipped": f"profiles/{os.path.basename(path)} does not cover kernel {name} exactly once: re-profile after changing the kernels"}
-        insts += sum(matches[0]) / len(matches[0])
+        if not matches:
+            return {"skipped": f"profiles/{os.path.basename(path)} does not cover kernel {name}: re-profile after changing the kernels"}
+        n_inst = sum(sum(v) / len(v) for v in matches)  # a short name may cover several device kernels (k_hlist: count + scatter)
+        insts += n_inst
         t_ms += ms
-    counts = {len(v) for v in by_kernel.values()}
+        per_kernel[name] = {"valu_wave_instr": n_inst, "ms": ms, "G_wave_instr_per_s": n_inst / (ms * 1e-3) / 1e9,
+                            "frac_of_spec": n_inst / (ms * 1e-3) / FP64_VALU_SPEC, "frac_of_measured": n_inst / (ms * 1e-3) / FP64_VALU_MEASURED}
     extra = [k for k in by_kernel if not any(kernel_matches(n, k) for n in kern)]
-    if len(counts) != 1 or extra:
-        return {"skipped": f"profiles/{os.path.basename(path)} holds other kernels or uneven launch counts ({sorted(extra)[:2]}): re-profile"}
+    if extra:
+        return {"skipped": f"profiles/{os.path.basename(path)} holds kernels this run did not launch ({sorted(extra)[:2]}): re-profile"}
     achieved = insts / (t_ms * 1e-3)
     return {"bound": "fp64-valu-issue", "achieved": achieved / 1e9, "unit": "G wave-instr/s",
             "peak_spec": FP64_VALU_SPEC / 1e9, "frac_of_spec": achieved / FP64_VALU_SPEC,
             "peak_measured": FP64_VALU_MEASURED / 1e9, "frac_of_measured": achieved / FP64_VALU_MEASURED,
-            "valu_wave_instr_per_step": insts, "kernel_ms_per_step": t_ms, "source": os.path.basename(path),
+            "valu_wave_instr_per_step": insts, "kernel_ms_per_step": t_ms, "per_kernel": per_kernel, "source": os.path.basename(path),
             "note": "peak_spec = 256 CU x 4 SIMD x 2.4 GHz / 4 cycles per wave64 fp64 instruction; peak_measured = scripts/fp64_peak.hip on this part"}
 
 
@@ -398,9 +414,16 @@ class Runner:
             syn.close()
 
 
-def timed(runner, steps, warmup, world, local, settle_s=0.5):
+def timed(runner, steps, warmup, world, local, settle_s=0.5, cold=True):
+    """-> dict(elapsed = max over ranks of the K timed steps after warm-up + settling, local = this rank's own time for them
+    (before the closing barrier), cold = max over ranks of K steps timed right after the W requested warm-up steps, settle = number
+    of untimed settling steps)."""
+    import gc
+
     import torch
     import torch.distributed as dist
+
+    dev = f"cuda:{local}" if (world > 1 and dist.get_backend() == "nccl") else "cpu"
 
     def fence():
         torch.cuda.synchronize()
@@ -408,10 +431,34 @@ def timed(runner, steps, warmup, world, local, settle_s=0.5):
             dist.barrier()
         torch.cuda.synchronize()
 
+    def rank_max(x, dtype):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=dtype, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.item()
+
+    def run(k):
+        gc_was_on = gc.isenabled()
+        gc.disable()  # a collection pause between two enqueues leaves the device idle for longer than a step takes
+        t0 = time.perf_counter()
+        for _ in range(k):
+            runner.step()
+        runner.drain()
+        torch.cuda.synchronize()
+        t_local = time.perf_counter() - t0
+        fence()
+        t_all = time.perf_counter() - t0
+        if gc_was_on:
+            gc.enable()
+        return float(rank_max(t_all, torch.float64)), t_local
+
     for _ in range(warmup):
         runner.step()
     runner.drain()
     fence()
+    # the K steps right after the W requested warm-up steps: clocks still ramping (reported as ms_per_step_cold)
+    t_cold = run(steps)[0] if cold else None
     # clocks and caches settle over the first tenths of a second of work: a short --steps run would otherwise time the ramp
     # (measured: 20 timed steps right after 0.1 s of settling varied between 102 and 116 us per step from run to run)
     # (untimed extra steps; the same number on every rank)
@@ -420,32 +467,154 @@ def timed(runner, steps, warmup, world, local, settle_s=0.5):
     runner.drain()
     torch.cuda.synchronize()
     one = max(time.perf_counter() - t0, 1e-6)
-    extra = int(min(10000, settle_s / one))
-    if world > 1:
-        t = torch.tensor([extra], dtype=torch.int64, device=f"cuda:{local}" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        extra = int(t.item())
+    extra = int(rank_max(int(min(10000, settle_s / one)), torch.int64))
     for _ in range(extra):
         runner.step()
     runner.drain()
     fence()
-    import gc
+    elapsed, t_local = run(steps)
+    return dict(elapsed=elapsed, local=t_local, cold=t_cold, settle=extra + 1)
 
-    gc_was_on = gc.isenabled()
-    gc.disable()  # a collection pause between two enqueues leaves the device idle for longer than a step takes
+
+def n1_same_workload(w, local, steps, use_graph):
+    """The whole grid of `w` on ONE GPU (this rank's), graph-replayed like the timed loop: the denominator of the strong-scaling
+    speed-up, measured in the same process and run."""
+    import torch
+
+    from stardis_amd import _lib
+    from stardis_amd.engine import SpectralSynthesizer
+
+    atm, nus = w["atm"], w["nus"]
+    ctx = _lib.Context(local)
+    syn = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], w["thetas"], w["weights"], w["lines"], w["cont"], ctx=ctx,
+                              track_evaluations=False, keep_line=False)
+    if use_graph:
+        syn.capture()
+    t_end = time.perf_counter() + 0.3
+    n = 0
+    while n < 3 or time.perf_counter() < t_end:
+        syn.step()
+        ctx.synchronize()
+        n += 1
     t0 = time.perf_counter()
     for _ in range(steps):
-        runner.step()
-    runner.drain()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if gc_was_on:
-        gc.enable()
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    return elapsed, extra + 1
+        syn.step()
+    ctx.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    syn.close()
+    ctx.close()
+    torch.cuda.synchronize()
+    return {"ms_per_step": ms, "value": nus.size * atm["temperatures"].size / (ms * 1e-3), "steps": steps,
+            "how": "the unsharded grid on rank 0's GPU, same process, after the timed region (other ranks wait at a barrier)"}
+
+
+def collective_info(world, runner):
+    import torch
+    import torch.distributed as dist
+
+    if world == 1:
+        return None
+    info = {"op": "all_gather_into_tensor of the zero-padded F_nu[-1] shards", "backend": dist.get_backend(), "world_size_seen_by_dist": dist.get_world_size(),
+            "bytes_per_rank": int(runner.lanes[0][2].per * 8), "overlapped_with_next_step": bool(runner.overlap)}
+    if dist.get_backend() == "nccl":
+        try:
+            info["nccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:  # noqa: BLE001
+            pass
+    return info
+
+
+def s_c5_block(device, steps, check):
+    """BASELINE configs[4]: the full solar spectrum synthesised with the fp32-mixed tolerance path, then F_lambda, the instrumental
+    LSF and the rotational kernel on the device (postprocess.DeviceSpectrum) — step + chain timed, parity of the mixed spectrum
+    against the fp64 one in the line."""
+    from stardis_amd import _lib, postprocess, synth
+    from stardis_amd import constants as K
+    from stardis_amd.engine import SpectralSynthesizer
+
+    tag = "S-c5"
+    cfg = synth.WORKLOADS[tag]
+    w = synth.make_workload(tag)
+    atm, nus = w["atm"], w["nus"]
+    fwhm_pix = cfg["R"] / cfg["lsf_resolution"]
+    sigma_pix, vel_per_pix = fwhm_pix / 2.355, K.C_KMS / cfg["lsf_resolution"] / fwhm_pix
+    res = {}
+    for mode in ((0, 1) if check else (1,)):
+        ctx = _lib.Context(device)
+        ctx.set_option("mixed_precision", mode)
+        syn = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], w["thetas"], w["weights"], w["lines"], w["cont"], ctx=ctx,
+                                  track_evaluations=False, keep_line=False, keep_total=False)
+        syn.capture()
+        spec = postprocess.DeviceSpectrum(syn)
+
+        def chain():
+            syn.step()
+            return spec.broadened(sigma_pix=sigma_pix, velocity_per_pix=vel_per_pix, v_rot=cfg["v_rot_kms"])
+
+        for _ in range(3):
+            out = chain()
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            syn.step()
+        ctx.synchronize()
+        t_step = (time.perf_counter() - t0) / steps
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = chain()
+        ctx.synchronize()
+        t_chain = (time.perf_counter() - t0) / steps
+        res[mode] = dict(step_ms=t_step * 1e3, chain_ms=t_chain * 1e3, F=syn.F_nu()[-1], broad=out.numpy())
+        syn.close()
+        ctx.close()
+    m = res[1]
+    nd = atm["temperatures"].size
+    out = {"workload": synth_desc(tag).replace("fp64", "fp32-mixed line opacity (stated tolerance 1e-4 on the flux), fp64 continuum and formal solution")
+           + f"; then F_lambda, Gaussian LSF (R = {cfg['lsf_resolution']:.0f}) and rotation (v sin i = {cfg['v_rot_kms']:.0f} km/s) on the device",
+           "n_nu": int(nus.size), "steps": steps, "ms_per_step_synthesis": m["step_ms"], "ms_per_step_with_postprocessing": m["chain_ms"],
+           "spectral_points_per_s": nus.size * nd / (m["chain_ms"] * 1e-3)}
+    if 0 in res:
+        f = res[0]
+        out["fp64_ms_per_step_synthesis"] = f["step_ms"]
+        out["mixed_vs_fp64"] = {"emergent_flux_max_rel_err": float(np.max(np.abs(m["F"] - f["F"]) / np.abs(f["F"]))),
+                                "broadened_spectrum_max_rel_err": float(np.max(np.abs(m["broad"] - f["broad"]) / np.abs(f["broad"]))),
+                                "stated_tolerance": 1e-4, "speedup_of_the_step": f["step_ms"] / m["step_ms"]}
+    return out
+
+
+def linelist_block(tag, device, steps):
+    """SURVEY §8 f1 at the size it exists for: the line list as ~100 B of scalars per line, alpha / gamma / Doppler width generated
+    in the pre-pass, beside the dense-input step of the same workload (secondary[tag])."""
+    from stardis_amd import _lib
+    from stardis_amd.engine import SpectralSynthesizer
+
+    w = build_workload(tag, 1, "linelist")
+    atm, nus = w["atm"], w["nus"]
+    ctx = _lib.Context(device)
+    syn = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], w["thetas"], w["weights"], w["lines"], w["cont"], ctx=ctx,
+                              track_evaluations=False, keep_line=False)
+    syn.step()
+    ctx.synchronize()
+    kern = kernel_times(ctx, syn, 5)
+    syn.capture()
+    for _ in range(2):
+        syn.step()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        syn.step()
+    ctx.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    nd = atm["temperatures"].size
+    dense_bytes = 8 * syn.n_lines * (1 + 2 * nd + syn.gamma_cols)
+    list_bytes = syn.n_lines * syn.linelist.host.bytes_per_line() + 8 * syn.linelist.host.pop.size
+    out = {"workload": synth_desc(tag) + ", line list as per-line scalars (parameters generated on the device)", "n_lines": int(syn.n_lines),
+           "steps": steps, "ms_per_step": ms, "spectral_points_per_s": nus.size * nd / (ms * 1e-3), "avg_kernel_ms": kern,
+           "line_list_bytes": int(list_bytes), "dense_tables_bytes": int(dense_bytes), "hbm_bytes_saved": int(dense_bytes - list_bytes),
+           "algorithmic_bytes": int(syn.algorithmic_bytes())}
+    syn.close()
+    ctx.close()
+    return out
 
 
 def main():
@@ -453,16 +622,20 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="S-c2")
+    ap.add_argument("--workload", default=None, help="default: S-c2 (BASELINE configs[1]) on one GPU, S-c3 (configs[2]) on several")
     ap.add_argument("--inputs", choices=("dense", "linelist"), default="dense",
                     help="line list as the reference's dense (N_l, N_d) tables, or as per-line scalars expanded on the device")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
-                    help="what `value` measures at N > 1. weak (default): fixed grid points per GPU; strong: the workload's grid split across "
-                         "the GPUs in shards of equal estimated work (stardis_amd.parallel.balanced_shards)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=None,
+                    help="what `value` measures at N > 1. strong (default): the workload's grid split across the GPUs in shards of equal "
+                         "estimated work (stardis_amd.parallel.balanced_shards); weak: fixed grid points per GPU (N x the resolving power)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip every leg that runs the CPU oracle (baseline and parity checks)")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the S-c3 / S-c4m / strong / drop-in blocks")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the S-c3 / S-c4m / S-c5 / drop-in blocks")
     args = ap.parse_args()
+    if args.workload is None:
+        args.workload = "S-c2" if args.gpus == 1 else "S-c3"
+    if args.scaling is None:
+        args.scaling = "weak" if args.gpus == 1 else "strong"
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args, sys.argv[1:]))
@@ -494,22 +667,23 @@ def main():
     # of step k+1; a buffer is reused only after its gather has been waited for.  SDX_BENCH_SYNC_GATHER=1: blocking gather.
     overlap = os.environ.get("SDX_BENCH_SYNC_GATHER") != "1"
     runner = Runner(w, world, rank, local, ctx, args.scaling, not args.no_graph, overlap)
-    elapsed, settle = timed(runner, args.steps, args.warmup, world, local)
+    tm = timed(runner, args.steps, args.warmup, world, local)
+    elapsed, settle = tm["elapsed"], tm["settle"]
     syn, flux, count, evals = runner.syn, runner.flux, runner.count, runner.evals
     kern = kernel_times(ctx, syn, 20)
 
-    # strong scaling of BASELINE configs[2] (fixed 120 398-point grid split N ways), next to the weak-scaling `value`
-    strong = None
-    if world > 1 and not args.no_secondary and not (args.scaling == "strong" and args.workload == "S-c3"):
-        w3 = build_workload("S-c3", world, "dense", "strong")
-        r3 = Runner(w3, world, rank, local, ctx, "strong", not args.no_graph, overlap)
-        k3 = max(5, min(args.steps, 40))
-        e3, _ = timed(r3, k3, 3, world, local, settle_s=0.05)
-        if rank == 0:
-            strong = {"workload": synth_desc("S-c3"), "scaling": "strong", "n_gpus": world, "steps": k3, "ms_per_step": e3 / k3 * 1e3,
-                      "spectral_points_per_s": w3["nus"].size * nd * k3 / e3, "shards": [[int(b), int(c)] for b, c in (r3.shards or [])],
-                      "note": "shards of equal estimated work (parallel.column_cost + balanced_shards); speed-up = the N=1 S-c3 step time in `secondary` / this"}
-        r3.close()
+    # N > 1: what every rank did (shard, its own time for the timed steps, per-kernel times), gathered on rank 0, and the
+    # one-GPU step of the same workload on rank 0's GPU
+    per_rank, n1 = None, None
+    if world > 1:
+        mine = {"rank": rank, "device": local, "shard": [int(runner.begin), int(runner.count)], "ms_per_step_own": tm["local"] / args.steps * 1e3,
+                "avg_kernel_ms": kern}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+        if rank == 0 and args.scaling == "strong":
+            n1 = n1_same_workload(w, local, max(5, min(args.steps, 40)), not args.no_graph)
+        torch.cuda.synchronize()
+        dist.barrier()
 
     # secondary figure (not `value`): two independent syntheses in flight on two streams — what a parameter grid
     # of stars would use; each is still a full pass, they only overlap on the device
@@ -547,6 +721,8 @@ def main():
         }.get(dom, syn.algorithmic_bytes())
         achieved = alg_bytes / (kern[dom] * 1e-3) / 1e9
         line_ms = kern.get("k_line_all", 0.0) + kern.get("k_line_wide", 0.0) + kern.get("k_line_narrow", 0.0)
+        scaling_text = {"weak": "weak (fixed points per GPU: N x the resolving power on the same window)",
+                        "strong": "strong (BASELINE's fixed grid split N ways in shards of equal estimated work)"}[args.scaling]
         out = {
             "metric": "spectral points/sec (N_nu x N_depth)",
             "value": value,
@@ -555,6 +731,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
+            "ms_per_step_cold": (tm["cold"] / args.steps * 1e3) if tm["cold"] is not None else None,
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
@@ -562,7 +739,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": synth_desc(args.workload),
-                "scaling": args.scaling + (" (fixed points per GPU: N x the resolving power on the same window)" if args.scaling == "weak" else " (fixed grid split N ways)"),
+                "scaling": scaling_text if world > 1 else "one GPU",
                 "n_nu_global": int(nus.size),
                 "n_nu_per_gpu": int(count),
                 "n_depth": int(nd),
@@ -574,6 +751,7 @@ def main():
                 "line_inputs": args.inputs,
                 "outputs": "F_nu and total_alphas (N_d, N_nu); the optional alpha_line plane is not written",
                 "untimed_settle_steps_after_warmup": settle,
+                "ms_per_step_cold": "the same K steps timed right after the W requested warm-up steps, before the untimed settling (clocks still ramping)",
             },
             "roofline": {
                 "bound": "hbm",
@@ -591,6 +769,13 @@ def main():
                 "voigt_evaluations_per_s": (evals / world) / (line_ms * 1e-3) if line_ms else None,
             },
         }
+        if world > 1:
+            out["collective"] = collective_info(world, runner)
+            out["per_rank"] = per_rank
+            out["config"]["shards"] = [[int(b), int(c)] for b, c in (runner.shards or [])] or "equal blocks of ceil(N_nu / N)"
+            if n1 is not None:
+                out["n1_same_workload"] = n1
+                out["speedup_vs_n1"] = n1["ms_per_step"] / ms_per_step
         valu = profiled_valu(args.workload, kern) if world == 1 else None
         if valu is not None:
             out["roofline_fp64_valu"] = valu
@@ -605,11 +790,11 @@ def main():
             out["speedup_vs_cpu_baseline"] = value / base["value"]
         if pipelined is not None:
             out["throughput_two_syntheses_in_flight"] = pipelined
-        if strong is not None:
-            out["strong"] = strong
         if world == 1 and not args.no_secondary:
             runner.close()
             out["secondary"] = {tag: secondary_block(tag, local, 10, check) for tag in ("S-c3", "S-c4m")}
+            out["secondary"]["S-c5"] = s_c5_block(local, 10, check)
+            out["secondary"]["S-c4m-linelist"] = linelist_block("S-c4m", local, 10)
             out["dropin"] = dropin_block(local, check)
         print(json.dumps(out))
     if world > 1:

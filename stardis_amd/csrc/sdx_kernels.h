@@ -27,9 +27,17 @@ __device__ __forceinline__ void wave_sync()
 // d_nu = -max(diff(nus))  (opacities_solvers/base.py:524-526): partial maxima, finished by consumers.
 constexpr int kDnuPartials = 256;
 
+__device__ __forceinline__ void shard_range(int64_t n_nu, const double* __restrict__ nus, int64_t n_lines, const double* __restrict__ line_nus,
+                                            int64_t nu_begin, int64_t nu_count, int* __restrict__ sel);
+
 __global__ __launch_bounds__(kBlock) void k_dnu_partial(int64_t n_nu, const double* __restrict__ nus,
-                                                        double* __restrict__ partial, int* __restrict__ zero, int64_t n_zero)
+                                                        double* __restrict__ partial, int* __restrict__ zero, int64_t n_zero,
+                                                        int64_t n_lines, const double* __restrict__ line_nus, int64_t nu_begin, int64_t nu_count,
+                                                        int* __restrict__ sel)
 {
+    // culled pre-pass of a frequency shard: two threads of the LAST block find the shard's line range on the side (two binary
+    // searches — a chain of dependent loads that a launch of its own would spend 7 us on)
+    if (sel && blockIdx.x == gridDim.x - 1) shard_range(n_nu, nus, n_lines, line_nus, nu_begin, nu_count, sel);  // (four threads)
     // (culled pre-pass: the per-line maxima the classification pass accumulates into are cleared here, not by a memset node)
     for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < n_zero; k += (int64_t)gridDim.x * kBlock) zero[k] = 0;
     double m = -INFINITY;
@@ -177,16 +185,23 @@ struct LineWork {
     // long line lists: ascending indices of the lines whose widest window exceeds kMediumHalfWidth (they may reach any tile and
     // are scanned completely; all other lines are found by centre range).  nullptr for short lists (every line is scanned).
     int* hlist;
-    int* hcount;     // [0] entries of hlist, [1] entries of wlist
+    int* hcount;     // [0] entries of hlist, [1] entries of wlist, [2] entries of xlist
+    // frequency shards of long lists: the lines with a wide window whose centre lies within kMediumHalfWidth of the shard's
+    // columns but outside the blocks of consecutive lines the shard prepares anyway (centres within 2 kNarrowReach) — with
+    // hlist the lines the gather blocks of a culled pre-pass prepare.  nullptr otherwise.
+    int* xlist;
     // ... and the other lines with a wide window (kNarrowHalfWidth < widest window <= kMediumHalfWidth), ascending, with
     // wrank[l] = number of wlist entries below line l ([N_l + 1]): the lines centred near a tile are a contiguous range of
     // line indices (cnt_ge), hence a contiguous range [wrank[la], wrank[lb]) of wlist
     int* wlist;
     int* wrank;
     WideScan* hscan;  // [N_d][N_l] rows, entry k of row d = wscan[d][hlist[k]]: the huge lines' scan words, contiguous
-    // frequency-sharded runs of long lists: the pre-pass only has to prepare the lines this shard can touch — sel[0..1] = the
-    // index range [la, lb) of the lines whose centre lies within kMediumHalfWidth of the shard's columns (device memory,
-    // written by k_shard_range; nullptr: every line) — plus, in a second launch with gather = 1, the lines of hlist
+    // frequency-sharded runs of long lists: the pre-pass only has to prepare the lines this shard can touch.  sel (device
+    // memory, written on the side of k_dnu_partial; nullptr: every line): [0..1] = the index range [la, lb) of the lines whose
+    // centre lies within kMediumHalfWidth of the shard's columns — the only ones a medium window can reach it from;
+    // [2..3] = [na, nb), those within 2 kNarrowReach — every line there may touch the shard (narrow windows, delegated
+    // cores) and is prepared by the range blocks; outside [na, nb) only lines with a wide window matter: hlist (any distance)
+    // and xlist (within [la, lb)), prepared by the gather blocks
     const int* sel;
     int n_pix;      // pixel blocks (cnt_ge) behind the line blocks of the pre-pass grid
     int gather;     // gather blocks behind those: block g prepares hlist[g kPreLines ...] (0: none)
@@ -254,14 +269,20 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
     // which lines this block prepares: kPreLines consecutive ones, or — gather blocks — kPreLines consecutive entries of hlist
     __shared__ int s_l[kPreLines];
     int nl = (int)min((int64_t)kPreLines, n_lines - l0);
+    int n_h = 0;
     if (gather) {
-        const int n_h = *w.hcount;
-        if (l0 >= n_h) return;  // block-uniform
-        nl = min(kPreLines, n_h - (int)l0);
-        if (threadIdx.x < kPreLines) s_l[threadIdx.x] = threadIdx.x < nl ? w.hlist[l0 + threadIdx.x] : 0;
+        // the gather list: hlist, then xlist
+        n_h = w.hcount[0];
+        const int n_g = n_h + (w.xlist ? w.hcount[2] : 0);
+        if (l0 >= n_g) return;  // block-uniform
+        nl = min(kPreLines, n_g - (int)l0);
+        if (threadIdx.x < kPreLines) {
+            const int k = (int)l0 + threadIdx.x;
+            s_l[threadIdx.x] = threadIdx.x < nl ? (k < n_h ? w.hlist[k] : w.xlist[k - n_h]) : 0;
+        }
         __syncthreads();
     } else {
-        if (w.sel && (l0 + kPreLines <= w.sel[0] || l0 >= w.sel[1])) return;  // no line of this block can reach the shard
+        if (w.sel && (l0 + kPreLines <= w.sel[2] || l0 >= w.sel[3])) return;  // not a block of the shard's own line range
         if (threadIdx.x < kPreLines) s_l[threadIdx.x] = (int)(l0 + threadIdx.x);
         // (no barrier needed: the non-gather path indexes with l0 + ll directly)
     }
@@ -417,7 +438,7 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
             w.wscan[o] = sc;
             // a gather block knows its lines' positions in hlist: the list-ordered copy of the scan word is written here
             // (culled runs; otherwise k_hscan makes it once the list exists)
-            if (gather && w.hscan) w.hscan[(size_t)(d0 + dd) * n_lines + l0 + ll] = sc;
+            if (gather && w.hscan && l0 + ll < n_h) w.hscan[(size_t)(d0 + dd) * n_lines + l0 + ll] = sc;
         }
         // the second pass writes the NARROW arrays: a narrow item's window, or the delegated core of a wide item; the sign
         // bit of the stashed upper bound tells the two apart from "nothing for the narrow role"
@@ -773,47 +794,64 @@ __device__ __forceinline__ void line_wide_walk(const int tile_idx, const int spl
 constexpr int kHlistBlock = 1024;
 __device__ __forceinline__ int line_class(int whw) { return whw > kMediumHalfWidth ? 2 : (whw > kNarrowHalfWidth ? 1 : 0); }
 
-__global__ __launch_bounds__(kHlistBlock) void k_hlist_count(int64_t n_lines, const int* __restrict__ whw_max, int* __restrict__ block_cnt)
+// (xlist: the class-1 lines of [sel[0], sel[1]) outside the blocks of pre_lines consecutive lines that cover [sel[2], sel[3]))
+__device__ __forceinline__ bool in_xlist(int64_t l, int cls, const int* __restrict__ sel, int pre_lines)
 {
-    __shared__ int s_wave[2][kHlistBlock / 64];
+    if (!sel || cls != 1) return false;
+    const int ra = sel[2] / pre_lines * pre_lines, rb = (sel[3] + pre_lines - 1) / pre_lines * pre_lines;
+    return l >= sel[0] && l < sel[1] && !(sel[3] > sel[2] && l >= ra && l < rb);
+}
+
+__global__ __launch_bounds__(kHlistBlock) void k_hlist_count(int64_t n_lines, const int* __restrict__ whw_max, int* __restrict__ block_cnt,
+                                                            const int* __restrict__ sel, int pre_lines)
+{
+    __shared__ int s_wave[3][kHlistBlock / 64];
     const int64_t l = (int64_t)blockIdx.x * kHlistBlock + threadIdx.x;
     const int cls = l < n_lines ? line_class(whw_max[l]) : 0;
-    const unsigned long long mh = __ballot(cls == 2), mw = __ballot(cls == 1);
-    if ((threadIdx.x & 63) == 0) s_wave[0][threadIdx.x >> 6] = __popcll(mh), s_wave[1][threadIdx.x >> 6] = __popcll(mw);
+    const unsigned long long mh = __ballot(cls == 2), mw = __ballot(cls == 1), mx = __ballot(in_xlist(l, cls, sel, pre_lines));
+    if ((threadIdx.x & 63) == 0)
+        s_wave[0][threadIdx.x >> 6] = __popcll(mh), s_wave[1][threadIdx.x >> 6] = __popcll(mw), s_wave[2][threadIdx.x >> 6] = __popcll(mx);
     __syncthreads();
-    if (threadIdx.x < 2) {
+    if (threadIdx.x < 3) {
         int tot = 0;
         for (int k = 0; k < kHlistBlock / 64; ++k) tot += s_wave[threadIdx.x][k];
-        block_cnt[2 * blockIdx.x + threadIdx.x] = tot;
+        block_cnt[3 * blockIdx.x + threadIdx.x] = tot;
     }
 }
 __global__ __launch_bounds__(kHlistBlock) void k_hlist_scatter(int64_t n_lines, const int* __restrict__ whw_max, const int* __restrict__ block_cnt,
                                                               int* __restrict__ hlist, int* __restrict__ wlist, int* __restrict__ wrank,
-                                                              int* __restrict__ hcount)
+                                                              int* __restrict__ hcount, int* __restrict__ xlist, const int* __restrict__ sel,
+                                                              int pre_lines)
 {
-    __shared__ int s_wave[2][kHlistBlock / 64];
-    __shared__ int s_red[2][kHlistBlock / 64];
+    __shared__ int s_wave[3][kHlistBlock / 64];
+    __shared__ int s_red[3][kHlistBlock / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int bh = 0, bw = 0;
-    for (int k = threadIdx.x; k < (int)blockIdx.x; k += kHlistBlock) bh += block_cnt[2 * k], bw += block_cnt[2 * k + 1];
-    for (int off = 32; off > 0; off >>= 1) bh += __shfl_xor(bh, off), bw += __shfl_xor(bw, off);
+    int bh = 0, bw = 0, bx = 0;
+    for (int k = threadIdx.x; k < (int)blockIdx.x; k += kHlistBlock) bh += block_cnt[3 * k], bw += block_cnt[3 * k + 1], bx += block_cnt[3 * k + 2];
+    for (int off = 32; off > 0; off >>= 1) bh += __shfl_xor(bh, off), bw += __shfl_xor(bw, off), bx += __shfl_xor(bx, off);
     const int64_t l = (int64_t)blockIdx.x * kHlistBlock + threadIdx.x;
     const int cls = l < n_lines ? line_class(whw_max[l]) : 0;
-    const unsigned long long mh = __ballot(cls == 2), mw = __ballot(cls == 1);
-    if (lane == 0) s_red[0][wave] = bh, s_red[1][wave] = bw, s_wave[0][wave] = __popcll(mh), s_wave[1][wave] = __popcll(mw);
+    const bool isx = in_xlist(l, cls, sel, pre_lines);
+    const unsigned long long mh = __ballot(cls == 2), mw = __ballot(cls == 1), mx = __ballot(isx);
+    if (lane == 0) {
+        s_red[0][wave] = bh, s_red[1][wave] = bw, s_red[2][wave] = bx;
+        s_wave[0][wave] = __popcll(mh), s_wave[1][wave] = __popcll(mw), s_wave[2][wave] = __popcll(mx);
+    }
     __syncthreads();
-    int base_h = 0, base_w = 0;
-    for (int k = 0; k < kHlistBlock / 64; ++k) base_h += s_red[0][k], base_w += s_red[1][k];
-    for (int k = 0; k < wave; ++k) base_h += s_wave[0][k], base_w += s_wave[1][k];
+    int base_h = 0, base_w = 0, base_x = 0;
+    for (int k = 0; k < kHlistBlock / 64; ++k) base_h += s_red[0][k], base_w += s_red[1][k], base_x += s_red[2][k];
+    for (int k = 0; k < wave; ++k) base_h += s_wave[0][k], base_w += s_wave[1][k], base_x += s_wave[2][k];
     const unsigned long long below = (1ull << lane) - 1ull;
-    const int pos_h = base_h + __popcll(mh & below), pos_w = base_w + __popcll(mw & below);
+    const int pos_h = base_h + __popcll(mh & below), pos_w = base_w + __popcll(mw & below), pos_x = base_x + __popcll(mx & below);
     if (cls == 2) hlist[pos_h] = (int)l;
     if (cls == 1) wlist[pos_w] = (int)l;
+    if (isx) xlist[pos_x] = (int)l;
     if (l < n_lines) wrank[l] = pos_w;
     if (l == n_lines - 1) {
         wrank[n_lines] = pos_w + (cls == 1);
         hcount[0] = pos_h + (cls == 2);
         hcount[1] = pos_w + (cls == 1);
+        hcount[2] = pos_x + (isx ? 1 : 0);
     }
 }
 
@@ -829,15 +867,17 @@ __global__ __launch_bounds__(kBlock) void k_hscan(int n_depth, int64_t n_lines, 
         hscan[(size_t)d * n_lines + k] = wscan[(size_t)d * n_lines + hlist[k]];
 }
 
-// sel[0..1] = [la, lb): the lines whose centre c satisfies begin - H < c < end + H for the shard's columns [begin, end)
+// sel[0..1] = [la, lb): the lines whose centre c satisfies begin - H < c < end + H for the shard's columns [begin, end) and
+// H = kMediumHalfWidth; sel[2..3] = [na, nb): the same with H = 2 kNarrowReach
 // (centre_l = #{i : nus[i] >= line_nu_l}; lines ascend in frequency, so centres descend with the line index)
 __device__ __forceinline__ void shard_range(int64_t n_nu, const double* __restrict__ nus, int64_t n_lines, const double* __restrict__ line_nus,
                                             int64_t nu_begin, int64_t nu_count, int* __restrict__ sel)
 {
-    if (threadIdx.x >= 2) return;
+    if (threadIdx.x >= 4) return;
     // lines with centre >= p  <=>  line_nu <= nus[p - 1]: their number is cnt_ge[p]
-    const int64_t pa = max(nu_begin - kMediumHalfWidth + 1, (int64_t)0), pb = min(nu_begin + nu_count + kMediumHalfWidth - 1, n_nu);
-    const int64_t p = threadIdx.x == 0 ? pb + 1 : pa;  // sel[0] = cnt_ge[pb + 1], sel[1] = cnt_ge[pa]
+    const int64_t H = threadIdx.x < 2 ? kMediumHalfWidth : 2 * kNarrowReach;
+    const int64_t pa = max(nu_begin - H + 1, (int64_t)0), pb = min(nu_begin + nu_count + H - 1, n_nu);
+    const int64_t p = (threadIdx.x & 1) == 0 ? pb + 1 : pa;  // sel[0] = cnt_ge[pb + 1], sel[1] = cnt_ge[pa]
     int64_t cnt;
     if (p == 0) cnt = n_lines;
     else if (p >= n_nu + 1) cnt = 0;
@@ -855,31 +895,31 @@ __device__ __forceinline__ void shard_range(int64_t n_nu, const double* __restri
 
 // Frequency-sharded runs of long lists, stage A: the widest window of every line (over all depths), from the window rule
 // alone (:561-575; no centre needed for the half-width) — a streaming pass over the dense inputs that tells which lines can
-// reach any column (whw_max > kMediumHalfWidth -> hlist) before the full pre-pass runs on the lines the shard needs.
-__global__ __launch_bounds__(kBlock) void k_classify(int n_depth, int64_t n_nu, int64_t n_lines, const double* __restrict__ dnu_partial,
-                                                     int n_partial, const double* __restrict__ doppler, const double* __restrict__ gammas,
-                                                     int gamma_cols, const double* __restrict__ alphas, int* __restrict__ whw_max,
-                                                     const double* __restrict__ nus, const double* __restrict__ line_nus, int64_t nu_begin,
-                                                     int64_t nu_count, int* __restrict__ sel)
+// reach any column (whw_max > kMediumHalfWidth -> hlist) or, from just outside the shard's own line range, its edge columns
+// (-> xlist), before the full pre-pass runs on the lines the shard needs.  Block `bid` of `n_blocks` strides over the
+// (line, depth) items.  (Running this stream as a ROLE of the fused pre-pass launch, overlapped with the latency-bound range
+// blocks and the continuum, was measured in round 3: the launch grew from 65 to 94 us and a separate gather launch cost 24 us
+// more — the same 0.600 ms per step of an eighth of S-c3 either way; removed.)
+__device__ __forceinline__ void classify_block(const int bid, const int n_blocks, int n_depth, int64_t n_nu, int64_t n_lines,
+                                               const double* __restrict__ dnu_partial, int n_partial, const double* __restrict__ doppler,
+                                               const double* __restrict__ gammas, int gamma_cols, const double* __restrict__ alphas,
+                                               int* __restrict__ whw_max, double* s_red)
 {
-    __shared__ double s_red[kBlock / 64];
-    // two threads of the first block find the shard's line range on the side (two binary searches: a chain of dependent loads
-    // that a launch of its own would spend 7 us on)
-    if (blockIdx.x == 0 && sel) shard_range(n_nu, nus, n_lines, line_nus, nu_begin, nu_count, sel);
     const double d_nu = block_dnu(dnu_partial, n_partial, s_red);
     const int64_t n = n_lines * n_depth;
     const double scale = 20.0 / d_nu;
+    const int64_t bdim = blockDim.x;
     // a fixed number of blocks strides over the items (the grid-spacing reduction above is paid once per block, not once per
     // 1024 items); four items per thread and trip, a block apart: twelve independent loads in flight per lane.  (16-byte loads
     // of item pairs were measured: the same 47 us for 201 MB at 1.5e5 lines — the stream runs at 4.3 TB/s either way.)
-    for (int64_t base = (int64_t)blockIdx.x * (4 * kBlock); base < n; base += (int64_t)gridDim.x * (4 * kBlock)) {
+    for (int64_t base = (int64_t)bid * (4 * bdim); base < n; base += (int64_t)n_blocks * (4 * bdim)) {
         const int64_t k0 = base + threadIdx.x;
         const int64_t l_first = base / n_depth;  // the line of the trip's first item
         double dw[4], al[4], g[4];
         int64_t ls[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int64_t k = k0 + j * kBlock;
+            const int64_t k = k0 + j * bdim;
             ls[j] = -1;
             dw[j] = al[j] = g[j] = 0.0;
             if (k < n) {
@@ -906,6 +946,14 @@ __global__ __launch_bounds__(kBlock) void k_classify(int n_depth, int64_t n_nu, 
             if (hw > kNarrowHalfWidth) atomicMax(&whw_max[ls[j]], (int)hw);
         }
     }
+}
+
+__global__ __launch_bounds__(kBlock) void k_classify(int n_depth, int64_t n_nu, int64_t n_lines, const double* __restrict__ dnu_partial,
+                                                     int n_partial, const double* __restrict__ doppler, const double* __restrict__ gammas,
+                                                     int gamma_cols, const double* __restrict__ alphas, int* __restrict__ whw_max)
+{
+    __shared__ double s_red[kBlock / 64];
+    classify_block(blockIdx.x, gridDim.x, n_depth, n_nu, n_lines, dnu_partial, n_partial, doppler, gammas, gamma_cols, alphas, whw_max, s_red);
 }
 
 
@@ -1049,9 +1097,21 @@ __device__ __forceinline__ void line_all_body(int n_wide, int tiles, int n_split
         // XCD-aware tile order: workgroup i runs on XCD i % 8, each with its own L2.  Within a depth the workgroups of one XCD
         // take CONTIGUOUS tiles (position p -> tile prefix(p % 8) + p / 8), so neighbouring tiles, whose line ranges
         // overlap, hit the same L2 instead of pulling the same records into all eight.
-        const int p = b % tiles, d = b / tiles;
-        int tile = p >> 3;
-        for (int f = 0; f < (p & 7); ++f) tile += (tiles - f + 7) >> 3;
+        const int wg = (roles >> 4) & 15;  // 0: one contiguous eighth of the tiles per XCD; g > 0: groups of g tiles going round the XCDs
+        int tile, d;
+        if (wg == 0) {
+            const int p = b % tiles;
+            d = b / tiles;
+            tile = p >> 3;
+            for (int f = 0; f < (p & 7); ++f) tile += (tiles - f + 7) >> 3;
+        } else {
+            // (the host pads the tiles of a depth to whole rounds of 8 g workgroups: b % 8 is then the XCD within every depth)
+            const int tiles_pad = (tiles + 8 * wg - 1) / (8 * wg) * (8 * wg);
+            const int p = b % tiles_pad, j = p >> 3;
+            d = b / tiles_pad;
+            tile = ((j / wg) * 8 + (p & 7)) * wg + j % wg;
+            if (tile >= tiles) return;
+        }
         line_wide_walk<R, MIXED>(tile, wave, n_split, d, n_nu, nus, nu_begin, nu_count, n_lines, w, planes, pld, s_wide);
     } else {
         if (!(roles & 2)) return;

@@ -174,7 +174,8 @@ LineWork carve(sdx_ctx* ctx, int n_depth, int64_t n_lines)
     w.hlist = nullptr;  // set for long lists (set_line_lists)
     w.wlist = nullptr;
     w.wrank = nullptr;
-    w.hcount = w.whw_max + 4 * n_lines + 8;  // behind hlist [n], wlist [n], wrank [n + 1]
+    w.xlist = nullptr;
+    w.hcount = w.whw_max + 5 * n_lines + 8;  // behind hlist [n], wlist [n], wrank [n + 1], xlist [n]
     w.evals = (unsigned long long*)((char*)ctx->small_ws + 2048);
     return w;
 }
@@ -224,14 +225,16 @@ inline dim3 grid2(int64_t n, int rows) { return dim3((unsigned)((n + kBlock - 1)
 inline unsigned blocks1(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 
 // d_nu partial maxima into small_ws
-int launch_dnu(sdx_ctx* ctx, int64_t n_nu, const double* nus, int* n_partial, int* zero = nullptr, int64_t n_zero = 0)
+int launch_dnu(sdx_ctx* ctx, int64_t n_nu, const double* nus, int* n_partial, int* zero = nullptr, int64_t n_zero = 0, int64_t n_lines = 0,
+               const double* line_nus = nullptr, int64_t nu_begin = 0, int64_t nu_count = 0, int* sel = nullptr)
 {
     int rc = ensure(ctx, &ctx->small_ws, &ctx->small_ws_bytes, kSmallHeader);
     if (rc) return rc;
     const int nb = (int)std::min<int64_t>(kDnuPartials, std::max<int64_t>(1, (n_nu + kBlock * 8 - 1) / (kBlock * 8)));
     {
         LaunchScope ls(ctx, "k_dnu_partial");
-        hipLaunchKernelGGL(k_dnu_partial, dim3(nb), dim3(kBlock), 0, ctx->stream, n_nu, nus, (double*)ctx->small_ws, zero, n_zero);
+        hipLaunchKernelGGL(k_dnu_partial, dim3(nb), dim3(kBlock), 0, ctx->stream, n_nu, nus, (double*)ctx->small_ws, zero, n_zero, n_lines, line_nus,
+                           nu_begin, nu_count, sel);
     }
     *n_partial = nb;
     return check_launch("k_dnu_partial");
@@ -673,16 +676,17 @@ static bool use_segmented_raytrace(const sdx_ctx* ctx, int n_depth, int64_t n_nu
 }
 
 // long lists: hlist / wlist / wrank from whw_max (two small launches)
-static void launch_line_lists(sdx_ctx* ctx, int64_t n_lines, LineWork& w)
+static void launch_line_lists(sdx_ctx* ctx, int64_t n_lines, LineWork& w, int pre_lines)
 {
     w.hlist = w.whw_max + n_lines;
     w.wlist = w.hlist + n_lines;
     w.wrank = w.wlist + n_lines;
+    w.xlist = w.sel ? w.wrank + n_lines + 1 : nullptr;  // culled runs only
     const unsigned hb = (unsigned)((n_lines + kHlistBlock - 1) / kHlistBlock);
-    int* block_cnt = w.hcount + 16;  // 2 hb ints behind the counters and sel (reserved in cnt_ws)
-    hipLaunchKernelGGL(k_hlist_count, dim3(hb), dim3(kHlistBlock), 0, ctx->stream, n_lines, (const int*)w.whw_max, block_cnt);
+    int* block_cnt = w.hcount + 16;  // 3 hb ints behind the counters and sel (reserved in cnt_ws)
+    hipLaunchKernelGGL(k_hlist_count, dim3(hb), dim3(kHlistBlock), 0, ctx->stream, n_lines, (const int*)w.whw_max, block_cnt, w.sel, pre_lines);
     hipLaunchKernelGGL(k_hlist_scatter, dim3(hb), dim3(kHlistBlock), 0, ctx->stream, n_lines, (const int*)w.whw_max, (const int*)block_cnt, w.hlist,
-                       w.wlist, w.wrank, w.hcount);
+                       w.wlist, w.wrank, w.hcount, w.xlist, w.sel, pre_lines);
 }
 
 static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t n_lines, const double* line_nus,
@@ -705,8 +709,8 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
         rc = ensure(ctx, &ctx->line_ws, &ctx->line_ws_bytes, line_ws_need(n_depth, n_lines));
         if (rc) return rc;
         ctx->cnt_ge_len = (size_t)(n_nu + 2 + 63) / 64 * 64;
-        // cnt_ge, then per line: centre, nhw_max, whw_max, hlist, wlist, wrank; then hcount, sel and the per-block counts
-        rc = ensure(ctx, &ctx->cnt_ws, &ctx->cnt_ws_bytes, (ctx->cnt_ge_len + 7 * (size_t)n_lines + 128 + 2 * ((size_t)n_lines / 1024 + 8)) * sizeof(int));
+        // cnt_ge, then per line: centre, nhw_max, whw_max, hlist, wlist, wrank, xlist; then hcount, sel and the per-block counts
+        rc = ensure(ctx, &ctx->cnt_ws, &ctx->cnt_ws_bytes, (ctx->cnt_ge_len + 8 * (size_t)n_lines + 128 + 3 * ((size_t)n_lines / 1024 + 8)) * sizeof(int));
         if (rc) return rc;
         w = carve(ctx, n_depth, n_lines);
         if (n_depth > kPreDepths) HIP_TRY(hipMemsetAsync(w.nhw_max, 0, (size_t)2 * n_lines * sizeof(int), ctx->stream));  // nhw_max and whw_max
@@ -725,18 +729,24 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
     // change what it computes for them.
     static const bool no_cull = std::getenv("SDX_NO_CULL") != nullptr;
     const bool cull = fill_work && !no_cull && n_lines >= ctx->indexed_min_lines && !count_evals && !gen && !scan_in_block && nu_count < n_nu;
-    // the grid-spacing reduction (it also clears whw_max for the classification pass of a culled run)
-    if (!scan_in_block && (rc = launch_dnu(ctx, n_nu, nus, &n_partial, cull ? w.whw_max : nullptr, cull ? n_lines : 0))) return rc;
+    // the grid-spacing reduction (a culled run: it also clears whw_max for the classification pass and finds the shard's line range)
+    int* const sel = cull ? w.hcount + 4 : nullptr;
+    if (!scan_in_block && (rc = launch_dnu(ctx, n_nu, nus, &n_partial, cull ? w.whw_max : nullptr, cull ? n_lines : 0, n_lines, line_nus, nu_begin,
+                                           nu_count, sel)))
+        return rc;
+    // culled runs: classification stream, the line lists, then ONE pre-pass launch with range + gather blocks
     if (cull) {
-        int* sel = w.hcount + 4;
+        w.sel = sel;
         {
             LaunchScope ls(ctx, "k_classify");
             hipLaunchKernelGGL(k_classify, dim3((unsigned)std::min<int64_t>((n_lines * n_depth + 4 * kBlock - 1) / (4 * kBlock), (int64_t)8 * ctx->n_cu)), dim3(kBlock), 0, ctx->stream, n_depth, n_nu, n_lines,
-                               (const double*)ctx->small_ws, n_partial, doppler, gammas, gamma_cols, alphas, w.whw_max, nus, line_nus, nu_begin, nu_count, sel);
-            launch_line_lists(ctx, n_lines, w);
+                               (const double*)ctx->small_ws, n_partial, doppler, gammas, gamma_cols, alphas, w.whw_max);
         }
-        w.sel = sel;
-        w.gather = n_line_blocks;  // worst case: every line in hlist; blocks beyond the list's end return at once
+        {
+            LaunchScope ls(ctx, "k_hlist");
+            launch_line_lists(ctx, n_lines, w, pre_lines);
+        }
+        w.gather = n_line_blocks;  // worst case: every line listed; blocks beyond the lists' end return at once
     }
     const dim3 grid((unsigned)(n_line_blocks + n_pixel_blocks + w.gather), (unsigned)((n_depth + kPreDepths - 1) / kPreDepths));
     if (job) {
@@ -765,6 +775,7 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
             cont_rows = (unsigned)((n_depth + dgs - 1) / dgs);
         }
         const unsigned total_blocks = grid.x * grid.y + (unsigned)cont_tiles * cont_rows;
+        {
         LaunchScope ls(ctx, "k_prepass_continuum");
 #define SDX_PRE_ARGS (int)grid.x, (int)grid.y, cont_tiles, n_depth, n_nu, nus, scan_in_block ? (const double*)nullptr : (const double*)ctx->small_ws, \
                      n_partial, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, w, n_line_blocks, job->nu_begin, job->nu_count, ca,          \
@@ -774,6 +785,7 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
         else if (pre_lines == 16) hipLaunchKernelGGL((k_prepass_continuum<false, 16>), dim3(total_blocks), dim3(kPreBlock), shmem, ctx->stream, SDX_PRE_ARGS);
         else hipLaunchKernelGGL((k_prepass_continuum<false, 32>), dim3(total_blocks), dim3(kPreBlock), shmem, ctx->stream, SDX_PRE_ARGS);
 #undef SDX_PRE_ARGS
+        }
     } else {
         LaunchScope ls(ctx, "k_line_prepass");
 #define SDX_PRE_ARGS n_depth, n_nu, nus, scan_in_block ? (const double*)nullptr : (const double*)ctx->small_ws, n_partial, n_lines, line_nus, doppler, \
@@ -840,7 +852,7 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
     const int indexed = n_lines >= ctx->indexed_min_lines ? 1 : 0;
     if (indexed && !w.hlist) {  // (a culled pre-pass has built the lists already)
         LaunchScope ls(ctx, "k_hlist");
-        launch_line_lists(ctx, n_lines, w);
+        launch_line_lists(ctx, n_lines, w, 32);
     }
     static const bool no_hscan = std::getenv("SDX_NO_HSCAN") != nullptr;  // A/B knob
     if (no_hscan) w.hscan = nullptr;
@@ -857,7 +869,12 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
     // tiles are aligned to the GLOBAL grid (multiples of 64 Rm points from index 0), whatever the shard: which points share a
     // tile — and with it how a (line, depth, tile) is classified and which points share a reciprocal — is a property of the grid
     const int tiles = (int)((nu_begin + nu_count + 64 * Rm - 1) / (64 * Rm) - nu_begin / (64 * Rm));
-    const int64_t n_wide = (int64_t)tiles * n_depth;
+    // order of the wide role's tiles over the XCDs: one contiguous eighth each (0), or groups of g tiles going round them —
+    // better balance where an eighth is only a few tiles (a shard's), at the price of fewer neighbouring tiles per L2
+    static const int wide_group_env = std::getenv("SDX_WIDE_GROUP") ? std::atoi(std::getenv("SDX_WIDE_GROUP")) & 15 : -1;
+    const int wide_group = wide_group_env >= 0 ? wide_group_env : 0;
+    const int64_t tiles_pad = wide_group ? ((int64_t)tiles + 8 * wide_group - 1) / (8 * wide_group) * (8 * wide_group) : tiles;
+    const int64_t n_wide = tiles_pad * n_depth;
     // workgroups of n_split waves, rounded up to whole rounds of the XCD-aware order (surplus workgroups return at once)
     const int64_t n_narrow = (((nu_count * ((n_depth + 63) / 64) + n_split - 1) / n_split + 31) / 32) * 32;
     static const int narrow_order = std::getenv("SDX_NARROW_ORDER") ? atoi(std::getenv("SDX_NARROW_ORDER")) & 3 : 0;
@@ -866,7 +883,7 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
     const size_t shmem = (size_t)n_split * kWideLdsDoubles * sizeof(double);
     const dim3 g((unsigned)(n_wide + n_narrow)), blk((unsigned)(64 * n_split));
     for (int pass = 0; pass < (split_launches ? 2 : 1); ++pass) {
-        const int roles = (split_launches ? (1 << pass) : 3) | (narrow_order << 2);
+        const int roles = (split_launches ? (1 << pass) : 3) | (narrow_order << 2) | (wide_group << 4);
         LaunchScope ls(ctx, split_launches ? (pass ? "k_line_narrow" : "k_line_wide") : "k_line_all");
 #define SDX_LINE_ARGS (int)n_wide, tiles, n_split, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, part, pld, roles
         if (ctx->mixed_precision && Rm == 8) hipLaunchKernelGGL((k_line_all_mixed<8>), g, blk, shmem, ctx->stream, SDX_LINE_ARGS);
