@@ -1761,6 +1761,25 @@ __global__ __launch_bounds__(kPreBlock) __attribute__((amdgpu_num_sgpr(80))) voi
     }
 }
 
+// Culled shards of the fused step: the classification stream (HBM-bound, vector units idle) and the continuum plane (arithmetic,
+// no traffic to speak of) in ONE launch of 256-thread blocks — blocks [0, n_cls) stream, the rest are continuum tiles.
+__global__ __launch_bounds__(kBlock) void k_classify_continuum(int n_cls, int n_depth, int64_t n_nu, int64_t n_lines, const double* __restrict__ dnu_partial,
+                                                               int n_partial, const double* __restrict__ doppler, const double* __restrict__ gammas,
+                                                               int gamma_cols, const double* __restrict__ alphas, int* __restrict__ whw_max,
+                                                               const double* __restrict__ nus, int cont_tiles, int64_t nu_begin, int64_t nu_count,
+                                                               ContinuumArgs ca, double* __restrict__ cont_plane, int64_t cont_ld, int stage_table)
+{
+    const int b = blockIdx.x;
+    if (b < n_cls) {
+        __shared__ double s_red[kBlock / 64];
+        classify_block(b, n_cls, n_depth, n_nu, n_lines, dnu_partial, n_partial, doppler, gammas, gamma_cols, alphas, whw_max, s_red);
+    } else {
+        const int c = b - n_cls;
+        continuum_tile_block(c % cont_tiles, c / cont_tiles, (stage_table >> 4) & 15, n_depth, nu_begin, nu_count, nus, ca, cont_plane, cont_ld,
+                             (stage_table & 1) != 0);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Formal solution (radiation_field_solvers/base.py:85-346).  A group of G adjacent lanes of one wave
 // owns one frequency (64/G groups per wave); lane g of the group traces angles g, g+G, ... (at most P of

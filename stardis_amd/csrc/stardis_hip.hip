@@ -734,13 +734,71 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
     if (!scan_in_block && (rc = launch_dnu(ctx, n_nu, nus, &n_partial, cull ? w.whw_max : nullptr, cull ? n_lines : 0, n_lines, line_nus, nu_begin,
                                            nu_count, sel)))
         return rc;
-    // culled runs: classification stream, the line lists, then ONE pre-pass launch with range + gather blocks
+    // continuum blocks of the fused step: one per (frequency tile of `threads` points, group of dgs depths) when the per-depth
+    // factors of a group fit LDS (always, for a handful of bound-free levels), else one per (tile, depth) evaluating every point
+    // from scratch
+    struct ContPlan {
+        ContinuumArgs ca;
+        size_t shmem;
+        int cont_tiles, stage_table;
+        unsigned cont_rows;
+        bool tiled;
+    };
+    auto plan_continuum = [&](int threads, ContPlan* p) -> int {
+        p->ca = to_args(job->cont, nullptr);
+        ContinuumArgs& ca = p->ca;
+        ca.bf_level_density = job->cont->bf_level_density;
+        p->shmem = 8;
+        if (ca.bf_n_species > 0) {
+            REQUIRE(job->cont->bf_n_levels > 0 && job->cont->bf_n_levels <= 4096, "synthesize: bf_n_levels must be set (1..4096)");
+            p->shmem = (size_t)job->cont->bf_n_levels * sizeof(double);
+        }
+        p->stage_table = ca.table_sigma && ca.n_table > 0 && ca.n_table <= 1024;  // 1-D cross-section table searched from LDS
+        if (p->stage_table) p->shmem = ((ca.bf_n_species > 0 ? (size_t)job->cont->bf_n_levels : 0) + 2 * (size_t)ca.n_table) * sizeof(double);
+        p->cont_tiles = (int)((job->nu_count + (int64_t)threads * kContPoints - 1) / ((int64_t)threads * kContPoints));
+        const size_t n_lev = ca.bf_n_species > 0 ? (size_t)job->cont->bf_n_levels : 0;
+        const size_t tile_shmem = ((size_t)kContDepths * (n_lev + 6) + (p->stage_table ? 2 * (size_t)ca.n_table : 0)) * sizeof(double);
+        p->cont_rows = (unsigned)n_depth;
+        p->tiled = false;
+        static const int cont_dgs_env = std::getenv("SDX_CONT_DGS") ? std::atoi(std::getenv("SDX_CONT_DGS")) : -1;  // experiment knob: 0 = per-point blocks
+        if (tile_shmem <= 48 * 1024 && cont_dgs_env != 0) {
+            // depths per block: as many as leave ~2 x 1024 threads of such blocks per CU (one depth per block on small grids)
+            int dgs = (int)std::max<int64_t>(1, std::min<int64_t>(kContDepths, ((int64_t)p->cont_tiles * threads / kPreBlock * n_depth) / (2 * (int64_t)ctx->n_cu)));
+            if (cont_dgs_env > 0) dgs = std::min(cont_dgs_env, kContDepths);
+            p->stage_table |= 2 | (dgs << 4);
+            p->shmem = tile_shmem;
+            p->cont_rows = (unsigned)((n_depth + dgs - 1) / dgs);
+            p->tiled = true;
+        }
+        return SDX_OK;
+    };
+    // culled runs: classification stream, the line lists, then ONE pre-pass launch with range + gather blocks.  In the fused
+    // step the continuum plane rides with the classification launch — an HBM stream that leaves the vector units idle —
+    // instead of the pre-pass launch, which a shard's line blocks already fill (S-c3 / 8: 540 line + gather blocks and 590
+    // continuum blocks on 512 block slots)
+    bool continuum_done = false;
     if (cull) {
         w.sel = sel;
+        const unsigned n_cls = (unsigned)std::min<int64_t>((n_lines * n_depth + 4 * kBlock - 1) / (4 * kBlock), (int64_t)8 * ctx->n_cu);
+        ContPlan cp;
+        static const bool no_ride = std::getenv("SDX_NO_CONT_RIDE") != nullptr;  // A/B knob
+        if (job && !no_ride) {
+            if ((rc = plan_continuum(kBlock, &cp))) return rc;
+            continuum_done = cp.tiled;
+        }
         {
             LaunchScope ls(ctx, "k_classify");
-            hipLaunchKernelGGL(k_classify, dim3((unsigned)std::min<int64_t>((n_lines * n_depth + 4 * kBlock - 1) / (4 * kBlock), (int64_t)8 * ctx->n_cu)), dim3(kBlock), 0, ctx->stream, n_depth, n_nu, n_lines,
-                               (const double*)ctx->small_ws, n_partial, doppler, gammas, gamma_cols, alphas, w.whw_max);
+            if (continuum_done) {
+                // half the classification blocks (16 of 32 wave slots per CU: the stream keeps its bytes in flight), the
+                // continuum blocks take the other slots
+                const unsigned n_cls_half = std::max(1u, n_cls / 2);
+                hipLaunchKernelGGL(k_classify_continuum, dim3(n_cls_half + (unsigned)cp.cont_tiles * cp.cont_rows), dim3(kBlock), cp.shmem, ctx->stream, (int)n_cls_half,
+                                   n_depth, n_nu, n_lines, (const double*)ctx->small_ws, n_partial, doppler, gammas, gamma_cols, alphas, w.whw_max, nus,
+                                   cp.cont_tiles, job->nu_begin, job->nu_count, cp.ca, job->plane, job->nu_count, cp.stage_table);
+            } else {
+                hipLaunchKernelGGL(k_classify, dim3(n_cls), dim3(kBlock), 0, ctx->stream, n_depth, n_nu, n_lines, (const double*)ctx->small_ws, n_partial,
+                                   doppler, gammas, gamma_cols, alphas, w.whw_max);
+            }
         }
         {
             LaunchScope ls(ctx, "k_hlist");
@@ -749,32 +807,13 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
         w.gather = n_line_blocks;  // worst case: every line listed; blocks beyond the lists' end return at once
     }
     const dim3 grid((unsigned)(n_line_blocks + n_pixel_blocks + w.gather), (unsigned)((n_depth + kPreDepths - 1) / kPreDepths));
-    if (job) {
-        ContinuumArgs ca = to_args(job->cont, nullptr);
-        ca.bf_level_density = job->cont->bf_level_density;
-        size_t shmem = 8;
-        if (ca.bf_n_species > 0) {
-            REQUIRE(job->cont->bf_n_levels > 0 && job->cont->bf_n_levels <= 4096, "synthesize: bf_n_levels must be set (1..4096)");
-            shmem = (size_t)job->cont->bf_n_levels * sizeof(double);
-        }
-        int stage_table = ca.table_sigma && ca.n_table > 0 && ca.n_table <= 1024;  // 1-D cross-section table searched from LDS
-        if (stage_table) shmem = ((ca.bf_n_species > 0 ? (size_t)job->cont->bf_n_levels : 0) + 2 * (size_t)ca.n_table) * sizeof(double);
-        const int cont_tiles = (int)((job->nu_count + kPreBlock * kContPoints - 1) / (kPreBlock * kContPoints));
-        // continuum blocks: one per (frequency tile, group of kContDepths depths) when the per-depth factors of a group fit LDS
-        // (always, for a handful of bound-free levels), else one per (tile, depth) evaluating every point from scratch
-        const size_t n_lev = ca.bf_n_species > 0 ? (size_t)job->cont->bf_n_levels : 0;
-        const size_t tile_shmem = ((size_t)kContDepths * (n_lev + 6) + (stage_table ? 2 * (size_t)ca.n_table : 0)) * sizeof(double);
-        unsigned cont_rows = (unsigned)n_depth;
-        static const int cont_dgs_env = std::getenv("SDX_CONT_DGS") ? std::atoi(std::getenv("SDX_CONT_DGS")) : -1;  // experiment knob: 0 = per-point blocks
-        if (tile_shmem <= 48 * 1024 && cont_dgs_env != 0) {
-            // depths per block: as many as leave ~2 blocks per CU (one depth per block on small grids)
-            int dgs = (int)std::max<int64_t>(1, std::min<int64_t>(kContDepths, ((int64_t)cont_tiles * n_depth) / (2 * (int64_t)ctx->n_cu)));
-            if (cont_dgs_env > 0) dgs = std::min(cont_dgs_env, kContDepths);
-            stage_table |= 2 | (dgs << 4);
-            shmem = tile_shmem;
-            cont_rows = (unsigned)((n_depth + dgs - 1) / dgs);
-        }
-        const unsigned total_blocks = grid.x * grid.y + (unsigned)cont_tiles * cont_rows;
+    if (job && !continuum_done) {
+        ContPlan cp;
+        if ((rc = plan_continuum(kPreBlock, &cp))) return rc;
+        const ContinuumArgs& ca = cp.ca;
+        const int cont_tiles = cp.cont_tiles, stage_table = cp.stage_table;
+        const size_t shmem = cp.shmem;
+        const unsigned total_blocks = grid.x * grid.y + (unsigned)cont_tiles * cp.cont_rows;
         {
         LaunchScope ls(ctx, "k_prepass_continuum");
 #define SDX_PRE_ARGS (int)grid.x, (int)grid.y, cont_tiles, n_depth, n_nu, nus, scan_in_block ? (const double*)nullptr : (const double*)ctx->small_ws, \
@@ -787,7 +826,7 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
 #undef SDX_PRE_ARGS
         }
     } else {
-        LaunchScope ls(ctx, "k_line_prepass");
+        LaunchScope ls(ctx, job ? "k_prepass_continuum" : "k_line_prepass");
 #define SDX_PRE_ARGS n_depth, n_nu, nus, scan_in_block ? (const double*)nullptr : (const double*)ctx->small_ws, n_partial, n_lines, line_nus, doppler, \
                      gammas, gamma_cols, alphas, w, (int*)lo_ref, (int*)hi_ref, n_line_blocks, lp
         if (gen && pre_lines == 16) hipLaunchKernelGGL((k_line_prepass<true, 16>), grid, dim3(kPreBlock), 0, ctx->stream, SDX_PRE_ARGS);

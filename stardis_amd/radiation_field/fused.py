@@ -30,6 +30,42 @@ from stardis_amd.radiation_field.opacities.opacities_solvers.util import get_num
 F8 = np.float64
 RAYLEIGH_CUTOFF = 2.3e15  # opacities_solvers/base.py:99
 
+# What this module derives from the plasma's pandas objects (sorted line tables, level tables, density vectors) is kept per
+# OBJECT: the key is the identity of the frames / series it was read from (a strong reference is held, so an id cannot be
+# recycled), a handful of entries, least recently used first out.  A TARDIS plasma hands out fresh objects whenever it is
+# recomputed, which misses the cache as it should; editing a table IN PLACE between two calls is not seen — call clear_cache().
+_MEMO = {}
+_MEMO_MAX = 16
+
+
+def clear_cache():
+    _MEMO.clear()
+
+
+def _memo(tag, objects, extra, build):
+    key = (tag, tuple(id(o) for o in objects), extra)
+    hit = _MEMO.get(key)
+    if hit is not None:
+        _MEMO[key] = _MEMO.pop(key)  # most recently used last
+        return hit[1]
+    value = build()
+    _MEMO[key] = (objects, value)
+    while len(_MEMO) > _MEMO_MAX:
+        _MEMO.pop(next(iter(_MEMO)))
+    return value
+
+
+_QUADRATURE = {}
+
+
+def _leggauss(n):
+    """np.polynomial.legendre.leggauss(n) as RadiationField.__init__ maps it (radiation_field/base.py:61-63), once per n."""
+    q = _QUADRATURE.get(n)
+    if q is None:
+        nodes, weights = np.polynomial.legendre.leggauss(n)
+        q = _QUADRATURE[n] = ((nodes / 2) + 0.5 * np.pi / 2, weights * np.pi / 2)
+    return q[0].copy(), q[1].copy()
+
 
 class _Thunk:
     """A dictionary entry that has not been asked for yet."""
@@ -139,6 +175,12 @@ def _mass_of(nuclide_masses, atomic_number):
 
 
 def _bf_arrays(stellar_plasma, species):
+    p = stellar_plasma
+    return _memo("bf", (p.levels, p.excitation_energy, p.level_number_density, p.ionization_data, p.ion_number_density, p.electron_densities),
+                 tuple(species), lambda: _bf_arrays_build(p, species))
+
+
+def _bf_arrays_build(stellar_plasma, species):
     """_bf_levels of the general mirror without a pandas look-up per level: levels of each species in plasma order."""
     levels = stellar_plasma.levels
     z_all = np.asarray(levels.get_level_values(0))
@@ -161,6 +203,25 @@ def _bf_arrays(stellar_plasma, species):
             np.concatenate(cutoffs) if cutoffs else np.zeros(0), np.vstack(densities) if densities else np.zeros((0, n_depth)))
 
 
+def _sorted_line_tables(lines, alpha_table, nuclide_masses, with_vald):
+    """Both tables in the row order of `_in_grid` (opacities_solvers/base.py:392-397: sort_values("nu"); pandas sorts one float
+    column with ndarray.argsort(kind="quicksort")), as plain arrays.  None when NaNs would need pandas' special casing."""
+    nu_l = np.asarray(lines["nu"].to_numpy(), dtype=F8)
+    nu_a = np.asarray(alpha_table["nu"].to_numpy(), dtype=F8)
+    if np.isnan(nu_l).any() or np.isnan(nu_a).any():
+        return None
+    order_l, order_a = np.argsort(nu_l, kind="quicksort"), np.argsort(nu_a, kind="quicksort")
+    col = lambda name, dt=F8: np.ascontiguousarray(np.asarray(lines[name].to_numpy(), dtype=dt)[order_l])  # noqa: E731  (pd.to_numeric of :411)
+    out = dict(nu=nu_l[order_l], nu_alpha=nu_a[order_a], z=col("atomic_number", np.int64), ion=col("ion_number", np.int64),
+               e_ion=col("ionization_energy"), e_up=col("level_energy_upper"), e_lo=col("level_energy_lower"), a_ul=col("A_ul"))
+    if with_vald:
+        out["stark"], out["waals"] = col("stark"), col("waals")
+    alpha_cols = [c for c in alpha_table.columns if c != "nu"]
+    out["alphas"] = np.ascontiguousarray(np.asarray(alpha_table[alpha_cols].to_numpy(), dtype=F8)[order_a])
+    out["mass"] = _mass_of(nuclide_masses, out["z"])
+    return out
+
+
 def _line_arrays(stellar_plasma, stellar_model, nus, cfg):
     """calc_alpha_line_at_nu's host preparation (:362-421) as flat arrays: the selected lines in ascending frequency with
     their dense alphas and per-line broadening scalars.  None when this path does not cover the configuration."""
@@ -170,30 +231,61 @@ def _line_arrays(stellar_plasma, stellar_model, nus, cfg):
         if alpha_table is None:
             return None  # parameters generated on the device (f1): general path
     else:
-        lines, alpha_table = B._atomic_line_table(stellar_plasma), stellar_plasma.alpha_line
-    lo, hi = nus.min(), nus.max()
-    nu_l = np.asarray(lines["nu"].to_numpy(), dtype=F8)
-    nu_a = np.asarray(alpha_table["nu"].to_numpy(), dtype=F8)
-    sel_l, sel_a = _sorted_in_grid(nu_l, lo, hi), _sorted_in_grid(nu_a, lo, hi)
-    if sel_l is None or sel_a is None or sel_l.size != sel_a.size:
-        return None
-    col = lambda name, dt=F8: np.asarray(lines[name].to_numpy(), dtype=dt)[sel_l]  # noqa: E731  (pd.to_numeric of :411)
-    out = dict(nu=nu_l[sel_l], z=col("atomic_number", np.int64), ion=col("ion_number", np.int64), e_ion=col("ionization_energy"),
-               e_up=col("level_energy_upper"), e_lo=col("level_energy_lower"), a_ul=col("A_ul"))
+        p = stellar_plasma
+        lines = _memo("atomic_line_table", (p.lines, p.ionization_data, p.atomic_data.levels.energy), None, lambda: B._atomic_line_table(p))
+        alpha_table = stellar_plasma.alpha_line
     vald_broadening = bool(vald.use_vald_broadening and vald.use_linelist)
-    if vald_broadening:
-        out["stark"], out["waals"] = col("stark"), col("waals")
-    alpha_cols = [c for c in alpha_table.columns if c != "nu"]
-    alphas = np.asarray(alpha_table[alpha_cols].to_numpy(), dtype=F8)[sel_a]
+    masses = stellar_model.composition.nuclide_masses
+    tab = _memo("line_tables", (lines, alpha_table, masses), vald_broadening,
+                lambda: _sorted_line_tables(lines, alpha_table, masses, vald_broadening))
+    if tab is None:
+        return None
+    # nu.between(min, max) (:393-395) on sorted columns is a slice
+    lo, hi = nus.min(), nus.max()
+    i0, i1 = np.searchsorted(tab["nu"], lo, "left"), np.searchsorted(tab["nu"], hi, "right")
+    j0, j1 = np.searchsorted(tab["nu_alpha"], lo, "left"), np.searchsorted(tab["nu_alpha"], hi, "right")
+    if i1 - i0 != j1 - j0:
+        return None
+    out = {k: v[i0:i1] for k, v in tab.items() if k not in ("alphas", "nu_alpha")}
+    alphas = tab["alphas"][j0:j1]
     if not vald.use_vald_broadening:  # auto-ionising lines are dropped unless VALD broadening is used (:413-421)
         keep = ~(out["e_up"] > out["e_ion"])
         if not keep.all():
             out = {k: v[keep] for k, v in out.items()}
             alphas = alphas[keep]
-    out["alphas"] = np.ascontiguousarray(alphas)
-    out["mass"] = _mass_of(stellar_model.composition.nuclide_masses, out["z"])
+    out["alphas"] = alphas
     out["vald_broadening"] = vald_broadening
     return out
+
+
+def _depth_vectors(stellar_plasma, opacity, file_source, rayleigh_species):
+    """Every per-depth vector the step reads from the plasma, as float64 arrays (get_number_density, util.py:111-166)."""
+    p = stellar_plasma
+    ff_species = tuple(opacity.ff.keys() if hasattr(opacity.ff, "keys") else opacity.ff)
+
+    def build():
+        ions = p.ion_number_density
+        out = {"n_e": np.ascontiguousarray(plain(p.electron_densities), dtype=F8).reshape(-1)}
+        if file_source is not None:
+            out["file"] = np.asarray(plain(get_number_density(p, file_source)[0]), dtype=F8)
+        ff_ions, ff_dens = [], []
+        for spec in ff_species:
+            number_density, _, ion_number = get_number_density(p, spec + "_ff")
+            ff_ions.append(ion_number), ff_dens.append(np.asarray(plain(number_density), dtype=F8))
+        out["ff_ions"], out["ff_dens"] = ff_ions, ff_dens
+        if True:  # neutral hydrogen: van der Waals broadening and Rayleigh scattering
+            out["n_h"] = np.asarray(plain(ions.loc[1, 0]), dtype=F8)
+        if "He" in rayleigh_species:
+            out["n_he"] = np.asarray(plain(ions.loc[2, 0]), dtype=F8)
+        if "H2" in rayleigh_species:
+            out["n_h2"] = np.asarray(plain(p.h2_density), dtype=F8)
+        return out
+
+    objs = [p.ion_number_density, p.electron_densities]
+    for name in ("h_minus_density", "h2_density", "h2_plus_density"):
+        if getattr(p, name, None) is not None:
+            objs.append(getattr(p, name))
+    return _memo("depth", tuple(objs), (file_source, ff_species, tuple(rayleigh_species)), build)
 
 
 def try_fused(field_cls, tracing_nus, stellar_model, stellar_plasma, config, source_function):
@@ -233,14 +325,14 @@ def try_fused(field_cls, tracing_nus, stellar_model, stellar_plasma, config, sou
             return None
     ctx = default_context()
     temps = np.ascontiguousarray(plain(stellar_model.temperatures), dtype=F8).reshape(-1)
-    n_e = np.ascontiguousarray(plain(stellar_plasma.electron_densities), dtype=F8).reshape(-1)
+    file_source = next(iter(opacity.file)) if table is not None else None
+    dv = _depth_vectors(stellar_plasma, opacity, file_source, rayleigh_species)
+    n_e = dv["n_e"]
 
     field = field_cls.__new__(field_cls)  # the attributes of RadiationField.__init__ (:38-68) without its zero-filled planes
     field.frequencies = tracing_nus
     field.source_function = source_function
-    nodes, weights = np.polynomial.legendre.leggauss(int(config.no_of_thetas))
-    field.thetas = (nodes / 2) + 0.5 * np.pi / 2
-    field.I_nus_weights = weights * np.pi / 2
+    field.thetas, field.I_nus_weights = _leggauss(int(config.no_of_thetas))
     field.track_individual_intensities = False
     opac = FusedOpacities((nd, nus.size))
     field.opacities = opac
@@ -258,30 +350,23 @@ def try_fused(field_cls, tracing_nus, stellar_model, stellar_plasma, config, sou
     add("ray", dist.reshape(-1, 1) / np.cos(field.thetas))  # radiation_field_solvers/base.py:302-305
     add("wts", field.I_nus_weights)
     add("lambdas", K.nu_to_angstrom(nus))
-    file_source = None
     if table is not None:
-        file_source = next(iter(opacity.file))
-        density, _, _ = get_number_density(stellar_plasma, file_source)
-        add("tab_x", table[1]), add("tab_y", table[2]), add("tab_n", plain(density))
+        add("tab_x", table[1]), add("tab_y", table[2]), add("tab_n", dv["file"])
     add("bf_off", bf[0], np.int32), add("bf_ion", bf[1], np.int32), add("bf_cut", bf[2]), add("bf_den", bf[3])
-    ff_ions, ff_dens = [], []
-    for spec in (opacity.ff.keys() if hasattr(opacity.ff, "keys") else opacity.ff):
-        number_density, _, ion_number = get_number_density(stellar_plasma, spec + "_ff")
-        ff_ions.append(ion_number), ff_dens.append(np.asarray(plain(number_density), dtype=F8))
+    ff_ions, ff_dens = dv["ff_ions"], dv["ff_dens"]
     add("ff_ion", ff_ions, np.int32), add("ff_den", np.vstack(ff_dens) if ff_dens else np.zeros((0, nd)))
-    ions = stellar_plasma.ion_number_density
     if "H" in rayleigh_species:
-        add("ray_h", plain(ions.loc[1, 0]))
+        add("ray_h", dv["n_h"])
     if "He" in rayleigh_species:
-        add("ray_he", plain(ions.loc[2, 0]))
+        add("ray_he", dv["n_he"])
     if "H2" in rayleigh_species:
-        add("ray_h2", plain(stellar_plasma.h2_density))
+        add("ray_h2", dv["n_h2"])
     if not opacity.disable_electron_scattering:
         add("n_e", n_e)
     n_lines = 0
     if line is not None:
         n_lines = line["nu"].size
-        n_h = np.asarray(plain(ions.loc[1, 0]), dtype=F8)
+        n_h = dv["n_h"]
         add("l_nu", line["nu"]), add("l_alpha", line["alphas"]), add("l_z", line["z"], np.int32), add("l_ion", line["ion"] + 1, np.int32)
         for k in ("e_ion", "e_up", "e_lo", "a_ul", "mass"):
             add("l_" + k, line[k])

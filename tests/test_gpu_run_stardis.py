@@ -199,3 +199,34 @@ def test_fused_path_declines_what_it_does_not_cover(ctx, monkeypatch, tmp_path):
     monkeypatch.setattr(rf, "FUSED", False)
     plain_field = rf.create_stellar_radiation_field(g["nus"].copy(), model, plasma, config)
     assert np.array_equal(quiet.F_nu, plain_field.F_nu)
+
+
+def test_plasma_tables_are_cached_per_object_not_per_value(ctx, monkeypatch, tmp_path):
+    """The fused path keeps what it derives from the plasma's pandas objects keyed on their IDENTITY: the same objects hit the
+    cache, a replaced table (what a recomputed plasma hands out) misses it, an in-place edit needs clear_cache()."""
+    import stardis_amd.radiation_field.base as rf
+    from stardis_amd.radiation_field import fused
+    from test_gpu_dropin import rebuild
+
+    g, plasma, model, cfg = rebuild("vald", tmp_path)
+    config = NS(opacity=cfg, no_of_thetas=4, result_options=NS(return_radiation_field=False))
+
+    def run(use_fused=True):
+        monkeypatch.setattr(rf, "FUSED", use_fused)
+        return rf.create_stellar_radiation_field(g["nus"].copy(), model, plasma, config).F_nu
+
+    fused.clear_cache()
+    first = run()
+    n_cached = len(fused._MEMO)
+    assert n_cached >= 3 and np.array_equal(run(), first) and len(fused._MEMO) == n_cached  # second call: all hits
+    stronger = plasma.alpha_line_from_linelist.copy()
+    stronger[stronger.columns[:-1]] *= 3.0  # every column but "nu"
+    assert stronger.columns[-1] == "nu"
+    plasma.alpha_line_from_linelist = stronger  # a NEW object: must not be served from the cache
+    changed = run()
+    assert not np.array_equal(changed, first) and np.array_equal(changed, run(use_fused=False))
+    plasma.electron_densities = plasma.electron_densities * 1.0  # new object, same values
+    assert np.array_equal(run(), changed)
+    stronger.iloc[:, 0] *= 2.0  # in place: not seen until the cache is cleared
+    fused.clear_cache()
+    assert np.array_equal(run(), run(use_fused=False))
