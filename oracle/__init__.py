@@ -131,6 +131,29 @@ def calc_alan_entries(no_of_depth_points, tracing_nus_values, line_nus, doppler_
     return (out, ne.value) if return_evals else out
 
 
+def calc_alan_entries_columns(cols, no_of_depth_points, tracing_nus_values, line_nus, doppler_widths, gammas, alphas_array, return_evals=False):
+    """opacities_solvers/base.py:487-592 evaluated at the listed grid columns only (ascending global indices), with the window
+    rule of the WHOLE grid (global d_nu, global centre, global clamp) -> (N_d, len(cols))"""
+    nus, pn = _d(tracing_nus_values)
+    ln, pl = _d(line_nus)
+    nd = int(no_of_depth_points)
+    cols = np.ascontiguousarray(cols, dtype=np.int64)
+    if cols.size and (np.any(np.diff(cols) <= 0) or cols[0] < 0 or cols[-1] >= nus.size):
+        raise ValueError("cols must be strictly ascending grid indices")
+    dw, pdw = _d(np.asarray(doppler_widths).reshape(ln.size, nd))
+    g, pg = _d(np.asarray(gammas).reshape(ln.size, -1) if ln.size else np.zeros((0, 1)))
+    a, pa = _d(np.asarray(alphas_array).reshape(ln.size, nd))
+    out = np.empty((nd, cols.size))
+    ne = C.c_int64()
+    rc = lib().orc_calc_alan_entries_columns(
+        C.c_int(nd), C.c_int64(nus.size), pn, C.c_int64(cols.size), cols.ctypes.data_as(C.POINTER(C.c_int64)), C.c_int64(ln.size), pl, pdw, pg,
+        C.c_int(g.shape[1] if ln.size else 1), pa, out.ctypes.data_as(_dp), C.byref(ne),
+    )
+    if rc:
+        raise MemoryError("oracle allocation failed")
+    return (out, ne.value) if return_evals else out
+
+
 def blackbody_flux_at_nu(tracing_nus, temps):
     """blackbody.py:10-35; temps (N_d,1) or (N_d,)"""
     nus, pn = _d(tracing_nus)

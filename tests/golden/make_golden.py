@@ -1,6 +1,12 @@
 """Generate golden input/output vectors by EXECUTING the reference (un-jitted) here.
 
-    /opt/conda/bin/python3.9 tests/golden/make_golden.py
+    /opt/conda/bin/python3.9 tests/golden/make_golden.py [g1 g2 ...]            regenerate (all, or the named fixtures)
+    /opt/conda/bin/python3.9 tests/golden/make_golden.py --verify [g1 g2 ...]   regenerate into a temporary directory and compare
+                                                                                every array with the committed file
+
+Every fixture draws from ITS OWN generator, np.random.default_rng([20250926, k]) for fixture Gk: what a fixture contains does
+not depend on which other fixtures were requested in the same run (tests/test_golden_recipe.py runs --verify where the reference
+is available).
 
 Runs only in the authoring container (needs /root/reference and astropy).  The
 outputs are data: seeded inputs and what the reference's own functions return
@@ -30,8 +36,18 @@ NS = types.SimpleNamespace
 REF_DATA = Path("/root/reference/stardis/data")
 
 
+OUT_DIR = HERE      # --verify: a temporary directory
+DATA_DIR = os.path.join(REPO, "stardis_amd", "data")
+SEED = 20250926
+
+
+def rng_for(k):
+    """The generator of fixture Gk."""
+    return np.random.default_rng([SEED, k])
+
+
 def save(name, **arrays):
-    path = os.path.join(HERE, name + ".npz")
+    path = os.path.join(OUT_DIR, name + ".npz")
     np.savez_compressed(path, **arrays)
     print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB")
 
@@ -40,13 +56,13 @@ def save(name, **arrays):
 def capture_data():
     m = R.mk.read_marcs_model(Path("/root/reference/docs/quickstart/sun.mod"), gzipped=False)
     cols = {c: [float(x) for x in m.data[c].values] for c in ("t", "depth", "pe", "pg")}
-    os.makedirs(os.path.join(REPO, "stardis_amd", "data"), exist_ok=True)
-    with open(os.path.join(REPO, "stardis_amd", "data", "sun_marcs_columns.json"), "w") as fh:
+    os.makedirs(DATA_DIR, exist_ok=True)
+    with open(os.path.join(DATA_DIR, "sun_marcs_columns.json"), "w") as fh:
         json.dump(cols, fh)
     tab = pd.read_csv(
         REF_DATA / "h_minus_bf_W1979.dat", header=None, comment="#", names=["wavelength", "cross_section"]
     )
-    with open(os.path.join(REPO, "stardis_amd", "data", "hminus_bf_wishart1979.json"), "w") as fh:
+    with open(os.path.join(DATA_DIR, "hminus_bf_wishart1979.json"), "w") as fh:
         json.dump(
             dict(
                 wavelength=[float(x) for x in tab.wavelength.values],
@@ -56,7 +72,7 @@ def capture_data():
         )
     # the reference's own MARCS test model (io/model/tests/data/marcs_test.mod.gz: Teff 3800 K, log g 4.0): a cool dwarf
     cool = R.mk.read_marcs_model(Path("/root/reference/stardis/io/model/tests/data/marcs_test.mod.gz"), gzipped=True)
-    with open(os.path.join(REPO, "stardis_amd", "data", "marcs_t3800_g4_columns.json"), "w") as fh:
+    with open(os.path.join(DATA_DIR, "marcs_t3800_g4_columns.json"), "w") as fh:
         json.dump({c: [float(x) for x in cool.data[c].values] for c in ("t", "depth", "pe", "pg")}, fh)
     geometry = m.to_geometry()
     return m, geometry
@@ -83,7 +99,7 @@ def dump_constants():
         SQRT_PI=float(R.vg.SQRT_PI),
         ALPHA_COEFFICIENT=float(ref_loader.load_plasma().base.ALPHA_COEFFICIENT.value),
     )
-    with open(os.path.join(HERE, "constants.json"), "w") as fh:
+    with open(os.path.join(OUT_DIR, "constants.json"), "w") as fh:
         json.dump({k: float(v).hex() for k, v in c.items()}, fh, indent=1)
 
 
@@ -878,33 +894,34 @@ def g13_alpha_line_levels(atm, cont):
     )
 
 
-def main():
-    rng = np.random.default_rng(20250926)
+ALL = ("g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13")
+
+
+def generate(which):
     capture_data()
     dump_constants()
     from stardis_amd import synth
 
     atm = atmosphere()
     cont = synth.synth_continuum_state(atm)
-    which = set(sys.argv[1:]) or {"g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"}
     if "g1" in which:
-        g1_faddeeva(rng)
+        g1_faddeeva(rng_for(1))
     if "g2" in which:
-        g2_voigt(rng)
+        g2_voigt(rng_for(2))
     if "g3" in which:
-        g3_broadening(rng, atm, cont)
+        g3_broadening(rng_for(3), atm, cont)
     if "g4" in which:
-        g4_alan(rng, atm)
+        g4_alan(rng_for(4), atm)
     if "g5" in which:
         g5_continuum(atm, cont)
     if "g6" in which:
-        g6_weights(rng)
+        g6_weights(rng_for(6))
     if "g7" in which:
-        g7_raytrace(rng, atm, cont)
+        g7_raytrace(rng_for(7), atm, cont)
     if "g8" in which:
-        g8_rotation(rng)
+        g8_rotation(rng_for(8))
     if "g9" in which:
-        g9_end_to_end(rng, atm, cont)
+        g9_end_to_end(rng_for(9), atm, cont)
     if "g10" in which:
         g10_spherical(atm)
     if "g11" in which:
@@ -913,6 +930,55 @@ def main():
         g12_sigma_tables(atm)
     if "g13" in which:
         g13_alpha_line_levels(atm, cont)
+
+
+def verify(which):
+    """Regenerate into a temporary directory and compare with the committed files, array by array (names, dtypes, shapes,
+    bits; NaNs must coincide).  -> number of files that differ."""
+    import glob
+    import tempfile
+
+    global OUT_DIR, DATA_DIR
+    committed_dir, committed_data = OUT_DIR, DATA_DIR
+    bad = 0
+    with tempfile.TemporaryDirectory(prefix="golden_verify_") as tmp:
+        OUT_DIR, DATA_DIR = tmp, os.path.join(tmp, "data")
+        try:
+            generate(which)
+        finally:
+            OUT_DIR, DATA_DIR = committed_dir, committed_data
+        for path in sorted(glob.glob(os.path.join(tmp, "*.npz"))):
+            name = os.path.basename(path)
+            ref_path = os.path.join(committed_dir, name)
+            if not os.path.exists(ref_path):
+                print(f"VERIFY {name}: no committed file")
+                bad += 1
+                continue
+            new, old = np.load(path, allow_pickle=False), np.load(ref_path, allow_pickle=False)
+            diffs = [k for k in sorted(set(new.files) | set(old.files))
+                     if k not in new.files or k not in old.files or new[k].dtype != old[k].dtype or new[k].shape != old[k].shape
+                     or not np.array_equal(new[k], old[k], equal_nan=new[k].dtype.kind in "fc")]
+            print(f"VERIFY {name}: " + ("identical" if not diffs else f"DIFFERS in {diffs[:6]}"))
+            bad += bool(diffs)
+        for path in sorted(glob.glob(os.path.join(tmp, "data", "*.json"))):
+            name = os.path.basename(path)
+            same = os.path.exists(os.path.join(committed_data, name)) and json.load(open(path)) == json.load(open(os.path.join(committed_data, name)))
+            print(f"VERIFY data/{name}: " + ("identical" if same else "DIFFERS"))
+            bad += not same
+    return bad
+
+
+def main():
+    args = [a for a in sys.argv[1:] if a != "--verify"]
+    which = set(args) or set(ALL)
+    unknown = which - set(ALL)
+    if unknown:
+        raise SystemExit(f"unknown fixtures {sorted(unknown)}")
+    if "--verify" in sys.argv[1:]:
+        bad = verify(which)
+        print("VERIFY: " + ("all identical" if not bad else f"{bad} file(s) differ"))
+        raise SystemExit(1 if bad else 0)
+    generate(which)
 
 
 if __name__ == "__main__":

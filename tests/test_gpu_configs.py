@@ -4,6 +4,9 @@ Voigt evaluations in a test):
 * the pre-pass's evaluation count equals the window rule evaluated on the host (opacities_solvers/base.py:524-575);
 * the formal solution is column-independent: a strided subset of columns recomputed by the oracle from the GPU's own
   total opacity must match the GPU flux (radiation_field_solvers/base.py:85-346);
+* the line opacity with EVERY line of the list present — candidate lists, culling, tile classification of the full-size
+  kernels — against the oracle on >= 200 columns (oracle.calc_alan_entries_columns: the whole grid's window rule, terms only
+  at those columns; ~1e7 evaluations), and with it the total opacity and the flux of those columns end to end;
 * the line opacity is linear in the line list: a strided subset of the lines, run alone on the full grid, equals the
   oracle's calc_alan_entries for that subset (opacities_solvers/base.py:487-592);
 * config 5 = config 3 + fp32-mixed synthesis + instrumental LSF + rotational kernel without leaving the device
@@ -45,6 +48,15 @@ def full_size_checks(ctx, tag, line_stride, col_stride):
     c_ref = c_ref + oracle.alpha_ff(nus[cols], atm["temperatures"], [1], cont["n_e"] * cont["n_h2"])
     c_ref = c_ref + oracle.alpha_electron(cols.size, cont["n_e"])
     assert rel_err(total[:, cols], c_ref + line[:, cols]) < 1e-15
+    # every line of the list, on these columns, against the oracle (global window rule, evaluated at the columns only), and the
+    # flux of these columns from the oracle's own total: the whole chain without the GPU in it
+    line_ref, ev_cols = oracle.calc_alan_entries_columns(cols, 56, nus, lines["line_nus"], lines["doppler_widths"], lines["gammas"], lines["alphas"],
+                                                         return_evals=True)
+    assert cols.size >= 200 and ev_cols > 1e6
+    assert np.array_equal(line[:, cols] == 0, line_ref == 0)
+    assert rel_err(line[:, cols], line_ref) < 1e-12
+    F_cpu, _ = oracle.raytrace(nus[cols], atm["temperatures"], atm["dist"], w["thetas"], w["weights"], c_ref + line_ref)
+    assert rel_err(F[1:, cols], F_cpu[1:]) < 1e-10
     del syn
     sub = {k: np.ascontiguousarray(v[::line_stride]) for k, v in lines.items()}
     s2 = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], w["thetas"], w["weights"], sub, w["cont"], ctx=ctx)
@@ -91,6 +103,11 @@ def test_config5_mixed_precision_then_lsf_and_rotation_on_the_device(ctx):
             f_lambda = spec.spectrum_lambda().numpy()
             broad = spec.broadened(sigma_pix=sigma_pix, velocity_per_pix=vel_per_pix, v_rot=cfg["v_rot_kms"]).numpy()
             out[mode] = dict(F=syn.F_nu()[-1], f_lambda=f_lambda, broad=broad, line=syn.alpha_line())
+            if mode == 0:  # the fp64 leg of configs[4] itself against the oracle: all lines on 201 columns
+                cols = np.arange(300, nus.size, 601)
+                ln = w["lines"]
+                line_ref = oracle.calc_alan_entries_columns(cols, 56, nus, ln["line_nus"], ln["doppler_widths"], ln["gammas"], ln["alphas"])
+                assert cols.size >= 200 and rel_err(out[0]["line"][:, cols], line_ref) < 1e-12
             # the device chain is the host chain of the walk-through, operation for operation
             F = out[mode]["F"]
             assert np.array_equal(f_lambda, F * nus / lam)

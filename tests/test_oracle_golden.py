@@ -214,3 +214,26 @@ def test_gaussian_line_spread_function_matches_scipy():
     g = load_golden("g8_rotation")
     for sigma in (0.4, 2.76, 27.6):
         assert rel_err(oracle.gaussian_filter1d(g["flux"], sigma), gaussian_filter1d(g["flux"], sigma)) < 1e-15
+
+
+def test_column_subset_oracle_equals_the_full_one_on_its_columns():
+    """oracle.calc_alan_entries_columns (the window rule of the whole grid, terms only at the listed columns) against
+    oracle.calc_alan_entries — itself pinned to the reference by G4 above — incl. edge lines, empty and single-column lists."""
+    g = load_golden("g4_alan_entries")
+    keys = sorted({k.split("_")[0] for k in g.files})
+    assert keys
+    for case in keys:
+        nus, ln = g[case + "_nus"], g[case + "_line_nus"]
+        dw, gam, al = g[case + "_doppler_widths"], g[case + "_gammas"], g[case + "_alphas"]
+        nd = dw.shape[1]
+        full, ev_full = oracle.calc_alan_entries(nd, nus, ln, dw, gam, al, return_evals=True)
+        assert rel_err(full, g[case + "_alpha_line_at_nu"]) < 1e-14  # the reference's own output
+        for cols in (np.arange(0, nus.size, 7), np.array([0, nus.size - 1]), np.array([nus.size // 2]), np.arange(nus.size), np.zeros(0, dtype=np.int64)):
+            sub, ev = oracle.calc_alan_entries_columns(cols, nd, nus, ln, dw, gam, al, return_evals=True)
+            assert sub.shape == (nd, cols.size)
+            # the same terms in the same per-thread order up to the slab reduction: a few ulp
+            assert rel_err(sub, full[:, cols]) < 1e-14, case
+            if cols.size == nus.size:
+                assert ev == ev_full
+    with pytest.raises(ValueError):
+        oracle.calc_alan_entries_columns([3, 2], nd, nus, ln, dw, gam, al)
