@@ -167,8 +167,11 @@ struct LineWork {
     // NARROW items (half-width <= kNarrowHalfWidth) and the delegated cores of wide items, LINE-major [N_l][N_d] so that
     // lane <-> depth reads coalesce.  Separate arrays: one 32-byte record per item was measured 45 % slower in the narrow
     // role (a wave's load then touches 28 cache lines three times over instead of 4 + 4 + 7 + 7 + 7)
-    int* nlo;        // window, 0/0 when the narrow role has nothing to do for this (line, depth)
-    int* nhi;
+    // half-width h of the narrow role's window [max(c - h, 0), min(c + h, N_nu)) around the line's centre c — a narrow item's
+    // own half-width (<= kNarrowHalfWidth) or the delegated core's (<= kNarrowReach); 0: nothing to do for this (line, depth).
+    // One byte instead of the two clamped bounds: the clamp is implied by the frequency index being a grid index.
+    unsigned char* nhw;
+    int skip_unlisted_scan;  // long lists, one depth block per line: wscan is written only for lines with a wide window somewhere
     double* n_inv;   // 1 / doppler
     double* n_y;
     double* n_amp;
@@ -196,6 +199,9 @@ struct LineWork {
     int* wlist;
     int* wrank;
     WideScan* hscan;  // [N_d][N_l] rows, entry k of row d = wscan[d][hlist[k]]: the huge lines' scan words, contiguous
+    // (list-ordered copies of the huge lines' RECORDS and of the wlist scan words as well were measured in round 3: the wide
+    // role fetches 0.36 GB per launch at 1e6 lines either way — its 16 GB were the narrow role's — and the copies cost more
+    // than the walk gained; removed)
     // frequency-sharded runs of long lists: the pre-pass only has to prepare the lines this shard can touch.  sel (device
     // memory, written on the side of k_dnu_partial; nullptr: every line): [0..1] = the index range [la, lb) of the lines whose
     // centre lies within kMediumHalfWidth of the shard's columns — the only ones a medium window can reach it from;
@@ -382,7 +388,13 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
     // ONE arithmetic pass, line fastest (depth-major stores coalesce).  The derived constants replace the inputs in
     // LDS so that the line-major stores below need no second evaluation.
     unsigned long long ev = 0;
-    for (int k = threadIdx.x; k < nl * nd; k += nthreads) {
+    __shared__ unsigned char s_h[kPreLines * kStride];
+    WideScan sc_keep[kPreItems];
+#pragma unroll
+    for (int it = 0; it < kPreItems; ++it) {
+        const int k = threadIdx.x + it * kPreBlock;
+        sc_keep[it] = WideScan{0, 0, 0, 0};
+        if (k >= nl * nd) continue;
         const int dd = k / nl, ll = k - dd * nl;
         const int sidx = ll * kStride + dd;
         const double dw = s_dw[sidx], g = s_g[sidx], a = s_a[sidx];
@@ -398,7 +410,7 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
         s_dw[sidx] = inv;
         s_g[sidx] = yy;
         s_a[sidx] = amp;
-        int core_lo = 0, core_hi = 0;
+        int core_lo = 0, core_hi = 0, core_hw = 0;
         bool delegated = false;
         if (w.wscan) {
             const size_t o = (size_t)(d0 + dd) * n_lines + SDX_LINE_OF(ll);  // depth-major (wide kernel)
@@ -419,6 +431,7 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
                 // depth): the narrow arrays below get [clo, chi) as this item's window and the wide role leaves those points out.
                 core_lo = sc.clo, core_hi = sc.chi;
                 delegated = chw > 0 && chw <= kNarrowReach && sc.chi > sc.clo;
+                core_hw = (int)min(chw, hw);  // the core is clipped by the window (64 < hw < chw happens)
                 if (delegated) {
                     atomicMax(&s_hwmax[ll], (int)chw);
                     sc.clo = -sc.clo - 1;  // the sign marks the delegation
@@ -435,7 +448,7 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
             } else if (narrow) {
                 atomicMax(&s_hwmax[ll], (int)hw);
             }
-            w.wscan[o] = sc;
+            sc_keep[it] = sc;  // stored below, once the line's widest window is known
             // a gather block knows its lines' positions in hlist: the list-ordered copy of the scan word is written here
             // (culled runs; otherwise k_hscan makes it once the list exists)
             if (gather && w.hscan && l0 + ll < n_h) w.hscan[(size_t)(d0 + dd) * n_lines + l0 + ll] = sc;
@@ -444,9 +457,23 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
         // bit of the stashed upper bound tells the two apart from "nothing for the narrow role"
         s_lo[sidx] = delegated ? core_lo : lo;
         s_hi[sidx] = narrow ? hi : (delegated ? core_hi : -hi - 1);
+        s_h[sidx] = (unsigned char)(narrow ? (int)hw : (delegated ? core_hw : 0));
         if (hi > lo) ev += (unsigned long long)(hi - lo);
     }
     __syncthreads();
+    // the scan words (depth-major): every tile of the wide role scans the word of a line it considers — all lines of a short
+    // list, the hlist / wlist lines of a long one.  A line of a long list without a wide window at any depth is in neither
+    // list: its 16 bytes per depth (0.9 of 2.8 GB of pre-pass writes at 1e6 lines) are not written.
+    if (w.wscan) {
+#pragma unroll
+        for (int it = 0; it < kPreItems; ++it) {
+            const int k = threadIdx.x + it * kPreBlock;
+            if (k >= nl * nd) continue;
+            const int dd = k / nl, ll = k - dd * nl;
+            if (w.skip_unlisted_scan && s_whwmax[ll] == 0) continue;
+            w.wscan[(size_t)(d0 + dd) * n_lines + SDX_LINE_OF(ll)] = sc_keep[it];
+        }
+    }
     // per-line summary for the narrow kernel's candidate test: centre index and the largest narrow half-width
     if (w.nhw_max && threadIdx.x < nl) {
         if (gy == 1) w.nhw_max[SDX_LINE_OF(threadIdx.x)] = s_hwmax[threadIdx.x], w.whw_max[SDX_LINE_OF(threadIdx.x)] = s_whwmax[threadIdx.x];
@@ -461,7 +488,7 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
         }
     }
     // line-major outputs: the stashed values, depth fastest so the stores coalesce
-    if (w.nlo || out_lo_ref) {
+    if (w.nhw || out_lo_ref) {
         for (int k = threadIdx.x; k < nl * nd; k += nthreads) {
             const int ll = k / nd, dd = k - ll * nd;
             const int sidx = ll * kStride + dd;
@@ -473,9 +500,8 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
                 out_lo_ref[o] = lo;
                 out_hi_ref[o] = hi;
             }
-            if (w.nlo) {
-                w.nlo[o] = narrow ? lo : 0;
-                w.nhi[o] = narrow ? hi : 0;
+            if (w.nhw) {
+                w.nhw[o] = s_h[sidx];
                 if (narrow && w.n_inv32) {
                     w.n_inv32[o] = (float)s_dw[sidx];
                     w.n_y32[o] = (float)s_g[sidx];
@@ -542,8 +568,8 @@ __global__ __launch_bounds__(kPreBlock) __attribute__((amdgpu_num_sgpr(80))) voi
 constexpr int kWideLdsDoubles = 64 * 8;  // per wave: R <= 8 partial sums per lane
 
 template <int R>
-__device__ __forceinline__ void wide_reduce_and_store(const int split, const int n_split, double (&acc)[R], const int (&idx)[R], const bool (&keep)[R],
-                                                      double* __restrict__ lds_all, int64_t nu_begin, double* __restrict__ plane, int64_t pld,
+__device__ __forceinline__ void wide_reduce_and_store(const int split, const int n_split, double (&acc)[R], const int idx0, const int64_t s0,
+                                                      const int64_t s1, double* __restrict__ lds_all, double* __restrict__ plane, int64_t pld,
                                                       const int d)
 {
     const int lane = threadIdx.x & 63;
@@ -565,7 +591,7 @@ __device__ __forceinline__ void wide_reduce_and_store(const int split, const int
     if (split == 0) {
 #pragma unroll
         for (int r = 0; r < R; ++r)
-            if (keep[r]) plane[(size_t)d * pld + (idx[r] - nu_begin)] = acc[r];
+            if (idx0 + 64 * r >= s0 && idx0 + 64 * r < s1) plane[(size_t)d * pld + (idx0 + 64 * r - s0)] = acc[r];  // the shard's columns only
     }
 }
 
@@ -611,8 +637,9 @@ __device__ __forceinline__ void line_wide_walk(const int tile_idx, const int spl
     // register budget
     double dnu[MIXED ? 1 : R], acc[R];
     float2v nu_h[MIXED ? R / 2 : 1], nu_l[MIXED ? R / 2 : 1], acc32[MIXED ? R / 2 : 1];  // pairs of points (r, r + 1)
-    int idx[R];
-    bool keep[R];
+    // (grid index of point r of this lane: it0 + lane + 64 r, formed where it is needed — an edge test, the final store —
+    // instead of living in registers through the walk)
+    const int idx0 = it0 + lane;
     // (both halves through readfirstlane: the base is wave-uniform and ends up in an SGPR pair)
     const double nu_base_v = nus[t0];
     const double nu_base = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(nu_base_v)), __builtin_amdgcn_readfirstlane(__double2loint(nu_base_v)));
@@ -623,8 +650,6 @@ __device__ __forceinline__ void line_wide_walk(const int tile_idx, const int spl
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int64_t i = t0 + lane + r * 64;
-        idx[r] = i < t1 ? (int)i : -1;
-        keep[r] = i >= s0 && i < s1;
         const double nu = i < t1 ? nus[i] : nu_base;
         acc[r] = 0.0;
         if constexpr (MIXED) {
@@ -754,7 +779,8 @@ __device__ __forceinline__ void line_wide_walk(const int tile_idx, const int spl
                         if (z <= jlo || a >= jhi || a >= it1) continue;
                         const bool over_core = !(z <= jclo || a >= jchi);
                         if (!over_core || delegated) {
-                            const bool take = idx[r] >= jlo && idx[r] < jhi && !(over_core && idx[r] >= jclo && idx[r] < jchi);
+                            const int ir = idx0 + 64 * r;  // (points beyond the grid's end lie beyond every window: jhi <= N_nu)
+                            const bool take = ir >= jlo && ir < jhi && !(over_core && ir >= jclo && ir < jchi);
                             if constexpr (MIXED) {  // the tolerance path evaluates window edges in fp32 too (pairs of blocks)
                                 acc32[r >> 1][r & 1] = take ? term32[r >> 1][r & 1] : acc32[r >> 1][r & 1];
                             } else {
@@ -763,7 +789,7 @@ __device__ __forceinline__ void line_wide_walk(const int tile_idx, const int spl
                         } else {
                             const double nu_r = MIXED ? (double)nu_h[MIXED ? r >> 1 : 0][r & 1] + (double)nu_l[MIXED ? r >> 1 : 0][r & 1] : dnu[MIXED ? 0 : r] + nu_base;  // exact
                             const WideSlow sl = slow_row[e];
-                            if (idx[r] >= jlo && idx[r] < jhi) acc[r] = voigt_add(acc[r], nu_r - cur.lnu, cur.inv, sl.y, sl.amp, k1);
+                            if (idx0 + 64 * r >= jlo && idx0 + 64 * r < jhi) acc[r] = voigt_add(acc[r], nu_r - cur.lnu, cur.inv, sl.y, sl.amp, k1);
                         }
                     }
                 }
@@ -784,7 +810,7 @@ __device__ __forceinline__ void line_wide_walk(const int tile_idx, const int spl
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] += (double)acc32[r >> 1][r & 1];
     }
-    wide_reduce_and_store<R>(split, n_split, acc, idx, keep, lds_all, nu_begin, plane, pld, d);
+    wide_reduce_and_store<R>(split, n_split, acc, idx0, s0, s1, lds_all, plane, pld, d);
 }
 
 // Long line lists: two stable compactions of the per-line classes in two small launches (per-block counts, then every
@@ -856,8 +882,7 @@ __global__ __launch_bounds__(kHlistBlock) void k_hlist_scatter(int64_t n_lines, 
 }
 
 // hscan[d][k] = wscan[d][hlist[k]]: every tile scans ALL the huge lines; gathering their 16-byte scan words through the
-// list costs a 64-byte sector each, (tiles x depths) times over — 17 GB per step at 1e6 lines.  Copied once into list
-// order they are read as contiguous kilobytes.
+// list costs a 64-byte sector each.  Copied once into list order they are read as contiguous kilobytes.
 __global__ __launch_bounds__(kBlock) void k_hscan(int n_depth, int64_t n_lines, const int* __restrict__ hlist, const int* __restrict__ hcount,
                                                   const WideScan* __restrict__ wscan, WideScan* __restrict__ hscan)
 {
@@ -988,38 +1013,120 @@ __device__ __forceinline__ void line_narrow_wave(const int64_t i, const int dept
         // only the relevant ones, in ascending line order
         const int lc = base + lane;
         bool rel = false;
+        int c = 0;
         if (lc < lb) {
-            const int hwm = w.nhw_max[lc], c = w.centre[lc];
+            const int hwm = w.nhw_max[lc];
+            c = w.centre[lc];
             rel = hwm > 0 && ii >= c - hwm && ii < c + hwm;
         }
         unsigned long long m = __ballot(rel);
         // the parameters of the NEXT relevant line are requested before the current one is evaluated (all six loads at
         // once, used or not): one global-memory round trip per line hides behind the previous line's arithmetic
-        int lo = 0, hi = 0;
+        int h = 0, cl = 0;  // this depth's half-width, the line's centre (scalar)
         double y = 0.0, amp = 0.0, inv = 0.0, lnu = 0.0;
         // addresses: a per-line base (uniform: scalar arithmetic) + the lane's depth as an unsigned 32-bit offset
         if (m) {
-            const int l = base + __builtin_ctzll(m);
+            const int bit = __builtin_ctzll(m);
+            const int l = base + bit;
             const size_t ob = (size_t)l * n_depth;
-            lo = (w.nlo + ob)[dcu], hi = (w.nhi + ob)[dcu], y = (w.n_y + ob)[dcu], amp = (w.n_amp + ob)[dcu], inv = (w.n_inv + ob)[dcu], lnu = line_nus[l];
+            cl = __builtin_amdgcn_readlane(c, bit);
+            h = (w.nhw + ob)[dcu], y = (w.n_y + ob)[dcu], amp = (w.n_amp + ob)[dcu], inv = (w.n_inv + ob)[dcu], lnu = line_nus[l];
         }
         while (m) {
             m &= m - 1;
-            int lo_n = 0, hi_n = 0;
+            int h_n = 0, cl_n = 0;
             double y_n = 0.0, amp_n = 0.0, inv_n = 0.0, lnu_n = 0.0;
             if (m) {
-                const int l = base + __builtin_ctzll(m);
+                const int bit = __builtin_ctzll(m);
+                const int l = base + bit;
                 const size_t ob = (size_t)l * n_depth;
-                lo_n = (w.nlo + ob)[dcu], hi_n = (w.nhi + ob)[dcu], y_n = (w.n_y + ob)[dcu], amp_n = (w.n_amp + ob)[dcu], inv_n = (w.n_inv + ob)[dcu], lnu_n = line_nus[l];
+                cl_n = __builtin_amdgcn_readlane(c, bit);
+                h_n = (w.nhw + ob)[dcu], y_n = (w.n_y + ob)[dcu], amp_n = (w.n_amp + ob)[dcu], inv_n = (w.n_inv + ob)[dcu], lnu_n = line_nus[l];
             }
-            if (valid && ii >= lo && ii < hi) {
+            if (valid && ii >= cl - h && ii < cl + h) {  // (h = 0: empty)
                 const RegionI k1 = region1_setup(y, amp);
                 acc = voigt_add(acc, nu_i - lnu, inv, y, amp, k1);
             }
-            lo = lo_n, hi = hi_n, y = y_n, amp = amp_n, inv = inv_n, lnu = lnu_n;
+            h = h_n, cl = cl_n, y = y_n, amp = amp_n, inv = inv_n, lnu = lnu_n;
         }
     }
     if (valid) plane[(size_t)d * pld + (i - nu_begin)] = acc;
+}
+
+// The same walk for F CONSECUTIVE frequencies per wave (F = 2, 4; groups aligned to the global grid index): the records of a
+// visited line — five coalesced loads, 1.9 KB per wave — serve up to F evaluations instead of one, the candidate test and the
+// region-I constants are shared, and a lane has F independent evaluations in flight.  At 1e6 lines the one-frequency walk
+// fetched 16 GB per launch through its record loads (each of the ~20 frequencies of a weak line's window loaded them again,
+// and 900 waves per XCD, each with its own 170 lines, do not fit the L2); a group fetches a line's records once.  Every
+// frequency still adds its lines in ascending line order: the bits are those of the one-frequency walk, whatever F — which
+// may therefore depend on the size of the launch (small grids keep F = 1: they need the waves).
+template <int F>
+__device__ __forceinline__ void line_narrow_group(const int64_t i0, const int depth_chunk, int n_depth, int64_t n_nu, const double* __restrict__ nus,
+                                                  int64_t nu_begin, int64_t nu_count, int64_t n_lines, const double* __restrict__ line_nus,
+                                                  LineWork w, double* __restrict__ plane, int64_t pld)
+{
+    const int lane = threadIdx.x & 63;
+    const int d = depth_chunk * 64 + lane;
+    const bool valid = d < n_depth;
+    const int dc = valid ? d : n_depth - 1;
+    const unsigned dcu = (unsigned)dc;
+    const int ia = (int)i0;
+    // lines with centre c in [i0 - H + 1, i0 + F - 1 + H]
+    const int64_t pa = max(i0 - kNarrowReach + 1, (int64_t)0);
+    const int64_t pb = min(i0 + F - 1 + kNarrowReach, n_nu);
+    const int la = __builtin_amdgcn_readfirstlane(w.cnt_ge[pb + 1]);
+    const int lb = __builtin_amdgcn_readfirstlane(w.cnt_ge[pa]);
+    double nu_k[F], acc[F];
+    bool act[F];  // the frequency belongs to this launch's columns (wave-uniform)
+#pragma unroll
+    for (int k = 0; k < F; ++k) {
+        act[k] = i0 + k >= nu_begin && i0 + k < nu_begin + nu_count;
+        nu_k[k] = nus[min(i0 + k, n_nu - 1)];
+        acc[k] = 0.0;
+    }
+    for (int base = la; base < lb; base += 64) {
+        const int lc = base + lane;
+        bool rel = false;
+        int c = 0;
+        if (lc < lb) {
+            const int hwm = w.nhw_max[lc];
+            c = w.centre[lc];
+            rel = hwm > 0 && ia + (F - 1) >= c - hwm && ia < c + hwm;
+        }
+        unsigned long long m = __ballot(rel);
+        int h = 0, cl = 0;
+        double y = 0.0, amp = 0.0, inv = 0.0, lnu = 0.0;
+        if (m) {
+            const int bit = __builtin_ctzll(m);
+            const int l = base + bit;
+            const size_t ob = (size_t)l * n_depth;
+            cl = __builtin_amdgcn_readlane(c, bit);
+            h = (w.nhw + ob)[dcu], y = (w.n_y + ob)[dcu], amp = (w.n_amp + ob)[dcu], inv = (w.n_inv + ob)[dcu], lnu = line_nus[l];
+        }
+        while (m) {
+            m &= m - 1;
+            int h_n = 0, cl_n = 0;
+            double y_n = 0.0, amp_n = 0.0, inv_n = 0.0, lnu_n = 0.0;
+            if (m) {
+                const int bit = __builtin_ctzll(m);
+                const int l = base + bit;
+                const size_t ob = (size_t)l * n_depth;
+                cl_n = __builtin_amdgcn_readlane(c, bit);
+                h_n = (w.nhw + ob)[dcu], y_n = (w.n_y + ob)[dcu], amp_n = (w.n_amp + ob)[dcu], inv_n = (w.n_inv + ob)[dcu], lnu_n = line_nus[l];
+            }
+            const int lo = cl - h, hi = cl + h;  // (h = 0: empty; the clamp to the grid is implied by ia + k being a grid index)
+            if (valid && ia + (F - 1) >= lo && ia < hi) {
+                const RegionI k1 = region1_setup(y, amp);
+#pragma unroll
+                for (int k = 0; k < F; ++k)
+                    if (act[k] && ia + k >= lo && ia + k < hi) acc[k] = voigt_add(acc[k], nu_k[k] - lnu, inv, y, amp, k1);
+            }
+            h = h_n, cl = cl_n, y = y_n, amp = amp_n, inv = inv_n, lnu = lnu_n;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < F; ++k)
+        if (valid && act[k]) plane[(size_t)d * pld + (i0 + k - nu_begin)] = acc[k];
 }
 
 // The narrow role of the mixed-precision mode: the same walk, every term evaluated by voigt_add32 (packed fp32, all four
@@ -1045,32 +1152,38 @@ __device__ __forceinline__ void line_narrow_wave32(const int64_t i, const int de
     for (int base = la; base < lb; base += 64) {
         const int lc = base + lane;
         bool rel = false;
+        int c = 0;
         if (lc < lb) {
-            const int hwm = w.nhw_max[lc], c = w.centre[lc];
+            const int hwm = w.nhw_max[lc];
+            c = w.centre[lc];
             rel = hwm > 0 && ii >= c - hwm && ii < c + hwm;
         }
         unsigned long long m = __ballot(rel);
         float acc32 = 0.f;
-        int lo = 0, hi = 0;
+        int h = 0, cl = 0;
         float y = 0.f, amp = 0.f, inv = 0.f;
         float2v lnu = {0.f, 0.f};
         if (m) {
-            const int l = base + __builtin_ctzll(m);
+            const int bit = __builtin_ctzll(m);
+            const int l = base + bit;
             const size_t o = (size_t)l * n_depth + dc;
-            lo = w.nlo[o], hi = w.nhi[o], y = w.n_y32[o], amp = w.n_amp32[o], inv = w.n_inv32[o], lnu = w.lnu32[l];
+            cl = __builtin_amdgcn_readlane(c, bit);
+            h = w.nhw[o], y = w.n_y32[o], amp = w.n_amp32[o], inv = w.n_inv32[o], lnu = w.lnu32[l];
         }
         while (m) {
             m &= m - 1;
-            int lo_n = 0, hi_n = 0;
+            int h_n = 0, cl_n = 0;
             float y_n = 0.f, amp_n = 0.f, inv_n = 0.f;
             float2v lnu_n = {0.f, 0.f};
             if (m) {
-                const int l = base + __builtin_ctzll(m);
+                const int bit = __builtin_ctzll(m);
+                const int l = base + bit;
                 const size_t o = (size_t)l * n_depth + dc;
-                lo_n = w.nlo[o], hi_n = w.nhi[o], y_n = w.n_y32[o], amp_n = w.n_amp32[o], inv_n = w.n_inv32[o], lnu_n = w.lnu32[l];
+                cl_n = __builtin_amdgcn_readlane(c, bit);
+                h_n = w.nhw[o], y_n = w.n_y32[o], amp_n = w.n_amp32[o], inv_n = w.n_inv32[o], lnu_n = w.lnu32[l];
             }
-            if (valid && ii >= lo && ii < hi) acc32 = voigt_add32(acc32, ((nih - lnu.x) + (nil - lnu.y)) * inv, y, amp);
-            lo = lo_n, hi = hi_n, y = y_n, amp = amp_n, inv = inv_n, lnu = lnu_n;
+            if (valid && ii >= cl - h && ii < cl + h) acc32 = voigt_add32(acc32, ((nih - lnu.x) + (nil - lnu.y)) * inv, y, amp);
+            h = h_n, cl = cl_n, y = y_n, amp = amp_n, inv = inv_n, lnu = lnu_n;
         }
         acc += (double)acc32;
     }
@@ -1121,7 +1234,12 @@ __device__ __forceinline__ void line_all_body(int n_wide, int tiles, int n_split
         // of frequencies, the groups going round the XCDs.  (Giving each XCD one contiguous eighth of the grid was measured
         // 45 % slower: the lines per grid point follow the frequency, so one XCD gets several times the work of another.)
         constexpr int kNarrowGroup = 4;
-        const int64_t n_narrow = nu_count * ((n_depth + 63) / 64);
+        // F consecutive frequencies per wave (roles bits 8-11: 1, 2 or 4 — 8 was measured slower —; the mixed-precision walk takes one), groups aligned
+        // to the global grid
+        const int F = MIXED ? 1 : max(1, (roles >> 8) & 15);
+        const int64_t g0 = nu_begin / F;
+        const int64_t n_grp = (nu_begin + nu_count + F - 1) / F - g0;
+        const int64_t n_narrow = n_grp * ((n_depth + 63) / 64);
         const int64_t n_nb = (n_narrow + n_split - 1) / n_split;
         const int64_t p = b - n_wide, j = p >> 3;
         const int order = (roles >> 2) & 3;  // analysis knob (SDX_NARROW_ORDER): 0 grouped (default), 1 plain, 2 one block per XCD
@@ -1131,11 +1249,16 @@ __device__ __forceinline__ void line_all_body(int n_wide, int tiles, int n_split
         if ((order == 2 && j >= (n_nb + 7) / 8) || wg >= n_nb) return;
         const int64_t c = wg * n_split + wave;
         if (c >= n_narrow) return;
-        if constexpr (MIXED)
-            line_narrow_wave32(nu_begin + c % nu_count, (int)(c / nu_count), n_depth, n_nu, nus, nu_begin, nu_count, w, planes + (size_t)n_depth * pld, pld);
-        else
-            line_narrow_wave(nu_begin + c % nu_count, (int)(c / nu_count), n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w,
-                             planes + (size_t)n_depth * pld, pld);
+        const int64_t i0 = (g0 + c % n_grp) * F;
+        const int chunk = (int)(c / n_grp);
+        double* __restrict__ nplane = planes + (size_t)n_depth * pld;
+        if constexpr (MIXED) {
+            line_narrow_wave32(i0, chunk, n_depth, n_nu, nus, nu_begin, nu_count, w, nplane, pld);
+        } else {
+            if (F == 4) line_narrow_group<4>(i0, chunk, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, nplane, pld);
+            else if (F == 2) line_narrow_group<2>(i0, chunk, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, nplane, pld);
+            else line_narrow_wave(i0, chunk, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, nplane, pld);
+        }
     }
 }
 

@@ -156,8 +156,8 @@ LineWork carve(sdx_ctx* ctx, int n_depth, int64_t n_lines)
     w.n_inv = (double*)(rec32 + n);  // 8 n each
     w.n_y = w.n_inv + n;
     w.n_amp = w.n_y + n;
-    w.nlo = (int*)(w.n_amp + n);     // 4 n each
-    w.nhi = w.nlo + n;
+    w.nhw = (unsigned char*)(w.n_amp + n);  // 1 n (the 8 n bytes of the former window bounds stay reserved)
+    w.skip_unlisted_scan = 0;
     w.n_inv32 = w.n_y32 = w.n_amp32 = nullptr;
     w.lnu32 = nullptr;
     if (ctx->mixed_precision) {  // the narrow role's records as floats in the same 24 n bytes, + the line frequencies as float pairs
@@ -166,7 +166,7 @@ LineWork carve(sdx_ctx* ctx, int n_depth, int64_t n_lines)
         w.n_amp32 = w.n_y32 + n;
         w.lnu32 = (float2v*)(w.n_amp32 + n);
     }
-    w.hscan = (WideScan*)(w.nhi + n);  // 16 n (only the first hcount[0] entries of a row are used)
+    w.hscan = (WideScan*)((int*)(w.n_amp + n) + 2 * n);  // 16 n (only the first hcount[0] entries of a row are used)
     w.cnt_ge = (int*)ctx->cnt_ws;
     w.centre = w.cnt_ge + ctx->cnt_ge_len;
     w.nhw_max = w.centre + n_lines;
@@ -720,6 +720,9 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
     }
     w.sel = nullptr;
     w.gather = 0;
+    // long lists find their wide lines through hlist / wlist: the scan words of a line without a wide window anywhere are never
+    // read (needs the line's widest window inside one block: one depth block per line)
+    w.skip_unlisted_scan = (fill_work && n_lines >= ctx->indexed_min_lines && n_depth <= kPreDepths) ? 1 : 0;
     w.n_pix = n_pixel_blocks;
     w.shard_begin = nu_begin;
     w.shard_end = nu_begin + nu_count;
@@ -915,14 +918,24 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
     const int64_t tiles_pad = wide_group ? ((int64_t)tiles + 8 * wide_group - 1) / (8 * wide_group) * (8 * wide_group) : tiles;
     const int64_t n_wide = tiles_pad * n_depth;
     // workgroups of n_split waves, rounded up to whole rounds of the XCD-aware order (surplus workgroups return at once)
-    const int64_t n_narrow = (((nu_count * ((n_depth + 63) / 64) + n_split - 1) / n_split + 31) / 32) * 32;
+    // narrow role: F consecutive frequencies per wave (a line's records, loaded once, serve F evaluations) for DENSE lists —
+    // at least one line per two grid points, where a frequency visits many lines and the walk is bound by its loads and
+    // instructions — as long as a few thousand such waves remain (they share the launch with the wide role's); sparse lists
+    // on small grids (S-c2: 2000 lines on 7634 points, a latency-bound launch) keep one frequency per wave.  Pure scheduling:
+    // every frequency adds its lines in the same order whatever F.  (F = 8 was measured slower than 4 at every size.)
+    static const int narrow_f_env = std::getenv("SDX_NARROW_F") ? std::atoi(std::getenv("SDX_NARROW_F")) : 0;  // A/B knob: 1, 2, 4
+    int narrow_f = 1;
+    if (!ctx->mixed_precision && 2 * n_lines >= n_nu) narrow_f = nu_count >= 8192 ? 4 : (nu_count >= 4096 ? 2 : 1);
+    if (!ctx->mixed_precision && (narrow_f_env == 1 || narrow_f_env == 2 || narrow_f_env == 4)) narrow_f = narrow_f_env;
+    const int64_t n_grp = (nu_begin + nu_count + narrow_f - 1) / narrow_f - nu_begin / narrow_f;
+    const int64_t n_narrow = (((n_grp * ((n_depth + 63) / 64) + n_split - 1) / n_split + 31) / 32) * 32;
     static const int narrow_order = std::getenv("SDX_NARROW_ORDER") ? atoi(std::getenv("SDX_NARROW_ORDER")) & 3 : 0;
     REQUIRE(n_wide + n_narrow < ((int64_t)1 << 31), "line opacity: grid too large for one launch");
     static const bool split_launches = std::getenv("SDX_SPLIT_LAUNCHES") != nullptr;  // analysis knob: time the two roles apart
     const size_t shmem = (size_t)n_split * kWideLdsDoubles * sizeof(double);
     const dim3 g((unsigned)(n_wide + n_narrow)), blk((unsigned)(64 * n_split));
     for (int pass = 0; pass < (split_launches ? 2 : 1); ++pass) {
-        const int roles = (split_launches ? (1 << pass) : 3) | (narrow_order << 2) | (wide_group << 4);
+        const int roles = (split_launches ? (1 << pass) : 3) | (narrow_order << 2) | (wide_group << 4) | (narrow_f << 8);
         LaunchScope ls(ctx, split_launches ? (pass ? "k_line_narrow" : "k_line_wide") : "k_line_all");
 #define SDX_LINE_ARGS (int)n_wide, tiles, n_split, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, part, pld, roles
         if (ctx->mixed_precision && Rm == 8) hipLaunchKernelGGL((k_line_all_mixed<8>), g, blk, shmem, ctx->stream, SDX_LINE_ARGS);
