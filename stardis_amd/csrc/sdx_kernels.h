@@ -787,9 +787,18 @@ __device__ __forceinline__ void line_wide_walk(const int tile_idx, const int spl
                                 acc[r] = region1_add_if(acc[r], fma(dnu[MIXED ? 0 : r], cur.inv, c0), k1, take);
                             }
                         } else {
-                            const double nu_r = MIXED ? (double)nu_h[MIXED ? r >> 1 : 0][r & 1] + (double)nu_l[MIXED ? r >> 1 : 0][r & 1] : dnu[MIXED ? 0 : r] + nu_base;  // exact
                             const WideSlow sl = slow_row[e];
-                            if (idx0 + 64 * r >= jlo && idx0 + 64 * r < jhi) acc[r] = voigt_add(acc[r], nu_r - cur.lnu, cur.inv, sl.y, sl.amp, k1);
+                            if (idx0 + 64 * r >= jlo && idx0 + 64 * r < jhi) {
+                                if constexpr (MIXED) {
+                                    const double nu_r = (double)nu_h[MIXED ? r >> 1 : 0][r & 1] + (double)nu_l[MIXED ? r >> 1 : 0][r & 1];
+                                    acc[r] = voigt_add(acc[r], nu_r - cur.lnu, cur.inv, sl.y, sl.amp, k1);
+                                } else {
+                                    // x from the tile offsets like every other point of the tile (a core kept here is wider than 128
+                                    // points: |c0| stays below ~50, x is good to 1e-14 absolute) — forming nu_i = dnu + nu_base instead
+                                    // made the compiler hoist four sums out of the walk and spill them to scratch in every wave
+                                    acc[r] = voigt_add_x(acc[r], fma(dnu[MIXED ? 0 : r], cur.inv, c0), sl.y, sl.amp, k1);
+                                }
+                            }
                         }
                     }
                 }

@@ -371,14 +371,17 @@ __device__ __attribute__((noinline)) double faddeeva_re_core(double x, double y,
 //   y      = (gamma / (sqrt(pi) * pi)) / doppler_width        (voigt.py:148, exact operations)
 //   amp    = alpha / (sqrt(pi) * doppler_width)               (voigt.py:149 and base.py:627)
 // voigt_add returns acc + the term (see region1_add for why the sum is inside).
-__device__ __forceinline__ double voigt_add(double acc, double delta_nu, double inv_dw, double y, double amp, const RegionI& k)
+__device__ __forceinline__ double voigt_add_x(double acc, double x, double y, double amp, const RegionI& k)
 {
-    const double x = delta_nu * inv_dw;
     const double ax = fabs(x);
     if (add_rn(ax, y) > 15.0) return region1_add(acc, x, k);  // amp is inside k
     const double core = faddeeva_re_core(x, y, ax);
     asm("v_fma_f64 %0, %1, %2, %0" : "+v"(acc) : "v"(amp), "v"(core));
     return acc;
+}
+__device__ __forceinline__ double voigt_add(double acc, double delta_nu, double inv_dw, double y, double amp, const RegionI& k)
+{
+    return voigt_add_x(acc, delta_nu * inv_dw, y, amp, k);
 }
 __device__ __forceinline__ double voigt_term(double delta_nu, double inv_dw, double y, double amp, const RegionI& k)
 {

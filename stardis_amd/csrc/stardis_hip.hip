@@ -920,12 +920,13 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
     // workgroups of n_split waves, rounded up to whole rounds of the XCD-aware order (surplus workgroups return at once)
     // narrow role: F consecutive frequencies per wave (a line's records, loaded once, serve F evaluations) for DENSE lists —
     // at least one line per two grid points, where a frequency visits many lines and the walk is bound by its loads and
-    // instructions — as long as a few thousand such waves remain (they share the launch with the wide role's); sparse lists
+    // instructions — as long as >= 8192 such waves remain: an eighth of S-c3 (11 000 - 21 000 columns) with F = 4 ran its
+    // line kernel 20 % SLOWER (414 against 345 us: a few thousand four-times-longer waves are the launch's tail); sparse lists
     // on small grids (S-c2: 2000 lines on 7634 points, a latency-bound launch) keep one frequency per wave.  Pure scheduling:
     // every frequency adds its lines in the same order whatever F.  (F = 8 was measured slower than 4 at every size.)
     static const int narrow_f_env = std::getenv("SDX_NARROW_F") ? std::atoi(std::getenv("SDX_NARROW_F")) : 0;  // A/B knob: 1, 2, 4
     int narrow_f = 1;
-    if (!ctx->mixed_precision && 2 * n_lines >= n_nu) narrow_f = nu_count >= 8192 ? 4 : (nu_count >= 4096 ? 2 : 1);
+    if (!ctx->mixed_precision && 2 * n_lines >= n_nu) narrow_f = nu_count >= 32768 ? 4 : (nu_count >= 16384 ? 2 : 1);
     if (!ctx->mixed_precision && (narrow_f_env == 1 || narrow_f_env == 2 || narrow_f_env == 4)) narrow_f = narrow_f_env;
     const int64_t n_grp = (nu_begin + nu_count + narrow_f - 1) / narrow_f - nu_begin / narrow_f;
     const int64_t n_narrow = (((n_grp * ((n_depth + 63) / 64) + n_split - 1) / n_split + 31) / 32) * 32;
@@ -1966,13 +1967,36 @@ RcclApi* rccl_api()
     static RcclApi api;
     std::lock_guard<std::mutex> lock(m);
     if (api.handle) return &api;
-    const char* path = std::getenv("SDX_RCCL_LIB");  // another build of RCCL (or, in tests, a path that does not exist)
-    if (!path || !*path) path = "librccl.so.1";
-    void* h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
-    if (!h && !std::getenv("SDX_RCCL_LIB")) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    // Which RCCL: the one that sits NEXT TO THE HIP RUNTIME THIS LIBRARY IS BOUND TO.  A process may hold two ROCm stacks — the
+    // system's and the one a PyTorch wheel bundles (its own libamdhip64 and librccl under torch/lib) — and whichever HIP runtime
+    // was loaded first serves everybody; an RCCL from the other stack on top of it fails in ncclCommInitAll ("unhandled cuda
+    // error": seen when this library was loaded before torch and "librccl.so.1" then resolved to torch's copy).  An absolute
+    // path also keeps the loader from handing back a same-named library that is already mapped.  SDX_RCCL_LIB overrides.
+    const char* env = std::getenv("SDX_RCCL_LIB");
+    void* h = nullptr;
+    std::string tried;
+    if (env && *env) {
+        h = dlopen(env, RTLD_NOW | RTLD_LOCAL);
+        tried = env;
+    } else {
+        Dl_info info{};
+        std::string dir;
+        if (dladdr((const void*)&hipGetDeviceCount, &info) && info.dli_fname) {
+            dir = info.dli_fname;
+            const size_t slash = dir.rfind('/');
+            dir = slash == std::string::npos ? std::string() : dir.substr(0, slash + 1);
+        }
+        const std::string candidates[] = {dir + "librccl.so.1", dir + "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+        for (const std::string& c : candidates) {
+            if (c.empty() || (c[0] != '/' && c != "librccl.so.1")) continue;
+            h = dlopen(c.c_str(), RTLD_NOW | RTLD_LOCAL);
+            tried += (tried.empty() ? "" : ", ") + c;
+            if (h) break;
+        }
+    }
     if (!h) {
         const char* e = dlerror();
-        api.error = std::string("RCCL not available: ") + (e ? e : "dlopen failed");
+        api.error = std::string("RCCL not available (tried ") + tried + "): " + (e ? e : "dlopen failed");
         return &api;
     }
     bool ok = true;

@@ -121,3 +121,21 @@ def test_rccl_failure_is_sdx_err_comm():
     proc = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SDX_RCCL_LIB="/nonexistent/librccl.so.1"), capture_output=True, text=True,
                           timeout=300)
     assert proc.returncode == 0 and "COMM -3" in proc.stdout and "RCCL not available" in proc.stdout, proc.stdout + proc.stderr
+
+
+@pytest.mark.parametrize("torch_first", [True, False])
+def test_group_works_whichever_rocm_stack_was_loaded_first(torch_first):
+    """A PyTorch wheel bundles its own HIP runtime and RCCL; the process runs on whichever HIP runtime was loaded first.  The
+    group must open the RCCL that belongs to THAT runtime (an RCCL of the other stack fails in ncclCommInitAll) — both import
+    orders, the collective through RCCL each time."""
+    first = "import torch\nfrom stardis_amd import _lib\n_lib.load()\n" if torch_first else "from stardis_amd import _lib\n_lib.load()\nimport torch\n"
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests')\n" % (ROOT, ROOT) + first +
+            "import numpy as np\nfrom test_gpu_group import workload, single_gpu\nfrom stardis_amd.group import DeviceGroup\n"
+            "atm, nus, lines, cont, th, w = workload(n_lines=200)\n"
+            "grp = DeviceGroup(1)\nout = grp.synthesize(nus, atm['temperatures'], atm['dist'], th, w, lines, cont)\n"
+            "info = grp.last_gather(); grp.close()\n"
+            "ref = single_gpu(_lib.default_context(), atm, nus, lines, cont, th, w)\n"
+            "assert info['backend'] == 'rccl' and info['rccl_version'] > 0, info\n"
+            "assert np.array_equal(out['F_nu'], ref['F_nu'])\nprint('OK', info['rccl_version'])\n")
+    proc = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0 and "OK" in proc.stdout, proc.stdout[-1500:] + proc.stderr[-3000:]
