@@ -22,10 +22,10 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/S-c3shard
 # the two roles of k_line_all launched apart
 export SDX_SPLIT_LAUNCHES=1
 for T in S-c3 S-c4m; do
-  timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $O/roles_${T}_SQ -- python3 scripts/profile_step.py $T 2 > $O/roles_${T}_SQ.log 2>&1
-  timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/roles_${T}_FETCH -- python3 scripts/profile_step.py $T 2 > $O/roles_${T}_FETCH.log 2>&1
-  timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/roles_${T}_WRITE -- python3 scripts/profile_step.py $T 2 > $O/roles_${T}_WRITE.log 2>&1
-  timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/roles_${T}_kt -- python3 scripts/profile_step.py $T 3 > $O/roles_${T}_kt.log 2>&1
+  timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $O/${T}roles_SQ -- python3 scripts/profile_step.py $T 2 > $O/${T}roles_SQ.log 2>&1
+  timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${T}roles_FETCH -- python3 scripts/profile_step.py $T 2 > $O/${T}roles_FETCH.log 2>&1
+  timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${T}roles_WRITE -- python3 scripts/profile_step.py $T 2 > $O/${T}roles_WRITE.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/${T}roles_kt -- python3 scripts/profile_step.py $T 3 > $O/${T}roles_kt.log 2>&1
 done
 unset SDX_SPLIT_LAUNCHES
 python3 scripts/roles_summary.py $O > $O/roles.txt 2>&1

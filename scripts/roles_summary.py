@@ -6,14 +6,14 @@ root = sys.argv[1]
 for tag in ("S-c3", "S-c4m"):
     vals = collections.defaultdict(lambda: collections.defaultdict(list))
     for kind in ("SQ", "FETCH", "WRITE"):
-        for f in glob.glob(os.path.join(root, f"roles_{tag}_{kind}", "**", "*counter_collection.csv"), recursive=True):
+        for f in glob.glob(os.path.join(root, f"{tag}roles_{kind}", "**", "*counter_collection.csv"), recursive=True):
             rows = [r for r in csv.DictReader(open(f)) if "k_line_all" in r["Kernel_Name"]]
             ids = sorted({int(r["Dispatch_Id"]) for r in rows})
             role = {d: ("wide", "narrow")[k % 2] for k, d in enumerate(ids)}
             for r in rows:
                 vals[role[int(r["Dispatch_Id"])]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     times = collections.defaultdict(list)
-    for f in glob.glob(os.path.join(root, f"roles_{tag}_kt", "**", "*kernel_trace.csv"), recursive=True):
+    for f in glob.glob(os.path.join(root, f"{tag}roles_kt", "**", "*kernel_trace.csv"), recursive=True):
         rows = sorted((r for r in csv.DictReader(open(f)) if "k_line_all" in r["Kernel_Name"]), key=lambda r: int(r["Start_Timestamp"]))
         for k, r in enumerate(rows):
             times[("wide", "narrow")[k % 2]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
