@@ -1199,6 +1199,82 @@ __device__ __forceinline__ void line_narrow_wave32(const int64_t i, const int de
     if (valid) plane[(size_t)d * pld + (i - nu_begin)] = acc;
 }
 
+// ... and for F consecutive frequencies per wave, like line_narrow_group: a visited line's fp32 records serve up to F evaluations.
+template <int F>
+__device__ __forceinline__ void line_narrow_group32(const int64_t i0, const int depth_chunk, int n_depth, int64_t n_nu, const double* __restrict__ nus,
+                                                    int64_t nu_begin, int64_t nu_count, LineWork w, double* __restrict__ plane, int64_t pld)
+{
+    const int lane = threadIdx.x & 63;
+    const int d = depth_chunk * 64 + lane;
+    const bool valid = d < n_depth;
+    const int dc = valid ? d : n_depth - 1;
+    const int ia = (int)i0;
+    const int64_t pa = max(i0 - kNarrowReach + 1, (int64_t)0);
+    const int64_t pb = min(i0 + F - 1 + kNarrowReach, n_nu);
+    const int la = __builtin_amdgcn_readfirstlane(w.cnt_ge[pb + 1]);
+    const int lb = __builtin_amdgcn_readfirstlane(w.cnt_ge[pa]);
+    float nih[F], nil[F];
+    double acc[F];
+    bool act[F];
+#pragma unroll
+    for (int k = 0; k < F; ++k) {
+        act[k] = i0 + k >= nu_begin && i0 + k < nu_begin + nu_count;
+        const double nu = nus[min(i0 + k, n_nu - 1)];
+        nih[k] = (float)nu;
+        nil[k] = (float)(nu - (double)nih[k]);
+        acc[k] = 0.0;
+    }
+    for (int base = la; base < lb; base += 64) {
+        const int lc = base + lane;
+        bool rel = false;
+        int c = 0;
+        if (lc < lb) {
+            const int hwm = w.nhw_max[lc];
+            c = w.centre[lc];
+            rel = hwm > 0 && ia + (F - 1) >= c - hwm && ia < c + hwm;
+        }
+        unsigned long long m = __ballot(rel);
+        float acc32[F];
+#pragma unroll
+        for (int k = 0; k < F; ++k) acc32[k] = 0.f;
+        int h = 0, cl = 0;
+        float y = 0.f, amp = 0.f, inv = 0.f;
+        float2v lnu = {0.f, 0.f};
+        if (m) {
+            const int bit = __builtin_ctzll(m);
+            const int l = base + bit;
+            const size_t o = (size_t)l * n_depth + dc;
+            cl = __builtin_amdgcn_readlane(c, bit);
+            h = w.nhw[o], y = w.n_y32[o], amp = w.n_amp32[o], inv = w.n_inv32[o], lnu = w.lnu32[l];
+        }
+        while (m) {
+            m &= m - 1;
+            int h_n = 0, cl_n = 0;
+            float y_n = 0.f, amp_n = 0.f, inv_n = 0.f;
+            float2v lnu_n = {0.f, 0.f};
+            if (m) {
+                const int bit = __builtin_ctzll(m);
+                const int l = base + bit;
+                const size_t o = (size_t)l * n_depth + dc;
+                cl_n = __builtin_amdgcn_readlane(c, bit);
+                h_n = w.nhw[o], y_n = w.n_y32[o], amp_n = w.n_amp32[o], inv_n = w.n_inv32[o], lnu_n = w.lnu32[l];
+            }
+            const int lo = cl - h, hi = cl + h;
+            if (valid && ia + (F - 1) >= lo && ia < hi) {
+#pragma unroll
+                for (int k = 0; k < F; ++k)
+                    if (act[k] && ia + k >= lo && ia + k < hi) acc32[k] = voigt_add32(acc32[k], ((nih[k] - lnu.x) + (nil[k] - lnu.y)) * inv, y, amp);
+            }
+            h = h_n, cl = cl_n, y = y_n, amp = amp_n, inv = inv_n, lnu = lnu_n;
+        }
+#pragma unroll
+        for (int k = 0; k < F; ++k) acc[k] += (double)acc32[k];
+    }
+#pragma unroll
+    for (int k = 0; k < F; ++k)
+        if (valid && act[k]) plane[(size_t)d * pld + (i0 + k - nu_begin)] = acc[k];
+}
+
 // Both line kernels in ONE launch of workgroups of S waves (S = number of line subsets): workgroups [0, n_wide) take the
 // wide role — one (depth, tile) each, wave s walks subset s — depth slowest, hottest layers first; the rest take the narrow
 // role, one frequency per wave.  The two roles only share the pre-pass, and each leaves issue slots idle on its own; a
@@ -1243,9 +1319,9 @@ __device__ __forceinline__ void line_all_body(int n_wide, int tiles, int n_split
         // of frequencies, the groups going round the XCDs.  (Giving each XCD one contiguous eighth of the grid was measured
         // 45 % slower: the lines per grid point follow the frequency, so one XCD gets several times the work of another.)
         constexpr int kNarrowGroup = 4;
-        // F consecutive frequencies per wave (roles bits 8-11: 1, 2 or 4 — 8 was measured slower —; the mixed-precision walk takes one), groups aligned
+        // F consecutive frequencies per wave (roles bits 8-11: 1, 2 or 4 — 8 was measured slower), groups aligned
         // to the global grid
-        const int F = MIXED ? 1 : max(1, (roles >> 8) & 15);
+        const int F = max(1, (roles >> 8) & 15);
         const int64_t g0 = nu_begin / F;
         const int64_t n_grp = (nu_begin + nu_count + F - 1) / F - g0;
         const int64_t n_narrow = n_grp * ((n_depth + 63) / 64);
@@ -1262,7 +1338,9 @@ __device__ __forceinline__ void line_all_body(int n_wide, int tiles, int n_split
         const int chunk = (int)(c / n_grp);
         double* __restrict__ nplane = planes + (size_t)n_depth * pld;
         if constexpr (MIXED) {
-            line_narrow_wave32(i0, chunk, n_depth, n_nu, nus, nu_begin, nu_count, w, nplane, pld);
+            if (F == 4) line_narrow_group32<4>(i0, chunk, n_depth, n_nu, nus, nu_begin, nu_count, w, nplane, pld);
+            else if (F == 2) line_narrow_group32<2>(i0, chunk, n_depth, n_nu, nus, nu_begin, nu_count, w, nplane, pld);
+            else line_narrow_wave32(i0, chunk, n_depth, n_nu, nus, nu_begin, nu_count, w, nplane, pld);
         } else {
             if (F == 4) line_narrow_group<4>(i0, chunk, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, nplane, pld);
             else if (F == 2) line_narrow_group<2>(i0, chunk, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, nplane, pld);

@@ -926,8 +926,8 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
     // every frequency adds its lines in the same order whatever F.  (F = 8 was measured slower than 4 at every size.)
     static const int narrow_f_env = std::getenv("SDX_NARROW_F") ? std::atoi(std::getenv("SDX_NARROW_F")) : 0;  // A/B knob: 1, 2, 4
     int narrow_f = 1;
-    if (!ctx->mixed_precision && 2 * n_lines >= n_nu) narrow_f = nu_count >= 32768 ? 4 : (nu_count >= 16384 ? 2 : 1);
-    if (!ctx->mixed_precision && (narrow_f_env == 1 || narrow_f_env == 2 || narrow_f_env == 4)) narrow_f = narrow_f_env;
+    if (2 * n_lines >= n_nu) narrow_f = nu_count >= 32768 ? 4 : (nu_count >= 16384 ? 2 : 1);
+    if (narrow_f_env == 1 || narrow_f_env == 2 || narrow_f_env == 4) narrow_f = narrow_f_env;
     const int64_t n_grp = (nu_begin + nu_count + narrow_f - 1) / narrow_f - nu_begin / narrow_f;
     const int64_t n_narrow = (((n_grp * ((n_depth + 63) / 64) + n_split - 1) / n_split + 31) / 32) * 32;
     static const int narrow_order = std::getenv("SDX_NARROW_ORDER") ? atoi(std::getenv("SDX_NARROW_ORDER")) & 3 : 0;
