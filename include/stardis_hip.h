@@ -47,6 +47,9 @@ const char* sdx_version(void);
 const char* sdx_last_error_string(void);
 int sdx_last_error_code(void); /* the SDX_ERR_* behind the last message (for entry points that return a pointer) */
 int sdx_device_count(void); /* number of visible HIP devices, 0 when none (never an error) */
+/* hipSetDevice for the calling thread: for callers that allocate device memory of their own next to a context (every sdx_* entry
+ * point that takes a context selects the context's device itself where it matters) */
+int sdx_set_device(int device);
 
 /* One context per device.  stream = NULL: the context creates its own non-blocking stream;
  * otherwise an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream). */

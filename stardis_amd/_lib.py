@@ -90,6 +90,7 @@ PROTOTYPES = {
     "sdx_synthesize_sharded_f64": (_int, [_vp, _int, _i64, _vp, _i64, _vp, _vp, _vp, _int, _vp, C.POINTER(Continuum), _int, _vp, _vp, _vp, _vp,
                                           _vp, _vp, _vp, _vp, _vp]),
     "sdx_device_count": (_int, []),
+    "sdx_set_device": (_int, [_int]),
     "sdx_create": (_vp, [_int, _vp]),
     "sdx_destroy": (None, [_vp]),
     "sdx_set_stream": (_int, [_vp, _vp]),

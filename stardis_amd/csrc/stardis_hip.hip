@@ -302,6 +302,12 @@ int sdx_device_count(void)
     return n;
 }
 
+int sdx_set_device(int device)
+{
+    HIP_TRY(hipSetDevice(device));
+    return SDX_OK;
+}
+
 sdx_ctx* sdx_create(int device, void* stream)
 {
     if (hipSetDevice(device) != hipSuccess) {

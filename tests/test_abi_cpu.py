@@ -61,6 +61,7 @@ def test_library_reports_no_device_and_product_raises():
         ops.voigt_profile(0.0, 1.0, 0.0)  # no silent CPU fallback
     assert lib.sdx_create(0, None) is None
     assert b"hipSetDevice" in lib.sdx_last_error_string() or lib.sdx_last_error_string()
+    assert lib.sdx_set_device(0) == -2 and lib.sdx_last_error_code() == -2  # SDX_ERR_HIP: no device to select
 
 
 def test_product_never_imports_the_oracle():
