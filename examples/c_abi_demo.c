@@ -3,11 +3,14 @@
  * Builds a small deterministic problem, calls the two host-buffer entry points that replace the reference's numba kernels
  * (calc_alan_entries, opacities_solvers/base.py:487-592; the raytrace loop, radiation_field_solvers/base.py:271-346) and
  * prints every number it got back with 17 significant digits; tests/test_gpu_c_abi.py rebuilds the same inputs in Python
- * and checks the output against the CPU oracle. */
+ * and checks the output against the CPU oracle.  It then runs the whole fused synthesis twice — sdx_synthesize_f64 on one
+ * context, and sdx_synthesize_sharded_f64 on a group of every visible GPU (one RCCL all-gather of the emergent flux inside the
+ * library) — and reports whether the two agree bit for bit. */
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "stardis_hip.h"
 
@@ -65,8 +68,38 @@ int main(void)
     /* error path: an ascending grid must be refused with -1 */
     double bad[3] = {1.0, 2.0, 3.0}, o3[ND * 3];
     const int rc_bad = sdx_line_opacity_f64(ctx, ND, 3, bad, NL, line_nus, dw, gam, ND, al, o3, NULL);
-    printf("version %s\nevaluations %lld\nbad_grid_rc %d\n", sdx_version(), (long long)evals, rc_bad);
-    for (int k = 0; k < ND * NNU; ++k) printf("%.17g %.17g\n", out[k], F[k]);
+    /* the fused synthesis on host buffers (electron scattering as the only continuum source), on one context and on a group of
+     * all visible GPUs: the sharded call returns the same F_nu, and the gathered emergent flux is its last row */
+    static double ne[ND], F1[ND * NNU], F2[ND * NNU], flux[NNU];
+    for (int d = 0; d < ND; ++d) ne[d] = 1.0e14 / (1 + d);
+    sdx_continuum cont;
+    memset(&cont, 0, sizeof cont);
+    cont.electron_density = ne;
+    cont.temperature = temps;
+    rc = sdx_synthesize_f64(ctx, ND, NNU, nus, NL, line_nus, dw, gam, ND, al, &cont, NTH, temps, dist, wts, NULL, NULL, F1, NULL);
+    if (rc) {
+        fprintf(stderr, "sdx_synthesize_f64: %d %s\n", rc, sdx_last_error_string());
+        return 1;
+    }
+    const int n_gpus = sdx_device_count();
+    sdx_group* grp = sdx_group_create(n_gpus, NULL);
+    if (!grp) {
+        fprintf(stderr, "sdx_group_create: %d %s\n", sdx_last_error_code(), sdx_last_error_string());
+        return 1;
+    }
+    rc = sdx_synthesize_sharded_f64(grp, ND, NNU, nus, NL, line_nus, dw, gam, ND, al, &cont, NTH, temps, dist, wts, NULL, NULL, NULL, F2, flux, NULL);
+    if (rc) {
+        fprintf(stderr, "sdx_synthesize_sharded_f64: %d %s\n", rc, sdx_last_error_string());
+        return 1;
+    }
+    int ranks = 0, rccl = 0;
+    int64_t bytes = 0;
+    sdx_group_last_gather(grp, &ranks, &bytes, &rccl);
+    const int same = memcmp(F1, F2, sizeof F1) == 0 && memcmp(flux, F2 + (ND - 1) * NNU, sizeof flux) == 0;
+    sdx_group_destroy(grp);
+    printf("version %s\nevaluations %lld\nbad_grid_rc %d\nsharded ranks %d bytes_per_rank %lld rccl %d identical %d\n", sdx_version(), (long long)evals,
+           rc_bad, ranks, (long long)bytes, rccl, same);
+    for (int k = 0; k < ND * NNU; ++k) printf("%.17g %.17g %.17g\n", out[k], F[k], F1[k]);
     sdx_destroy(ctx);
     return 0;
 }

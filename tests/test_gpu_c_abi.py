@@ -58,8 +58,12 @@ def test_plain_c_program_through_the_abi(tmp_path):
     assert lines[0].startswith("version stardis_hip")
     evals = int(lines[1].split()[1])
     assert int(lines[2].split()[1]) == -1  # an ascending grid is refused as a bad argument
-    got = np.array([[float(x) for x in row.split()] for row in lines[3:]])
-    assert got.shape == (ND * NNU, 2)
+    # sdx_synthesize_sharded_f64 on a group of every visible GPU: RCCL ran (version reported), each rank contributed its padded
+    # shard, and F_nu / the gathered emergent flux are those of sdx_synthesize_f64 bit for bit
+    sh = lines[3].split()
+    assert sh[0] == "sharded" and int(sh[2]) >= 1 and int(sh[4]) == 8 * -(-NNU // int(sh[2])) and int(sh[6]) > 0 and int(sh[8]) == 1, lines[3]
+    got = np.array([[float(x) for x in row.split()] for row in lines[4:]])
+    assert got.shape == (ND * NNU, 3)
     nus, line_nus, dw, gam, al, temps, thetas, dist, wts = inputs()
     line, ref_evals = oracle.calc_alan_entries(ND, nus, line_nus, dw, gam, al, return_evals=True)
     assert evals == ref_evals
@@ -68,3 +72,8 @@ def test_plain_c_program_through_the_abi(tmp_path):
     F_ref, _ = oracle.raytrace(nus, temps, dist, thetas, wts, total)
     F = got[:, 1].reshape(ND, NNU)
     assert np.all(F[0] == 0) and rel_err(F[1:], F_ref[1:]) < 1e-10
+    # the fused synthesis: line opacity + Thomson scattering, then the formal solution
+    total_fused = oracle.alpha_electron(NNU, 1.0e14 / (1 + np.arange(ND))) + line
+    F_fused, _ = oracle.raytrace(nus, temps, dist, thetas, wts, total_fused)
+    F1 = got[:, 2].reshape(ND, NNU)
+    assert np.all(F1[0] == 0) and rel_err(F1[1:], F_fused[1:]) < 1e-10
