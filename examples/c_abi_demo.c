@@ -71,7 +71,7 @@ int main(void)
     /* the fused synthesis on host buffers (electron scattering as the only continuum source), on one context and on a group of
      * all visible GPUs: the sharded call returns the same F_nu, and the gathered emergent flux is its last row */
     static double ne[ND], F1[ND * NNU], F2[ND * NNU], flux[NNU];
-    for (int d = 0; d < ND; ++d) ne[d] = 1.0e14 / (1 + d);
+    for (int d = 0; d < ND; ++d) ne[d] = 1.0e17 / (1 + d); /* optical depths per gap of order 0.1-1: well inside the reference's exp branch (:36-45) */
     sdx_continuum cont;
     memset(&cont, 0, sizeof cont);
     cont.electron_density = ne;

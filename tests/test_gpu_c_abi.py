@@ -74,7 +74,7 @@ def test_plain_c_program_through_the_abi(tmp_path):
     F = got[:, 1].reshape(ND, NNU)
     assert np.all(F[0] == 0) and rel_err(F[1:], F_ref[1:]) < 1e-10
     # the fused synthesis: line opacity + Thomson scattering, then the formal solution
-    total_fused = oracle.alpha_electron(NNU, 1.0e14 / (1 + np.arange(ND))) + line
+    total_fused = oracle.alpha_electron(NNU, 1.0e17 / (1 + np.arange(ND))) + line
     F_fused, _ = oracle.raytrace(nus, temps, dist, thetas, wts, total_fused)
     F1 = got[:, 2].reshape(ND, NNU)
     assert np.all(F1[0] == 0) and rel_err(F1[1:], F_fused[1:]) < 1e-10
