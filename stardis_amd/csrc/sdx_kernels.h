@@ -31,13 +31,8 @@ __device__ __forceinline__ void shard_range(int64_t n_nu, const double* __restri
                                             int64_t nu_begin, int64_t nu_count, int* __restrict__ sel);
 
 __global__ __launch_bounds__(kBlock) void k_dnu_partial(int64_t n_nu, const double* __restrict__ nus,
-                                                        double* __restrict__ partial, int* __restrict__ zero, int64_t n_zero,
-                                                        int64_t n_lines, const double* __restrict__ line_nus, int64_t nu_begin, int64_t nu_count,
-                                                        int* __restrict__ sel)
+                                                        double* __restrict__ partial, int* __restrict__ zero, int64_t n_zero)
 {
-    // culled pre-pass of a frequency shard: two threads of the LAST block find the shard's line range on the side (two binary
-    // searches — a chain of dependent loads that a launch of its own would spend 7 us on)
-    if (sel && blockIdx.x == gridDim.x - 1) shard_range(n_nu, nus, n_lines, line_nus, nu_begin, nu_count, sel);  // (four threads)
     // (culled pre-pass: the per-line maxima the classification pass accumulates into are cleared here, not by a memset node)
     for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < n_zero; k += (int64_t)gridDim.x * kBlock) zero[k] = 0;
     double m = -INFINITY;
@@ -984,9 +979,14 @@ __device__ __forceinline__ void classify_block(const int bid, const int n_blocks
 
 __global__ __launch_bounds__(kBlock) void k_classify(int n_depth, int64_t n_nu, int64_t n_lines, const double* __restrict__ dnu_partial,
                                                      int n_partial, const double* __restrict__ doppler, const double* __restrict__ gammas,
-                                                     int gamma_cols, const double* __restrict__ alphas, int* __restrict__ whw_max)
+                                                     int gamma_cols, const double* __restrict__ alphas, int* __restrict__ whw_max,
+                                                     const double* __restrict__ nus, const double* __restrict__ line_nus, int64_t nu_begin,
+                                                     int64_t nu_count, int* __restrict__ sel)
 {
     __shared__ double s_red[kBlock / 64];
+    // four threads of the LAST block find the shard's line ranges on the side (four binary searches: chains of dependent loads
+    // that vanish behind this 50 us stream; on the side of the 5 us k_dnu_partial they doubled its length)
+    if (sel && blockIdx.x == gridDim.x - 1) shard_range(n_nu, nus, n_lines, line_nus, nu_begin, nu_count, sel);
     classify_block(blockIdx.x, gridDim.x, n_depth, n_nu, n_lines, dnu_partial, n_partial, doppler, gammas, gamma_cols, alphas, whw_max, s_red);
 }
 
@@ -1977,11 +1977,14 @@ __global__ __launch_bounds__(kBlock) void k_classify_continuum(int n_cls, int n_
                                                                int n_partial, const double* __restrict__ doppler, const double* __restrict__ gammas,
                                                                int gamma_cols, const double* __restrict__ alphas, int* __restrict__ whw_max,
                                                                const double* __restrict__ nus, int cont_tiles, int64_t nu_begin, int64_t nu_count,
-                                                               ContinuumArgs ca, double* __restrict__ cont_plane, int64_t cont_ld, int stage_table)
+                                                               ContinuumArgs ca, double* __restrict__ cont_plane, int64_t cont_ld, int stage_table,
+                                                               const double* __restrict__ line_nus, int64_t shard_begin, int64_t shard_count,
+                                                               int* __restrict__ sel)
 {
     const int b = blockIdx.x;
     if (b < n_cls) {
         __shared__ double s_red[kBlock / 64];
+        if (sel && b == n_cls - 1) shard_range(n_nu, nus, n_lines, line_nus, shard_begin, shard_count, sel);  // (four threads, on the side)
         classify_block(b, n_cls, n_depth, n_nu, n_lines, dnu_partial, n_partial, doppler, gammas, gamma_cols, alphas, whw_max, s_red);
     } else {
         const int c = b - n_cls;

@@ -225,16 +225,14 @@ inline dim3 grid2(int64_t n, int rows) { return dim3((unsigned)((n + kBlock - 1)
 inline unsigned blocks1(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 
 // d_nu partial maxima into small_ws
-int launch_dnu(sdx_ctx* ctx, int64_t n_nu, const double* nus, int* n_partial, int* zero = nullptr, int64_t n_zero = 0, int64_t n_lines = 0,
-               const double* line_nus = nullptr, int64_t nu_begin = 0, int64_t nu_count = 0, int* sel = nullptr)
+int launch_dnu(sdx_ctx* ctx, int64_t n_nu, const double* nus, int* n_partial, int* zero = nullptr, int64_t n_zero = 0)
 {
     int rc = ensure(ctx, &ctx->small_ws, &ctx->small_ws_bytes, kSmallHeader);
     if (rc) return rc;
     const int nb = (int)std::min<int64_t>(kDnuPartials, std::max<int64_t>(1, (n_nu + kBlock * 8 - 1) / (kBlock * 8)));
     {
         LaunchScope ls(ctx, "k_dnu_partial");
-        hipLaunchKernelGGL(k_dnu_partial, dim3(nb), dim3(kBlock), 0, ctx->stream, n_nu, nus, (double*)ctx->small_ws, zero, n_zero, n_lines, line_nus,
-                           nu_begin, nu_count, sel);
+        hipLaunchKernelGGL(k_dnu_partial, dim3(nb), dim3(kBlock), 0, ctx->stream, n_nu, nus, (double*)ctx->small_ws, zero, n_zero);
     }
     *n_partial = nb;
     return check_launch("k_dnu_partial");
@@ -738,11 +736,9 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
     // change what it computes for them.
     static const bool no_cull = std::getenv("SDX_NO_CULL") != nullptr;
     const bool cull = fill_work && !no_cull && n_lines >= ctx->indexed_min_lines && !count_evals && !gen && !scan_in_block && nu_count < n_nu;
-    // the grid-spacing reduction (a culled run: it also clears whw_max for the classification pass and finds the shard's line range)
+    // the grid-spacing reduction (a culled run: it also clears whw_max for the classification pass)
     int* const sel = cull ? w.hcount + 4 : nullptr;
-    if (!scan_in_block && (rc = launch_dnu(ctx, n_nu, nus, &n_partial, cull ? w.whw_max : nullptr, cull ? n_lines : 0, n_lines, line_nus, nu_begin,
-                                           nu_count, sel)))
-        return rc;
+    if (!scan_in_block && (rc = launch_dnu(ctx, n_nu, nus, &n_partial, cull ? w.whw_max : nullptr, cull ? n_lines : 0))) return rc;
     // continuum blocks of the fused step: one per (frequency tile of `threads` points, group of dgs depths) when the per-depth
     // factors of a group fit LDS (always, for a handful of bound-free levels), else one per (tile, depth) evaluating every point
     // from scratch
@@ -803,10 +799,11 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
                 const unsigned n_cls_half = std::max(1u, n_cls / 2);
                 hipLaunchKernelGGL(k_classify_continuum, dim3(n_cls_half + (unsigned)cp.cont_tiles * cp.cont_rows), dim3(kBlock), cp.shmem, ctx->stream, (int)n_cls_half,
                                    n_depth, n_nu, n_lines, (const double*)ctx->small_ws, n_partial, doppler, gammas, gamma_cols, alphas, w.whw_max, nus,
-                                   cp.cont_tiles, job->nu_begin, job->nu_count, cp.ca, job->plane, job->nu_count, cp.stage_table);
+                                   cp.cont_tiles, job->nu_begin, job->nu_count, cp.ca, job->plane, job->nu_count, cp.stage_table, line_nus, nu_begin, nu_count,
+                                   sel);
             } else {
                 hipLaunchKernelGGL(k_classify, dim3(n_cls), dim3(kBlock), 0, ctx->stream, n_depth, n_nu, n_lines, (const double*)ctx->small_ws, n_partial,
-                                   doppler, gammas, gamma_cols, alphas, w.whw_max);
+                                   doppler, gammas, gamma_cols, alphas, w.whw_max, nus, line_nus, nu_begin, nu_count, sel);
             }
         }
         {
