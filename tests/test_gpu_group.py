@@ -86,6 +86,14 @@ for kw in (dict(), dict(seed=5, n_lines=9000, lam=(6450.0, 6650.0), step=0.004, 
             assert np.array_equal(out["emergent_flux"], ref["F_nu"][-1]), "spectrum differs"
             assert np.array_equal(out["F_nu"], ref["F_nu"]) and np.array_equal(out["alpha_line"], ref["alpha_line"]) and np.array_equal(out["total_alphas"], ref["total_alphas"])
         grp.close()
+# more ranks than columns: empty shards take part in the gather with nothing to contribute
+atm, nus, lines, cont, th, w = workload(n_lines=30, lam=(6560.0, 6560.05), step=0.01)
+assert nus.size < 7
+ref = single_gpu(ctx, atm, nus, lines, cont, th, w)
+grp = DeviceGroup(devices=[0] * 7)
+out = grp.synthesize(nus, atm["temperatures"], atm["dist"], th, w, lines, cont)
+assert np.array_equal(out["emergent_flux"], ref["F_nu"][-1]) and np.array_equal(out["F_nu"], ref["F_nu"])
+grp.close()
 print("IDENTICAL")
 """
 

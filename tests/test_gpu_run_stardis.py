@@ -230,3 +230,27 @@ def test_plasma_tables_are_cached_per_object_not_per_value(ctx, monkeypatch, tmp
     stronger.iloc[:, 0] *= 2.0  # in place: not seen until the cache is cleared
     fused.clear_cache()
     assert np.array_equal(run(), run(use_fused=False))
+
+
+def test_fused_path_with_no_line_on_the_grid(ctx, monkeypatch, tmp_path):
+    """A grid between the lines: the selection of calc_alpha_line_at_nu (:392-395) is empty.  Fused and general path agree
+    (continuum only), the dictionary has its eight keys, the line entry is a zero plane."""
+    import stardis_amd.radiation_field.base as rf
+    from test_gpu_dropin import rebuild
+
+    g, plasma, model, cfg = rebuild("vald", tmp_path)
+    config = NS(opacity=cfg, no_of_thetas=4, result_options=NS(return_radiation_field=False))
+    line_nu = np.sort(plasma.lines_from_linelist.nu.to_numpy())
+    gap = int(np.argmax(np.diff(line_nu)))
+    nus = np.linspace(line_nu[gap + 1], line_nu[gap], 64)[1:-1].copy()  # strictly inside the widest gap, descending
+    assert nus[0] > nus[-1]
+    fields = {}
+    for fused_on in (True, False):
+        monkeypatch.setattr(rf, "FUSED", fused_on)
+        fields[fused_on] = rf.create_stellar_radiation_field(nus.copy(), model, plasma, config)
+    a, b = fields[True], fields[False]
+    assert type(a.opacities).__name__ == "FusedOpacities"
+    assert np.array_equal(a.F_nu, b.F_nu) and (a.F_nu[-1] > 0).all()
+    assert list(a.opacities.opacities_dict.keys()) == list(b.opacities.opacities_dict.keys())
+    assert not np.asarray(a.opacities.opacities_dict["alpha_line_at_nu"]).any()
+    assert np.array_equal(a.opacities.total_alphas, b.opacities.total_alphas)
