@@ -1,7 +1,7 @@
 """GPU experiment: strong scaling of one workload by frequency sharding, emulated on one GPU — each rank's step is timed
 alone (ranks are independent: no data-path exchange; the flux gather overlaps the next step), the projected speed-up is
 t(1) / max_r t_r(P).  Steps are replayed as hipGraphs, like bench.py; the slowest rank's per-kernel times are printed.
-python scripts/strong_scaling_probe.py [TAG] [WORLD ...] [--balanced] [--all-ranks]"""
+python scripts/strong_scaling_probe.py [TAG] [WORLD ...] [--balanced] [--all-ranks] [--verbose]"""
 import ctypes as C, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stardis_amd import synth, parallel, _lib
@@ -14,7 +14,7 @@ w = synth.make_workload(tag)
 atm, nus, ln = w["atm"], w["nus"], w["lines"]
 # per-column cost: window evaluations + the column's share of the formal solution and continuum (~6000 evaluation-equivalents)
 work = parallel.column_cost(nus, ln, **{k: float(os.environ[e]) for k, e in (("scan_weight", "SDX_SCAN_WEIGHT"), ("core_weight", "SDX_CORE_WEIGHT"), ("fixed", "SDX_FIXED")) if e in os.environ}) if balanced else None
-KERNELS = ("k_dnu_partial", "k_classify", "k_prepass_continuum", "k_line_prepass", "k_hlist", "k_gather", "k_line_all", "k_raytrace")
+KERNELS = ("k_dnu_partial", "k_classify", "k_prepass_continuum", "k_line_prepass", "k_hlist", "k_gather", "k_line_all", "k_line_wide", "k_line_narrow", "k_raytrace")
 
 
 def rank_time(world, rank, reps=8):
@@ -49,3 +49,7 @@ for world in worlds:
     t1 = t1 or slow[0]
     print(f"{tag} world {world}: slowest rank {slow[0] * 1e3:.3f} ms (mean {sum(r[0] for r in res) / len(res) * 1e3:.3f}) -> projected speed-up {t1 / slow[0]:.2f}x; "
           f"slowest rank's shard {slow[2]} kernels [us] {slow[1]}", flush=True)
+    if "--verbose" in sys.argv:
+        for r, (t, kern, shard) in zip(ranks, res):
+            print(f"    rank {r}: {t * 1e3:.3f} ms shard {shard} {kern}")
+        print("    sum over ranks [us]:", {k: round(sum(x[1].get(k, 0.0) for x in res), 1) for k in KERNELS})
