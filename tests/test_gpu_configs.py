@@ -79,6 +79,31 @@ def test_config4_cool_dwarf_million_lines(ctx):
     full_size_checks(ctx, "S-c4m", line_stride=400, col_stride=601)
 
 
+def test_saturation_grid_ten_times_the_resolving_power(ctx):
+    """SURVEY §8d's saturation case, S-big: the grid of configs[2] at R = 1e6 (1 203 973 frequencies) with the 1e6-line list of
+    configs[3] — 2.9e11 evaluations, every window ten times as many points wide: the largest index arithmetic the path sees."""
+    w = synth.make_workload("S-big")
+    atm, nus, lines, cont = w["atm"], w["nus"], w["lines"], w["cont"]
+    assert nus.size == 1203973 and lines["line_nus"].size == 1000000
+    syn = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], w["thetas"], w["weights"], lines, cont, ctx=ctx)
+    syn.step()
+    assert syn.evaluations() == parallel.window_evaluations(nus, lines["line_nus"], lines["doppler_widths"], lines["gammas"], lines["alphas"])
+    cols = np.arange(300, nus.size, nus.size // 200)
+    F, total, line = (np.ascontiguousarray(a[:, cols]) for a in (syn.F_nu(), syn.total_alphas(), syn.alpha_line()))
+    del syn
+    cutoff = (cont["ionization_energy"] - cont["level_excitation"]) / K.H_CGS
+    c_ref = oracle.alpha_file_1d(K.nu_to_angstrom(nus[cols]), cont["hminus_bf_wavelength"], cont["hminus_bf_cross_section"], cont["n_hminus"])
+    c_ref = c_ref + oracle.alpha_bf(nus[cols], [0, len(cutoff)], [0], cutoff, cont["level_density"])
+    c_ref = c_ref + oracle.alpha_ff(nus[cols], atm["temperatures"], [1], cont["n_e"] * cont["n_h2"])
+    c_ref = c_ref + oracle.alpha_electron(cols.size, cont["n_e"])
+    line_ref = oracle.calc_alan_entries_columns(cols, 56, nus, lines["line_nus"], lines["doppler_widths"], lines["gammas"], lines["alphas"])
+    assert np.array_equal(line == 0, line_ref == 0)
+    assert rel_err(line, line_ref) < 1e-12
+    assert rel_err(total, c_ref + line_ref) < 1e-12
+    F_cpu, _ = oracle.raytrace(nus[cols], atm["temperatures"], atm["dist"], w["thetas"], w["weights"], c_ref + line_ref)
+    assert rel_err(F[1:], F_cpu[1:]) < 1e-10
+
+
 def test_config5_mixed_precision_then_lsf_and_rotation_on_the_device(ctx):
     """BASELINE configs[4].  fp64 and fp32-mixed syntheses of the full spectrum; both spectra go through F_lambda ->
     gaussian_filter1d -> rotation_broadening on the device."""
