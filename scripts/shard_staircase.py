@@ -1,11 +1,11 @@
 """GPU experiment: line-kernel time of a shard (0, n) of S-c3 against its width n — the staircase of wave generations.
-python scripts/shard_staircase.py [BEGIN] TILES...   (SDX_SPLIT_LAUNCHES=1 times the two roles apart)"""
+python scripts/shard_staircase.py BEGIN TILES...   (SDX_SPLIT_LAUNCHES=1 times the two roles apart; SDX_TAG: another workload)"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stardis_amd import synth, _lib
 from stardis_amd.engine import SpectralSynthesizer
 
-w = synth.make_workload("S-c3")
+w = synth.make_workload(os.environ.get("SDX_TAG", "S-c3"))
 atm, nus = w["atm"], w["nus"]
 begin = int(sys.argv[1])
 for tiles in [int(a) for a in sys.argv[2:]]:
