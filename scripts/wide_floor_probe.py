@@ -13,6 +13,7 @@ for name, mix in (("weak only", (1.0, 0.0, 0.0)), ("weak + medium", (0.9, 0.1, 0
     lines = synth.synth_lines(nus, atm, 2000, seed=synth.SEED, mix=mix)
     syn = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], w["thetas"], w["weights"], lines, w["cont"], track_evaluations=True, keep_line=False)
     ctx = syn.ctx
+    if "SDX_INDEXED_MIN" in os.environ: ctx.set_option("indexed_min_lines", int(os.environ["SDX_INDEXED_MIN"]))  # the indexed wide path on a short list
     syn.step()
     ev = syn.evaluations()
     syn.capture()
@@ -22,7 +23,7 @@ for name, mix in (("weak only", (1.0, 0.0, 0.0)), ("weak + medium", (0.9, 0.1, 0
     for _ in range(5): syn.enqueue()
     ctx.synchronize()
     kern = {}
-    for k in ("k_line_all", "k_line_wide", "k_line_narrow", "k_raytrace", "k_prepass_continuum"):
+    for k in ("k_line_all", "k_line_wide", "k_line_narrow", "k_raytrace", "k_prepass_continuum", "k_hlist"):
         cnt, ms = C.c_int64(), C.c_double()
         _lib.check(ctx.lib.sdx_profile_get(ctx.handle, k.encode(), C.byref(cnt), C.byref(ms)))
         if cnt.value: kern[k] = round(ms.value / 5 * 1e3, 1)
