@@ -210,6 +210,11 @@ struct LineWork {
     unsigned long long* evals;
 };
 
+// k / d for 0 <= k < 65536 and 1 <= d < 65536 with the divisor's reciprocal m = small_div_magic(d) = ceil(2^32 / d): one multiply-high
+// instead of the ~30 instructions of a 32-bit division by a run-time value (the pre-pass indexes its (line, depth) items six times)
+__device__ __forceinline__ unsigned small_div_magic(int d) { return d > 1 ? 0xFFFFFFFFu / (unsigned)d + 1u : 0u; }
+__device__ __forceinline__ int small_div(int k, unsigned magic) { return magic ? (int)__umulhi((unsigned)k, magic) : k; }
+
 template <bool GEN, int kPreLines>
 __device__ __forceinline__ void prepass_block(const int bx, const int by, const int gy, int n_depth, int64_t n_nu, const double* __restrict__ nus,
                                                          const double* __restrict__ dnu_partial, int n_partial,
@@ -289,6 +294,7 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
     }
 #define SDX_LINE_OF(ll) (gather ? (int64_t)s_l[ll] : l0 + (ll))
     const int nd = min(kPreDepths, n_depth - d0);
+    const unsigned nd_magic = small_div_magic(nd), nl_magic = small_div_magic(nl);  // (items k < kPreLines kPreDepths = 2048)
     // The block's dense inputs are requested first (kPreItems per thread), so their latency hides behind the centre search
     // below instead of following it.
     double r_dw[kPreItems], r_a[kPreItems], r_g[kPreItems];
@@ -298,7 +304,7 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
             const int k = threadIdx.x + it * kPreBlock;
             r_dw[it] = r_a[it] = r_g[it] = 0.0;
             if (k < nl * nd) {
-                const int ll = k / nd, dd = k - ll * nd;
+                const int ll = small_div(k, nd_magic), dd = k - ll * nd;
                 const int64_t l = SDX_LINE_OF(ll);
                 const int d = d0 + dd;
                 r_dw[it] = doppler[l * n_depth + d];
@@ -357,7 +363,7 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
         else if (threadIdx.x >= 64 && threadIdx.x < 64 + nl) s_gl[threadIdx.x - 64] = gen_line(lp, line_nus[SDX_LINE_OF(threadIdx.x - 64)], SDX_LINE_OF(threadIdx.x - 64));
         __syncthreads();
         for (int k = threadIdx.x; k < nl * nd; k += nthreads) {
-            const int ll = k / nd, dd = k - ll * nd;
+            const int ll = small_div(k, nd_magic), dd = k - ll * nd;
             const int64_t l = SDX_LINE_OF(ll);
             const GenDepth& D = s_gd[dd];  // fields are read from LDS where they are used: copies would cost ~40 VGPRs
             const GenLine& L = s_gl[ll];
@@ -371,7 +377,7 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
         for (int it = 0; it < kPreItems; ++it) {
             const int k = threadIdx.x + it * kPreBlock;
             if (k < nl * nd) {
-                const int ll = k / nd, dd = k - ll * nd;
+                const int ll = small_div(k, nd_magic), dd = k - ll * nd;
                 s_dw[ll * kStride + dd] = r_dw[it];
                 s_a[ll * kStride + dd] = r_a[it];
                 s_g[ll * kStride + dd] = r_g[it];
@@ -390,7 +396,7 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
         const int k = threadIdx.x + it * kPreBlock;
         sc_keep[it] = WideScan{0, 0, 0, 0};
         if (k >= nl * nd) continue;
-        const int dd = k / nl, ll = k - dd * nl;
+        const int dd = small_div(k, nl_magic), ll = k - dd * nl;
         const int sidx = ll * kStride + dd;
         const double dw = s_dw[sidx], g = s_g[sidx], a = s_a[sidx];
         int lo, hi;
@@ -464,7 +470,7 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
         for (int it = 0; it < kPreItems; ++it) {
             const int k = threadIdx.x + it * kPreBlock;
             if (k >= nl * nd) continue;
-            const int dd = k / nl, ll = k - dd * nl;
+            const int dd = small_div(k, nl_magic), ll = k - dd * nl;
             if (w.skip_unlisted_scan && s_whwmax[ll] == 0) continue;
             w.wscan[(size_t)(d0 + dd) * n_lines + SDX_LINE_OF(ll)] = sc_keep[it];
         }
@@ -485,7 +491,7 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
     // line-major outputs: the stashed values, depth fastest so the stores coalesce
     if (w.nhw || out_lo_ref) {
         for (int k = threadIdx.x; k < nl * nd; k += nthreads) {
-            const int ll = k / nd, dd = k - ll * nd;
+            const int ll = small_div(k, nd_magic), dd = k - ll * nd;
             const int sidx = ll * kStride + dd;
             const int lo = s_lo[sidx], hcode = s_hi[sidx];
             const bool narrow = hcode >= 0;

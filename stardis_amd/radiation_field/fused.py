@@ -273,8 +273,7 @@ def _depth_vectors(stellar_plasma, opacity, file_source, rayleigh_species):
             number_density, _, ion_number = get_number_density(p, spec + "_ff")
             ff_ions.append(ion_number), ff_dens.append(np.asarray(plain(number_density), dtype=F8))
         out["ff_ions"], out["ff_dens"] = ff_ions, ff_dens
-        if True:  # neutral hydrogen: van der Waals broadening and Rayleigh scattering
-            out["n_h"] = np.asarray(plain(ions.loc[1, 0]), dtype=F8)
+        out["n_h"] = np.asarray(plain(ions.loc[1, 0]), dtype=F8)  # neutral hydrogen: van der Waals broadening and Rayleigh scattering
         if "He" in rayleigh_species:
             out["n_he"] = np.asarray(plain(ions.loc[2, 0]), dtype=F8)
         if "H2" in rayleigh_species:
@@ -420,10 +419,7 @@ def try_fused(field_cls, tracing_nus, stellar_model, stellar_plasma, config, sou
     put = lambda key, value: dict.__setitem__(entries, key, value)  # noqa: E731
 
     def twin(dev):
-        def make():
-            host_array = B._download(dev)
-            return host_array
-        return _Thunk(make)
+        return _Thunk(lambda: B._download(dev))
 
     def remembered(key, make):
         def run():
