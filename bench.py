@@ -261,7 +261,7 @@ def dropin_block(device, check):
         nus = synth.tracing_grid(cfg["lam0"], cfg["lam1"], cfg.get("R"), cfg.get("step"))
         plasma, model, config, arrays = synth.fake_plasma(nus, atm, n_lines, synth.SEED)
 
-        def bench_path(fused, n=6):
+        def bench_path(fused, n=12):
             was = rf.FUSED
             rf.FUSED = fused
             try:
@@ -275,7 +275,7 @@ def dropin_block(device, check):
             return times, field
 
         times, field = bench_path(True)
-        gen_times, gen_field = bench_path(False, 4)
+        gen_times, gen_field = bench_path(False, 6)
         entry = {"n_nu": int(nus.size), "n_lines": int(n_lines), "first_call_ms": times[0] * 1e3, "steady_ms": min(times[1:]) * 1e3,
                  "spectral_points_per_s": nus.size * 56 / min(times[1:]), "path": type(field.opacities).__name__,
                  "general_path_ms": min(gen_times[1:]) * 1e3, "fused_equals_general_bit_for_bit": bool(np.array_equal(field.F_nu, gen_field.F_nu))}

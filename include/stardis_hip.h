@@ -88,6 +88,14 @@ int sdx_free(sdx_ctx* ctx, void* ptr);
 int sdx_memcpy_h2d(sdx_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes); /* async on ctx stream */
 int sdx_memcpy_d2h(sdx_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes); /* synchronises */
 int sdx_memset(sdx_ctx* ctx, void* dst_dev, int value, size_t bytes);
+/* Page-locked host memory (hipHostMalloc) for callers that keep staging / result buffers of their own, and copies that move it
+ * by DMA directly — sdx_memcpy_h2d / _d2h above take pageable pointers and go through a bounce buffer of the context.
+ * sdx_memcpy_h2d_pinned is asynchronous on the context's stream: the source must stay untouched until a synchronising call
+ * (sdx_memcpy_d2h[_pinned], sdx_synchronize) has returned.  sdx_host_alloc returns NULL on failure (-4 in sdx_last_error_code). */
+void* sdx_host_alloc(sdx_ctx* ctx, size_t bytes);
+int sdx_host_free(void* ptr);
+int sdx_memcpy_h2d_pinned(sdx_ctx* ctx, void* dst_dev, const void* src_pinned, size_t bytes);
+int sdx_memcpy_d2h_pinned(sdx_ctx* ctx, void* dst_pinned, const void* src_dev, size_t bytes); /* synchronises */
 
 /* Scratch the line-opacity call needs for n_lines x n_depth; call once before stream capture. */
 int sdx_reserve_line_workspace(sdx_ctx* ctx, int n_depth, int64_t n_lines);

@@ -6,6 +6,7 @@ MI355X is visible, every compute entry point raises.
 import ctypes as C
 import os
 import threading
+import weakref
 
 import numpy as np
 
@@ -102,6 +103,10 @@ PROTOTYPES = {
     "sdx_memcpy_h2d": (_int, [_vp, _vp, _vp, C.c_size_t]),
     "sdx_memcpy_d2h": (_int, [_vp, _vp, _vp, C.c_size_t]),
     "sdx_memset": (_int, [_vp, _vp, _int, C.c_size_t]),
+    "sdx_host_alloc": (_vp, [_vp, C.c_size_t]),
+    "sdx_host_free": (_int, [_vp]),
+    "sdx_memcpy_h2d_pinned": (_int, [_vp, _vp, _vp, C.c_size_t]),
+    "sdx_memcpy_d2h_pinned": (_int, [_vp, _vp, _vp, C.c_size_t]),
     "sdx_reserve_line_workspace": (_int, [_vp, _int, _i64]),
     "sdx_graph_begin": (_int, [_vp]),
     "sdx_graph_end": (_int, [_vp, C.POINTER(_vp)]),
@@ -249,6 +254,73 @@ class Context:
     def call(self, name, *args):
         check(getattr(self.lib, name)(self.handle, *args))
 
+    @property
+    def pinned(self):
+        """The context's pool of page-locked host arrays (PinnedPool)."""
+        pool = getattr(self, "_pinned", None)
+        if pool is None:
+            pool = self._pinned = PinnedPool(self)
+        return pool
+
+
+class PinnedPool:
+    """numpy arrays in page-locked host memory (sdx_host_alloc), for buffers the device reads or writes by DMA: a staging area
+    that lives as long as the pool, and result arrays whose memory comes back to the pool when the last view of them is gone
+    (idle blocks are kept up to `keep` bytes: hipHostMalloc costs ~0.1 ms).  No more than `limit` bytes are out at a time;
+    beyond that `empty` returns None and the caller uses pageable memory and the bounce-buffer copies."""
+
+    def __init__(self, ctx, keep=256 << 20, limit=1 << 30):
+        self.ctx, self.keep, self.limit = ctx, keep, limit  # bytes of idle blocks kept; bytes handed out at most
+        self._free = {}
+        self._idle = 0
+        self._out = 0
+        self._lock = threading.Lock()
+
+    @staticmethod
+    def _capacity(nbytes):
+        return max(4096, 1 << (int(nbytes) - 1).bit_length())
+
+    def _take(self, cap):
+        with self._lock:
+            if self._out + cap > self.limit:
+                return None
+            blocks = self._free.get(cap)
+            ptr = blocks.pop() if blocks else None
+            if ptr is not None:
+                self._idle -= cap
+            self._out += cap
+        if ptr is None:
+            ptr = self.ctx.lib.sdx_host_alloc(self.ctx.handle, cap)
+            if not ptr:
+                with self._lock:
+                    self._out -= cap
+                return None
+        return ptr
+
+    def _give_back(self, ptr, cap):
+        with self._lock:
+            self._out -= cap
+            if self._idle + cap <= self.keep:
+                self._free.setdefault(cap, []).append(ptr)
+                self._idle += cap
+                return
+        try:
+            self.ctx.lib.sdx_host_free(ptr)
+        except Exception:
+            pass
+
+    def empty(self, shape, dtype=np.float64):
+        dtype = np.dtype(dtype)
+        count = int(np.prod(shape, dtype=np.int64))
+        nbytes = max(count * dtype.itemsize, 1)
+        cap = self._capacity(nbytes)
+        ptr = self._take(cap)
+        if ptr is None:
+            return None
+        block = (C.c_char * nbytes).from_address(ptr)
+        weakref.finalize(block, self._give_back, ptr, cap)  # every view of the array keeps `block` alive through .base
+        return np.frombuffer(block, dtype=dtype, count=count).reshape(shape)
+
 
 class DeviceArray:
     """A device buffer allocated through the C ABI (sdx_malloc): pointer + shape, nothing more."""
@@ -263,6 +335,12 @@ class DeviceArray:
             raise MemoryError(ctx.lib.sdx_last_error_string().decode())
 
     def numpy(self):
+        # planes land in page-locked memory by DMA (PinnedPool: back to the pool when the array is dropped); small arrays and
+        # whatever exceeds the pool's limit take the bounce-buffer copy into pageable memory
+        out = self.ctx.pinned.empty(self.shape, self.dtype) if self.nbytes >= (64 << 10) else None
+        if out is not None:
+            check(self.ctx.lib.sdx_memcpy_d2h_pinned(self.ctx.handle, out.ctypes.data, self.ptr, self.nbytes))
+            return out
         out = np.empty(self.shape, dtype=self.dtype)
         check(self.ctx.lib.sdx_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr, self.nbytes))
         return out

@@ -526,6 +526,47 @@ int sdx_memcpy_d2h(sdx_ctx* ctx, void* dst, const void* src, size_t bytes)
     return SDX_OK;
 }
 
+// Page-locked host memory for callers that keep their own staging / result buffers there (the Python mirror's fused call): the
+// copies below move it by DMA directly, without the bounce buffer and its memcpy.
+void* sdx_host_alloc(sdx_ctx* ctx, size_t bytes)
+{
+    if (!ctx || bytes == 0) {
+        fail(SDX_ERR_ARG, "sdx_host_alloc: null context or zero size");
+        return nullptr;
+    }
+    void* p = nullptr;
+    if (hipSetDevice(ctx->device) != hipSuccess || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        fail(SDX_ERR_OOM, "sdx_host_alloc: hipHostMalloc of " + std::to_string(bytes) + " bytes failed");
+        return nullptr;
+    }
+    return p;
+}
+
+int sdx_host_free(void* ptr)
+{
+    if (!ptr) return SDX_OK;
+    HIP_TRY(hipHostFree(ptr));
+    return SDX_OK;
+}
+
+int sdx_memcpy_h2d_pinned(sdx_ctx* ctx, void* dst, const void* src_pinned, size_t bytes)
+{
+    REQUIRE(ctx && (bytes == 0 || (dst && src_pinned)), "sdx_memcpy_h2d_pinned: null pointer");
+    if (bytes == 0) return SDX_OK;
+    HIP_TRY(hipMemcpyAsync(dst, src_pinned, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return SDX_OK;
+}
+
+int sdx_memcpy_d2h_pinned(sdx_ctx* ctx, void* dst_pinned, const void* src, size_t bytes)
+{
+    REQUIRE(ctx && (bytes == 0 || (dst_pinned && src)), "sdx_memcpy_d2h_pinned: null pointer");
+    if (bytes == 0) return SDX_OK;
+    HIP_TRY(hipMemcpyAsync(dst_pinned, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SDX_OK;
+}
+
 int sdx_memset(sdx_ctx* ctx, void* dst, int value, size_t bytes)
 {
     REQUIRE(ctx && (bytes == 0 || dst), "sdx_memset: null pointer");

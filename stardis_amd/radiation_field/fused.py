@@ -145,15 +145,26 @@ class FusedOpacities(Opacities):
 
 
 def _packed_upload(ctx, arrays):
-    """One staging copy for many small arrays: -> (DeviceArray holding them all, [device address of each])."""
+    """One staging copy for many small arrays: -> (DeviceArray holding them all, [device address of each]).  The arrays are
+    packed straight into page-locked memory and go up by DMA from there (asynchronous: the call's final download, which
+    synchronises, comes before the staging block can be handed out again)."""
     offs, total = [], 0
     for a in arrays:
         offs.append(total)
         total += (a.nbytes + 255) & ~255
-    blob = np.empty(max(total, 256), dtype=np.uint8)
+    total = max(total, 256)
+    blob = ctx.pinned.empty(total, np.uint8)
+    pinned = blob is not None
+    if not pinned:
+        blob = np.empty(total, dtype=np.uint8)
     for a, o in zip(arrays, offs):
         blob[o:o + a.nbytes] = a.reshape(-1).view(np.uint8)
-    dev = ctx.upload(blob, np.uint8)
+    if pinned:
+        dev = ctx.empty(total, np.uint8)
+        ctx.call("sdx_memcpy_h2d_pinned", dev.ptr, blob.ctypes.data, total)
+        dev._staging = blob  # stays out of the pool while the device copy may still be reading it
+    else:
+        dev = ctx.upload(blob, np.uint8)
     return dev, [dev.ptr + o for o in offs]
 
 
@@ -409,8 +420,15 @@ def try_fused(field_cls, tracing_nus, stellar_model, stellar_plasma, config, sou
     ctx.call("sdx_synthesize_dev", nd, nus.size, P("nus"), 0, nus.size, n_lines, P("l_nu"), d_doppler.ptr if n_lines else None,
              d_gamma.ptr if n_lines else None, nd, P("l_alpha"), C.byref(c), int(config.no_of_thetas), P("temps"), P("ray"), P("wts"),
              d_line.ptr if n_lines else None, d_total.ptr, d_F.ptr, nus.size, None)
-    field.F_nu = np.empty((nd, nus.size))
-    _lib.check(ctx.lib.sdx_memcpy_d2h(ctx.handle, field.F_nu.ctypes.data, d_F.ptr, field.F_nu.nbytes))
+    # F_nu lands in page-locked memory by DMA (no bounce buffer, no second copy); the block returns to the context's pool when
+    # the last reference to the array is gone
+    field.F_nu = ctx.pinned.empty((nd, nus.size))
+    if field.F_nu is not None:
+        ctx.call("sdx_memcpy_d2h_pinned", field.F_nu.ctypes.data, d_F.ptr, field.F_nu.nbytes)
+    else:
+        field.F_nu = np.empty((nd, nus.size))
+        ctx.call("sdx_memcpy_d2h", field.F_nu.ctypes.data, d_F.ptr, field.F_nu.nbytes)
+    blob._staging = None  # (the download above synchronised: the staging block may go back to the pool)
     opac._total_twin = d_total
     field._device_blob = blob  # keeps the staged inputs alive as long as the lazy entries may need them
 

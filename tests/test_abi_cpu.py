@@ -62,6 +62,8 @@ def test_library_reports_no_device_and_product_raises():
     assert lib.sdx_create(0, None) is None
     assert b"hipSetDevice" in lib.sdx_last_error_string() or lib.sdx_last_error_string()
     assert lib.sdx_set_device(0) == -2 and lib.sdx_last_error_code() == -2  # SDX_ERR_HIP: no device to select
+    assert lib.sdx_host_alloc(None, 4096) is None and lib.sdx_last_error_code() == -1  # page-locked memory needs a context
+    assert lib.sdx_host_free(None) == 0
 
 
 def test_product_never_imports_the_oracle():
