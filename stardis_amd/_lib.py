@@ -276,9 +276,13 @@ class PinnedPool:
         self._out = 0
         self._lock = threading.Lock()
 
+    BIGGEST = 128 << 20  # larger arrays are not worth page-locking per call: they take the pageable path
+
     @staticmethod
     def _capacity(nbytes):
-        return max(4096, 1 << (int(nbytes) - 1).bit_length())
+        """Size class: powers of two up to 1 MiB, whole MiB above."""
+        nbytes = int(nbytes)
+        return max(4096, 1 << (nbytes - 1).bit_length()) if nbytes <= (1 << 20) else (nbytes + (1 << 20) - 1) & ~((1 << 20) - 1)
 
     def _take(self, cap):
         with self._lock:
@@ -313,6 +317,8 @@ class PinnedPool:
         dtype = np.dtype(dtype)
         count = int(np.prod(shape, dtype=np.int64))
         nbytes = max(count * dtype.itemsize, 1)
+        if nbytes > self.BIGGEST:
+            return None
         cap = self._capacity(nbytes)
         ptr = self._take(cap)
         if ptr is None:

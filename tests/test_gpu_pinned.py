@@ -33,6 +33,8 @@ def test_pinned_arrays_round_trip_and_return_to_the_pool(ctx):
     assert c.ctypes.data == addr
     # beyond the limit the pool declines (the caller falls back to pageable memory)
     assert pool.empty(1 << 20, np.uint8) is None
+    assert _lib.PinnedPool._capacity(5000) == 8192 and _lib.PinnedPool._capacity((3 << 20) + 1) == 4 << 20
+    assert _lib.PinnedPool(ctx).empty(_lib.PinnedPool.BIGGEST + 1, np.uint8) is None  # too large to page-lock per call
     del a, c
     gc.collect()
     assert pool._out == 0
