@@ -221,6 +221,8 @@ class Context:
 
     def close(self):
         if getattr(self, "handle", None):
+            if getattr(self, "_pinned", None) is not None:
+                self._pinned.release_idle()
             self.lib.sdx_destroy(self.handle)
             self.handle = None
 
@@ -312,6 +314,19 @@ class PinnedPool:
             self.ctx.lib.sdx_host_free(ptr)
         except Exception:
             pass
+
+    def release_idle(self):
+        """Free the idle blocks (Context.close); blocks still held by arrays are freed when those arrays go."""
+        with self._lock:
+            blocks = [p for v in self._free.values() for p in v]
+            self._free.clear()
+            self._idle = 0
+            self.keep = 0
+        for p in blocks:
+            try:
+                self.ctx.lib.sdx_host_free(p)
+            except Exception:
+                pass
 
     def empty(self, shape, dtype=np.float64):
         dtype = np.dtype(dtype)

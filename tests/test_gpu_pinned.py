@@ -51,3 +51,20 @@ def test_planes_read_back_through_the_pool_equal_the_bounce_copy(ctx):
     ctx.call("sdx_memcpy_d2h", plain.ctypes.data, dev.ptr, dev.nbytes)
     assert np.array_equal(plain, host)
     assert ctx.lib.sdx_host_free(None) == 0
+
+
+def test_closing_a_context_frees_its_idle_blocks():
+    c = _lib.Context(0)
+    a = c.pinned.empty((10, 1000))
+    b = c.pinned.empty((10, 1000))
+    del a
+    gc.collect()
+    assert c.pinned._idle > 0
+    pool = c.pinned
+    c.close()
+    assert pool._idle == 0 and not pool._free
+    b[:] = 1.0  # an array handed out earlier stays valid; its block is freed, not pooled, when it goes
+    del b
+    gc.collect()
+    assert pool._idle == 0 and pool._out == 0
+    assert pool.empty(16) is None  # no context left to allocate from
