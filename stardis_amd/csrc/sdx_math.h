@@ -330,37 +330,48 @@ __device__ __attribute__((noinline)) double faddeeva_re_core(double x, double y,
         return fma(n.re, d.im, -(n.im * d.re)) * recip(fma(d.re, d.re, d.im * d.im));
     }
     const c64 t = {y, -x};
-    if (y >= sub_rn(mul_rn(0.195, ax), 0.176)) {  // region III
-        c64 p = {fma(0.5642236, t.re, 3.778987), 0.5642236 * t.im};
-        p = horner_add(11.96482, t, p);
-        p = horner_add(20.20933, t, p);
-        p = horner_add(16.4955, t, p);
-        c64 q = {t.re + 6.699398, t.im};
-        q = horner_add(21.69274, t, q);
-        q = horner_add(39.27121, t, q);
-        q = horner_add(38.82363, t, q);
-        q = horner_add(16.4955, t, q);
+    // Regions III and IV are quotients of polynomials with REAL coefficients in a complex argument v = (a, b).  Such a
+    // polynomial is evaluated by dividing it by the real quadratic that has v as a root, z^2 - r z + s with r = 2 a, s = |v|^2:
+    //     b_n = c_n,  b_(n-1) = c_(n-1) + r b_n,  b_k = c_k + r b_(k+1) - s b_(k+2)   ->   p(v) = b_0 - conj(v) b_1
+    // two real FMAs per coefficient where the complex Horner step of the reference (voigt.py:60-64, :70-84) takes four; the value
+    // is the same polynomial's, rounded differently in the last place (tests/test_gpu_hot_faddeeva.py pins it point by point
+    // against the reference's vectors).  The general Faddeeva evaluations are a fifth of the step with 1e6 lines
+    // (profiles/r03_all_region1_experiment.txt).
+    if (y >= sub_rn(mul_rn(0.195, ax), 0.176)) {  // region III: v = t = (y, -x)
+        const double r = y + y, ms = -fma(x, x, y * y);
+        double b2 = 0.5642236, b1 = fma(r, b2, 3.778987), b0;
+        b0 = fma(r, b1, fma(ms, b2, 11.96482)), b2 = b1, b1 = b0;
+        b0 = fma(r, b1, fma(ms, b2, 20.20933)), b2 = b1, b1 = b0;
+        b0 = fma(r, b1, fma(ms, b2, 16.4955));
+        const c64 p = {fma(-y, b1, b0), -(x * b1)};  // b0 - conj(v) b1, conj(v) = (y, x)
+        double d1 = r + 6.699398, d2 = 1.0, d0;      // leading coefficient 1
+        d0 = fma(r, d1, ms + 21.69274), d2 = d1, d1 = d0;
+        d0 = fma(r, d1, fma(ms, d2, 39.27121)), d2 = d1, d1 = d0;
+        d0 = fma(r, d1, fma(ms, d2, 38.82363)), d2 = d1, d1 = d0;
+        d0 = fma(r, d1, fma(ms, d2, 16.4955));
+        const c64 q = {fma(-y, d1, d0), -(x * d1)};
         return fma(p.re, q.re, p.im * q.im) * recip(fma(q.re, q.re, q.im * q.im));
     }
-    // region IV
+    // region IV: polynomials in v = -u (the nested "c - u (...)" form of the reference has all-positive coefficients in -u)
     const c64 u = cmul(t, t);
-    // (P and Q as real two-term recurrences — synthetic division by the real quadratic with root -u, 13 + 15 instructions instead
-    // of 22 + 26 — pass the point-wise pins too (round 3) but bought 1.4 % of the S-c3 line kernel, within run-to-run noise:
-    // the narrow role is not bound by this arithmetic alone.  Not kept.)
-    c64 p = {fma(-u.re, 0.56419, 1.320522), -(u.im * 0.56419)};
-    p = horner_sub(35.7668, u, p);
-    p = horner_sub(219.031, u, p);
-    p = horner_sub(1540.787, u, p);
-    p = horner_sub(3321.99, u, p);
-    p = horner_sub(36183.31, u, p);
+    const double va = -u.re, vb = -u.im;
+    const double r = va + va, ms = -fma(va, va, vb * vb);
+    double b2 = 0.56419, b1 = fma(r, b2, 1.320522), b0;
+    b0 = fma(r, b1, fma(ms, b2, 35.7668)), b2 = b1, b1 = b0;
+    b0 = fma(r, b1, fma(ms, b2, 219.031)), b2 = b1, b1 = b0;
+    b0 = fma(r, b1, fma(ms, b2, 1540.787)), b2 = b1, b1 = b0;
+    b0 = fma(r, b1, fma(ms, b2, 3321.99)), b2 = b1, b1 = b0;
+    b0 = fma(r, b1, fma(ms, b2, 36183.31));
+    const c64 p = {fma(-va, b1, b0), vb * b1};  // b0 - conj(v) b1, conj(v) = (va, -vb)
     const c64 n = cmul(t, p);
-    c64 q = {1.84144 - u.re, -u.im};
-    q = horner_sub(61.5704, u, q);
-    q = horner_sub(364.219, u, q);
-    q = horner_sub(2186.18, u, q);
-    q = horner_sub(9022.23, u, q);
-    q = horner_sub(24322.8, u, q);
-    q = horner_sub(32066.6, u, q);
+    double d1 = r + 1.84144, d2 = 1.0, d0;
+    d0 = fma(r, d1, ms + 61.5704), d2 = d1, d1 = d0;
+    d0 = fma(r, d1, fma(ms, d2, 364.219)), d2 = d1, d1 = d0;
+    d0 = fma(r, d1, fma(ms, d2, 2186.18)), d2 = d1, d1 = d0;
+    d0 = fma(r, d1, fma(ms, d2, 9022.23)), d2 = d1, d1 = d0;
+    d0 = fma(r, d1, fma(ms, d2, 24322.8)), d2 = d1, d1 = d0;
+    d0 = fma(r, d1, fma(ms, d2, 32066.6));
+    const c64 q = {fma(-va, d1, d0), vb * d1};
     const double frac = fma(n.re, q.re, n.im * q.im) * recip(fma(q.re, q.re, q.im * q.im));
     // exp(u.re): -30.3 < u.re < 0.81 here; exp_neg is the device library's exp, operation for operation, on the argument -tau
     return fma(exp_neg(-u.re), cos_small(u.im), -frac);
