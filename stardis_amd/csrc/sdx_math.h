@@ -353,7 +353,13 @@ __device__ __attribute__((noinline)) double faddeeva_re_core(double x, double y,
         return fma(p.re, q.re, p.im * q.im) * recip(fma(q.re, q.re, q.im * q.im));
     }
     // region IV: polynomials in v = -u (the nested "c - u (...)" form of the reference has all-positive coefficients in -u)
-    const c64 u = cmul(t, t);
+    c64 u = cmul(t, t);
+    // exp(u.re) cos(u.im) first, and the polynomials only after it (the empty statement ties their inputs to its results): scheduled
+    // the other way round the long cosine keeps the recurrences' operands alive and the routine needs two more registers than the
+    // line kernel has to spare under its 72 (it spilled the scan's prefetched line index, 0.7 GB of scratch writes at 1e6 lines).
+    // exp(u.re): -30.3 < u.re < 0.81 here; exp_neg is the device library's exp, operation for operation, on the argument -tau
+    double ex = exp_neg(-u.re), cs = cos_small(u.im);
+    asm("" : "+v"(ex), "+v"(cs), "+v"(u.re), "+v"(u.im));
     const double va = -u.re, vb = -u.im;
     const double r = va + va, ms = -fma(va, va, vb * vb);
     double b2 = 0.56419, b1 = fma(r, b2, 1.320522), b0;
@@ -373,8 +379,7 @@ __device__ __attribute__((noinline)) double faddeeva_re_core(double x, double y,
     d0 = fma(r, d1, fma(ms, d2, 32066.6));
     const c64 q = {fma(-va, d1, d0), vb * d1};
     const double frac = fma(n.re, q.re, n.im * q.im) * recip(fma(q.re, q.re, q.im * q.im));
-    // exp(u.re): -30.3 < u.re < 0.81 here; exp_neg is the device library's exp, operation for operation, on the argument -tau
-    return fma(exp_neg(-u.re), cos_small(u.im), -frac);
+    return fma(ex, cs, -frac);
 }
 
 // Per-(line, depth) constants the pre-pass stores for the line kernel.
