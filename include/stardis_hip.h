@@ -281,6 +281,14 @@ typedef struct sdx_continuum {
     /* electron */
     const double* electron_density; /* NULL = disable_electron_scattering */
     const double* temperature;      /* [n_depth] */
+    /* further alpha_file_<source> planes, already formed on the device (sdx_alpha_file_1d_dev / sdx_alpha_file_2d_dev: the
+     * two-dimensional tables Hminus_ff and H2plus_bf, or several tabulated sources at once): [n_depth][file_plane_ld] each,
+     * column 0 = grid index 0, added right after the 1-D table above in this order — with the table left out (table_sigma NULL)
+     * the planes are calc_alphas' file loop (:666-677) in the configuration's own order.  Device pointers only: the host-buffer
+     * entry points (*_f64) refuse a description that carries planes. */
+    int n_file_planes;              /* 0 .. 4 */
+    const double* file_plane[4];
+    int64_t file_plane_ld;
 } sdx_continuum;
 
 int sdx_total_alphas_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin,

@@ -44,6 +44,9 @@ class Continuum(C.Structure):
         ("rayleigh_enabled", _int),
         ("electron_density", _vp),
         ("temperature", _vp),
+        ("n_file_planes", _int),
+        ("file_plane", _vp * 4),
+        ("file_plane_ld", _i64),
     ]
 
 

@@ -1628,6 +1628,9 @@ struct ContinuumArgs {
     int rayleigh_enabled;
     const double* electron_density;
     const double* temperature;
+    int n_file_planes;             // further tabulated sources as finished planes [n_depth][file_plane_ld], global columns
+    const double* file_plane[4];
+    int64_t file_plane_ld;
 };
 
 __device__ inline double alpha_bf_point(int n_depth, int d, double nu, int n_species, const int* __restrict__ offs,
@@ -1820,6 +1823,7 @@ __device__ __forceinline__ void total_alphas_block(const int bx, const int d, in
     if (a.table_sigma)
         t = add_rn(t, mul_rn(stage_table ? interp1(a.lambdas[i], a.n_table, s_xp, s_fp) : interp1(a.lambdas[i], a.n_table, a.table_wavelength, a.table_sigma),
                              a.table_density[d]));
+    for (int k = 0; k < a.n_file_planes; ++k) t = add_rn(t, a.file_plane[k][(size_t)d * a.file_plane_ld + i]);  // (wave-uniform count and pointers)
     {
         double bf = 0.0;
         for (int sp = 0; sp < a.bf_n_species; ++sp) {
@@ -1929,6 +1933,7 @@ __device__ __forceinline__ void continuum_tile_block(const int tile, const int d
         const double* coef = s_coef + dd * n_levels;
         double t = 0.0;
         if (a.table_sigma) t = add_rn(t, mul_rn(sig, dep[0]));
+        for (int k = 0; k < a.n_file_planes; ++k) t = add_rn(t, a.file_plane[k][(size_t)(d0 + dd) * a.file_plane_ld + i]);
         double bf = 0.0;
         for (int sp = 0; sp < a.bf_n_species; ++sp) {
             double spec = 0.0;  // alpha_spec (:214), levels in plasma order (:221-233)

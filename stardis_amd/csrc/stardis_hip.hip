@@ -238,6 +238,14 @@ int launch_dnu(sdx_ctx* ctx, int64_t n_nu, const double* nus, int* n_partial, in
     return check_launch("k_dnu_partial");
 }
 
+static int check_file_planes(const sdx_continuum* c, int64_t n_nu)
+{
+    REQUIRE(c->n_file_planes >= 0 && c->n_file_planes <= 4, "continuum: n_file_planes must be 0..4");
+    for (int k = 0; k < c->n_file_planes; ++k) REQUIRE(c->file_plane[k], "continuum: null file plane");
+    REQUIRE(c->n_file_planes == 0 || c->file_plane_ld >= n_nu, "continuum: file_plane_ld must cover the grid");
+    return SDX_OK;
+}
+
 ContinuumArgs to_args(const sdx_continuum* c, const double* bf_coef)
 {
     ContinuumArgs a{};
@@ -261,6 +269,9 @@ ContinuumArgs to_args(const sdx_continuum* c, const double* bf_coef)
     a.rayleigh_enabled = c->rayleigh_enabled;
     a.electron_density = c->electron_density;
     a.temperature = c->temperature;
+    a.n_file_planes = std::max(0, std::min(4, c->n_file_planes));
+    for (int k = 0; k < a.n_file_planes; ++k) a.file_plane[k] = c->file_plane[k];
+    a.file_plane_ld = c->file_plane_ld;
     return a;
 }
 
@@ -1576,6 +1587,7 @@ int sdx_total_alphas_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
     REQUIRE(ctx && cont && nus && n_depth > 0, "total_alphas: bad arguments");
     REQUIRE(nu_begin >= 0 && nu_count >= 0 && nu_begin + nu_count <= n_nu, "total_alphas: shard outside the grid");
     REQUIRE(nu_count == 0 || (total && total_ld >= nu_count && (!alpha_line || line_ld >= nu_count)), "total_alphas: bad buffers");
+    if (int rc = check_file_planes(cont, n_nu)) return rc;
     if (nu_count == 0) return SDX_OK;
     return launch_total(ctx, n_depth, nus, nu_begin, nu_count, cont, alpha_line, line_ld, 1, nullptr, 0, total, total_ld);
 }
@@ -1787,6 +1799,7 @@ static int synthesize_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double
     REQUIRE(cont && temps && ray_dist && wts && n_theta > 0 && n_depth >= 2, "synthesize: bad arguments");
     REQUIRE(nu_begin >= 0 && nu_count >= 0 && nu_begin + nu_count <= n_nu, "synthesize: shard outside the grid");
     REQUIRE(nu_count == 0 || (F_nu && ld >= nu_count), "synthesize: bad output buffers");
+    if ((rc = check_file_planes(cont, n_nu))) return rc;
     if (nu_count == 0) return SDX_OK;
     // Three launches on one stream: [pre-pass + continuum plane] -> [wide + narrow line kernels] -> [raytrace, which
     // forms total = continuum + line while staging its columns].  Independent work shares a launch instead of a
@@ -1889,6 +1902,7 @@ static int synthesize_host_check(sdx_ctx* ctx, int n_depth, int64_t n_nu, const 
     for (int64_t k = 0; k < n_lines * n_depth; ++k)
         if (doppler[k] == 0.0) return fail(SDX_ERR_ARG, "doppler_width == 0 (ZeroDivisionError in the reference, voigt.py:148)");
     REQUIRE(cont->bf_n_species == 0 || !cont->bf_cutoff || cont->bf_n_levels > 0, "synthesize: bf_n_levels must be set");
+    REQUIRE(cont->n_file_planes == 0, "synthesize: file planes are device planes (sdx_synthesize_dev); the host-buffer entry points take tabulated sources as the 1-D table only");
     return SDX_OK;
 }
 

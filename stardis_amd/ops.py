@@ -214,14 +214,25 @@ def alpha_file_2d(sigma, density, ctx=None):
     return out
 
 
-def sigma_table_2d(wave, axis2, cell_simplices, transform, simplex_values, lambdas, second, scale_kind=0, temperatures=None, ctx=None):
+def upload_sigma_table(wave, axis2, cell_simplices, transform, simplex_values, ctx=None):
+    """The table side of sigma_table_2d on the device, for callers that evaluate the same table again and again."""
+    ctx = ctx or default_context()
+    return tuple(ctx.upload(_host(x)) for x in (np.reshape(_host(wave), -1), np.reshape(_host(axis2), -1), transform, simplex_values)) + (
+        ctx.upload(_host(cell_simplices, np.int32), np.int32),)
+
+
+def sigma_table_2d(wave, axis2, cell_simplices, transform, simplex_values, lambdas, second, scale_kind=0, temperatures=None, ctx=None,
+                   table_dev=None):
     """opacities/opacities_solvers/util.py:35-91: LinearNDInterpolator on the table's triangulation at the mesh
-    (lambdas, second) -> (sigma DeviceArray (len(second), len(lambdas)), rows that contain an exact zero)."""
+    (lambdas, second) -> (sigma DeviceArray (len(second), len(lambdas)), rows that contain an exact zero).
+    table_dev: what upload_sigma_table returned for this table (skips five uploads)."""
     ctx = ctx or default_context()
     wave, axis2 = _host(wave).reshape(-1), _host(axis2).reshape(-1)
     lam, sec = _host(lambdas).reshape(-1), _host(second).reshape(-1)
-    d = [ctx.upload(x) for x in (wave, axis2, _host(transform), _host(simplex_values), lam, sec)]
-    d_cells = ctx.upload(_host(cell_simplices, np.int32), np.int32)
+    if table_dev is None:
+        table_dev = upload_sigma_table(wave, axis2, cell_simplices, transform, simplex_values, ctx)
+    d = list(table_dev[:4]) + [ctx.upload(lam), ctx.upload(sec)]
+    d_cells = table_dev[4]
     d_t = ctx.upload(_host(temperatures).reshape(-1)) if temperatures is not None else None
     out = ctx.empty((sec.size, lam.size))
     zero = ctx.empty((sec.size,), np.int32)

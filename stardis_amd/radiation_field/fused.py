@@ -10,7 +10,7 @@ called (`alpha_bf`, `alpha_ff`, ...: same device functions, bit-identical planes
 of disabled sources and `F_nu` accumulation semantics are the reference's (opacities_solvers/base.py:655-738,
 radiation_field_solvers/base.py:324-338).
 
-`try_fused` returns None for configurations the fused step does not cover (2-D tabulated cross-sections, molecules,
+`try_fused` returns None for configurations the fused step does not cover (more than four tabulated sources, molecules,
 spherical geometry, tracked intensities, a foreign source function, frequencies the Rayleigh cut-off would clip, line lists
 without a dense alpha table); the caller then takes the general path.
 """
@@ -19,13 +19,13 @@ from pathlib import Path
 
 import numpy as np
 
-from stardis_amd import _lib
+from stardis_amd import _lib, ops
 from stardis_amd import constants as K
 from stardis_amd._lib import Continuum, default_context, plain
 from stardis_amd.radiation_field.opacities import Opacities
 from stardis_amd.radiation_field.opacities.opacities_solvers import base as B
 from stardis_amd.radiation_field.opacities.opacities_solvers.broadening import _microturbulence_cgs, _switches
-from stardis_amd.radiation_field.opacities.opacities_solvers.util import get_number_density, read_table
+from stardis_amd.radiation_field.opacities.opacities_solvers.util import get_number_density, read_table, sigma_file_device
 
 F8 = np.float64
 RAYLEIGH_CUTOFF = 2.3e15  # opacities_solvers/base.py:99
@@ -305,7 +305,7 @@ def try_fused(field_cls, tracing_nus, stellar_model, stellar_plasma, config, sou
         return None
     if getattr(source_function, "__name__", "") != "blackbody_flux_at_nu" or opacity.line.include_molecules:
         return None
-    if int(config.no_of_thetas) > 64 or len(opacity.file) > 1:
+    if int(config.no_of_thetas) > 64 or len(opacity.file) > 4:
         return None
     nus = np.ascontiguousarray(plain(tracing_nus), dtype=F8).reshape(-1)
     nd = int(stellar_model.no_of_depth_points)
@@ -314,11 +314,14 @@ def try_fused(field_cls, tracing_nus, stellar_model, stellar_plasma, config, sou
     rayleigh_species = list(opacity.rayleigh)
     if rayleigh_species and nus.max() > RAYLEIGH_CUTOFF:
         return None  # the reference clips the caller's frequencies in place there (:99): general path reproduces it
+    # tabulated sources (:666-677).  One 1-D table (Hminus_bf): interpolated inside the step.  A two-dimensional table
+    # (Hminus_ff, H2plus_bf) or several sources: each becomes a plane on the device first — by the calls the general path makes,
+    # so the same bits — and the step adds the planes in the configuration's order (sdx_continuum.file_plane).
     table = None
-    for source, fpath in opacity.file.items():
-        table = read_table(Path(fpath), source)
-        if table[0] != "1d":
-            return None
+    tables = [(source, Path(fpath), read_table(Path(fpath), source)) for source, fpath in opacity.file.items()]
+    plane_sources = tables if (len(tables) > 1 or any(t[2][0] != "1d" for t in tables)) else []
+    if not plane_sources and tables:
+        table = tables[0][2]
     bf_species = list(opacity.bf.keys()) if hasattr(opacity.bf, "keys") else list(opacity.bf)
     bf = _bf_arrays(stellar_plasma, bf_species)
     if bf is None or bf[2].size > 4096:
@@ -335,7 +338,7 @@ def try_fused(field_cls, tracing_nus, stellar_model, stellar_plasma, config, sou
             return None
     ctx = default_context()
     temps = np.ascontiguousarray(plain(stellar_model.temperatures), dtype=F8).reshape(-1)
-    file_source = next(iter(opacity.file)) if table is not None else None
+    file_source = tables[0][0] if table is not None else None
     dv = _depth_vectors(stellar_plasma, opacity, file_source, rayleigh_species)
     n_e = dv["n_e"]
 
@@ -388,9 +391,21 @@ def try_fused(field_cls, tracing_nus, stellar_model, stellar_plasma, config, sou
     blob, ptrs = _packed_upload(ctx, host)
     P = lambda name: ptrs[slot[name]] if name in slot else None  # noqa: E731
 
+    file_planes = []
+    for source, fpath, tab in plane_sources:
+        density = np.asarray(plain(get_number_density(stellar_plasma, source)[0]), dtype=F8)
+        if tab[0] == "1d":
+            file_planes.append(ops.alpha_file_1d(K.nu_to_angstrom(nus), tab[1], tab[2], density, ctx=ctx))
+        else:
+            file_planes.append(ops.alpha_file_2d(sigma_file_device(K.nu_to_angstrom(nus), temps, fpath, source), density, ctx=ctx))
+
     c = Continuum()
     c.temperature = P("temps")
     c.lambdas = P("lambdas")
+    c.n_file_planes = len(file_planes)
+    for k, plane in enumerate(file_planes):
+        c.file_plane[k] = plane.ptr
+    c.file_plane_ld = nus.size
     if table is not None:
         c.n_table, c.table_wavelength, c.table_sigma, c.table_density = int(np.size(table[1])), P("tab_x"), P("tab_y"), P("tab_n")
     if bf[1].size:
@@ -430,7 +445,7 @@ def try_fused(field_cls, tracing_nus, stellar_model, stellar_plasma, config, sou
         ctx.call("sdx_memcpy_d2h", field.F_nu.ctypes.data, d_F.ptr, field.F_nu.nbytes)
     blob._staging = None  # (the download above synchronised: the staging block may go back to the pool)
     opac._total_twin = d_total
-    field._device_blob = blob  # keeps the staged inputs alive as long as the lazy entries may need them
+    field._device_blob = (blob, file_planes)  # keeps the staged inputs alive as long as the lazy entries may need them
 
     # ---- dictionary entries, the reference's keys in the reference's order (:655-738); planes on first read
     entries = opac.opacities_dict
@@ -449,8 +464,11 @@ def try_fused(field_cls, tracing_nus, stellar_model, stellar_plasma, config, sou
         return _Thunk(run)
 
     fnus = field.frequencies
-    for source, fpath in opacity.file.items():
-        put(f"alpha_file_{source}", remembered(f"alpha_file_{source}", lambda s=source, f=fpath: B.calc_alpha_file(stellar_plasma, stellar_model, fnus, s, f)))
+    for k, (source, fpath) in enumerate(opacity.file.items()):
+        if file_planes:  # the plane the step added is the entry
+            put(f"alpha_file_{source}", twin(file_planes[k]))
+        else:
+            put(f"alpha_file_{source}", remembered(f"alpha_file_{source}", lambda s=source, f=fpath: B.calc_alpha_file(stellar_plasma, stellar_model, fnus, s, f)))
     put("alpha_bf", remembered("alpha_bf", lambda: B.calc_alpha_bf(stellar_plasma, stellar_model, fnus, opacity.bf)))
     put("alpha_ff", remembered("alpha_ff", lambda: B.calc_alpha_ff(stellar_plasma, stellar_model, fnus, opacity.ff)))
     put("alpha_rayleigh", remembered("alpha_rayleigh", lambda: B.calc_alpha_rayleigh(stellar_plasma, stellar_model, fnus, opacity.rayleigh)))

@@ -76,6 +76,9 @@ def cell_lookup(wave, axis2, simplices, values):
     return order.reshape(n_cells, 2).astype(np.int32), np.asarray(values, dtype=float).ravel()[simplices]
 
 
+_TRIANGULATION = {}  # id(parsed table) -> (the table — kept alive, so the id stays its own —, transform, cell lookup)
+
+
 def triangulate(wave, axis2, values):
     """The triangulation LinearNDInterpolator builds for the table (util.py:47-53, :75-81), as arrays."""
     from scipy.spatial import Delaunay
@@ -88,13 +91,23 @@ def triangulate(wave, axis2, values):
 def sigma_file_device(tracing_lambdas, temperatures, fpath, opacity_source):
     """sigma_file for the 2-D tables with the result left in HBM -> DeviceArray (N_T, N_lambda)."""
     from stardis_amd import ops
+    from stardis_amd._lib import default_context
 
     tracing_lambdas = np.asarray(tracing_lambdas, dtype=float)
     temperatures = np.asarray(temperatures, dtype=float)
-    _, wave, axis2, values = read_table(fpath, opacity_source)
+    table = read_table(fpath, opacity_source)
+    _, wave, axis2, values = table
     axis2 = np.asarray(axis2, dtype=float)
-    simplices, transform = triangulate(wave, axis2, values)
-    lookup = cell_lookup(wave, axis2, simplices, values)
+    # the triangulation belongs to the table: made once per parsed table (read_table hands out the same tuple until the file
+    # changes), not per call — scipy's Delaunay is a millisecond of host time
+    prepared = _TRIANGULATION.get(id(table))
+    if prepared is None or prepared[0] is not table:
+        simplices, transform = triangulate(wave, axis2, values)
+        prepared = (table, transform, cell_lookup(wave, axis2, simplices, values), {})
+        if len(_TRIANGULATION) > 16:
+            _TRIANGULATION.clear()
+        _TRIANGULATION[id(table)] = prepared
+    transform, lookup = prepared[1], prepared[2]
     if opacity_source == "Hminus_ff":
         second, kind, what = 5040 / temperatures, 2, "H- FF"
     else:
@@ -102,7 +115,12 @@ def sigma_file_device(tracing_lambdas, temperatures, fpath, opacity_source):
     if lookup is None:
         # never seen for these tables; there is no host evaluation path to fall back to
         raise NotImplementedError(f"the Delaunay triangulation of the {what} table is not two triangles per grid cell")
-    dev, zero_rows = ops.sigma_table_2d(wave, axis2, lookup[0], transform, lookup[1], tracing_lambdas, second, kind, temperatures)
+    ctx = default_context()
+    table_dev = prepared[3].get(id(ctx))  # the table's arrays stay on the device of the context that evaluates it
+    if table_dev is None or table_dev[0] is not ctx:
+        table_dev = prepared[3][id(ctx)] = (ctx, ops.upload_sigma_table(wave, axis2, lookup[0], transform, lookup[1], ctx))
+    dev, zero_rows = ops.sigma_table_2d(wave, axis2, lookup[0], transform, lookup[1], tracing_lambdas, second, kind, temperatures, ctx=ctx,
+                                        table_dev=table_dev[1])
     if zero_rows.size:
         logger.warning(
             "Outside of interpolation range for %s cross-sections at depth points %s. Assuming 0 opacity there.", what, zero_rows

@@ -36,8 +36,9 @@ def test_continuum_struct_matches_header():
     text = open(HEADER).read()
     body = re.search(r"typedef struct sdx_continuum \{(.*?)\} sdx_continuum;", text, flags=re.S).group(1)
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
-    fields = re.findall(r"\b([a-z_0-9]+)\s*;", body)
+    fields = re.findall(r"\b([a-z_0-9]+)(?:\[\d+\])?\s*;", body)
     assert fields == [f[0] for f in _lib.Continuum._fields_]
+    assert _lib.Continuum.file_plane.size == 4 * 8 and "file_plane[4]" in body
 
 
 def test_linelist_struct_matches_header():

@@ -1,0 +1,91 @@
+"""The fused create_stellar_radiation_field with SEVERAL tabulated sources, two of them two-dimensional tables — the opacity
+block of the reference's own test configurations (stardis/tests/stardis_test_config_broadening.yml: Hminus_bf, Hminus_ff,
+H2plus_bf; opacities_solvers/base.py:666-677, util.py:35-103).  Each source becomes a plane on the device by the calls the
+source-by-source path makes, and the fused step adds the planes in the configuration's order (sdx_continuum.file_plane)."""
+import numpy as np
+import pandas as pd
+import pytest
+
+import oracle
+import stardis_amd.radiation_field.base as rf
+from conftest import rel_err
+from stardis_amd import _lib, synth
+from stardis_amd.radiation_field.fused import FusedOpacities
+from test_gpu_sigma_tables import write_tables
+
+pytestmark = pytest.mark.gpu
+
+
+def three_source_case(tmp_path, order):
+    atm = synth.solar_atmosphere()
+    nus = synth.tracing_grid(6540.0, 6580.0, step=0.02)
+    plasma, model, config, arrays = synth.fake_plasma(nus, atm, 300, seed=11)
+    _, paths = write_tables(tmp_path)
+    files = {"Hminus_bf": config.opacity.file["Hminus_bf"], "Hminus_ff": str(paths["Hminus_ff"]), "H2plus_bf": str(paths["H2plus_bf"])}
+    config.opacity.file = {k: files[k] for k in order}
+    cols = np.arange(atm["temperatures"].size)
+    plasma.h2_plus_density = pd.Series(1e-9 * np.asarray(plasma.ion_number_density.loc[1, 0]) * np.linspace(1.0, 3.0, cols.size), index=cols)
+    return nus, plasma, model, config
+
+
+def both_paths(nus, model, plasma, config):
+    out = {}
+    was = rf.FUSED
+    try:
+        for fused in (True, False):
+            rf.FUSED = fused
+            out[fused] = rf.create_stellar_radiation_field(nus.copy(), model, plasma, config)
+    finally:
+        rf.FUSED = was
+    return out[True], out[False]
+
+
+@pytest.mark.parametrize("order", [("Hminus_bf", "Hminus_ff", "H2plus_bf"), ("H2plus_bf", "Hminus_bf", "Hminus_ff"), ("Hminus_ff",)])
+def test_fused_call_with_two_dimensional_tables_equals_the_source_by_source_path(tmp_path, order):
+    nus, plasma, model, config = three_source_case(tmp_path, order)
+    fused, general = both_paths(nus, model, plasma, config)
+    assert isinstance(fused.opacities, FusedOpacities) and not isinstance(general.opacities, FusedOpacities)
+    assert np.array_equal(fused.F_nu, general.F_nu)
+    assert list(fused.opacities.opacities_dict) == list(general.opacities.opacities_dict)
+    assert list(fused.opacities.opacities_dict)[:len(order)] == [f"alpha_file_{s}" for s in order]
+    for key in general.opacities.opacities_dict:
+        a, b = fused.opacities.opacities_dict[key], general.opacities.opacities_dict[key]
+        assert np.array_equal(np.asarray(a), np.asarray(b)), key
+    assert np.array_equal(fused.opacities.total_alphas, general.opacities.total_alphas)
+    # every tabulated source contributes: the total is the sum of the entries in insertion order (opacities/base.py:24-28)
+    total = np.zeros_like(general.F_nu)
+    for key, value in general.opacities.opacities_dict.items():
+        if "gammas" not in key and "doppler" not in key:
+            total += value
+    assert np.array_equal(total, fused.opacities.total_alphas)
+    for s in order:
+        assert (np.asarray(fused.opacities.opacities_dict[f"alpha_file_{s}"]) > 0).any(), s
+    # and the flux is the oracle's on that total
+    F_ref, _ = oracle.raytrace(nus, model.temperatures, model.geometry.dist_to_next_depth_point, fused.thetas, fused.I_nus_weights, total)
+    assert rel_err(fused.F_nu[1:], F_ref[1:]) < 1e-10
+
+
+def test_file_planes_are_validated(ctx):
+    import ctypes as C
+
+    c = _lib.Continuum()
+    t = ctx.upload(np.full(4, 5000.0))
+    nus = ctx.upload(np.linspace(5e14, 4e14, 16))
+    c.temperature = t.ptr
+    c.n_file_planes = 5
+    out = ctx.empty((4, 16))
+    with pytest.raises(ValueError, match="n_file_planes"):
+        ctx.call("sdx_total_alphas_dev", 4, 16, nus.ptr, 0, 16, C.byref(c), None, 0, out.ptr, 16)
+    c.n_file_planes = 1
+    with pytest.raises(ValueError, match="null file plane"):
+        ctx.call("sdx_total_alphas_dev", 4, 16, nus.ptr, 0, 16, C.byref(c), None, 0, out.ptr, 16)
+    plane = ctx.upload(np.arange(64.0).reshape(4, 16))
+    c.file_plane[0] = plane.ptr
+    c.file_plane_ld = 8
+    with pytest.raises(ValueError, match="file_plane_ld"):
+        ctx.call("sdx_total_alphas_dev", 4, 16, nus.ptr, 0, 16, C.byref(c), None, 0, out.ptr, 16)
+    c.file_plane_ld = 16
+    c.file_plane[1] = plane.ptr
+    c.n_file_planes = 2
+    ctx.call("sdx_total_alphas_dev", 4, 16, nus.ptr, 4, 8, C.byref(c), None, 0, out.ptr, 16)  # a shard: columns 4..11, planes are global
+    assert np.array_equal(out.numpy()[:, :8], 2.0 * np.arange(64.0).reshape(4, 16)[:, 4:12])
