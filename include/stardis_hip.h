@@ -315,6 +315,14 @@ int sdx_synthesize_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nu
                        const double* temperature, const double* ray_dist, const double* theta_weights,
                        double* alpha_line_out, double* total_alphas, double* F_nu, int64_t ld,
                        int64_t* n_evaluations_dev);
+/* The same step with RadiationField.track_individual_intensities (radiation_field/base.py:64-68, filled at
+ * radiation_field_solvers/base.py:324-338): I_nus [n_depth][nu_count][n_theta] receives the intensity of every ray at every depth
+ * point (row 0: zeros, the reference's initial condition :134). */
+int sdx_synthesize_tracked_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin, int64_t nu_count,
+                               int64_t n_lines, const double* line_nus, const double* doppler_widths, const double* gammas,
+                               int gamma_cols, const double* alphas, const sdx_continuum* cont, int n_theta,
+                               const double* temperatures, const double* ray_dist, const double* weights, double* alpha_line_out,
+                               double* total_alphas, double* F_nu, int64_t ld, double* I_nus, int64_t* n_evaluations_dev);
 
 /* The same synthesis for a caller whose data lives in host memory (plain C, or numpy through ctypes): every pointer,
  * including those inside `cont`, is a HOST pointer; arrays are uploaded, sdx_synthesize_dev runs, results come back.

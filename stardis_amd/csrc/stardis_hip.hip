@@ -1793,7 +1793,7 @@ static int synthesize_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double
                            int64_t n_lines, const double* line_nus, const double* doppler, const double* gammas, int gamma_cols,
                            const double* alphas, const sdx_continuum* cont, int n_theta, const double* temps,
                            const double* ray_dist, const double* wts, double* alpha_line_out, double* total_alphas, double* F_nu,
-                           int64_t ld, int64_t* n_evaluations_dev, const LineParams* gen)
+                           int64_t ld, int64_t* n_evaluations_dev, const LineParams* gen, double* I_nus = nullptr)
 {
     int rc;
     REQUIRE(cont && temps && ray_dist && wts && n_theta > 0 && n_depth >= 2, "synthesize: bad arguments");
@@ -1846,7 +1846,7 @@ static int synthesize_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double
         }
         rc = check_launch("k_reduce_partials");
         if (rc) return rc;
-        return raytrace_impl(ctx, n_depth, nu_count, n_theta, nus + nu_begin, temps, ray_dist, wts, total, tld, F_nu, ld, nullptr, 0, 0, nullptr, n_nu);
+        return raytrace_impl(ctx, n_depth, nu_count, n_theta, nus + nu_begin, temps, ray_dist, wts, total, tld, F_nu, ld, I_nus, 0, 0, nullptr, n_nu);
     }
     FusedTotal ft{};
     ft.cont = cont_plane;
@@ -1857,7 +1857,7 @@ static int synthesize_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double
     ft.total_out = total_alphas;
     ft.line_out = part ? alpha_line_out : nullptr;
     ft.out_ld = ld;
-    return raytrace_impl(ctx, n_depth, nu_count, n_theta, nus + nu_begin, temps, ray_dist, wts, nullptr, 0, F_nu, ld, nullptr, 0, 0, &ft, n_nu);
+    return raytrace_impl(ctx, n_depth, nu_count, n_theta, nus + nu_begin, temps, ray_dist, wts, nullptr, 0, F_nu, ld, I_nus, 0, 0, &ft, n_nu);
 }
 
 int sdx_synthesize_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin, int64_t nu_count,
@@ -1870,6 +1870,19 @@ int sdx_synthesize_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nu
     if (rc) return rc;
     return synthesize_impl(ctx, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, cont, n_theta,
                            temps, ray_dist, wts, alpha_line_out, total_alphas, F_nu, ld, n_evaluations_dev, nullptr);
+}
+
+int sdx_synthesize_tracked_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin, int64_t nu_count,
+                               int64_t n_lines, const double* line_nus, const double* doppler, const double* gammas, int gamma_cols,
+                               const double* alphas, const sdx_continuum* cont, int n_theta, const double* temps,
+                               const double* ray_dist, const double* wts, double* alpha_line_out, double* total_alphas, double* F_nu,
+                               int64_t ld, double* I_nus, int64_t* n_evaluations_dev)
+{
+    int rc = check_line_args(ctx, n_depth, n_nu, nus, n_lines, line_nus, doppler, gammas, gamma_cols, alphas);
+    if (rc) return rc;
+    REQUIRE(I_nus, "synthesize_tracked: null intensity array");
+    return synthesize_impl(ctx, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, cont, n_theta,
+                           temps, ray_dist, wts, alpha_line_out, total_alphas, F_nu, ld, n_evaluations_dev, nullptr, I_nus);
 }
 
 int sdx_synthesize_linelist_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin, int64_t nu_count,

@@ -11,7 +11,7 @@ of disabled sources and `F_nu` accumulation semantics are the reference's (opaci
 radiation_field_solvers/base.py:324-338).
 
 `try_fused` returns None for configurations the fused step does not cover (more than four tabulated sources, molecules,
-spherical geometry, tracked intensities, a foreign source function, frequencies the Rayleigh cut-off would clip, line lists
+spherical geometry, a foreign source function, frequencies the Rayleigh cut-off would clip, line lists
 without a dense alpha table); the caller then takes the general path.
 """
 import ctypes as C
@@ -142,6 +142,26 @@ class FusedOpacities(Opacities):
         if self._total_host is None and self._total_twin is not None:
             return self._total_twin
         return super().total_alphas_device(ctx)
+
+
+_TRACKED_CLASSES = {}
+
+
+def _tracked_class(field_cls):
+    """field_cls with `I_nus` (radiation_field/base.py:64-68) materialising from the device on first read: the array is
+    N_theta times the size of F_nu (68 MB at 7634 frequencies, 20 angles), and most callers never look at it."""
+    cls = _TRACKED_CLASSES.get(field_cls)
+    if cls is None:
+        def get(self):
+            if self._I_host is None:
+                self._I_host = self._I_dev.numpy()
+            return self._I_host
+
+        def put(self, value):
+            self._I_host = value
+
+        cls = _TRACKED_CLASSES[field_cls] = type("Fused" + field_cls.__name__, (field_cls,), {"I_nus": property(get, put), "_I_host": None, "_I_dev": None})
+    return cls
 
 
 def _packed_upload(ctx, arrays):
@@ -301,8 +321,9 @@ def _depth_vectors(stellar_plasma, opacity, file_source, rayleigh_species):
 def try_fused(field_cls, tracing_nus, stellar_model, stellar_plasma, config, source_function):
     """-> RadiationField computed by one fused device pass, or None when the configuration needs the general path."""
     opacity = config.opacity
-    if getattr(stellar_model, "spherical", False) or config.result_options.return_radiation_field:
+    if getattr(stellar_model, "spherical", False):
         return None
+    tracked = bool(config.result_options.return_radiation_field)
     if getattr(source_function, "__name__", "") != "blackbody_flux_at_nu" or opacity.line.include_molecules:
         return None
     if int(config.no_of_thetas) > 64 or len(opacity.file) > 4:
@@ -342,11 +363,12 @@ def try_fused(field_cls, tracing_nus, stellar_model, stellar_plasma, config, sou
     dv = _depth_vectors(stellar_plasma, opacity, file_source, rayleigh_species)
     n_e = dv["n_e"]
 
-    field = field_cls.__new__(field_cls)  # the attributes of RadiationField.__init__ (:38-68) without its zero-filled planes
+    cls = _tracked_class(field_cls) if tracked else field_cls
+    field = cls.__new__(cls)  # the attributes of RadiationField.__init__ (:38-68) without its zero-filled planes
     field.frequencies = tracing_nus
     field.source_function = source_function
     field.thetas, field.I_nus_weights = _leggauss(int(config.no_of_thetas))
-    field.track_individual_intensities = False
+    field.track_individual_intensities = tracked
     opac = FusedOpacities((nd, nus.size))
     field.opacities = opac
 
@@ -432,9 +454,14 @@ def try_fused(field_cls, tracing_nus, stellar_model, stellar_plasma, config, sou
         ctx.call("sdx_doppler_widths_dev", n_lines, nd, P("l_nu"), P("l_mass"), P("temps"), _microturbulence_cgs(stellar_model), d_doppler.ptr)
     d_F, d_total = ctx.empty((nd, nus.size)), ctx.empty((nd, nus.size))
     d_line = ctx.empty((nd, nus.size)) if n_lines else None
-    ctx.call("sdx_synthesize_dev", nd, nus.size, P("nus"), 0, nus.size, n_lines, P("l_nu"), d_doppler.ptr if n_lines else None,
-             d_gamma.ptr if n_lines else None, nd, P("l_alpha"), C.byref(c), int(config.no_of_thetas), P("temps"), P("ray"), P("wts"),
-             d_line.ptr if n_lines else None, d_total.ptr, d_F.ptr, nus.size, None)
+    step = (nd, nus.size, P("nus"), 0, nus.size, n_lines, P("l_nu"), d_doppler.ptr if n_lines else None, d_gamma.ptr if n_lines else None, nd,
+            P("l_alpha"), C.byref(c), int(config.no_of_thetas), P("temps"), P("ray"), P("wts"), d_line.ptr if n_lines else None, d_total.ptr,
+            d_F.ptr, nus.size)
+    if tracked:  # every ray's intensity at every depth point stays on the device until somebody reads field.I_nus
+        field._I_dev = ctx.empty((nd, nus.size, int(config.no_of_thetas)))
+        ctx.call("sdx_synthesize_tracked_dev", *step, field._I_dev.ptr, None)
+    else:
+        ctx.call("sdx_synthesize_dev", *step, None)
     # F_nu lands in page-locked memory by DMA (no bounce buffer, no second copy); the block returns to the context's pool when
     # the last reference to the array is gone
     field.F_nu = ctx.pinned.empty((nd, nus.size))

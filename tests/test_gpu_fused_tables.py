@@ -89,3 +89,26 @@ def test_file_planes_are_validated(ctx):
     c.n_file_planes = 2
     ctx.call("sdx_total_alphas_dev", 4, 16, nus.ptr, 4, 8, C.byref(c), None, 0, out.ptr, 16)  # a shard: columns 4..11, planes are global
     assert np.array_equal(out.numpy()[:, :8], 2.0 * np.arange(64.0).reshape(4, 16)[:, 4:12])
+
+
+def test_fused_call_with_tracked_intensities_equals_the_source_by_source_path(tmp_path):
+    """result_options.return_radiation_field (the reference's stardis_test_config.yml sets it): RadiationField keeps every ray's
+    intensity, I_nus (N_d, N_nu, N_theta) (radiation_field/base.py:64-68, radiation_field_solvers/base.py:324-338).  The fused
+    step writes it on the device (sdx_synthesize_tracked_dev) and the attribute materialises on first read."""
+    nus, plasma, model, config = three_source_case(tmp_path, ("Hminus_bf",))
+    config.result_options.return_radiation_field = True
+    fused, general = both_paths(nus, model, plasma, config)
+    assert isinstance(fused.opacities, FusedOpacities) and fused.track_individual_intensities and general.track_individual_intensities
+    assert isinstance(fused, rf.RadiationField) and fused._I_host is None  # nothing downloaded yet
+    assert np.array_equal(fused.F_nu, general.F_nu)
+    I = fused.I_nus
+    assert I.shape == general.I_nus.shape == (model.no_of_depth_points, nus.size, fused.thetas.size)
+    assert np.array_equal(I, general.I_nus) and fused.I_nus is I
+    assert np.all(I[0] == 0) and (I[-1] > 0).all()
+    # F_nu is the weighted sum of the intensities, angles in ascending order (:324-338)
+    F = np.zeros_like(fused.F_nu)
+    for k in range(fused.thetas.size):
+        F += I[:, :, k] * fused.I_nus_weights[k]
+    assert rel_err(fused.F_nu[1:], F[1:]) < 1e-14
+    fused.I_nus = np.zeros(3)  # the attribute stays assignable
+    assert fused.I_nus.shape == (3,)

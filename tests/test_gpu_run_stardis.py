@@ -179,10 +179,13 @@ def test_fused_path_declines_what_it_does_not_cover(ctx, monkeypatch, tmp_path):
     config = NS(opacity=cfg, no_of_thetas=4, result_options=NS(return_radiation_field=False))
     args = (rf.RadiationField, g["nus"].copy(), model, plasma, config, blackbody_flux_at_nu)
     assert fused.try_fused(*args) is not None
-    config.result_options.return_radiation_field = True  # tracked intensities
-    assert fused.try_fused(*args) is None
+    config.result_options.return_radiation_field = True  # tracked intensities: covered (I_nus stays on the device until read)
     field = rf.create_stellar_radiation_field(g["nus"].copy(), model, plasma, config)
-    assert field.I_nus.shape == (56, g["nus"].size, 4) and type(field.opacities).__name__ == "Opacities"
+    assert type(field.opacities).__name__ == "FusedOpacities" and isinstance(field, rf.RadiationField)
+    assert field.I_nus.shape == (56, g["nus"].size, 4)
+    monkeypatch.setattr(rf, "FUSED", False)
+    assert np.array_equal(field.I_nus, rf.create_stellar_radiation_field(g["nus"].copy(), model, plasma, config).I_nus)
+    monkeypatch.setattr(rf, "FUSED", True)
     config.result_options.return_radiation_field = False
     model.spherical = True
     assert fused.try_fused(*args) is None
