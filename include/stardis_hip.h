@@ -315,14 +315,17 @@ int sdx_synthesize_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nu
                        const double* temperature, const double* ray_dist, const double* theta_weights,
                        double* alpha_line_out, double* total_alphas, double* F_nu, int64_t ld,
                        int64_t* n_evaluations_dev);
-/* The same step with RadiationField.track_individual_intensities (radiation_field/base.py:64-68, filled at
- * radiation_field_solvers/base.py:324-338): I_nus [n_depth][nu_count][n_theta] receives the intensity of every ray at every depth
- * point (row 0: zeros, the reference's initial condition :134). */
-int sdx_synthesize_tracked_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin, int64_t nu_count,
-                               int64_t n_lines, const double* line_nus, const double* doppler_widths, const double* gammas,
-                               int gamma_cols, const double* alphas, const sdx_continuum* cont, int n_theta,
-                               const double* temperatures, const double* ray_dist, const double* weights, double* alpha_line_out,
-                               double* total_alphas, double* F_nu, int64_t ld, double* I_nus, int64_t* n_evaluations_dev);
+/* The same step with the two optional extras of RadiationField (radiation_field/base.py:38-68).  source: the caller's source
+ * function already evaluated, [n_depth][source_ld] with column 0 = column nu_begin (RadiationField.source_function is any callable
+ * (nu, T) -> (N_d, N_nu), radiation_field_solvers/base.py:133; NULL: the Planck function, evaluated by the kernel).  I_nus:
+ * track_individual_intensities (:64-68, filled at radiation_field_solvers/base.py:324-338), [n_depth][nu_count][n_theta] receives
+ * the intensity of every ray at every depth point (row 0: zeros, the reference's initial condition :134); NULL: not kept. */
+int sdx_synthesize_ex_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin, int64_t nu_count,
+                          int64_t n_lines, const double* line_nus, const double* doppler_widths, const double* gammas,
+                          int gamma_cols, const double* alphas, const sdx_continuum* cont, int n_theta,
+                          const double* temperatures, const double* ray_dist, const double* weights, double* alpha_line_out,
+                          double* total_alphas, double* F_nu, int64_t ld, const double* source, int64_t source_ld, double* I_nus,
+                          int64_t* n_evaluations_dev);
 
 /* The same synthesis for a caller whose data lives in host memory (plain C, or numpy through ctypes): every pointer,
  * including those inside `cont`, is a HOST pointer; arrays are uploaded, sdx_synthesize_dev runs, results come back.

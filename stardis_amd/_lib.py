@@ -150,8 +150,8 @@ PROTOTYPES = {
     "sdx_flux_nu_to_lambda_dev": (_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "sdx_synthesize_dev": (_int, [_vp, _int, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _int, _vp, C.POINTER(Continuum), _int,
                                   _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
-    "sdx_synthesize_tracked_dev": (_int, [_vp, _int, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _int, _vp, C.POINTER(Continuum), _int,
-                                          _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "sdx_synthesize_ex_dev": (_int, [_vp, _int, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _int, _vp, C.POINTER(Continuum), _int,
+                                     _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp]),
     "sdx_synthesize_f64": (_int, [_vp, _int, _i64, _vp, _i64, _vp, _vp, _vp, _int, _vp, C.POINTER(Continuum), _int, _vp, _vp, _vp, _vp, _vp,
                                   _vp, _vp]),
     "sdx_alpha_line_levels_dev": (_int, [_vp, _i64, _int, _int, _vp, _vp, _vp, _vp, C.c_double, _vp]),

@@ -1793,7 +1793,8 @@ static int synthesize_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double
                            int64_t n_lines, const double* line_nus, const double* doppler, const double* gammas, int gamma_cols,
                            const double* alphas, const sdx_continuum* cont, int n_theta, const double* temps,
                            const double* ray_dist, const double* wts, double* alpha_line_out, double* total_alphas, double* F_nu,
-                           int64_t ld, int64_t* n_evaluations_dev, const LineParams* gen, double* I_nus = nullptr)
+                           int64_t ld, int64_t* n_evaluations_dev, const LineParams* gen, double* I_nus = nullptr, const double* source = nullptr,
+                           int64_t source_ld = 0)
 {
     int rc;
     REQUIRE(cont && temps && ray_dist && wts && n_theta > 0 && n_depth >= 2, "synthesize: bad arguments");
@@ -1846,9 +1847,15 @@ static int synthesize_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double
         }
         rc = check_launch("k_reduce_partials");
         if (rc) return rc;
-        return raytrace_impl(ctx, n_depth, nu_count, n_theta, nus + nu_begin, temps, ray_dist, wts, total, tld, F_nu, ld, I_nus, 0, 0, nullptr, n_nu);
+        FusedTotal only_source{};  // (no fused total: the formal solution reads `total`; the caller's source plane still applies)
+        only_source.source = source;
+        only_source.sld = source_ld;
+        return raytrace_impl(ctx, n_depth, nu_count, n_theta, nus + nu_begin, temps, ray_dist, wts, total, tld, F_nu, ld, I_nus, 0, 0,
+                             source ? &only_source : nullptr, n_nu);
     }
     FusedTotal ft{};
+    ft.source = source;
+    ft.sld = source_ld;
     ft.cont = cont_plane;
     ft.cld = nu_count;
     ft.planes = part;
@@ -1872,17 +1879,17 @@ int sdx_synthesize_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nu
                            temps, ray_dist, wts, alpha_line_out, total_alphas, F_nu, ld, n_evaluations_dev, nullptr);
 }
 
-int sdx_synthesize_tracked_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin, int64_t nu_count,
-                               int64_t n_lines, const double* line_nus, const double* doppler, const double* gammas, int gamma_cols,
-                               const double* alphas, const sdx_continuum* cont, int n_theta, const double* temps,
-                               const double* ray_dist, const double* wts, double* alpha_line_out, double* total_alphas, double* F_nu,
-                               int64_t ld, double* I_nus, int64_t* n_evaluations_dev)
+int sdx_synthesize_ex_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin, int64_t nu_count,
+                          int64_t n_lines, const double* line_nus, const double* doppler, const double* gammas, int gamma_cols,
+                          const double* alphas, const sdx_continuum* cont, int n_theta, const double* temps,
+                          const double* ray_dist, const double* wts, double* alpha_line_out, double* total_alphas, double* F_nu,
+                          int64_t ld, const double* source, int64_t source_ld, double* I_nus, int64_t* n_evaluations_dev)
 {
     int rc = check_line_args(ctx, n_depth, n_nu, nus, n_lines, line_nus, doppler, gammas, gamma_cols, alphas);
     if (rc) return rc;
-    REQUIRE(I_nus, "synthesize_tracked: null intensity array");
+    REQUIRE(!source || source_ld >= nu_count, "synthesize_ex: source_ld must cover the columns");
     return synthesize_impl(ctx, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, cont, n_theta,
-                           temps, ray_dist, wts, alpha_line_out, total_alphas, F_nu, ld, n_evaluations_dev, nullptr, I_nus);
+                           temps, ray_dist, wts, alpha_line_out, total_alphas, F_nu, ld, n_evaluations_dev, nullptr, I_nus, source, source_ld);
 }
 
 int sdx_synthesize_linelist_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin, int64_t nu_count,

@@ -94,7 +94,7 @@ def test_file_planes_are_validated(ctx):
 def test_fused_call_with_tracked_intensities_equals_the_source_by_source_path(tmp_path):
     """result_options.return_radiation_field (the reference's stardis_test_config.yml sets it): RadiationField keeps every ray's
     intensity, I_nus (N_d, N_nu, N_theta) (radiation_field/base.py:64-68, radiation_field_solvers/base.py:324-338).  The fused
-    step writes it on the device (sdx_synthesize_tracked_dev) and the attribute materialises on first read."""
+    step writes it on the device (sdx_synthesize_ex_dev) and the attribute materialises on first read."""
     nus, plasma, model, config = three_source_case(tmp_path, ("Hminus_bf",))
     config.result_options.return_radiation_field = True
     fused, general = both_paths(nus, model, plasma, config)

@@ -190,7 +190,19 @@ def test_fused_path_declines_what_it_does_not_cover(ctx, monkeypatch, tmp_path):
     model.spherical = True
     assert fused.try_fused(*args) is None
     model.spherical = False
-    assert fused.try_fused(rf.RadiationField, g["nus"].copy(), model, plasma, config, lambda nu, t: 0.0) is None
+    # a source function other than the Planck function: evaluated on the host as the reference calls it (:133), covered
+    def grey(nu, t):
+        return 1.0e-13 * t**4 * (nu / nu[0]) ** 2
+
+    own = fused.try_fused(rf.RadiationField, g["nus"].copy(), model, plasma, config, grey)
+    assert own is not None and own.source_function is grey
+    from stardis_amd.radiation_field.radiation_field_solvers import raytrace
+
+    general = rf.RadiationField(g["nus"].copy(), grey, model, 4)
+    general.opacities.total_alphas = own.opacities.total_alphas.copy()
+    raytrace(model, general)
+    assert np.array_equal(own.F_nu, general.F_nu) and not np.array_equal(own.F_nu, fused.try_fused(*args).F_nu)
+    assert fused.try_fused(rf.RadiationField, g["nus"].copy(), model, plasma, config, lambda nu, t: np.zeros((3, 3))) is None  # does not broadcast
     hot = g["nus"].copy()
     hot[0] = 2.4e15  # the Rayleigh cut-off would clip the caller's grid in place (opacities_solvers/base.py:99)
     assert fused.try_fused(rf.RadiationField, hot, model, plasma, config, blackbody_flux_at_nu) is None
