@@ -132,6 +132,7 @@ constexpr int kNarrowReach = 128;       // ... which looks for its lines within 
                                         // half-width are delegated to it (lane <-> depth: one Faddeeva region per wave, where a
                                         // 64-point block of the wide role holds all four)
 constexpr int kMediumHalfWidth = 4096;  // class bound of the indexed wide path: medium lines are found by centre range
+constexpr int kMaxTile = 512;           // the widest tile of the wide role (64 R points, R <= 8)
 
 // What the pre-pass leaves for the line kernels.  WIDE (line, depth) items (half-width > kNarrowHalfWidth) are depth-major
 // [N_d][N_l] — a (depth, line-range) read is contiguous — and split by use:
@@ -234,9 +235,10 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
             // pixel blocks: cnt_ge[p] = #{l : centre_l >= p} = #{l : line_nu_l <= nus[p-1]}  (centre_l = #{i : nus[i] >= line_nu_l})
             if (by == 0 && w.cnt_ge) {
                 const int64_t pidx = (int64_t)(bx - n_line_blocks) * blockDim.x + threadIdx.x;
-                // a shard only reads cnt_ge within kMediumHalfWidth (+ a narrow window) of its columns
-                const bool needed = !w.sel || (pidx >= w.shard_begin - kMediumHalfWidth - 2 * kNarrowReach &&
-                                               pidx <= w.shard_end + kMediumHalfWidth + 2 * kNarrowReach);
+                // a shard only reads cnt_ge within kMediumHalfWidth (+ a narrow window) of the TILES that hold its columns: tiles
+                // are aligned to the global grid, so the first and last one reach up to kMaxTile - 1 points beyond the shard
+                const bool needed = !w.sel || (pidx >= w.shard_begin - kMediumHalfWidth - 2 * kNarrowReach - kMaxTile &&
+                                               pidx <= w.shard_end + kMediumHalfWidth + 2 * kNarrowReach + kMaxTile);
                 if (pidx <= n_nu + 1 && needed) {
                     int64_t cnt;
                     if (pidx == 0) cnt = n_lines;
@@ -680,6 +682,14 @@ __device__ __forceinline__ void line_wide_walk(const int tile_idx, const int spl
                 const int64_t pa = max(t0 - kMediumHalfWidth + 1, (int64_t)0), pb = min(t1 + kMediumHalfWidth - 1, n_nu);
                 ka = __builtin_amdgcn_readfirstlane(w.wrank[w.cnt_ge[pb + 1]]);
                 kb = __builtin_amdgcn_readfirstlane(w.wrank[w.cnt_ge[pa]]);
+                // A culled shard has prepared only the wlist lines centred within kMediumHalfWidth of ITS OWN columns (range
+                // blocks + xlist); a tile cut by the shard boundary reaches up to kTile - 1 points further, and the records of the
+                // lines centred out there are whatever the workspace held.  None of them can reach a STORED column (half-width <=
+                // kMediumHalfWidth), and a candidate's subset is its position in wlist, so leaving them out changes no stored bit.
+                if (w.sel) {
+                    ka = max(ka, __builtin_amdgcn_readfirstlane(w.wrank[w.sel[0]]));
+                    kb = min(kb, __builtin_amdgcn_readfirstlane(w.wrank[w.sel[1]]));
+                }
             }
         }
         if (kb <= ka) continue;

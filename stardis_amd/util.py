@@ -20,15 +20,17 @@ def _roman(text):
 
 
 def species_string_to_tuple(species):
-    """'H I' / 'Fe II' / 'He 1' -> (atomic_number, ion_number); same contract as
-    tardis.util.base.species_string_to_tuple, which opacities_solvers/util.py:5,160 uses."""
+    """'H I' / 'Fe II' / 'Si 2' -> (atomic_number, ion_number); same contract as tardis.util.base.species_string_to_tuple,
+    which opacities_solvers/util.py:6,156 calls: the second token is the SPECTROSCOPIC stage whether it is written as a
+    Roman numeral or in digits — 'Si II' and 'Si 2' are both (14, 1), 'Si IX' is (14, 8) — so a configuration key such as
+    `H_1` names neutral hydrogen."""
     m = re.match(r"^\s*([A-Za-z]+)[\s_]*([IVXLivxl]+|\d+)\s*$", species)
     if not m:
         raise ValueError(f"cannot parse species string {species!r}")
     sym, ion = m.groups()
     if sym.lower() not in _Z:
         raise ValueError(f"unknown element symbol in {species!r}")
-    ion_number = int(ion) if ion.isdigit() else _roman(ion) - 1
+    ion_number = (int(ion) if ion.isdigit() else _roman(ion)) - 1
     z = _Z[sym.lower()]
     if ion_number < 0 or ion_number > z:
         raise ValueError(f"species {species!r} has an impossible ionisation stage")

@@ -439,6 +439,10 @@ def g5_continuum(atm, cont):
         out[f"{tag}_lambdas"] = q().to(u.AA, u.spectral()).value
         out[f"{tag}_alpha_bf"] = R.ob.calc_alpha_bf(plasma, model, q(), cfg.bf)
         out[f"{tag}_alpha_ff"] = R.ob.calc_alpha_ff(plasma, model, q(), cfg.ff)
+        # the same sources named by a key with the stage in digits (`H_1`, what get_number_density hands to
+        # species_string_to_tuple as "H 1", util.py:154-156): neutral hydrogen again
+        out[f"{tag}_alpha_bf_digit_key"] = R.ob.calc_alpha_bf(plasma, model, q(), {"H_1": {}})
+        out[f"{tag}_alpha_ff_digit_key"] = R.ob.calc_alpha_ff(plasma, model, q(), {"H_1": {}})
         qq = q()
         out[f"{tag}_alpha_rayleigh"] = R.ob.calc_alpha_rayleigh(plasma, model, qq, cfg.rayleigh)
         out[f"{tag}_nus_after_rayleigh"] = qq.value  # the reference zeroes nu > 2.3e15 in place (:99)

@@ -86,12 +86,19 @@ def load():
         cuda=cuda,
     )
 
-    species = {"H I": (1, 0), "H II": (1, 1), "He I": (2, 0), "He II": (2, 1)}
+    def species(text):
+        """Stand-in for tardis.util.base.species_string_to_tuple (TARDIS is not on this box): element symbol, then the
+        spectroscopic stage as a Roman numeral or in digits — "H I" and "H 1" are both (1, 0)."""
+        symbol, stage = text.split()
+        z = {"h": 1, "he": 2}[symbol.lower()]
+        number = int(stage) if stage.isdigit() else {"i": 1, "ii": 2, "iii": 3}[stage.lower()]
+        return z, number - 1
+
     for n in ("tardis", "tardis.util", "tardis.io", "tardis.model", "tardis.model.matter"):
         _module(n)
     _module(
         "tardis.util.base",
-        species_string_to_tuple=lambda s: species[s],
+        species_string_to_tuple=species,
         element_symbol2atomic_number=None,
         atomic_number2element_symbol=None,
     )

@@ -88,9 +88,13 @@ def test_species_parser_and_shards():
     from stardis_amd.engine import shard_bounds
     from stardis_amd.util import species_string_to_tuple as s
 
-    assert s("H I") == (1, 0) and s("He II") == (2, 1) and s("Fe II") == (26, 1) and s("Ca 2") == (20, 2)
-    with pytest.raises(ValueError):
-        s("Xx I")
+    assert s("H I") == (1, 0) and s("He II") == (2, 1) and s("Fe II") == (26, 1)
+    # digits are the spectroscopic stage too (TARDIS's own vectors for tardis.util.base.species_string_to_tuple)
+    assert s("si ii") == (14, 1) and s("si 2") == (14, 1) and s("si ix") == (14, 8)
+    assert s("Ca 2") == (20, 1) and s("H 1") == (1, 0) and s("H_1") == (1, 0) and s("Fe26") == (26, 25)
+    for bad in ("Xx I", "H 0", "He 4", "H"):
+        with pytest.raises(ValueError):
+            s(bad)
     for n, world in ((7634, 1), (7634, 8), (10, 3), (5, 8), (120398, 8)):
         blocks = [shard_bounds(n, world, r) for r in range(world)]
         assert blocks[0][0] == 0 and sum(c for _, c in blocks) == n

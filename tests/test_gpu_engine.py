@@ -233,6 +233,38 @@ def test_shards_of_a_long_list_prepare_only_the_lines_they_need_and_change_nothi
     assert np.array_equal(np.concatenate(parts_F, axis=1), F_full)
 
 
+def test_culled_shards_on_a_context_dirtied_by_another_line_list(ctx):
+    """Tiles of the wide role are aligned to the global grid, so a tile cut by a shard boundary looks up to 255 points beyond
+    the shard; a culled pre-pass prepares only the lines that can reach the shard's OWN columns.  The lines centred in that
+    band must not be walked: their scan words and records are whatever the workspace held — here those of a different,
+    longer list made of wide lines only, run on the same context just before (round-3 advisor finding).  The expected
+    planes come from another context."""
+    from stardis_amd import _lib
+
+    atm = synth.solar_atmosphere()
+    nus = synth.tracing_grid(4000.0, 5000.0, R=1.0e5)
+    cont = synth.synth_continuum_state(atm)
+    th, w = synth.thetas_and_weights(4)
+    lines = synth.synth_lines(nus, atm, 9000, seed=71, mix=(0.6, 0.35, 0.05))
+    full = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], th, w, lines, cont, ctx=ctx, track_evaluations=False)
+    full.step()
+    F_full, line_full = full.F_nu(), full.alpha_line()
+    own = _lib.Context(0)
+    try:
+        for world in (3, 7):
+            for rank in range(world):
+                dirt = synth.synth_lines(nus, atm, 11000 + 13 * rank, seed=72 + rank, mix=(0.0, 0.6, 0.4))
+                d = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], th, w, dirt, cont, ctx=own, track_evaluations=False)
+                d.step()  # unsharded: every scan word and record of the workspace now belongs to `dirt`
+                begin, count = shard_bounds(nus.size, world, rank)
+                s = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], th, w, lines, cont, ctx=own, shard=(begin, count), track_evaluations=False)
+                s.step()
+                assert np.array_equal(s.alpha_line(), line_full[:, begin:begin + count]), (world, rank)
+                assert np.array_equal(s.F_nu(), F_full[:, begin:begin + count]), (world, rank)
+    finally:
+        own.close()
+
+
 def test_long_line_list_on_the_wide_grid(ctx):
     """BASELINE configs[2]/[3] shape: the 3000-10000 A grid at R = 1e5 (120 398 frequencies) with a line list long
     enough (20 000 lines, gamma given as an (N_l, 1) column like the molecular case) to take the indexed wide-window
