@@ -16,6 +16,22 @@
  *   - Return value: 0 = ok, <0 = error (SDX_ERR_*); text via sdx_last_error_string() (thread-local).
  *   - The library never keeps a caller pointer past the call.  Device scratch is owned by the context.
  *   - A context is bound to one device and one stream; use one context per host thread.
+ *
+ * Environment
+ *   The library's results do not depend on the environment.  Two variables are read unconditionally, neither changes a
+ *   computed number: SDX_RCCL_LIB (path of the RCCL library opened by sdx_group_create) and SDX_EXPERIMENT.  Everything
+ *   else is an experiment / analysis knob that is honoured ONLY when SDX_EXPERIMENT=1 is set as well (tests/test_gpu_round4.py
+ *   runs a synthesis under a hostile environment without the switch and compares bits):
+ *     changes kernel choice or summation order (last bits of a result; shards of one spectrum must agree on them):
+ *       SDX_WIDE_BLOCKS   target number of wide-role workgroups -> line subsets per (depth, tile)
+ *       SDX_RT_SEG        0 / 1: never / always the segmented formal-solution kernel (the option "segmented_raytrace" wins)
+ *       SDX_RT_NS         4: segmented kernel with 4 waves x 14 gaps instead of 8 x 7
+ *       SDX_RT_P          1, 2, 4: angles per lane of k_raytrace
+ *       SDX_R_MIXED       4 / 8: grid points per lane of a mixed-precision tile
+ *     scheduling and layout only (same bits): SDX_NARROW_F (1, 2, 4 frequencies per narrow wave), SDX_NARROW_ORDER,
+ *       SDX_WIDE_GROUP, SDX_CONT_DGS, SDX_NO_CULL, SDX_NO_CONT_RIDE, SDX_NO_HSCAN, SDX_NO_PINNED_STAGING,
+ *       SDX_SPLIT_LAUNCHES (the two roles of the line kernel as two launches, for profiling)
+ *     test hook: SDX_GROUP_LOOPBACK (see sdx_group_create).
  */
 #ifndef STARDIS_HIP_H
 #define STARDIS_HIP_H
@@ -77,7 +93,11 @@ int sdx_synchronize(sdx_ctx* ctx);
  *       a fixed constant (grids under 3 x 4 x 256 k_raytrace waves take the segmented kernel) — never from the shard's own
  *       width or the device's CU count, so that a frequency shard and the unsharded grid run the same arithmetic and stay
  *       bit-identical; 0: never the segmented kernel; 1: whenever it supports the shape.  The fp32-mixed twins (*_f32mix) that
- *       SURVEY §8b proposed are this library's "mixed_precision" option instead: one set of entry points, two modes. */
+ *       SURVEY §8b proposed are this library's "mixed_precision" option instead: one set of entry points, two modes.
+ *   "wide_hot_depths" (default -1): how many of the first (deepest, hottest) depth points have their wide-window line sums split
+ *       over twice the line subsets (two workgroups per (depth, 256-point tile)).  -1: n_depth / 4 — a function of the depth
+ *       count only, so that frequency shards and the unsharded grid add every point's terms in the same order; 0: none.
+ *       Changes the last bits of the line opacity (the order of summation), nothing else: set it identically on every rank. */
 int sdx_set_int_option(sdx_ctx* ctx, const char* name, int64_t value);
 
 /* device memory for callers that do not bring their own (numpy-only users) */
@@ -291,6 +311,17 @@ typedef struct sdx_continuum {
     int64_t file_plane_ld;
 } sdx_continuum;
 
+/* calc_alpha_file / calc_alpha_bf / calc_alpha_ff / calc_alpha_rayleigh / calc_alpha_electron (opacities_solvers/base.py:40-317)
+ * and their sum in calc_alphas' order (:655-700) for a caller that holds everything in HOST memory (numpy through ctypes, C):
+ * `cont` carries host pointers here (array lengths follow from the sizes in the struct; no file planes), every output is an
+ * optional host array [n_depth][n_nu]; one upload of the inputs, one download per requested plane, on the context's
+ * persistent staging.  alpha_rayleigh != NULL also reproduces the reference's side effect (:99): frequencies above 2.3e15 Hz
+ * are set to 0 in the caller's `nus`.  alpha_electron with electron_density == NULL is a plane of zeros (the reference
+ * returns the scalar 0 there, :164-165).  total_alphas = ((((file + bf) + ff) + rayleigh) + electron), sources that are
+ * absent contributing nothing. */
+int sdx_continuum_f64(sdx_ctx* ctx, int n_depth, int64_t n_nu, double* nus, const sdx_continuum* cont, double* alpha_file,
+                      double* alpha_bf, double* alpha_ff, double* alpha_rayleigh, double* alpha_electron, double* total_alphas);
+
 int sdx_total_alphas_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin,
                          int64_t nu_count, const sdx_continuum* cont, const double* alpha_line, int64_t line_ld,
                          double* total_alphas, int64_t total_ld);
@@ -351,7 +382,7 @@ int sdx_synthesize_f64(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nu
  *   outputs      all host, all optional except that one of F_nu / emergent_flux must be given: alpha_line_out, total_alphas,
  *                F_nu are [n_depth][n_nu] (each device fills the columns it owns), emergent_flux [n_nu] = the gathered F_nu[-1].
  * RCCL is opened at run time (librccl.so.1; env SDX_RCCL_LIB overrides the path); any RCCL failure returns SDX_ERR_COMM.
- * Test hook: with SDX_GROUP_LOOPBACK=1 in the environment a group may list one device several times and the gather is done
+ * Test hook: with SDX_EXPERIMENT=1 and SDX_GROUP_LOOPBACK=1 in the environment a group may list one device several times and the gather is done
  * with plain device copies instead of RCCL (RCCL refuses two ranks on one GPU) — for exercising the sharding logic on a
  * one-GPU box, never a product mode. */
 typedef struct sdx_group sdx_group;
@@ -420,6 +451,37 @@ int sdx_line_params_dev(sdx_ctx* ctx, int n_depth, const sdx_linelist* lines, do
 int sdx_alpha_line_levels_dev(sdx_ctx* ctx, int64_t n_lines, int n_depth, int n_levels, const double* level_density,
                               const int32_t* lower_index, const double* stim, const double* f_lu,
                               double alpha_coefficient, double* alphas);
+
+/* The fused step with everything optional a RadiationField configuration can ask for, in one description (the entry point the
+ * drop-in create_stellar_radiation_field binds for the configurations sdx_synthesize_dev / _ex_dev do not cover):
+ *   source / I_nus       as in sdx_synthesize_ex_dev;
+ *   inward_rays          spherical models (radiation_field_solvers/base.py:141-198, :296-300, :340-344): ray_dist is the chord table
+ *                        of calculate_spherical_ray (:349-381), the surface-to-centre sweep runs before the outward one and
+ *                        F_nu is finally scaled by photospheric_correction = (r[-1] / reference_r)^2;
+ *   line_plane[]         further line-opacity planes the caller has formed on the device ([n_depth][line_plane_ld], column 0 =
+ *                        column nu_begin; sdx_line_opacity_dev / _linelist_dev): the molecular list of include_molecules
+ *                        (opacities_solvers/base.py:444-484, :716-736), added AFTER the step's own line opacity in this order —
+ *                        total = ((continuum + line) + plane 0) + plane 1, what Opacities.calc_total_alphas does with the
+ *                        dictionary entries (opacities/base.py:24-28);
+ *   linelist             when set, the step's own lines come as per-line scalars (f1, below) and the dense arrays
+ *                        (line_nus ... alphas, n_lines) are ignored. */
+typedef struct sdx_synthesis_options {
+    const double* source;
+    int64_t source_ld;
+    double* I_nus;
+    int inward_rays;
+    double photospheric_correction;
+    int n_line_planes; /* 0 .. 2 */
+    const double* line_plane[2];
+    int64_t line_plane_ld;
+    const sdx_linelist* linelist;
+} sdx_synthesis_options;
+int sdx_synthesize_opt_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin, int64_t nu_count,
+                           int64_t n_lines, const double* line_nus, const double* doppler_widths, const double* gammas,
+                           int gamma_cols, const double* alphas, const sdx_continuum* cont, int n_theta,
+                           const double* temperatures, const double* ray_dist, const double* weights, double* alpha_line_out,
+                           double* total_alphas, double* F_nu, int64_t ld, const sdx_synthesis_options* options,
+                           int64_t* n_evaluations_dev);
 
 /* sdx_line_opacity_dev / sdx_synthesize_dev with the line parameters generated in the pre-pass. */
 int sdx_line_opacity_linelist_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin,

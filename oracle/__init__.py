@@ -131,6 +131,22 @@ def calc_alan_entries(no_of_depth_points, tracing_nus_values, line_nus, doppler_
     return (out, ne.value) if return_evals else out
 
 
+def count_region_flips(no_of_depth_points, tracing_nus_values, line_nus, doppler_widths, gammas, alphas_array, tile=256, near=1e-12):
+    """Every evaluation of calc_alan_entries (opacities_solvers/base.py:487-592) with the Humlicek region (voigt.py:31-44) decided
+    from the reference's x = delta_nu / doppler_width and from the two forms the HIP kernels use -> dict(evaluations,
+    flips_product_form, flips_tile_form, within_near_of_a_boundary)."""
+    nus, pn = _d(tracing_nus_values)
+    ln, pl = _d(line_nus)
+    nd = int(no_of_depth_points)
+    dw, pdw = _d(np.asarray(doppler_widths).reshape(ln.size, nd))
+    g, pg = _d(np.asarray(gammas).reshape(ln.size, -1) if ln.size else np.zeros((0, 1)))
+    a, pa = _d(np.asarray(alphas_array).reshape(ln.size, nd))
+    out = (C.c_int64 * 4)()
+    lib().orc_count_region_flips(C.c_int(nd), C.c_int64(nus.size), pn, C.c_int64(ln.size), pl, pdw, pg, C.c_int(g.shape[1] if ln.size else 1), pa,
+                                 C.c_int(int(tile)), C.c_double(float(near)), out)
+    return dict(evaluations=out[0], flips_product_form=out[1], flips_tile_form=out[2], within_near_of_a_boundary=out[3])
+
+
 def calc_alan_entries_columns(cols, no_of_depth_points, tracing_nus_values, line_nus, doppler_widths, gammas, alphas_array, return_evals=False):
     """opacities_solvers/base.py:487-592 evaluated at the listed grid columns only (ascending global indices), with the window
     rule of the WHOLE grid (global d_nu, global centre, global clamp) -> (N_d, len(cols))"""

@@ -81,6 +81,22 @@ class LineListStruct(C.Structure):
     ]
 
 
+class SynthesisOptions(C.Structure):
+    """struct sdx_synthesis_options (include/stardis_hip.h)"""
+
+    _fields_ = [
+        ("source", _vp),
+        ("source_ld", _i64),
+        ("I_nus", _vp),
+        ("inward_rays", _int),
+        ("photospheric_correction", C.c_double),
+        ("n_line_planes", _int),
+        ("line_plane", _vp * 2),
+        ("line_plane_ld", _i64),
+        ("linelist", C.POINTER(LineListStruct)),
+    ]
+
+
 # name -> (restype, argtypes); every function declared in include/stardis_hip.h
 PROTOTYPES = {
     "sdx_version": (C.c_char_p, []),
@@ -152,8 +168,11 @@ PROTOTYPES = {
                                   _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "sdx_synthesize_ex_dev": (_int, [_vp, _int, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _int, _vp, C.POINTER(Continuum), _int,
                                      _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp]),
+    "sdx_synthesize_opt_dev": (_int, [_vp, _int, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _int, _vp, C.POINTER(Continuum), _int,
+                                      _vp, _vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(SynthesisOptions), _vp]),
     "sdx_synthesize_f64": (_int, [_vp, _int, _i64, _vp, _i64, _vp, _vp, _vp, _int, _vp, C.POINTER(Continuum), _int, _vp, _vp, _vp, _vp, _vp,
                                   _vp, _vp]),
+    "sdx_continuum_f64": (_int, [_vp, _int, _i64, _vp, C.POINTER(Continuum), _vp, _vp, _vp, _vp, _vp, _vp]),
     "sdx_alpha_line_levels_dev": (_int, [_vp, _i64, _int, _int, _vp, _vp, _vp, _vp, C.c_double, _vp]),
     "sdx_line_params_dev": (_int, [_vp, _int, C.POINTER(LineListStruct), _vp, _vp, _vp]),
     "sdx_line_opacity_linelist_dev": (_int, [_vp, _int, _i64, _vp, _i64, _i64, C.POINTER(LineListStruct), _vp, _i64, _int, _vp]),

@@ -6,6 +6,8 @@
 //            (depth, line-range) read in the line kernel is contiguous.  32 B per (line, depth).
 //   outputs  [N_d][ld] with the frequency index contiguous: every kernel has lane <-> nu, coalesced.
 #pragma once
+#include <type_traits>
+
 #include "sdx_math.h"
 #include "sdx_broadening.h"
 
@@ -618,10 +620,13 @@ __device__ __forceinline__ float2v region1_f32x2(float2v acc, float2v nuh, float
 }
 
 template <int R, bool MIXED>
-__device__ __forceinline__ void line_wide_walk(const int tile_idx, const int split, const int n_split, const int d, int64_t n_nu,
+__device__ __forceinline__ void line_wide_walk(const int tile_idx, const int split, const int n_split, const int wave, const int n_waves,
+                                               const int d, int64_t n_nu,
                                                const double* __restrict__ nus, int64_t nu_begin, int64_t nu_count, int64_t n_lines,
                                                LineWork w, double* __restrict__ plane, int64_t pld, double* __restrict__ lds_all)
 {
+    // split of n_split: the line SUBSET this wave walks (chunk q of 64 candidates belongs to subset q mod n_split);
+    // wave of n_waves: its place in the workgroup, whose waves' sums meet in LDS and are added in wave order
     constexpr int kTile = 64 * R;
     // GLOBAL tiles: tile boundaries are multiples of kTile from grid index 0 whatever the shard, and a tile cut by a shard
     // boundary is classified and evaluated whole (only the stores are masked).  How a (line, depth, tile) is treated — test-free,
@@ -830,7 +835,7 @@ __device__ __forceinline__ void line_wide_walk(const int tile_idx, const int spl
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] += (double)acc32[r >> 1][r & 1];
     }
-    wide_reduce_and_store<R>(split, n_split, acc, idx0, s0, s1, lds_all, plane, pld, d);
+    wide_reduce_and_store<R>(wave, n_waves, acc, idx0, s0, s1, lds_all, plane, pld, d);
 }
 
 // Long line lists: two stable compactions of the per-line classes in two small launches (per-block counts, then every
@@ -1312,21 +1317,31 @@ __device__ __forceinline__ void line_all_body(int n_wide, int tiles, int n_split
         // take CONTIGUOUS tiles (position p -> tile prefix(p % 8) + p / 8), so neighbouring tiles, whose line ranges
         // overlap, hit the same L2 instead of pulling the same records into all eight.
         const int wg = (roles >> 4) & 15;  // 0: one contiguous eighth of the tiles per XCD; g > 0: groups of g tiles going round the XCDs
-        int tile, d;
+        int tile, row;
         if (wg == 0) {
             const int p = b % tiles;
-            d = b / tiles;
+            row = b / tiles;
             tile = p >> 3;
             for (int f = 0; f < (p & 7); ++f) tile += (tiles - f + 7) >> 3;
         } else {
             // (the host pads the tiles of a depth to whole rounds of 8 g workgroups: b % 8 is then the XCD within every depth)
             const int tiles_pad = (tiles + 8 * wg - 1) / (8 * wg) * (8 * wg);
             const int p = b % tiles_pad, j = p >> 3;
-            d = b / tiles_pad;
+            row = b / tiles_pad;
             tile = ((j / wg) * 8 + (p & 7)) * wg + j % wg;
             if (tile >= tiles) return;
         }
-        line_wide_walk<R, MIXED>(tile, wave, n_split, d, n_nu, nus, nu_begin, nu_count, n_lines, w, planes, pld, s_wide);
+        // The first `hot` depths — the deepest, hottest layers, whose tiles walk the longest hit lists: the launch cannot end
+        // before its heaviest wave does — are walked by TWICE the line subsets: rows 2 d and 2 d + 1 of the launch are the two
+        // halves of depth d, workgroup h taking subsets h n_split .. h n_split + n_split - 1 of 2 n_split and leaving its sum in
+        // plane 0 (h = 0) or plane 2 (h = 1).  `hot` is a function of the depth count alone: which points' terms meet in
+        // which order stays a property of the grid.
+        const int hot = (roles >> 16) & 0xFFF;
+        const int h = row < 2 * hot ? (row & 1) : 0;
+        const int d = row < 2 * hot ? (row >> 1) : row - hot;
+        const int n_sub = d < hot ? 2 * n_split : n_split;
+        double* __restrict__ wplane = h ? planes + (size_t)2 * n_depth * pld : planes;
+        line_wide_walk<R, MIXED>(tile, h * n_split + wave, n_sub, wave, n_split, d, n_nu, nus, nu_begin, nu_count, n_lines, w, wplane, pld, s_wide);
     } else {
         if (!(roles & 2)) return;
         // A wave writes one value into each of the N_d rows of the narrow plane: the waves that fill a 64-byte sector of a
@@ -1384,15 +1399,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(R == 4 ? 6 
 }
 
 // out (+)= sum over the S line subsets, in subset order
+// (plane 2 — the second half of the line subsets — exists for the first `hot` depths only)
 __global__ __launch_bounds__(kBlock) void k_reduce_partials(int n_depth, int64_t nu_count, int n_split,
                                                             const double* __restrict__ partial, int64_t pld,
-                                                            double* __restrict__ out, int64_t out_ld, int accumulate)
+                                                            double* __restrict__ out, int64_t out_ld, int accumulate, int hot)
 {
     const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int d = blockIdx.y;
     if (j >= nu_count) return;
     double v = partial[(size_t)d * pld + j];
-    for (int s = 1; s < n_split; ++s) v = add_rn(v, partial[((size_t)s * n_depth + d) * pld + j]);
+    for (int s = 1; s < n_split; ++s)
+        if (s < 2 || d < hot) v = add_rn(v, partial[((size_t)s * n_depth + d) * pld + j]);
     double* p = out + (size_t)d * out_ld + j;
     *p = accumulate ? add_rn(*p, v) : v;
 }
@@ -2143,6 +2160,7 @@ struct FusedTotal {
     int64_t cld;
     const double* planes;  // [n_planes][n_depth][pld] partial line-opacity planes, or nullptr (no lines)
     int n_planes;
+    int hot_depths;        // planes beyond the second hold something for depths below this only
     int64_t pld;
     double* total_out;     // [n_depth][out_ld], optional
     double* line_out;      // optional
@@ -2151,56 +2169,61 @@ struct FusedTotal {
     // (nu, T) -> (N_d, N_nu), radiation_field_solvers/base.py:133); nullptr: the Planck function, evaluated here
     const double* source;
     int64_t sld;
+    // further line-opacity planes [n_depth][eld] the caller has formed (the molecular list of include_molecules,
+    // opacities_solvers/base.py:716-736), added after the step's own line opacity in this order: total = (cont + line) + extra...
+    const double* extra[2];
+    int n_extra;
+    int64_t eld;
 };
 
-// One short-characteristic step (:208-249 outward, :150-198 inward): from a point with intensity `inten` and source
-// s0 across a gap of optical depth t0 (reciprocal r0) to the point with source s1; (t1, r1, s2) are the gap and point
-// beyond, which enter the second-order terms.
-__device__ __forceinline__ double rt_step(double inten, double t0, double r0, double t1, double r1, double s0, double s1, double s2)
-{
-    double w0, w1, w2;
-    rt_weights(t0, w0, w1, w2);
-    const double head = fma(w0, s1, (1.0 - w0) * inten);
-    const double bb = (s0 - s1) * r0, aa = (s2 - s1) * r1;
-    const double rs = recip_guarded(t0 + t1);
-    return (head + w1 * (bb * t1 - aa * t0) * rs) + w2 * (aa + bb) * rs;
-}
-
+// Formal solution, LDS-staged (grids that fill the chip; every geometry).  Lane <-> (frequency, angle): a group of G adjacent
+// lanes owns one frequency, lane g traces angle(s) g, g + G, ...  Staged once and kept in LDS:
+//   block    the ray-length table ray_dist[gap][theta] (:302-305);
+//   wave     per frequency of the wave, the G lanes of its group split the N_d depth points: the source function S (:133;
+//            planck_staged, or the caller's plane) and sqrt(alpha).  The geometric-mean opacity of a gap (:121,
+//            exp((log a[g+1] + log a[g]) / 2)) is the product of the two square roots at its ends — one correctly rounded
+//            square root per point instead of a logarithm per point and an exponential per gap, and within 1e-15 of the
+//            reference's value (whose own error is ~|log alpha| ulp);
+//   lane     walks the gaps for its own angle(s): tau = mean * ray_dist (:123-129), then one rt_coef (sdx_math.h: the
+//            step as an affine map of the incoming intensity, one reciprocal, the reference's weights) and one FMA;
+//   flux     I_theta * w_theta goes to the wave's LDS; every kBatch gaps the wave sums each (gap, frequency) over theta in
+//            two ascending halves and writes F_nu.
+// Only the ray table is shared by the block: after the staging barrier the waves never meet again (wave-level hand-overs).
+constexpr int kRtBlock = 256;
 template <int P>
-__global__ __launch_bounds__(kBlock) void k_raytrace(int n_depth, int64_t n_nu, int n_theta, int theta_stride, int G,
+__global__ __launch_bounds__(kRtBlock) void k_raytrace(int n_depth, int64_t n_nu, int n_theta, int theta_stride, int G,
                                                      const double* __restrict__ nus, const double* __restrict__ temps,
                                                      const double* __restrict__ ray_dist, const double* __restrict__ wts,
                                                      const double* __restrict__ alphas, int64_t ald, double* __restrict__ F,
                                                      int64_t fld, double* __restrict__ I_nus, int accumulate, int inward, int gpw, FusedTotal ft)
 {
-    constexpr int kBatch = P == 1 ? 8 : (P == 2 ? 4 : 2);
+    constexpr int kBatch = P == 1 ? 4 : 2;
     extern __shared__ double smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // gpw = groups (frequencies) per wave, <= 64 / G; the host lowers it when the LDS columns would not fit
     const int grp = lane / G, g = lane - grp * G;
     const int TH = P * G;  // theta slots per group, ascending theta = k*G + g
-    const int64_t i0 = ((int64_t)blockIdx.x * (kBlock / 64) + wave) * gpw;  // first frequency of this wave
+    const int64_t i0 = ((int64_t)blockIdx.x * (kRtBlock / 64) + wave) * gpw;  // first frequency of this wave
     const int64_t i = i0 + grp;
     const bool active = grp < gpw;
     const bool valid = active && i < n_nu;
     const int64_t ic = i < n_nu ? i : n_nu - 1;
     const int n_gap = n_depth - 1;
     const int col = n_depth;  // LDS row stride per group
-    const int scratch = max(gpw * col, kBatch * gpw * TH);
-    double* sRD = smem;                       // ray_dist       [n_gap][n_theta]
-    double* sIRD = sRD + n_gap * n_theta;     // 1 / ray_dist
-    double* wbase = sIRD + n_gap * n_theta + (size_t)wave * (3 * gpw * col + scratch);
-    double* sS = wbase;                       // source function      [gpw][col]
-    double* sM = sS + gpw * col;              // mean opacity         [gpw][col]
-    double* sIM = sM + gpw * col;             // 1 / mean opacity     [gpw][col]
-    double* sX = sIM + gpw * col;             // log(alpha) in phase 1, flux terms in phase 2
+    double* sRD = smem;                       // ray_dist [n_gap][n_theta]
+    double* wbase = sRD + n_gap * n_theta + (size_t)wave * (2 * gpw * col + kBatch * gpw * TH);
+    double* sS = wbase;                       // source function  [gpw][col]
+    double* sA = sS + gpw * col;              // sqrt(alpha)      [gpw][col]
+    double* sX = sA + gpw * col;              // flux terms       [kBatch][gpw][TH]
     const double nu = nus[ic];
 
-    for (int k = threadIdx.x; k < n_gap * n_theta; k += kBlock) {
-        const int gp = k / n_theta, t = k - gp * n_theta;
-        const double rd = ray_dist[(size_t)gp * theta_stride + t];
-        sRD[k] = rd;
-        sIRD[k] = 1.0 / rd;
+    if (theta_stride == n_theta) {
+        for (int k = threadIdx.x; k < n_gap * n_theta; k += kRtBlock) sRD[k] = ray_dist[k];
+    } else {
+        for (int k = threadIdx.x; k < n_gap * n_theta; k += kRtBlock) {
+            const int gp = k / n_theta, t = k - gp * n_theta;
+            sRD[k] = ray_dist[(size_t)gp * theta_stride + t];
+        }
     }
     if (active) {
         for (int d = g; d < n_depth; d += G) {
@@ -2209,29 +2232,24 @@ __global__ __launch_bounds__(kBlock) void k_raytrace(int n_depth, int64_t n_nu, 
                 a = ft.cont[(size_t)d * ft.cld + ic];
                 if (ft.planes) {
                     double line = ft.planes[(size_t)d * ft.pld + ic];
-                    for (int sp = 1; sp < ft.n_planes; ++sp) line = add_rn(line, ft.planes[((size_t)sp * n_depth + d) * ft.pld + ic]);
+                    for (int sp = 1; sp < ft.n_planes; ++sp)
+                        if (sp < 2 || d < ft.hot_depths) line = add_rn(line, ft.planes[((size_t)sp * n_depth + d) * ft.pld + ic]);
                     a = add_rn(a, line);
                     if (valid && ft.line_out) ft.line_out[(size_t)d * ft.out_ld + i] = line;
                 }
+                for (int x = 0; x < ft.n_extra; ++x) a = add_rn(a, ft.extra[x][(size_t)d * ft.eld + ic]);
                 if (valid && ft.total_out) ft.total_out[(size_t)d * ft.out_ld + i] = a;
             } else {
                 a = alphas[(size_t)d * ald + ic];
             }
-            sX[grp * col + d] = log(a);
-            sS[grp * col + d] = ft.source ? ft.source[(size_t)d * ft.sld + ic] : planck(nu, temps[d]);
+            sA[grp * col + d] = sqrt(a);
+            sS[grp * col + d] = ft.source ? ft.source[(size_t)d * ft.sld + ic] : planck_staged(nu, temps[d]);
         }
     }
     __syncthreads();
-    if (active)
-        for (int gp = g; gp < n_gap; gp += G) {
-            const double m = exp(mul_rn(add_rn(sX[grp * col + gp + 1], sX[grp * col + gp]), 0.5));
-            sM[grp * col + gp] = m;
-            sIM[grp * col + gp] = 1.0 / m;
-        }
-    __syncthreads();
 
     const int gi = (active ? grp : 0) * col;  // idle lanes shadow group 0 and never store
-    double inten[P], wt[P], tau0[P], r0[P];
+    double inten[P], wt[P];
     int th[P];
     bool on[P];
 #pragma unroll
@@ -2244,17 +2262,18 @@ __global__ __launch_bounds__(kBlock) void k_raytrace(int n_depth, int64_t n_nu, 
     if (inward) {
         // spherical geometry: sweep from the surface to the innermost point first (:141-198).  Only I[0] of this
         // sweep survives (the outward pass overwrites the other rows); gap 0 wraps to the LAST gap / depth exactly
-        // as the reference's negative index does.
+        // as the reference's negative index does.  Either optical depth zero: no change (:146-149).
         for (int gap = n_gap - 1; gap >= 0; --gap) {
             const int gm = gap > 0 ? gap - 1 : n_gap - 1;
             const int dm = gap > 0 ? gap - 1 : n_depth - 1;
             const double s0 = sS[gi + gap + 1], s1 = sS[gi + gap], s2 = sS[gi + dm];
-            const double mg = sM[gi + gap], img = sIM[gi + gap], mm = sM[gi + gm], imm = sIM[gi + gm];
+            const double mg = sA[gi + gap] * sA[gi + gap + 1], mm = sA[gi + gm] * sA[gi + gm + 1];
 #pragma unroll
             for (int k = 0; k < P; ++k) {
                 const double tg = mul_rn(mg, sRD[gap * n_theta + th[k]]), tm = mul_rn(mm, sRD[gm * n_theta + th[k]]);
-                if (tg != 0.0 && tm != 0.0)
-                    inten[k] = rt_step(inten[k], tg, img * sIRD[gap * n_theta + th[k]], tm, imm * sIRD[gm * n_theta + th[k]], s0, s1, s2);
+                double c, e;
+                rt_coef<false>(tg, tm, s0 - s1, s2 - s1, s1, c, e);
+                inten[k] = tm == 0.0 ? inten[k] : fma(c, inten[k], e);
             }
         }
 #pragma unroll
@@ -2262,66 +2281,62 @@ __global__ __launch_bounds__(kBlock) void k_raytrace(int n_depth, int64_t n_nu, 
             if (valid && I_nus && on[k]) I_nus[(size_t)i * theta_stride + th[k]] = inten[k];
             if (active) sX[grp * TH + k * G + g] = inten[k] * wt[k];
         }
-        __syncthreads();
+        wave_sync();
         if (F && lane < gpw && i0 + lane < n_nu) {
             double sum = 0.0;
             for (int t = 0; t < n_theta; ++t) sum = add_rn(sum, sX[lane * TH + t]);
             double* dst = F + i0 + lane;
             *dst = accumulate ? add_rn(*dst, sum) : sum;
         }
-        __syncthreads();
+        wave_sync();
     } else {
 #pragma unroll
         for (int k = 0; k < P; ++k)
             if (valid && I_nus && on[k]) I_nus[(size_t)i * theta_stride + th[k]] = 0.0;
         if (valid && g == 0 && F && !accumulate) F[i] = 0.0;
     }
+    // rolling state: optical depth of the current gap per angle, source at its two ends, sqrt(alpha) at its far end
+    double tau0[P];
+    double a1 = sA[gi + 1];
+    {
+        const double mean0 = sA[gi] * a1;
 #pragma unroll
-    for (int k = 0; k < P; ++k) {
-        tau0[k] = mul_rn(sM[gi], sRD[th[k]]);
-        r0[k] = sIM[gi] * sIRD[th[k]];
+        for (int k = 0; k < P; ++k) tau0[k] = mul_rn(mean0, sRD[th[k]]);
     }
-    double s0 = sS[gi], s1 = sS[gi + 1];
+    double s1 = sS[gi + 1], d10 = sS[gi] - s1;
 
     for (int gap0 = 0; gap0 < n_gap; gap0 += kBatch) {
         const int nb = min(kBatch, n_gap - gap0);
-#pragma unroll 2
         for (int b = 0; b < nb; ++b) {
             const int gap = gap0 + b;
-            const bool last = gap == n_gap - 1;
-            const int nx = last ? gap : gap + 1;  // clamp LDS reads of the step that has no successor
-            const double s2 = sS[gi + nx + 1];
-            const double mean1 = sM[gi + nx], imean1 = sIM[gi + nx];
-            const double d10 = s0 - s1, d21 = s2 - s1;
+            if (gap < n_gap - 1) {  // :208-249
+                const double s2 = sS[gi + gap + 2], a2 = sA[gi + gap + 2];
+                const double mean1 = a1 * a2, d21 = s2 - s1;
 #pragma unroll
-            for (int k = 0; k < P; ++k) {
-                const double t0 = tau0[k];
-                const double t1 = mul_rn(mean1, sRD[nx * n_theta + th[k]]);
-                const double r1 = imean1 * sIRD[nx * n_theta + th[k]];
-                double inew = inten[k];  // tau == 0: no change (:203-206, :253-254)
-                if (t0 != 0.0) {
-                    double w0, w1, w2;
-                    rt_weights(t0, w0, w1, w2);
-                    const double head = fma(w0, s1, (1.0 - w0) * inten[k]);
-                    const double bb = d10 * r0[k];
-                    if (!last) {  // :208-249
-                        const double rs = recip_guarded(t0 + t1);
-                        const double aa = d21 * r1;
-                        inew = (head + w1 * (bb * t1 - aa * t0) * rs) + w2 * (aa + bb) * rs;
-                    } else {  // :256-266
-                        inew = head + w2 * bb * r0[k];
-                    }
+                for (int k = 0; k < P; ++k) {
+                    const double t1 = mul_rn(mean1, sRD[(gap + 1) * n_theta + th[k]]);
+                    double c, e;
+                    rt_coef<false>(tau0[k], t1, d10, d21, s1, c, e);
+                    const double inew = fma(c, inten[k], e);
+                    inten[k] = inew;
+                    tau0[k] = t1;
+                    if (valid && I_nus && on[k]) I_nus[((size_t)(gap + 1) * n_nu + i) * theta_stride + th[k]] = inew;
+                    if (active) sX[(b * gpw + grp) * TH + k * G + g] = inew * wt[k];
                 }
-                inten[k] = inew;
-                tau0[k] = t1;
-                r0[k] = r1;
-                if (valid && I_nus && on[k]) I_nus[((size_t)(gap + 1) * n_nu + i) * theta_stride + th[k]] = inew;
-                if (active) sX[(b * gpw + grp) * TH + k * G + g] = inew * wt[k];
+                d10 = -d21, s1 = s2, a1 = a2;
+            } else {  // the final gap (:253-266)
+#pragma unroll
+                for (int k = 0; k < P; ++k) {
+                    double c, e;
+                    rt_coef<true>(tau0[k], 0.0, d10, 0.0, s1, c, e);
+                    const double inew = fma(c, inten[k], e);
+                    inten[k] = inew;
+                    if (valid && I_nus && on[k]) I_nus[((size_t)(gap + 1) * n_nu + i) * theta_stride + th[k]] = inew;
+                    if (active) sX[(b * gpw + grp) * TH + k * G + g] = inew * wt[k];
+                }
             }
-            s0 = s1;
-            s1 = s2;
         }
-        __syncthreads();
+        wave_sync();
         if (F) {
             // flux of the nb gaps: lanes <-> (gap, frequency, half of the angles); each half is summed in ascending theta
             // (the reference's order, :324-338) and the lower half is added to the upper one
@@ -2342,7 +2357,7 @@ __global__ __launch_bounds__(kBlock) void k_raytrace(int n_depth, int64_t n_nu, 
                 }
             }
         }
-        __syncthreads();
+        wave_sync();
     }
 }
 
@@ -2361,7 +2376,7 @@ __global__ __launch_bounds__(kBlock) void k_raytrace(int n_depth, int64_t n_nu, 
 // per workgroup by all its threads; the flux terms reuse that LDS after the barrier of step 2.
 // The intensity differs from k_raytrace's by the rounding of the composition (a few ulp; the tolerance is 1e-10).
 template <int NS, int LMAX>
-__global__ __launch_bounds__(64 * NS) __attribute__((amdgpu_waves_per_eu(NS >= 8 ? 7 : 4, 8))) void k_raytrace_seg(
+__global__ __launch_bounds__(64 * NS) __attribute__((amdgpu_waves_per_eu(NS >= 8 ? 6 : 4, 8))) void k_raytrace_seg(
     int n_depth, int64_t n_nu, int n_theta, int theta_stride, const double* __restrict__ nus, const double* __restrict__ temps,
     const double* __restrict__ ray_dist, const double* __restrict__ wts, const double* __restrict__ alphas,
     int64_t ald, double* __restrict__ F, int64_t fld, double* __restrict__ I_nus, int gpw, FusedTotal ft)
@@ -2383,31 +2398,19 @@ __global__ __launch_bounds__(64 * NS) __attribute__((amdgpu_waves_per_eu(NS >= 8
     const bool active = grp < gpw;
     const bool valid = active && i < n_nu;
     const int n_gap = n_depth - 1, col = n_depth;
+    const int rstride = n_gap | 1;             // odd row stride: the angles of a wave read distinct banks
     double* sAB = smem;                        // [NS][64][2] segment maps
-    double* sRD = sAB + NS * 128;              // ray_dist [n_gap][n_theta]
-    double* sIRD = sRD + n_gap * n_theta;      // 1 / ray_dist
-    double* sS = sIRD + n_gap * n_theta;       // source function [gpw][col]
-    double* sM = sS + gpw * col;               // mean opacity
-    double* sIM = sM + gpw * col;              // 1 / mean opacity
-    double* sX = sIM + gpw * col;              // log(alpha)
-    double* sFx = sRD;                         // after the barrier of step 2: flux terms [NS][LMAX][gpw][G]
+    double* sRT = sAB + NS * 128;              // ray_dist TRANSPOSED [n_theta][rstride]: a lane's gaps are consecutive (immediate offsets)
+    double* sS = sRT + n_theta * rstride;      // source function [gpw][col]
+    double* sA = sS + gpw * col;               // sqrt(alpha): the geometric-mean opacity of a gap (:121) is the product of its two ends'
+    double* sFx = sRT;                         // after the barrier of step 2: flux terms [NS][LMAX][gpw][G]
 
-    // staging without a division per item: the ray table is copied linearly when its rows are dense; a wave takes one
-    // frequency's column (lane <-> depth) — waves 0 .. gpw-1 log(alpha), the next gpw the Planck source
-    // (the reciprocals by the refined hardware reciprocal — four instructions, the neighbouring double in ~1 of 1e8 cases: every
-    // workgroup forms the table again, and an IEEE division per entry was a fifth of this kernel's instructions; a table
-    // made once by another launch cost that launch more than it saved here)
-    if (theta_stride == n_theta) {
-        for (int k = threadIdx.x; k < n_gap * n_theta; k += 64 * NS) {
-            const double rd = ray_dist[k];
-            sRD[k] = rd, sIRD[k] = recip_guarded(rd);
-        }
-    } else {
-        for (int k = threadIdx.x; k < n_gap * n_theta; k += 64 * NS) {
-            const int gp = k / n_theta, t = k - gp * n_theta;
-            const double rd = ray_dist[(size_t)gp * theta_stride + t];
-            sRD[k] = rd, sIRD[k] = recip_guarded(rd);
-        }
+    // staging without a division per item: lane <-> (one of 64 / n_theta gaps, angle) once; then a wave takes one frequency's
+    // column (lane <-> depth) — waves 0 .. gpw-1 sqrt(alpha), the next gpw the source function
+    {
+        const int per = 64 / G;  // gaps per wave and trip
+        if (grp < per)
+            for (int gp = seg * per + grp; gp < n_gap; gp += NS * per) sRT[g * rstride + gp] = ray_dist[(size_t)gp * theta_stride + g];
     }
     for (int part = seg; part < 2 * gpw; part += NS) {
         const bool source = part >= gpw;
@@ -2417,7 +2420,7 @@ __global__ __launch_bounds__(64 * NS) __attribute__((amdgpu_waves_per_eu(NS >= 8
         const int64_t ic = vq ? iq : n_nu - 1;
         if (source) {
             const double nu = nus[ic];
-            for (int d = lane; d < n_depth; d += 64) sS[gq * col + d] = ft.source ? ft.source[(size_t)d * ft.sld + ic] : planck(nu, temps[d]);
+            for (int d = lane; d < n_depth; d += 64) sS[gq * col + d] = ft.source ? ft.source[(size_t)d * ft.sld + ic] : planck_staged(nu, temps[d]);
             continue;
         }
         for (int d = lane; d < n_depth; d += 64) {
@@ -2426,68 +2429,81 @@ __global__ __launch_bounds__(64 * NS) __attribute__((amdgpu_waves_per_eu(NS >= 8
                 a = ft.cont[(size_t)d * ft.cld + ic];
                 if (ft.planes) {
                     double line = ft.planes[(size_t)d * ft.pld + ic];
-                    for (int sp = 1; sp < ft.n_planes; ++sp) line = add_rn(line, ft.planes[((size_t)sp * n_depth + d) * ft.pld + ic]);
+                    for (int sp = 1; sp < ft.n_planes; ++sp)
+                        if (sp < 2 || d < ft.hot_depths) line = add_rn(line, ft.planes[((size_t)sp * n_depth + d) * ft.pld + ic]);
                     a = add_rn(a, line);
                     if (vq && ft.line_out) ft.line_out[(size_t)d * ft.out_ld + iq] = line;
                 }
+                for (int x = 0; x < ft.n_extra; ++x) a = add_rn(a, ft.extra[x][(size_t)d * ft.eld + ic]);
                 if (vq && ft.total_out) ft.total_out[(size_t)d * ft.out_ld + iq] = a;
             } else {
                 a = alphas[(size_t)d * ald + ic];
             }
-            sX[gq * col + d] = log(a);
+            sA[gq * col + d] = sqrt(a);
         }
     }
     __syncthreads();
-    for (int gq = seg; gq < gpw; gq += NS)
-        for (int gp = lane; gp < n_gap; gp += 64) {
-            const double m = exp(mul_rn(add_rn(sX[gq * col + gp + 1], sX[gq * col + gp]), 0.5));
-            sM[gq * col + gp] = m;
-            sIM[gq * col + gp] = 1.0 / m;
-        }
-    __syncthreads();
 
-    // step 1: the coefficients of this wave's gaps [g_lo, g_lo + count)
+    // step 1: the coefficients of this wave's gaps [g_lo, g_lo + count).  The segments are aligned to the END of the ray — the first
+    // wave takes the short one — and a wave's gaps to the end of its LMAX register slots (slot j <-> gap g_lo + j - j0): the final
+    // gap, the one step with a formula of its own (:253-266), is then always slot LMAX - 1 of the last wave, a static place
     const int L = (n_gap + NS - 1) / NS;
-    const int g_lo = min(seg * L, n_gap - 1);
-    const int count = max(0, min(L, n_gap - seg * L));
+    const int g_end = n_gap - (NS - 1 - seg) * L;
+    const int g_lo = max(0, g_end - L);
+    const int count = max(0, g_end - g_lo);
+    const int j0 = LMAX - count;
     const int gi = (active ? grp : 0) * col;  // idle lanes shadow group 0 and never store
     const int th = min(g, n_theta - 1);
     const double wt = wts[th];
     double c[LMAX], e[LMAX];
     double A = 1.0, B = 0.0;
+    // the unrolled pass carries no per-lane exception handling: a lane with anything unusual (a transparent gap, a denominator
+    // outside the normal range) only raises the wave's flag, and the wave then redoes its segment in the reference's own form
+    unsigned long long redo = 0;
+    const int gc = count > 0 ? g_lo : 0;
     {
-        double t0 = mul_rn(sM[gi + g_lo], sRD[g_lo * n_theta + th]);
-        double r0 = sIM[gi + g_lo] * sIRD[g_lo * n_theta + th];
-        double s0 = sS[gi + g_lo], s1 = sS[gi + g_lo + 1];
+        const double* pS = sS + gi + gc - j0;
+        const double* pA = sA + gi + gc - j0;
+        const double* pR = sRT + th * rstride + gc - j0;
+        double a1 = pA[j0 + 1], s1 = pS[j0 + 1];
+        double d10 = pS[j0] - s1;
+        double t0 = mul_rn(pA[j0] * a1, pR[j0]);
 #pragma unroll
         for (int j = 0; j < LMAX; ++j) {
             c[j] = 1.0, e[j] = 0.0;
-            if (j < count) {
-                const int gap = g_lo + j;
-                const bool last = gap == n_gap - 1;
-                const int nx = last ? gap : gap + 1;  // clamp LDS reads of the step that has no successor
-                const double s2 = sS[gi + nx + 1];
-                const double t1 = mul_rn(sM[gi + nx], sRD[nx * n_theta + th]);
-                const double r1 = sIM[gi + nx] * sIRD[nx * n_theta + th];
-                if (t0 != 0.0) {  // tau == 0: no change (:203-206, :253-254)
-                    double w0, w1, w2;
-                    rt_weights(t0, w0, w1, w2);
-                    const double bb = (s0 - s1) * r0;
-                    double rest;
-                    if (!last) {  // :208-249
-                        const double rs = recip_guarded(t0 + t1);
-                        const double aa = (s2 - s1) * r1;
-                        rest = fma(w1 * (bb * t1 - aa * t0), rs, w2 * (aa + bb) * rs);
-                    } else {  // :256-266
-                        rest = w2 * bb * r0;
-                    }
-                    c[j] = 1.0 - w0;
-                    e[j] = fma(w0, s1, rest);
-                    A *= c[j];
-                    B = fma(c[j], B, e[j]);
+            if (j >= j0) {
+                if (j < LMAX - 1 || seg < NS - 1) {  // :208-249
+                    const double s2 = pS[j + 2], a2 = pA[j + 2];
+                    const double t1 = mul_rn(a1 * a2, pR[j + 1]);
+                    const double d21 = s2 - s1;
+                    redo |= rt_coef_fast<false>(t0, t1, d10, d21, s1, c[j], e[j]);
+                    t0 = t1, d10 = -d21, s1 = s2, a1 = a2;
+                } else {  // the final gap (:253-266)
+                    redo |= rt_coef_fast<true>(t0, 0.0, d10, 0.0, s1, c[j], e[j]);
                 }
-                t0 = t1, r0 = r1, s0 = s1, s1 = s2;
+                A *= c[j];
+                B = fma(c[j], B, e[j]);
             }
+        }
+    }
+    if (redo) {  // rare: a rolled loop, the coefficients find their registers through a (scalar) switch
+        A = 1.0, B = 0.0;
+        for (int j = j0; j < LMAX; ++j) {
+            const int gap = gc + j - j0;
+            const double s0 = sS[gi + gap], s1 = sS[gi + gap + 1];
+            const double t0 = mul_rn(sA[gi + gap] * sA[gi + gap + 1], sRT[th * rstride + gap]);
+            double cj, ej;
+            if (gap < n_gap - 1) {
+                const double t1 = mul_rn(sA[gi + gap + 1] * sA[gi + gap + 2], sRT[th * rstride + gap + 1]);
+                rt_coef_reference<false>(t0, t1, s0 - s1, sS[gi + gap + 2] - s1, s1, cj, ej);
+            } else {
+                rt_coef_reference<true>(t0, 0.0, s0 - s1, 0.0, s1, cj, ej);
+            }
+            A *= cj;
+            B = fma(cj, B, ej);
+#pragma unroll
+            for (int k = 0; k < LMAX; ++k)
+                if (k == j) c[k] = cj, e[k] = ej;
         }
     }
     sAB[(seg * 64 + lane) * 2] = A;
@@ -2508,10 +2524,10 @@ __global__ __launch_bounds__(64 * NS) __attribute__((amdgpu_waves_per_eu(NS >= 8
     const size_t istep = (size_t)n_nu * theta_stride;
 #pragma unroll
     for (int j = 0; j < LMAX; ++j) {
-        if (j < count) {
+        if (j >= j0) {
             inten = fma(c[j], inten, e[j]);
             if (ip) *ip = inten, ip += istep;
-            if (active) fx[j * gpw * G] = inten * wt;
+            if (active) fx[(j - j0) * gpw * G] = inten * wt;
         }
     }
     fx = sFx + (size_t)seg * LMAX * gpw * G;

@@ -510,5 +510,113 @@ __device__ __forceinline__ double planck(double nu, double temp)
     const double pre = mul_rn(mul_rn(2.0, kH), mul_rn(mul_rn(nu, nu), nu)) / mul_rn(kC, kC);
     return pre / sub_rn(exp(mul_rn(kH, nu) / mul_rn(kKB, temp)), 1.0);
 }
+// The same function as the formal-solution kernels stage it, (N_d x N_nu) times per synthesis: the two IEEE divisions become
+// refined reciprocals (each the correctly rounded quotient or its neighbour) and exp is exp_neg's sequence — h nu / (k T) lies
+// in (0, 700) for anything a stellar atmosphere offers; outside that range, for T <= 0 or non-finite arguments the reference-order
+// routine above runs instead.  Within 4 ulp of planck() (an ulp of the exponent x moves exp(x) by x ulp either way), 45 instructions
+// instead of ~110.
+__device__ __forceinline__ double planck_staged(double nu, double temp)
+{
+    const double kt = mul_rn(kKB, temp);
+    const double x = mul_rn(kH, nu) * recip(kt);
+    if (!(x > 1e-3 && x < 700.0 && kt > 1e-290 && kt < 1e290)) return planck(nu, temp);
+    const double pre = mul_rn(mul_rn(2.0, kH), mul_rn(mul_rn(nu, nu), nu)) * (1.0 / (kC * kC));
+    return pre * recip(exp_neg(-x) - 1.0);
+}
+
+// One short-characteristic step of the formal solution (radiation_field_solvers/base.py:200-266, van Noort 2002 eq. 14) as
+// an AFFINE MAP of the incoming intensity, I[g+1] = c I[g] + e:
+//     c = 1 - w0,   e = w0 S1 + w1 [(S1-S2) t0/t1 - (S1-S0) t1/t0] / (t0+t1) + w2 [(S2-S1)/t1 + (S0-S1)/t0] / (t0+t1)
+// with t0, t1 the optical depths of this gap and the next, S0 S1 S2 the source at the three points.  Over the common denominator
+// D = t0 t1 (t0 + t1) the two second-order terms are
+//     [ (S0-S1) t1 (w1 t1 + w2) + (S2-S1) t0 (w2 - w1 t0) ] / D:
+// ONE reciprocal per step and no 1/t0, 1/t1 (the kernels used to stage 1/mean-opacity and 1/ray-length tables for those).
+// The weights (:22-45) keep the reference's operations and order; tau >= 50 needs no branch of its own: with tau clamped to 64
+// the exponential form gives (1, 1, 2) exactly (e^-50 = 1.9e-22 is below half an ulp of 1, tau^2 e^-tau below half an ulp
+// of 2).  Which lanes take the series (tau < 5e-4) is decided per lane, whether the block runs at all per wave.
+// Anything unusual — t0 = 0 (no change, :203-206), t1 = 0, a denominator that is zero, subnormal, infinite or NaN — is caught
+// by ONE class test of D and redone per lane in the reference's own form, IEEE divisions and all: the same inf / NaN pattern.
+// LAST: the final gap (:253-266), e = w0 S1 + w2 (S0 - S1) / t0^2.
+__device__ __forceinline__ void rt_weights_wave(double tau, double& w0, double& w1, double& w2)
+{
+    const bool small = tau < 5e-4;
+    const unsigned long long m_small = __builtin_amdgcn_ballot_w64(small), m_all = __builtin_amdgcn_ballot_w64(true);
+    // (no initial values: every lane that is read below has been written — the exponential form unless ALL lanes take the
+    // series, the series in the lanes that select it; the empty statements only tell the compiler so.  Initial values, or an
+    // early return for the all-series case, cost the common path three register copies per step)
+    asm("; w0" : "=v"(w0));
+    asm("; w1" : "=v"(w1));
+    asm("; w2" : "=v"(w2));
+    if (m_small != m_all) {
+        // min(tau, 64) as the bare instruction (NaN -> 64: the reference's else-branch, (1, 1, 2), too); fmin() would first
+        // canonicalise its argument with a v_max_f64
+        double tc;
+        asm("v_min_f64 %0, %1, %2" : "=v"(tc) : "v"(tau), "s"(64.0));
+        const double e = exp_neg(tc);
+        w0 = sub_rn(1.0, e);
+        w1 = sub_rn(w0, mul_rn(tc, e));
+        w2 = sub_rn(mul_rn(2.0, w1), mul_rn(mul_rn(tc, tc), e));
+    }
+    if (m_small) {
+        const double a0 = mul_rn(tau, sub_rn(1.0, mul_rn(tau, 0.5)));
+        const double t2 = mul_rn(tau, tau);
+        const double a1 = mul_rn(t2, sub_rn(0.5, mul_rn(tau, 1.0 / 3)));
+        const double a2 = mul_rn(mul_rn(t2, tau), sub_rn(1.0 / 3, mul_rn(tau, 0.25)));
+        w0 = small ? a0 : w0;
+        w1 = small ? a1 : w1;
+        w2 = small ? a2 : w2;
+    }
+}
+constexpr int kClassUnusual = 0x3FF & ~0x100;  // everything but a positive normal number: NaNs, infinities, zeros, subnormals, negatives
+// the rare lanes, in the reference's own form (self-contained: nothing of the fast path has to stay alive for it)
+template <bool LAST>
+__device__ __forceinline__ void rt_coef_reference(double t0, double t1, double d10, double d21, double s1, double& c, double& e)
+{
+    if (t0 == 0.0) {  // :203-206, :253-254
+        c = 1.0, e = 0.0;
+        return;
+    }
+    double w0, w1, w2;
+    rt_weights(t0, w0, w1, w2);
+    c = sub_rn(1.0, w0);
+    if constexpr (LAST) {
+        e = add_rn(mul_rn(w0, s1), mul_rn(w2, d10) / mul_rn(t0, t0));
+    } else {
+        const double sum = add_rn(t0, t1);
+        const double second = mul_rn(w1, sub_rn(mul_rn(-d21, t0 / t1), mul_rn(-d10, t1 / t0))) / sum;
+        const double third = mul_rn(w2, add_rn(d21 / t1, d10 / t0)) / sum;
+        e = add_rn(add_rn(mul_rn(w0, s1), second), third);
+    }
+}
+// -> wave mask of the lanes whose (c, e) must be redone by rt_coef_reference
+template <bool LAST>
+__device__ __forceinline__ unsigned long long rt_coef_fast(double t0, double t1, double d10, double d21, double s1, double& c, double& e)
+{
+    double w0, w1, w2;
+    rt_weights_wave(t0, w0, w1, w2);
+    double den;
+    if constexpr (LAST) {
+        den = t0 * t0;
+        e = fma(w0, s1, (w2 * d10) * recip(den));
+    } else {
+        den = (t0 * t1) * (t0 + t1);
+        const double u = fma(w1, t1, w2), v = fma(-w1, t0, w2);
+        const double num = fma(d10 * t1, u, (d21 * t0) * v);
+        e = fma(w0, s1, num * recip(den));
+    }
+    c = 1.0 - w0;
+    // (the wave mask straight from the compare: through a bool the compiler materialises 0 / 1 per lane and compares again)
+    unsigned long long unusual;
+    asm("v_cmp_class_f64 %0, %1, %2" : "=s"(unusual) : "v"(den), "s"(kClassUnusual));
+    return unusual;
+}
+template <bool LAST>
+__device__ __forceinline__ void rt_coef(double t0, double t1, double d10, double d21, double s1, double& c, double& e)
+{
+    const unsigned long long unusual = rt_coef_fast<LAST>(t0, t1, d10, d21, s1, c, e);
+    if (unusual) {
+        if ((unusual >> (threadIdx.x & 63)) & 1) rt_coef_reference<LAST>(t0, t1, d10, d21, s1, c, e);
+    }
+}
 
 }  // namespace sdx

@@ -29,6 +29,19 @@ namespace {
 thread_local std::string g_error;
 thread_local int g_error_code = 0;
 
+// Experiment and analysis knobs (SDX_RT_SEG, SDX_WIDE_BLOCKS, SDX_SPLIT_LAUNCHES, ... — listed in include/stardis_hip.h): some of
+// them change the order of summation or the choice of kernel, i.e. the last bits of a result and the "union of shards ==
+// single GPU, bit for bit" invariant when ranks inherit different environments.  They are read ONLY when the one documented
+// switch SDX_EXPERIMENT=1 is set; without it the environment cannot change what the library computes.
+const char* knob(const char* name)
+{
+    static const bool on = [] {
+        const char* e = std::getenv("SDX_EXPERIMENT");
+        return e && std::atoi(e) == 1;
+    }();
+    return on ? std::getenv(name) : nullptr;
+}
+
 int fail(int code, const std::string& msg)
 {
     g_error = msg;
@@ -78,6 +91,7 @@ struct sdx_ctx {
     int64_t indexed_min_lines = 8192;  // line lists at least this long: wide lines found by centre range / the huge-line list instead of a full scan
     int64_t mixed_precision = 0;       // 1: fp32 rational for far-wing (region I) evaluations of whole-tile windows
     int64_t segmented_raytrace = -1;   // -1: by the size of the GLOBAL grid; 0 never; 1 whenever the kernel supports the shape
+    int64_t wide_hot_depths = -1;      // -1: the deepest quarter of the depth points get twice the line subsets; >= 0: that many
     // timing
     hipEvent_t t0 = nullptr, t1 = nullptr;
     void* cont_ws = nullptr;  // continuum plane [n_depth][nu_count] of the fused step
@@ -401,6 +415,10 @@ int sdx_set_int_option(sdx_ctx* ctx, const char* name, int64_t value)
         ctx->segmented_raytrace = value < 0 ? -1 : (value ? 1 : 0);
         return SDX_OK;
     }
+    if (std::strcmp(name, "wide_hot_depths") == 0) {
+        ctx->wide_hot_depths = value < 0 ? -1 : value;
+        return SDX_OK;
+    }
     return fail(SDX_ERR_ARG, std::string("unknown option ") + name);
 }
 
@@ -497,7 +515,7 @@ int sdx_memcpy_h2d(sdx_ctx* ctx, void* dst, const void* src, size_t bytes)
 {
     REQUIRE(ctx && (bytes == 0 || (dst && src)), "sdx_memcpy_h2d: null pointer");
     if (bytes == 0) return SDX_OK;
-    static const bool no_pin = std::getenv("SDX_NO_PINNED_STAGING") != nullptr;
+    static const bool no_pin = knob("SDX_NO_PINNED_STAGING") != nullptr;
     if (no_pin) {
         HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));  // pageable source: safe to reuse on return
@@ -519,7 +537,7 @@ int sdx_memcpy_d2h(sdx_ctx* ctx, void* dst, const void* src, size_t bytes)
 {
     REQUIRE(ctx && (bytes == 0 || (dst && src)), "sdx_memcpy_d2h: null pointer");
     if (bytes == 0) return SDX_OK;
-    static const bool no_pin = std::getenv("SDX_NO_PINNED_STAGING") != nullptr;
+    static const bool no_pin = knob("SDX_NO_PINNED_STAGING") != nullptr;
     if (no_pin) {
         HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -708,12 +726,14 @@ struct ContinuumJob {  // continuum plane computed by the trailing blocks of the
 
 // The segmented formal solution (k_raytrace_seg: the gaps of a ray over the 8 waves of a workgroup) pays ~40 % more
 // instructions for eight times the waves: it wins where k_raytrace would leave the chip under three waves per SIMD.
-static const int kSegWaves = std::getenv("SDX_RT_NS") && std::atoi(std::getenv("SDX_RT_NS")) == 4 ? 4 : 8;  // experiment knob: 4 waves x 14 gaps
+static const int kSegWaves = knob("SDX_RT_NS") && std::atoi(knob("SDX_RT_NS")) == 4 ? 4 : 8;  // experiment knob: 4 waves x 14 gaps
 static const int kSegMax = kSegWaves == 4 ? 14 : 7;
 static size_t seg_lds_doubles(int n_depth, int nth)
 {
     const int gpw = 64 / nth;
-    return (size_t)kSegWaves * 128 + std::max((size_t)2 * (n_depth - 1) * nth + (size_t)4 * gpw * n_depth, (size_t)kSegWaves * kSegMax * gpw * nth);
+    // segment maps, then the larger of the staging arrays (transposed ray table with an odd row stride, source and sqrt(alpha)
+    // columns) and the flux terms that reuse their space
+    return (size_t)kSegWaves * 128 + std::max((size_t)nth * ((n_depth - 1) | 1) + (size_t)2 * gpw * n_depth, (size_t)kSegWaves * kSegMax * gpw * nth);
 }
 // Which kernel runs must not depend on how the grid is sharded or on the device (the two differ by the rounding of the affine
 // composition, a few ulp: a shard below the threshold next to an unsharded run above it would break the bit-identity of
@@ -722,7 +742,7 @@ static size_t seg_lds_doubles(int n_depth, int nth)
 constexpr int64_t kSegLegacyWaves = (int64_t)3 * 4 * 256;
 static bool use_segmented_raytrace(const sdx_ctx* ctx, int n_depth, int64_t n_nu_global, int n_theta, bool plain)
 {
-    static const int env_mode = std::getenv("SDX_RT_SEG") ? std::atoi(std::getenv("SDX_RT_SEG")) : -1;  // A/B knob: 0 never, 1 whenever possible
+    static const int env_mode = knob("SDX_RT_SEG") ? std::atoi(knob("SDX_RT_SEG")) : -1;  // A/B knob: 0 never, 1 whenever possible
     const int mode = ctx->segmented_raytrace >= 0 ? (int)ctx->segmented_raytrace : env_mode;
     if (mode == 0 || !plain || n_theta > 64) return false;
     if ((n_depth - 1 + kSegWaves - 1) / kSegWaves > kSegMax || seg_lds_doubles(n_depth, n_theta) * sizeof(double) > 64 * 1024) return false;
@@ -786,7 +806,7 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
     // that can reach any column (-> hlist), the full pre-pass then runs on the lines centred near the shard plus those.
     // Everything is decided on the device (no host round trip, graph-capturable); which lines a shard prepares does not
     // change what it computes for them.
-    static const bool no_cull = std::getenv("SDX_NO_CULL") != nullptr;
+    static const bool no_cull = knob("SDX_NO_CULL") != nullptr;
     const bool cull = fill_work && !no_cull && n_lines >= ctx->indexed_min_lines && !count_evals && !gen && !scan_in_block && nu_count < n_nu;
     // the grid-spacing reduction (a culled run: it also clears whw_max for the classification pass)
     int* const sel = cull ? w.hcount + 4 : nullptr;
@@ -817,7 +837,7 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
         const size_t tile_shmem = ((size_t)kContDepths * (n_lev + 6) + (p->stage_table ? 2 * (size_t)ca.n_table : 0)) * sizeof(double);
         p->cont_rows = (unsigned)n_depth;
         p->tiled = false;
-        static const int cont_dgs_env = std::getenv("SDX_CONT_DGS") ? std::atoi(std::getenv("SDX_CONT_DGS")) : -1;  // experiment knob: 0 = per-point blocks
+        static const int cont_dgs_env = knob("SDX_CONT_DGS") ? std::atoi(knob("SDX_CONT_DGS")) : -1;  // experiment knob: 0 = per-point blocks
         if (tile_shmem <= 48 * 1024 && cont_dgs_env != 0) {
             // depths per block: as many as leave ~2 x 1024 threads of such blocks per CU (one depth per block on small grids)
             int dgs = (int)std::max<int64_t>(1, std::min<int64_t>(kContDepths, ((int64_t)p->cont_tiles * threads / kPreBlock * n_depth) / (2 * (int64_t)ctx->n_cu)));
@@ -838,7 +858,7 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
         w.sel = sel;
         const unsigned n_cls = (unsigned)std::min<int64_t>((n_lines * n_depth + 4 * kBlock - 1) / (4 * kBlock), (int64_t)8 * ctx->n_cu);
         ContPlan cp;
-        static const bool no_ride = std::getenv("SDX_NO_CONT_RIDE") != nullptr;  // A/B knob
+        static const bool no_ride = knob("SDX_NO_CONT_RIDE") != nullptr;  // A/B knob
         if (job && !no_ride) {
             if ((rc = plan_continuum(kBlock, &cp))) return rc;
             continuum_done = cp.tiled;
@@ -919,7 +939,7 @@ static int choose_splits(int n_depth, int64_t n_nu_global, int64_t n_lines, int 
     const int64_t tiles = (n_nu_global + 64 * R - 1) / (64 * R);
     const int64_t chunks = (n_lines + 63) / 64;
     int64_t target = 2560;  // S-c2: 2 subsets (4 measured the same, 8 slower: 40.4 / 40.7 / 50.1 us — the narrow role shares the workgroup size)
-    if (const char* e = std::getenv("SDX_WIDE_BLOCKS")) target = std::max(1, std::atoi(e));  // tuning knob
+    if (const char* e = knob("SDX_WIDE_BLOCKS")) target = std::max(1, std::atoi(e));  // tuning knob
     // at least two subsets (four for long lists): the choice must not depend on the shard (it fixes the summation order), and
     // a rank that owns 1/8 of a large grid still needs enough, small enough waves — a (tile, depth) of S-c3 is ~2e4
     // instructions per subset at S = 2, and a shard's last generation of such waves is most of its run time
@@ -933,7 +953,7 @@ static int choose_splits(int n_depth, int64_t n_nu_global, int64_t n_lines, int 
 static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin, int64_t nu_count,
                          int64_t n_lines, const double* line_nus, const double* doppler, const double* gammas, int gamma_cols,
                          const double* alphas, const double** partial_out, int64_t* pld_out, int* n_planes_out, LineWork* w_out,
-                         bool count_evals, const ContinuumJob* job = nullptr, const LineParams* gen = nullptr)
+                         bool count_evals, const ContinuumJob* job = nullptr, const LineParams* gen = nullptr, int* hot_out = nullptr)
 {
     constexpr int R = 4;       // grid points per lane of a wide-role tile (tile = 64 R points)
     constexpr int R_MIXED = 4;  // fp32 far wings (8 — twice the points per fetched record — measured slower: fewer tiles qualify as far wing)
@@ -941,7 +961,7 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
     int rc = line_prepass(ctx, n_depth, n_nu, nus, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, true, nullptr, nullptr, &w,
                           count_evals, job, gen, nu_begin, nu_count);
     if (rc) return rc;
-    static const int r_mixed_env = std::getenv("SDX_R_MIXED") ? std::atoi(std::getenv("SDX_R_MIXED")) : R_MIXED;  // experiment knob: 4 or 8
+    static const int r_mixed_env = knob("SDX_R_MIXED") ? std::atoi(knob("SDX_R_MIXED")) : R_MIXED;  // experiment knob: 4 or 8
     const int Rm = ctx->mixed_precision ? (r_mixed_env == 8 ? 8 : R_MIXED) : R;
     const int n_split = choose_splits(n_depth, n_nu, n_lines, Rm, n_lines >= ctx->indexed_min_lines ? 4 : 2);
     // long line lists: the lines with a window wider than kMediumHalfWidth are listed once (they are scanned by every tile);
@@ -951,15 +971,21 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
         LaunchScope ls(ctx, "k_hlist");
         launch_line_lists(ctx, n_lines, w, 32);
     }
-    static const bool no_hscan = std::getenv("SDX_NO_HSCAN") != nullptr;  // A/B knob
+    static const bool no_hscan = knob("SDX_NO_HSCAN") != nullptr;  // A/B knob
     if (no_hscan) w.hscan = nullptr;
     if (indexed && !no_hscan && !w.sel) {  // the huge lines' scan words in list order (a culled pre-pass has written them itself)
         LaunchScope ls(ctx, "k_hlist");
         hipLaunchKernelGGL(k_hscan, dim3(64, (unsigned)n_depth), dim3(kBlock), 0, ctx->stream, n_depth, n_lines, (const int*)w.hlist, (const int*)w.hcount,
                            (const WideScan*)w.wscan, w.hscan);
     }
-    // two planes: [0] wide windows (the S subsets are summed inside their workgroup), [1] narrow windows
-    rc = ensure(ctx, &ctx->part_ws, &ctx->part_ws_bytes, (size_t)2 * n_depth * nu_count * sizeof(double));
+    // The deepest quarter of the depth points — the hottest layers, whose tiles walk the longest hit lists — get twice the line
+    // subsets (two workgroups per (depth, tile)): a launch cannot end before its heaviest wave does, and on an eighth of the
+    // grid that wave alone was most of the line kernel's time.  A function of the depth count only (context option
+    // "wide_hot_depths" for experiments): the order of summation stays a property of the grid, not of the shard.
+    const int hot = (int)std::min<int64_t>(n_depth, ctx->wide_hot_depths >= 0 ? ctx->wide_hot_depths : n_depth / 4);
+    // planes: [0] wide windows (the subsets of a workgroup are summed inside it), [1] narrow windows, [2] the second half of the
+    // subsets of the hot depths (rows 0 .. hot - 1 only)
+    rc = ensure(ctx, &ctx->part_ws, &ctx->part_ws_bytes, (size_t)3 * n_depth * nu_count * sizeof(double));
     if (rc) return rc;
     double* part = (double*)ctx->part_ws;
     const int64_t pld = nu_count;
@@ -968,10 +994,10 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
     const int tiles = (int)((nu_begin + nu_count + 64 * Rm - 1) / (64 * Rm) - nu_begin / (64 * Rm));
     // order of the wide role's tiles over the XCDs: one contiguous eighth each (0), or groups of g tiles going round them —
     // better balance where an eighth is only a few tiles (a shard's), at the price of fewer neighbouring tiles per L2
-    static const int wide_group_env = std::getenv("SDX_WIDE_GROUP") ? std::atoi(std::getenv("SDX_WIDE_GROUP")) & 15 : -1;
+    static const int wide_group_env = knob("SDX_WIDE_GROUP") ? std::atoi(knob("SDX_WIDE_GROUP")) & 15 : -1;
     const int wide_group = wide_group_env >= 0 ? wide_group_env : 0;
     const int64_t tiles_pad = wide_group ? ((int64_t)tiles + 8 * wide_group - 1) / (8 * wide_group) * (8 * wide_group) : tiles;
-    const int64_t n_wide = tiles_pad * n_depth;
+    const int64_t n_wide = tiles_pad * (n_depth + hot);
     // workgroups of n_split waves, rounded up to whole rounds of the XCD-aware order (surplus workgroups return at once)
     // narrow role: F consecutive frequencies per wave (a line's records, loaded once, serve F evaluations) for DENSE lists —
     // at least one line per two grid points, where a frequency visits many lines and the walk is bound by its loads and
@@ -979,19 +1005,21 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
     // line kernel 20 % SLOWER (414 against 345 us: a few thousand four-times-longer waves are the launch's tail); sparse lists
     // on small grids (S-c2: 2000 lines on 7634 points, a latency-bound launch) keep one frequency per wave.  Pure scheduling:
     // every frequency adds its lines in the same order whatever F.  (F = 8 was measured slower than 4 at every size.)
-    static const int narrow_f_env = std::getenv("SDX_NARROW_F") ? std::atoi(std::getenv("SDX_NARROW_F")) : 0;  // A/B knob: 1, 2, 4
+    static const int narrow_f_env = knob("SDX_NARROW_F") ? std::atoi(knob("SDX_NARROW_F")) : 0;  // A/B knob: 1, 2, 4
     int narrow_f = 1;
     if (2 * n_lines >= n_nu) narrow_f = nu_count >= 32768 ? 4 : (nu_count >= 16384 ? 2 : 1);
     if (narrow_f_env == 1 || narrow_f_env == 2 || narrow_f_env == 4) narrow_f = narrow_f_env;
     const int64_t n_grp = (nu_begin + nu_count + narrow_f - 1) / narrow_f - nu_begin / narrow_f;
     const int64_t n_narrow = (((n_grp * ((n_depth + 63) / 64) + n_split - 1) / n_split + 31) / 32) * 32;
-    static const int narrow_order = std::getenv("SDX_NARROW_ORDER") ? atoi(std::getenv("SDX_NARROW_ORDER")) & 3 : 0;
-    REQUIRE(n_wide + n_narrow < ((int64_t)1 << 31), "line opacity: grid too large for one launch");
-    static const bool split_launches = std::getenv("SDX_SPLIT_LAUNCHES") != nullptr;  // analysis knob: time the two roles apart
+    static const int narrow_order = knob("SDX_NARROW_ORDER") ? atoi(knob("SDX_NARROW_ORDER")) & 3 : 0;
+    REQUIRE(n_wide + n_narrow < ((int64_t)1 << 31) && hot < 4096, "line opacity: grid too large for one launch");
+    static const bool split_launches = knob("SDX_SPLIT_LAUNCHES") != nullptr;  // analysis knob: time the two roles apart
     const size_t shmem = (size_t)n_split * kWideLdsDoubles * sizeof(double);
     const dim3 g((unsigned)(n_wide + n_narrow)), blk((unsigned)(64 * n_split));
     for (int pass = 0; pass < (split_launches ? 2 : 1); ++pass) {
-        const int roles = (split_launches ? (1 << pass) : 3) | (narrow_order << 2) | (wide_group << 4) | (narrow_f << 8);
+        // (raising the priority of the hot layers' waves with s_setprio was measured in round 4: the instruction has side effects as
+        // far as the compiler is concerned, the record fetches of the walk stopped being scalar loads and the kernel ran 37 % slower)
+        const int roles = (split_launches ? (1 << pass) : 3) | (narrow_order << 2) | (wide_group << 4) | (narrow_f << 8) | (hot << 16);
         LaunchScope ls(ctx, split_launches ? (pass ? "k_line_narrow" : "k_line_wide") : "k_line_all");
 #define SDX_LINE_ARGS (int)n_wide, tiles, n_split, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, part, pld, roles
         if (ctx->mixed_precision && Rm == 8) hipLaunchKernelGGL((k_line_all_mixed<8>), g, blk, shmem, ctx->stream, SDX_LINE_ARGS);
@@ -1001,7 +1029,8 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
     }
     *partial_out = part;
     *pld_out = pld;
-    *n_planes_out = 2;
+    *n_planes_out = hot > 0 ? 3 : 2;
+    if (hot_out) *hot_out = hot;
     if (w_out) *w_out = w;
     return check_launch("line kernels");
 }
@@ -1022,15 +1051,15 @@ static int line_opacity_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, const doub
     }
     const double* part;
     int64_t pld;
-    int n_split;
+    int n_split, hot = 0;
     LineWork w;
     rc = line_partials(ctx, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, &part, &pld,
-                       &n_split, &w, n_evaluations_dev != nullptr, nullptr, gen);
+                       &n_split, &w, n_evaluations_dev != nullptr, nullptr, gen, &hot);
     if (rc) return rc;
     {
         LaunchScope ls(ctx, "k_reduce_partials");
         hipLaunchKernelGGL(k_reduce_partials, grid2(nu_count, n_depth), dim3(kBlock), 0, ctx->stream, n_depth, nu_count, n_split,
-                           part, pld, out, out_ld, accumulate);
+                           part, pld, out, out_ld, accumulate, hot);
     }
     rc = check_launch("k_reduce_partials");
     if (rc) return rc;
@@ -1183,7 +1212,7 @@ struct HostIo {
     // sizes: total device bytes and total staged host bytes of the call (padded per array by the caller through need())
     int begin(size_t dev_need, size_t pin_need)
     {
-        static const bool no_pin = std::getenv("SDX_NO_PINNED_STAGING") != nullptr;
+        static const bool no_pin = knob("SDX_NO_PINNED_STAGING") != nullptr;
         pinned = !no_pin && pin_need <= kPinnedStagingMax;
         if (ctx->io_dev_bytes < dev_need) {
             HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -1681,21 +1710,19 @@ static int raytrace_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, c
         // Angles per lane P and lanes per frequency G = ceil(n_theta / P).  P = 1 (one lane per (frequency, angle)) is the
         // default at every size measured; SDX_RT_P overrides it for experiments.
         int P = 1;  // measured on MI355X at 7.6e3 and 1.2e5 frequencies: one angle per lane wins (more waves in flight)
-        if (const char* e = std::getenv("SDX_RT_P")) {  // tuning knob: angles per lane (1, 2 or 4)
+        if (const char* e = knob("SDX_RT_P")) {  // tuning knob: angles per lane (1, 2 or 4)
             const int v = std::atoi(e);
             if (v == 1 || v == 2 || v == 4) P = v;
         }
         const int G = (nth + P - 1) / P;
-        const int kbatch = P == 1 ? 8 : (P == 2 ? 4 : 2);
-        auto lds_bytes = [&](int groups) {
-            return ((size_t)2 * (n_depth - 1) * nth +
-                    (size_t)(kBlock / 64) * (3 * (size_t)groups * n_depth + std::max((size_t)groups * n_depth, (size_t)kbatch * groups * P * G))) *
-                   sizeof(double);
+        const int kbatch = P == 1 ? 4 : 2;
+        auto lds_bytes = [&](int groups) {  // ray table + per wave: source and sqrt(alpha) columns, flux terms of a batch of gaps
+            return ((size_t)(n_depth - 1) * nth + (size_t)(kRtBlock / 64) * (2 * (size_t)groups * n_depth + (size_t)kbatch * groups * P * G)) * sizeof(double);
         };
         int gpw = 64 / G;  // frequencies per wave; lowered (idle lanes) until the staged columns fit 64 KB of LDS
         while (gpw > 1 && lds_bytes(gpw) > 64 * 1024) --gpw;
         const size_t shmem = lds_bytes(gpw);
-        const unsigned blocks = (unsigned)((n_nu + (int64_t)gpw * (kBlock / 64) - 1) / ((int64_t)gpw * (kBlock / 64)));
+        const unsigned blocks = (unsigned)((n_nu + (int64_t)gpw * (kRtBlock / 64) - 1) / ((int64_t)gpw * (kRtBlock / 64)));
         const unsigned blocks_basic = (unsigned)((n_nu + (int64_t)(64 / G) * (kBlock / 64) - 1) / ((int64_t)(64 / G) * (kBlock / 64)));
         // plane-parallel, one angle per lane, nothing to add to, a small grid: the gaps of a ray split over the 8 waves of a
         // workgroup (k_raytrace_seg)
@@ -1718,9 +1745,9 @@ static int raytrace_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, c
             LaunchScope ls(ctx, "k_raytrace");
 #define SDX_RT_ARGS n_depth, n_nu, nth, n_theta, G, nus, temps, rd, w, alphas, ald, F, fld, inus, acc
             if (shmem <= 64 * 1024) {
-                if (P == 1) hipLaunchKernelGGL(k_raytrace<1>, dim3(blocks), dim3(kBlock), shmem, ctx->stream, SDX_RT_ARGS, inward, gpw, ft);
-                else if (P == 2) hipLaunchKernelGGL(k_raytrace<2>, dim3(blocks), dim3(kBlock), shmem, ctx->stream, SDX_RT_ARGS, inward, gpw, ft);
-                else hipLaunchKernelGGL(k_raytrace<4>, dim3(blocks), dim3(kBlock), shmem, ctx->stream, SDX_RT_ARGS, inward, gpw, ft);
+                if (P == 1) hipLaunchKernelGGL(k_raytrace<1>, dim3(blocks), dim3(kRtBlock), shmem, ctx->stream, SDX_RT_ARGS, inward, gpw, ft);
+                else if (P == 2) hipLaunchKernelGGL(k_raytrace<2>, dim3(blocks), dim3(kRtBlock), shmem, ctx->stream, SDX_RT_ARGS, inward, gpw, ft);
+                else hipLaunchKernelGGL(k_raytrace<4>, dim3(blocks), dim3(kRtBlock), shmem, ctx->stream, SDX_RT_ARGS, inward, gpw, ft);
             } else {  // very deep models: the column does not fit LDS, recompute per lane instead
                 REQUIRE(!ft.cont && !ft.source, "raytrace: fused total / caller's source plane not available for models this deep");
                 REQUIRE(!inward, "raytrace: spherical geometry needs (3*n_depth*64/n_theta + 2*n_depth*n_theta) doubles of LDS per wave; model too deep");
@@ -1794,13 +1821,17 @@ static int synthesize_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double
                            const double* alphas, const sdx_continuum* cont, int n_theta, const double* temps,
                            const double* ray_dist, const double* wts, double* alpha_line_out, double* total_alphas, double* F_nu,
                            int64_t ld, int64_t* n_evaluations_dev, const LineParams* gen, double* I_nus = nullptr, const double* source = nullptr,
-                           int64_t source_ld = 0)
+                           int64_t source_ld = 0, const sdx_synthesis_options* opt = nullptr)
 {
     int rc;
     REQUIRE(cont && temps && ray_dist && wts && n_theta > 0 && n_depth >= 2, "synthesize: bad arguments");
     REQUIRE(nu_begin >= 0 && nu_count >= 0 && nu_begin + nu_count <= n_nu, "synthesize: shard outside the grid");
     REQUIRE(nu_count == 0 || (F_nu && ld >= nu_count), "synthesize: bad output buffers");
     if ((rc = check_file_planes(cont, n_nu))) return rc;
+    const int inward = opt && opt->inward_rays ? 1 : 0;
+    const int n_extra = opt ? opt->n_line_planes : 0;
+    REQUIRE(n_extra >= 0 && n_extra <= 2, "synthesize: n_line_planes must be 0..2");
+    for (int k = 0; k < n_extra; ++k) REQUIRE(opt->line_plane[k] && opt->line_plane_ld >= nu_count, "synthesize: bad line plane");
     if (nu_count == 0) return SDX_OK;
     // Three launches on one stream: [pre-pass + continuum plane] -> [wide + narrow line kernels] -> [raytrace, which
     // forms total = continuum + line while staging its columns].  Independent work shares a launch instead of a
@@ -1809,16 +1840,26 @@ static int synthesize_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double
     if (rc2) return rc2;
     double* cont_plane = (double*)ctx->cont_ws;
     // the formal solution forms total = continuum + line planes while staging its columns when those fit LDS
-    const size_t lds_columns = ((size_t)2 * (n_depth - 1) * n_theta + (size_t)4 * (4 * (size_t)n_depth + 8 * 64)) * sizeof(double);
+    const size_t lds_columns = ((size_t)(n_depth - 1) * n_theta + (size_t)(kRtBlock / 64) * (2 * (size_t)n_depth + 4 * 64)) * sizeof(double);  // k_raytrace with one frequency per wave
     const bool fuse = n_theta <= 64 && lds_columns <= 64 * 1024;
+    // spherical geometry (opt->inward_rays): the inward sweep before the outward one, then F_nu *= (r[-1] / reference_r)^2
+    // (radiation_field_solvers/base.py:141-198, :340-344)
+    auto finish = [&](int rc_trace) -> int {
+        if (rc_trace || !inward) return rc_trace;
+        {
+            LaunchScope ls(ctx, "k_scale");
+            hipLaunchKernelGGL(k_scale, grid2(nu_count, n_depth), dim3(kBlock), 0, ctx->stream, n_depth, nu_count, F_nu, ld, opt->photospheric_correction);
+        }
+        return check_launch("k_scale");
+    };
     const ContinuumJob job{cont, nu_begin, nu_count, cont_plane};
     const double* part = nullptr;
     int64_t pld = 0;
-    int n_planes = 0;
+    int n_planes = 0, hot = 0;
     if (n_lines > 0) {
         LineWork w;
         rc = line_partials(ctx, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, &part, &pld,
-                           &n_planes, &w, n_evaluations_dev != nullptr, &job, gen);
+                           &n_planes, &w, n_evaluations_dev != nullptr, &job, gen, &hot);
         if (rc) return rc;
         if (n_evaluations_dev)
             HIP_TRY(hipMemcpyAsync(n_evaluations_dev, w.evals, sizeof(int64_t), hipMemcpyDeviceToDevice, ctx->stream));
@@ -1840,18 +1881,20 @@ static int synthesize_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double
             if (part) {
                 if (alpha_line_out)
                     hipLaunchKernelGGL(k_reduce_partials, grid2(nu_count, n_depth), dim3(kBlock), 0, ctx->stream, n_depth, nu_count,
-                                       n_planes, part, pld, alpha_line_out, ld, 0);
+                                       n_planes, part, pld, alpha_line_out, ld, 0, hot);
                 hipLaunchKernelGGL(k_reduce_partials, grid2(nu_count, n_depth), dim3(kBlock), 0, ctx->stream, n_depth, nu_count, n_planes,
-                                   part, pld, total, tld, 1);
+                                   part, pld, total, tld, 1, hot);
             }
         }
         rc = check_launch("k_reduce_partials");
         if (rc) return rc;
+        for (int k = 0; k < n_extra; ++k)
+            if ((rc = sdx_accumulate_dev(ctx, n_depth, nu_count, total, tld, opt->line_plane[k], opt->line_plane_ld))) return rc;
         FusedTotal only_source{};  // (no fused total: the formal solution reads `total`; the caller's source plane still applies)
         only_source.source = source;
         only_source.sld = source_ld;
-        return raytrace_impl(ctx, n_depth, nu_count, n_theta, nus + nu_begin, temps, ray_dist, wts, total, tld, F_nu, ld, I_nus, 0, 0,
-                             source ? &only_source : nullptr, n_nu);
+        return finish(raytrace_impl(ctx, n_depth, nu_count, n_theta, nus + nu_begin, temps, ray_dist, wts, total, tld, F_nu, ld, I_nus, 0, inward,
+                                    source ? &only_source : nullptr, n_nu));
     }
     FusedTotal ft{};
     ft.source = source;
@@ -1860,11 +1903,15 @@ static int synthesize_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double
     ft.cld = nu_count;
     ft.planes = part;
     ft.n_planes = n_planes;
+    ft.hot_depths = hot;
     ft.pld = pld;
     ft.total_out = total_alphas;
     ft.line_out = part ? alpha_line_out : nullptr;
     ft.out_ld = ld;
-    return raytrace_impl(ctx, n_depth, nu_count, n_theta, nus + nu_begin, temps, ray_dist, wts, nullptr, 0, F_nu, ld, I_nus, 0, 0, &ft, n_nu);
+    ft.n_extra = n_extra;
+    for (int k = 0; k < n_extra; ++k) ft.extra[k] = opt->line_plane[k];
+    ft.eld = n_extra ? opt->line_plane_ld : 0;
+    return finish(raytrace_impl(ctx, n_depth, nu_count, n_theta, nus + nu_begin, temps, ray_dist, wts, nullptr, 0, F_nu, ld, I_nus, 0, inward, &ft, n_nu));
 }
 
 int sdx_synthesize_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin, int64_t nu_count,
@@ -1906,6 +1953,30 @@ int sdx_synthesize_linelist_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const d
     return synthesize_impl(ctx, n_depth, n_nu, nus, nu_begin, nu_count, ll->n_lines, ll->nu, nullptr, nullptr,
                            ll->gamma_mode >= 2 ? 1 : n_depth, nullptr, cont, n_theta, temps, ray_dist, wts, alpha_line_out, total_alphas,
                            F_nu, ld, n_evaluations_dev, &lp);
+}
+
+int sdx_synthesize_opt_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin, int64_t nu_count,
+                           int64_t n_lines, const double* line_nus, const double* doppler, const double* gammas, int gamma_cols,
+                           const double* alphas, const sdx_continuum* cont, int n_theta, const double* temps,
+                           const double* ray_dist, const double* wts, double* alpha_line_out, double* total_alphas, double* F_nu,
+                           int64_t ld, const sdx_synthesis_options* opt, int64_t* n_evaluations_dev)
+{
+    REQUIRE(ctx && opt, "synthesize_opt: null context or options");
+    REQUIRE(!opt->source || opt->source_ld >= nu_count, "synthesize_opt: source_ld must cover the columns");
+    if (opt->linelist) {  // line parameters generated in the pre-pass (f1): the dense arrays are not read
+        REQUIRE(n_depth > 0 && n_nu >= 0 && n_nu < (int64_t)2147483647 && (n_nu == 0 || nus), "synthesize_opt: bad sizes");
+        LineParams lp{};
+        int rc = to_line_params(opt->linelist, n_depth, &lp);
+        if (rc) return rc;
+        return synthesize_impl(ctx, n_depth, n_nu, nus, nu_begin, nu_count, opt->linelist->n_lines, opt->linelist->nu, nullptr, nullptr,
+                               opt->linelist->gamma_mode >= 2 ? 1 : n_depth, nullptr, cont, n_theta, temps, ray_dist, wts, alpha_line_out,
+                               total_alphas, F_nu, ld, n_evaluations_dev, &lp, opt->I_nus, opt->source, opt->source_ld, opt);
+    }
+    int rc = check_line_args(ctx, n_depth, n_nu, nus, n_lines, line_nus, doppler, gammas, gamma_cols, alphas);
+    if (rc) return rc;
+    return synthesize_impl(ctx, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, cont, n_theta,
+                           temps, ray_dist, wts, alpha_line_out, total_alphas, F_nu, ld, n_evaluations_dev, nullptr, opt->I_nus, opt->source,
+                           opt->source_ld, opt);
 }
 
 // The fused synthesis for a caller that holds everything in host memory (C, or numpy through ctypes): uploads, runs
@@ -2013,6 +2084,103 @@ int sdx_synthesize_f64(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nu
     if ((rc = io.finish())) return rc;
     if (n_evaluations) *n_evaluations = ev;
     return SDX_OK;
+}
+
+// The continuum sources for a caller that holds everything in host memory: what calc_alpha_file / _bf / _ff / _rayleigh /
+// _electron (opacities_solvers/base.py:40-317) return, and their sum in calc_alphas' order (:655-700), from ONE upload of the
+// per-depth vectors and the table — on the context's persistent staging like the other *_f64 entry points.  Each plane is
+// produced by the device function the per-source *_dev entry point runs (the same bits); `total` by k_total_alphas.
+int sdx_continuum_f64(sdx_ctx* ctx, int n_depth, int64_t n_nu, double* nus, const sdx_continuum* cont, double* alpha_file,
+                      double* alpha_bf, double* alpha_ff, double* alpha_rayleigh, double* alpha_electron, double* total_alphas)
+{
+    REQUIRE(ctx && cont && n_depth > 0 && n_nu >= 0, "continuum: bad arguments");
+    REQUIRE(alpha_file || alpha_bf || alpha_ff || alpha_rayleigh || alpha_electron || total_alphas, "continuum: no output requested");
+    if (n_nu == 0) return SDX_OK;
+    REQUIRE(nus, "continuum: null frequency grid");
+    REQUIRE(cont->n_file_planes == 0, "continuum: file planes are device planes; the host-buffer entry point takes the 1-D table only");
+    const bool has_table = cont->table_sigma != nullptr, has_bf = cont->bf_cutoff && cont->bf_n_species > 0;
+    const bool has_ff = cont->ff_number_density && cont->ff_n_species > 0;
+    REQUIRE(!has_table || (cont->lambdas && cont->table_wavelength && cont->table_density && cont->n_table > 0), "continuum: incomplete table source");
+    REQUIRE(!has_bf || (cont->bf_n_levels > 0 && cont->bf_n_levels <= 4096 && cont->bf_species_offsets && cont->bf_species_ion_number && cont->bf_level_density),
+            "continuum: incomplete bound-free description (bf_n_levels must be set, 1..4096)");
+    REQUIRE(!has_ff || (cont->ff_species_ion_number && cont->temperature), "continuum: incomplete free-free description");
+    REQUIRE(!alpha_file || has_table, "continuum: alpha_file requested without a table");
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc;
+    const size_t f8 = sizeof(double), plane = (size_t)n_depth * n_nu * f8;
+    sdx_continuum c = *cont;
+    const int n_levels = has_bf ? c.bf_n_levels : 0;
+    struct In {
+        const void* src;
+        size_t bytes;
+        const void** dst;
+    };
+    const double* d_nus;
+    const In ins[] = {
+        {nus, (size_t)n_nu * f8, (const void**)&d_nus},
+        {cont->lambdas, (size_t)n_nu * f8, (const void**)&c.lambdas},
+        {cont->table_wavelength, (size_t)c.n_table * f8, (const void**)&c.table_wavelength},
+        {cont->table_sigma, (size_t)c.n_table * f8, (const void**)&c.table_sigma},
+        {cont->table_density, (size_t)n_depth * f8, (const void**)&c.table_density},
+        {cont->bf_species_offsets, (size_t)(c.bf_n_species + 1) * sizeof(int32_t), (const void**)&c.bf_species_offsets},
+        {cont->bf_species_ion_number, (size_t)c.bf_n_species * sizeof(int32_t), (const void**)&c.bf_species_ion_number},
+        {cont->bf_cutoff, (size_t)n_levels * f8, (const void**)&c.bf_cutoff},
+        {cont->bf_level_density, (size_t)n_levels * n_depth * f8, (const void**)&c.bf_level_density},
+        {cont->ff_species_ion_number, (size_t)c.ff_n_species * sizeof(int32_t), (const void**)&c.ff_species_ion_number},
+        {cont->ff_number_density, (size_t)c.ff_n_species * n_depth * f8, (const void**)&c.ff_number_density},
+        {cont->ray_n_h, (size_t)n_depth * f8, (const void**)&c.ray_n_h},
+        {cont->ray_n_he, (size_t)n_depth * f8, (const void**)&c.ray_n_he},
+        {cont->ray_n_h2, (size_t)n_depth * f8, (const void**)&c.ray_n_h2},
+        {cont->electron_density, (size_t)n_depth * f8, (const void**)&c.electron_density},
+        {cont->temperature, (size_t)n_depth * f8, (const void**)&c.temperature},
+    };
+    double* const outs[] = {total_alphas, alpha_file, alpha_bf, alpha_ff, alpha_rayleigh, alpha_electron};
+    int n_out = 0;
+    for (double* o : outs) n_out += o ? 1 : 0;
+    size_t dev_need = (size_t)n_out * HostIo::pad(plane) + 512, pin_need = (size_t)n_out * HostIo::pad(plane) + HostIo::pad((size_t)n_nu * f8) + 512;
+    for (const In& in : ins)
+        if (in.src) dev_need += HostIo::pad(in.bytes ? in.bytes : 8), pin_need += HostIo::pad(in.bytes);
+    HostIo io{ctx};
+    if ((rc = io.begin(dev_need, pin_need))) return rc;
+    for (const In& in : ins)
+        if (in.src && (rc = io.upload(in.src, in.bytes, in.dst))) return rc;
+    double* d_out[6];
+    for (int k = 0; k < 6; ++k) d_out[k] = outs[k] ? (double*)io.alloc(plane) : nullptr;
+    // the total first: it reads the caller's frequencies as they came (the Rayleigh source clips its own copy of a frequency
+    // above 2.3e15 Hz, :99, whether or not the array has been clipped yet)
+    if (total_alphas && (rc = launch_total(ctx, n_depth, d_nus, 0, n_nu, &c, nullptr, 0, 1, nullptr, 0, d_out[0], n_nu))) return rc;
+    if (alpha_file && (rc = sdx_alpha_file_1d_dev(ctx, n_depth, n_nu, c.lambdas, c.n_table, c.table_wavelength, c.table_sigma, c.table_density, d_out[1], n_nu)))
+        return rc;
+    if (alpha_bf) {
+        ContinuumArgs a{};
+        if (has_bf) {
+            double* coef = nullptr;
+            if ((rc = launch_bf_coef(ctx, n_depth, c.bf_n_species, n_levels, c.bf_species_offsets, c.bf_species_ion_number, c.bf_cutoff, c.bf_level_density, &coef)))
+                return rc;
+            a.bf_n_species = c.bf_n_species;
+            a.bf_species_offsets = (const int*)c.bf_species_offsets;
+            a.bf_species_ion_number = (const int*)c.bf_species_ion_number;
+            a.bf_cutoff = c.bf_cutoff;
+            a.bf_coef = coef;
+        }
+        if ((rc = launch_source(ctx, "k_alpha_bf", kSrcBf, n_depth, n_nu, d_nus, a, d_out[2], n_nu))) return rc;
+    }
+    if (alpha_ff && (rc = sdx_alpha_ff_dev(ctx, n_depth, n_nu, d_nus, c.temperature ? c.temperature : d_nus, has_ff ? c.ff_n_species : 0, c.ff_species_ion_number,
+                                           c.ff_number_density, d_out[3], n_nu)))
+        return rc;
+    const bool clip = alpha_rayleigh != nullptr;  // calc_alpha_rayleigh zeroes the caller's frequencies above 2.3e15 Hz in place (:99)
+    if (alpha_rayleigh && (rc = sdx_alpha_rayleigh_dev(ctx, n_depth, n_nu, (double*)d_nus, c.ray_n_h, c.ray_n_he, c.ray_n_h2, d_out[4], n_nu))) return rc;
+    if (alpha_electron) {
+        if (c.electron_density) {
+            if ((rc = sdx_alpha_electron_dev(ctx, n_depth, n_nu, c.electron_density, d_out[5], n_nu))) return rc;
+        } else {
+            HIP_TRY(hipMemsetAsync(d_out[5], 0, plane, ctx->stream));  // (the reference returns the scalar 0 when disabled, :164-165)
+        }
+    }
+    for (int k = 0; k < 6; ++k)
+        if (outs[k] && (rc = io.download(outs[k], d_out[k], plane))) return rc;
+    if (clip && (rc = io.download(nus, d_nus, (size_t)n_nu * f8))) return rc;
+    return io.finish();
 }
 
 }  // extern "C"
@@ -2160,7 +2328,7 @@ sdx_group* sdx_group_create(int n_gpus, const int* devices)
         fail(SDX_ERR_ARG, "sdx_group_create: n_gpus must be 1..64");
         return nullptr;
     }
-    const bool loopback = std::getenv("SDX_GROUP_LOOPBACK") && std::atoi(std::getenv("SDX_GROUP_LOOPBACK")) == 1;  // test hook, see header
+    const bool loopback = knob("SDX_GROUP_LOOPBACK") && std::atoi(knob("SDX_GROUP_LOOPBACK")) == 1;  // test hook, see header
     // RCCL first: without it there is no group, whatever the devices
     RcclApi* api = loopback ? nullptr : rccl_api();
     if (api && !api->handle) {

@@ -10,9 +10,15 @@ called (`alpha_bf`, `alpha_ff`, ...: same device functions, bit-identical planes
 of disabled sources and `F_nu` accumulation semantics are the reference's (opacities_solvers/base.py:655-738,
 radiation_field_solvers/base.py:324-338).
 
-`try_fused` returns None for configurations the fused step does not cover (more than four tabulated sources, molecules,
-spherical geometry, frequencies the Rayleigh cut-off would clip, line lists
-without a dense alpha table); the caller then takes the general path.
+Molecular lines (`include_molecules`, :444-484, :716-736) are a second list whose plane is formed first (sdx_line_opacity_dev /
+_linelist_dev, the calls the general path makes) and added by the step after the atomic one; spherical models
+(radiation_field_solvers/base.py:141-198, :296-300, :340-344) hand the step the chord table and the inward sweep; line lists
+without a dense alpha table go up as per-line scalars and the pre-pass generates alpha, gamma and the Doppler width (f1) — all
+through sdx_synthesize_opt_dev, all bit-identical to the general path (tests/test_gpu_round4.py).
+
+`try_fused` returns None for configurations the fused step does not cover (more than four tabulated sources, more than 64
+angles, frequencies the Rayleigh cut-off would clip, NaNs in a line table, a zero Doppler width); the caller then takes the
+general path.
 """
 import ctypes as C
 from pathlib import Path
@@ -21,12 +27,12 @@ import numpy as np
 
 from stardis_amd import _lib, ops
 from stardis_amd import constants as K
-from stardis_amd._lib import Continuum, default_context, plain
+from stardis_amd._lib import Continuum, LineListStruct, SynthesisOptions, default_context, plain
 from stardis_amd.radiation_field.opacities import Opacities
 from stardis_amd.radiation_field.opacities.opacities_solvers import base as B
 from stardis_amd.radiation_field.opacities.opacities_solvers.broadening import _microturbulence_cgs, _switches
 from stardis_amd.radiation_field.opacities.opacities_solvers.util import get_number_density, read_table, sigma_file_device
-from stardis_amd.radiation_field.radiation_field_solvers.base import _source_plane
+from stardis_amd.radiation_field.radiation_field_solvers.base import _source_plane, calculate_spherical_ray
 
 F8 = np.float64
 RAYLEIGH_CUTOFF = 2.3e15  # opacities_solvers/base.py:99
@@ -319,14 +325,101 @@ def _depth_vectors(stellar_plasma, opacity, file_source, rayleigh_species):
     return _memo("depth", tuple(objs), (file_source, ff_species, tuple(rayleigh_species)), build)
 
 
+def _fingerprint(a):
+    a = np.ascontiguousarray(a)
+    return (a.shape, hash(a.tobytes()))
+
+
+def _deferred_atomic(stellar_plasma, stellar_model, nus, cfg):
+    """The LineList calc_alpha_line_at_nu builds when the plasma carries no dense alpha table (base.py mirror, f1), kept per
+    set of plasma objects, grid range, model temperatures and broadening configuration."""
+    from stardis_amd.plasma.base import deferred_line_list
+
+    p, vald = stellar_plasma, cfg.vald_linelist
+    temps = np.asarray(plain(stellar_model.temperatures), dtype=F8)
+    return _memo("deferred_atomic", (p.lines_from_linelist, p.ion_number_density, p.partition_function, p.electron_densities,
+                                     stellar_model.composition.nuclide_masses),
+                 (float(nus.min()), float(nus.max()), tuple(cfg.broadening), bool(vald.use_vald_broadening), _fingerprint(temps),
+                  _microturbulence_cgs(stellar_model)),
+                 lambda: deferred_line_list(p.lines_from_linelist, nus, stellar_model, p, cfg.broadening, vald.use_vald_broadening))
+
+
+def _deferred_molecules(stellar_plasma, stellar_model, nus, cfg):
+    from stardis_amd.plasma.molecules import deferred_molecule_line_list
+
+    p = stellar_plasma
+    temps = np.asarray(plain(stellar_model.temperatures), dtype=F8)
+    return _memo("deferred_molecules", (p.molecule_lines_from_linelist, p.molecule_number_density, p.molecule_partition_function, p.molecule_ion_map,
+                                        stellar_model.composition.nuclide_masses),
+                 (float(nus.min()), float(nus.max()), tuple(cfg.broadening), _fingerprint(temps), _microturbulence_cgs(stellar_model)),
+                 lambda: deferred_molecule_line_list(p.molecule_lines_from_linelist, nus, stellar_model, p, cfg.broadening))
+
+
+def _sorted_molecule_tables(lines, alpha_table, ion_map, nuclide_masses):
+    """molecule_lines_from_linelist / molecule_alpha_line_from_linelist in the row order of `_in_grid`, as plain arrays, with
+    the summed mass of the two constituent nuclides (broadening.py:808-819)."""
+    nu_l = np.asarray(lines["nu"].to_numpy(), dtype=F8)
+    nu_a = np.asarray(alpha_table["nu"].to_numpy(), dtype=F8)
+    if np.isnan(nu_l).any() or np.isnan(nu_a).any():
+        return None
+    order_l, order_a = np.argsort(nu_l, kind="quicksort"), np.argsort(nu_a, kind="quicksort")
+    ions = ion_map.loc[lines["molecule"].to_numpy()[order_l]]
+    mass = nuclide_masses.loc[ions.Ion1].values + nuclide_masses.loc[ions.Ion2].values
+    alpha_cols = [c for c in alpha_table.columns if c != "nu"]
+    return dict(nu=nu_l[order_l], nu_alpha=nu_a[order_a], a_ul=np.ascontiguousarray(np.asarray(lines["A_ul"].to_numpy(), dtype=F8)[order_l]),
+                mass=np.asarray(mass, dtype=F8), alphas=np.ascontiguousarray(np.asarray(alpha_table[alpha_cols].to_numpy(), dtype=F8)[order_a]))
+
+
+def _molecule_arrays(stellar_plasma, stellar_model, nus):
+    p = stellar_plasma
+    lines, alpha_table = p.molecule_lines_from_linelist, p.molecule_alpha_line_from_linelist
+    masses = stellar_model.composition.nuclide_masses
+    tab = _memo("molecule_tables", (lines, alpha_table, p.molecule_ion_map, masses), None,
+                lambda: _sorted_molecule_tables(lines, alpha_table, p.molecule_ion_map, masses))
+    if tab is None:
+        return None
+    lo, hi = nus.min(), nus.max()
+    i0, i1 = np.searchsorted(tab["nu"], lo, "left"), np.searchsorted(tab["nu"], hi, "right")
+    j0, j1 = np.searchsorted(tab["nu_alpha"], lo, "left"), np.searchsorted(tab["nu_alpha"], hi, "right")
+    if i1 - i0 != j1 - j0:
+        return None
+    return dict(nu=tab["nu"][i0:i1], a_ul=tab["a_ul"][i0:i1], mass=tab["mass"][i0:i1], alphas=tab["alphas"][j0:j1])
+
+
+_LL_F8 = ("nu", "e_low_ev", "g_lo", "strength", "mass", "ionization_energy", "upper_energy", "lower_energy", "A_ul", "stark", "waals",
+          "temperature", "electron_density", "h_density")
+_LL_I4 = ("pop_row", "atomic_number", "ion_number")
+
+
+def _stage_linelist(spec, tag, add):
+    """Queue a LineList's arrays for the staging copy."""
+    for name in _LL_F8:
+        if getattr(spec, name) is not None:
+            add(f"{tag}_{name}", getattr(spec, name))
+    for name in _LL_I4:
+        if getattr(spec, name) is not None:
+            add(f"{tag}_{name}", getattr(spec, name), np.int32)
+    add(f"{tag}_pop", spec.pop)
+
+
+def _linelist_struct(spec, tag, P):
+    """struct sdx_linelist over the staged arrays (what linelist.DeviceLineList builds from separate uploads)."""
+    s = LineListStruct()
+    s.n_lines = spec.n_lines
+    for name in _LL_F8 + _LL_I4:
+        if getattr(spec, name) is not None:
+            setattr(s, name, P(f"{tag}_{name}"))
+    s.pop, s.n_pop_rows = P(f"{tag}_pop"), spec.pop.shape[0]
+    s.alpha_coefficient, s.microturbulence = spec.alpha_coefficient, spec.microturbulence
+    s.gamma_mode, s.broadening_flags = spec.gamma_mode, spec.flags
+    return s
+
+
 def try_fused(field_cls, tracing_nus, stellar_model, stellar_plasma, config, source_function):
     """-> RadiationField computed by one fused device pass, or None when the configuration needs the general path."""
     opacity = config.opacity
-    if getattr(stellar_model, "spherical", False):
-        return None
+    spherical = bool(getattr(stellar_model, "spherical", False))
     tracked = bool(config.result_options.return_radiation_field)
-    if opacity.line.include_molecules:
-        return None
     if int(config.no_of_thetas) > 64 or len(opacity.file) > 4:
         return None
     nus = np.ascontiguousarray(plain(tracing_nus), dtype=F8).reshape(-1)
@@ -348,16 +441,44 @@ def try_fused(field_cls, tracing_nus, stellar_model, stellar_plasma, config, sou
     bf = _bf_arrays(stellar_plasma, bf_species)
     if bf is None or bf[2].size > 4096:
         return None
-    line = None
+    line = line_spec = None
+    positive_temps = bool(np.all(np.asarray(plain(stellar_model.temperatures), dtype=F8) > 0))
     if not opacity.line.disable:
-        line = _line_arrays(stellar_plasma, stellar_model, nus, opacity.line)
-        if line is None:
-            return None
-        if line["nu"].size and np.any(np.diff(line["nu"]) < 0):
-            return None
-        # a zero Doppler width (nu = 0, or T = 0 without microturbulence) raises in the general path (voigt.py:148): leave it to it
-        if np.any(line["nu"] == 0) or np.any(line["mass"] <= 0) or not np.all(np.asarray(plain(stellar_model.temperatures), dtype=F8) > 0):
-            return None
+        if opacity.line.vald_linelist.use_linelist and getattr(stellar_plasma, "alpha_line_from_linelist", None) is None:
+            # no dense alpha table on the plasma: per-line scalars go up and the pre-pass generates alpha, gamma and the Doppler
+            # width (f1), as calc_alpha_line_at_nu does there (its LineList, its kernel)
+            try:
+                line_spec = _deferred_atomic(stellar_plasma, stellar_model, nus, opacity.line)
+            except (ZeroDivisionError, KeyError, AttributeError):
+                return None  # the general path raises what the reference raises
+            if line_spec.n_lines and (np.any(np.diff(line_spec.nu) < 0) or np.any(line_spec.nu == 0) or not positive_temps):
+                return None
+        else:
+            line = _line_arrays(stellar_plasma, stellar_model, nus, opacity.line)
+            if line is None:
+                return None
+            if line["nu"].size and np.any(np.diff(line["nu"]) < 0):
+                return None
+            # a zero Doppler width (nu = 0, or T = 0 without microturbulence) raises in the general path (voigt.py:148): leave it to it
+            if np.any(line["nu"] == 0) or np.any(line["mass"] <= 0) or not positive_temps:
+                return None
+    # molecular lines (:716-736): a second list, its plane added after the atomic one
+    mol = mol_spec = None
+    molecules = bool(opacity.line.include_molecules) and not opacity.line.disable
+    if molecules:
+        if getattr(stellar_plasma, "molecule_alpha_line_from_linelist", None) is None:
+            try:
+                mol_spec = _deferred_molecules(stellar_plasma, stellar_model, nus, opacity.line)
+            except (ZeroDivisionError, KeyError, AttributeError):
+                return None
+            if mol_spec.n_lines and (np.any(np.diff(mol_spec.nu) < 0) or np.any(mol_spec.nu == 0) or not positive_temps):
+                return None
+        else:
+            mol = _molecule_arrays(stellar_plasma, stellar_model, nus)
+            if mol is None or (mol["nu"].size and (np.any(np.diff(mol["nu"]) < 0) or np.any(mol["nu"] == 0) or np.any(mol["mass"] <= 0) or not positive_temps)):
+                return None
+            if mol["alphas"].shape != (mol["nu"].size, nd):
+                return None
     ctx = default_context()
     temps = np.ascontiguousarray(plain(stellar_model.temperatures), dtype=F8).reshape(-1)
     file_source = tables[0][0] if table is not None else None
@@ -380,10 +501,17 @@ def try_fused(field_cls, tracing_nus, stellar_model, stellar_plasma, config, sou
         slot[name] = len(host)
         host.append(np.ascontiguousarray(a, dtype=dt).reshape(-1))
 
-    dist = np.asarray(plain(stellar_model.geometry.dist_to_next_depth_point), dtype=F8)
+    correction = 1.0
+    if spherical:  # radiation_field_solvers/base.py:296-300, :340-344
+        radii = np.asarray(plain(stellar_model.geometry.r), dtype=F8)
+        ray_table = calculate_spherical_ray(field.thetas, radii)
+        correction = (radii[-1] / float(plain(stellar_model.geometry.reference_r))) ** 2
+    else:
+        dist = np.asarray(plain(stellar_model.geometry.dist_to_next_depth_point), dtype=F8)
+        ray_table = dist.reshape(-1, 1) / np.cos(field.thetas)  # :302-305
     add("nus", nus)
     add("temps", temps)
-    add("ray", dist.reshape(-1, 1) / np.cos(field.thetas))  # radiation_field_solvers/base.py:302-305
+    add("ray", ray_table)
     add("wts", field.I_nus_weights)
     add("lambdas", K.nu_to_angstrom(nus))
     if table is not None:
@@ -411,6 +539,21 @@ def try_fused(field_cls, tracing_nus, stellar_model, stellar_plasma, config, sou
         add("b_ne", n_e), add("b_nh", n_h)
         if n_lines and np.any(line["alphas"].shape != (n_lines, nd)):
             return None
+    elif line_spec is not None:
+        n_lines = line_spec.n_lines
+        if n_lines:
+            _stage_linelist(line_spec, "ls", add)
+    n_mol = 0
+    if mol is not None:
+        n_mol = mol["nu"].size
+        add("m_nu", mol["nu"]), add("m_alpha", mol["alphas"]), add("m_mass", mol["mass"])
+        radiation = "radiation" in opacity.line.broadening
+        # gamma = A_ul as one column, or — without "radiation" — the reference's (N_l, N_d) zeros (broadening.py:799-806)
+        add("m_gamma", mol["a_ul"] if radiation else np.zeros((n_mol, nd)))
+    elif mol_spec is not None:
+        n_mol = mol_spec.n_lines
+        if n_mol:
+            _stage_linelist(mol_spec, "ms", add)
     # a source function other than the Planck function is evaluated on the host, the way the reference calls it (:133), and goes up
     # with everything else
     try:
@@ -451,7 +594,7 @@ def try_fused(field_cls, tracing_nus, stellar_model, stellar_plasma, config, sou
     c.electron_density = P("n_e")
 
     d_gamma = d_doppler = None
-    if n_lines:
+    if n_lines and line is not None:
         lin, quad, vdw, rad = _switches(opacity.line.broadening)
         flags = (1 if lin else 0) | (2 if quad else 0) | (4 if vdw else 0) | (8 if rad else 0)
         d_gamma, d_doppler = ctx.empty((n_lines, nd)), ctx.empty((n_lines, nd))
@@ -461,14 +604,39 @@ def try_fused(field_cls, tracing_nus, stellar_model, stellar_plasma, config, sou
         else:  # broadening.py:550-656 with the argument preparation of :706-721
             ctx.call("sdx_calc_gamma_dev", *common, P("b_ne"), P("temps"), P("b_nh"), flags, d_gamma.ptr)
         ctx.call("sdx_doppler_widths_dev", n_lines, nd, P("l_nu"), P("l_mass"), P("temps"), _microturbulence_cgs(stellar_model), d_doppler.ptr)
+    # the molecular plane first (the line workspace of the context is the step's afterwards): the calls the general path makes
+    d_mol = d_mol_doppler = mol_struct = None
+    if n_mol:
+        d_mol = ctx.empty((nd, nus.size))
+        if mol is not None:
+            d_mol_doppler = ctx.empty((n_mol, nd))
+            ctx.call("sdx_doppler_widths_dev", n_mol, nd, P("m_nu"), P("m_mass"), P("temps"), _microturbulence_cgs(stellar_model), d_mol_doppler.ptr)
+            ctx.call("sdx_line_opacity_dev", nd, nus.size, P("nus"), 0, nus.size, n_mol, P("m_nu"), d_mol_doppler.ptr, P("m_gamma"),
+                     1 if "radiation" in opacity.line.broadening else nd, P("m_alpha"), d_mol.ptr, nus.size, 0, None)
+        else:
+            mol_struct = _linelist_struct(mol_spec, "ms", P)
+            ctx.call("sdx_line_opacity_linelist_dev", nd, nus.size, P("nus"), 0, nus.size, C.byref(mol_struct), d_mol.ptr, nus.size, 0, None)
     d_F, d_total = ctx.empty((nd, nus.size)), ctx.empty((nd, nus.size))
     d_line = ctx.empty((nd, nus.size)) if n_lines else None
-    step = (nd, nus.size, P("nus"), 0, nus.size, n_lines, P("l_nu"), d_doppler.ptr if n_lines else None, d_gamma.ptr if n_lines else None, nd,
+    dense = line is not None and n_lines
+    step = (nd, nus.size, P("nus"), 0, nus.size, n_lines if dense else 0, P("l_nu"), d_doppler.ptr if dense else None, d_gamma.ptr if dense else None, nd,
             P("l_alpha"), C.byref(c), int(config.no_of_thetas), P("temps"), P("ray"), P("wts"), d_line.ptr if n_lines else None, d_total.ptr,
             d_F.ptr, nus.size)
-    if tracked or source is not None:
-        if tracked:  # every ray's intensity at every depth point stays on the device until somebody reads field.I_nus
-            field._I_dev = ctx.empty((nd, nus.size, int(config.no_of_thetas)))
+    if tracked:  # every ray's intensity at every depth point stays on the device until somebody reads field.I_nus
+        field._I_dev = ctx.empty((nd, nus.size, int(config.no_of_thetas)))
+    line_struct = None
+    if spherical or n_mol or (line_spec is not None and n_lines):
+        opt = SynthesisOptions()
+        opt.source, opt.source_ld = P("source"), nus.size
+        opt.I_nus = field._I_dev.ptr if tracked else None
+        opt.inward_rays, opt.photospheric_correction = (1 if spherical else 0), float(correction)
+        if n_mol:
+            opt.n_line_planes, opt.line_plane[0], opt.line_plane_ld = 1, d_mol.ptr, nus.size
+        if line_spec is not None and n_lines:
+            line_struct = _linelist_struct(line_spec, "ls", P)
+            opt.linelist = C.pointer(line_struct)
+        ctx.call("sdx_synthesize_opt_dev", *step, C.byref(opt), None)
+    elif tracked or source is not None:
         ctx.call("sdx_synthesize_ex_dev", *step, P("source"), nus.size, field._I_dev.ptr if tracked else None, None)
     else:
         ctx.call("sdx_synthesize_dev", *step, None)
@@ -511,8 +679,25 @@ def try_fused(field_cls, tracing_nus, stellar_model, stellar_plasma, config, sou
     put("alpha_rayleigh", remembered("alpha_rayleigh", lambda: B.calc_alpha_rayleigh(stellar_plasma, stellar_model, fnus, opacity.rayleigh)))
     put("alpha_electron", 0 if opacity.disable_electron_scattering else remembered(
         "alpha_electron", lambda: B.calc_alpha_electron(stellar_plasma, stellar_model, fnus, False)))
+    def tables_of(spec):
+        """gammas / doppler_widths of a deferred list, formed the way the general path forms them (sdx_line_params_dev) on
+        first read of either entry."""
+        cache = {}
+
+        def get(k):
+            if not cache:
+                from stardis_amd import linelist as LL
+
+                _, cache["g"], cache["d"] = LL.line_params(spec, ctx, alphas=False) if B.RETURN_BROADENING_TABLES else (None, None, None)
+            return cache[k]
+        return _Thunk(lambda: get("g")), _Thunk(lambda: get("d"))
+
     if opacity.line.disable:
         put("alpha_line_at_nu", 0), put("alpha_line_at_nu_gammas", 0), put("alpha_line_at_nu_doppler_widths", 0)
+    elif line_spec is not None:
+        put("alpha_line_at_nu", twin(d_line) if n_lines else np.zeros((nd, nus.size)))
+        g_thunk, d_thunk = tables_of(line_spec)
+        put("alpha_line_at_nu_gammas", g_thunk), put("alpha_line_at_nu_doppler_widths", d_thunk)
     elif n_lines:
         put("alpha_line_at_nu", twin(d_line))
         put("alpha_line_at_nu_gammas", _Thunk(d_gamma.numpy))
@@ -520,4 +705,17 @@ def try_fused(field_cls, tracing_nus, stellar_model, stellar_plasma, config, sou
     else:  # no line on the grid: what the general path returns for an empty selection
         put("alpha_line_at_nu", np.zeros((nd, nus.size)))
         put("alpha_line_at_nu_gammas", np.zeros((0, nd))), put("alpha_line_at_nu_doppler_widths", np.zeros((0, nd)))
+    if opacity.line.include_molecules:  # (:716-736)
+        if opacity.line.disable:
+            put("molecule_alpha_line_at_nu", 0), put("molecule_alpha_line_at_nu_gammas", 0), put("molecule_alpha_line_at_nu_doppler_widths", 0)
+        elif mol_spec is not None:
+            put("molecule_alpha_line_at_nu", twin(d_mol) if n_mol else np.zeros((nd, nus.size)))
+            g_thunk, d_thunk = tables_of(mol_spec)
+            put("molecule_alpha_line_at_nu_gammas", g_thunk), put("molecule_alpha_line_at_nu_doppler_widths", d_thunk)
+        else:
+            radiation = "radiation" in opacity.line.broadening
+            put("molecule_alpha_line_at_nu", twin(d_mol) if n_mol else np.zeros((nd, nus.size)))
+            a_ul = mol["a_ul"]
+            put("molecule_alpha_line_at_nu_gammas", a_ul[:, np.newaxis].copy() if radiation else np.zeros((n_mol, nd)))
+            put("molecule_alpha_line_at_nu_doppler_widths", _Thunk(d_mol_doppler.numpy) if n_mol else np.zeros((0, nd)))
     return field

@@ -49,6 +49,15 @@ def test_linelist_struct_matches_header():
     assert fields == [f[0] for f in _lib.LineListStruct._fields_]
 
 
+def test_synthesis_options_struct_matches_header():
+    text = open(HEADER).read()
+    body = re.search(r"typedef struct sdx_synthesis_options \{(.*?)\} sdx_synthesis_options;", text, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = re.findall(r"\b([A-Za-z_0-9]+)(?:\[\d+\])?\s*;", body)
+    assert fields == [f[0] for f in _lib.SynthesisOptions._fields_]
+    assert _lib.SynthesisOptions.line_plane.size == 2 * 8 and "line_plane[2]" in body
+
+
 def test_library_reports_no_device_and_product_raises():
     lib = _lib.load()
     assert lib.sdx_version().startswith(b"stardis_hip")

@@ -147,7 +147,7 @@ def test_species_keys_with_the_stage_in_digits(ctx, tmp_path):
     assert rel_err(B.calc_alpha_bf(plasma, model, nus, {"H_1": {}}), g["od_alpha_bf"]) < 1e-13
     assert rel_err(B.calc_alpha_ff(plasma, model, nus, {"H_1": {}}), g["od_alpha_ff"]) < 1e-13
     cfg.bf, cfg.ff = {"H_1": {}}, {"H_1": {}}
-    cfg.no_of_thetas, cfg.result_options = 6, NS(return_radiation_field=False)
-    field = RB.create_stellar_radiation_field(nus, model, plasma, cfg)
+    config = NS(opacity=cfg, no_of_thetas=6, result_options=NS(return_radiation_field=False))
+    field = RB.create_stellar_radiation_field(nus, model, plasma, config)
     assert rel_err(field.F_nu, g["F_nu"]) < 1e-10
     assert rel_err(field.opacities.opacities_dict["alpha_bf"], g["od_alpha_bf"]) < 1e-13

@@ -101,7 +101,7 @@ print("IDENTICAL")
 def test_sharding_logic_with_several_ranks_on_one_device():
     """2 and 3 ranks on device 0 through the loop-back test hook (SDX_GROUP_LOOPBACK=1): shards of a short and of a long line
     list (culled pre-pass), equal and balanced, padded shards — the assembled result is the single-GPU one bit for bit."""
-    env = dict(os.environ, SDX_GROUP_LOOPBACK="1")
+    env = dict(os.environ, SDX_EXPERIMENT="1", SDX_GROUP_LOOPBACK="1")
     proc = subprocess.run([sys.executable, "-c", _LOOPBACK.format(root=ROOT)], env=env, capture_output=True, text=True, timeout=900)
     assert proc.returncode == 0 and "IDENTICAL" in proc.stdout, proc.stdout[-2000:] + proc.stderr[-3000:]
 

@@ -187,8 +187,8 @@ def test_fused_path_declines_what_it_does_not_cover(ctx, monkeypatch, tmp_path):
     assert np.array_equal(field.I_nus, rf.create_stellar_radiation_field(g["nus"].copy(), model, plasma, config).I_nus)
     monkeypatch.setattr(rf, "FUSED", True)
     config.result_options.return_radiation_field = False
-    model.spherical = True
-    assert fused.try_fused(*args) is None
+    model.spherical, model.geometry.reference_r = True, 0.97 * model.geometry.r[-1]  # spherical models: covered (tests/test_gpu_round4.py)
+    assert fused.try_fused(*args) is not None
     model.spherical = False
     # a source function other than the Planck function: evaluated on the host as the reference calls it (:133), covered
     def grey(nu, t):
