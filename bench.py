@@ -18,7 +18,7 @@ rank's shard and kernel times.  (--workload / --scaling override both, e.g. --wo
 
 Besides `value` the JSON line carries
   roofline              HBM roofline of the dominant kernel (live HIP-event durations), traffic from profiles/
-  roofline_fp64_valu    the bound that really limits the path, against BOTH the spec issue rate and the measured ceiling
+  roofline_fp64_valu    the bound that really limits the path: wave-level fp64 instructions per second against the spec issue rate
   cpu_baseline          the oracle (reference algorithm restated in C) on this box's host cores: one_core / best / all_cores
   secondary             BASELINE configs[2] and [3] at full size (S-c3: 1.5e5 lines, S-c4m: 1e6 lines): step time, per-kernel
                         times, Voigt evaluations/s, strided-column parity against the oracle
@@ -41,10 +41,10 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 FP64_VECTOR_PEAK_TFLOPS = 78.6
-# wave-level fp64 VALU instructions per second: spec = 256 CU x 4 SIMD x 2.4 GHz / 4 cycles per wave64 fp64 instruction;
-# measured = what scripts/fp64_peak.hip sustains on this part (55 TFLOP/s of FMA at 8 waves per SIMD)
+# wave-level fp64 VALU instructions per second: 256 CU x 4 SIMD x 2.4 GHz / 4 cycles per wave64 fp64 instruction — the ONE
+# ceiling the VALU fractions are quoted against.  (Round 3 also quoted a "measured" 439 G/s from a pure-FMA loop; the line
+# kernels beat it — the part clocks higher under their instruction mix — so it was not a ceiling of anything and is gone.)
 FP64_VALU_SPEC = 256 * 4 * 2.4e9 / 4
-FP64_VALU_MEASURED = 439.0e9
 KERNELS = ("k_dnu_partial", "k_classify", "k_prepass_continuum", "k_line_prepass", "k_hlist", "k_gather", "k_line_all", "k_line_wide",
            "k_line_narrow", "k_reduce_partials", "k_total_alphas", "k_raytrace")
 
@@ -241,6 +241,11 @@ def secondary_block(tag, device, steps, check):
     valu = profiled_valu(tag, kern)
     if valu is not None:
         out["roofline_fp64_valu"] = valu
+    n_l, g_cols = syn.n_lines, syn.gamma_cols
+    traffic = traffic_table(tag, kern, {"k_line_all": 8 * (n_l * (1 + 2 * nd + g_cols) + nus.size + nd * nus.size), "k_raytrace": 16 * nd * nus.size,
+                                        "step": syn.algorithmic_bytes()})
+    if traffic is not None:
+        out["hbm_traffic"] = traffic
     syn.close()
     ctx.close()
     return out
@@ -294,6 +299,44 @@ def dropin_block(device, check):
             entry["oracle_threads"] = oracle.num_threads()
             entry["emergent_flux_max_rel_err_vs_oracle"] = float(np.max(np.abs(field.F_nu[-1] - F_cpu[-1]) / np.abs(F_cpu[-1])))
         out[label] = entry
+    # the configurations the fused call declined until round 4 — a molecular list next to the atomic one (include_molecules),
+    # a spherical model, a line list without a dense alpha table (per-line scalars, f1) — at S-c2 size, fused against general
+    cfg = synth.WORKLOADS["S-c2"]
+    atm = synth.solar_atmosphere()
+    nus = synth.tracing_grid(cfg["lam0"], cfg["lam1"], cfg.get("R"), cfg.get("step"))
+
+    def variant(name):
+        plasma, model, config, _ = synth.fake_plasma(nus, atm, 2000, synth.SEED, n_molecule_lines=2000 if "molecules" in name else 0)
+        if "molecules" in name:
+            config.opacity.line.include_molecules = True
+        if "spherical" in name:
+            r = 6.96e10 + np.asarray(model.geometry.r, dtype=np.float64) - float(model.geometry.r[0])
+            model.spherical, model.geometry.r, model.geometry.reference_r = True, r, float(r[-8])
+        if "linelist" in name:
+            plasma.alpha_line_from_linelist = None
+            if "molecules" in name:
+                plasma.molecule_alpha_line_from_linelist = None
+        return plasma, model, config
+
+    for name in ("S-c2 + molecules", "S-c2 spherical", "S-c2 linelist inputs (f1)", "S-c2 spherical + molecules + linelist inputs"):
+        plasma, model, config = variant(name)
+        res = {}
+        for fused_on, n in ((True, 10), (False, 4)):
+            was = rf.FUSED
+            rf.FUSED = fused_on
+            try:
+                times = []
+                for _ in range(n):
+                    t0 = time.perf_counter()
+                    field = rf.create_stellar_radiation_field(nus.copy(), model, plasma, config)
+                    times.append(time.perf_counter() - t0)
+            finally:
+                rf.FUSED = was
+            res[fused_on] = (times, field)
+        (t_f, f_f), (t_g, f_g) = res[True], res[False]
+        out[name] = {"n_nu": int(nus.size), "first_call_ms": t_f[0] * 1e3, "steady_ms": min(t_f[1:]) * 1e3, "path": type(f_f.opacities).__name__,
+                     "general_path_ms": min(t_g[1:]) * 1e3, "fused_equals_general_bit_for_bit": bool(np.array_equal(f_f.F_nu, f_g.F_nu)),
+                     "dictionary_keys": list(f_f.opacities.opacities_dict.keys())[-3:]}
     return out
 
 
@@ -318,6 +361,47 @@ def profiled_traffic(workload, kernel):
             return None
         total += sum(vals) / len(vals) * 1024.0
     return total
+
+
+def traffic_table(workload, kern, alg_bytes):
+    """Per kernel of a step: counted HBM traffic per launch (committed FETCH_SIZE + WRITE_SIZE passes) and — for the kernels
+    SURVEY §8d gives an algorithmic figure for — its ratio to the algorithmic bytes; plus the whole step."""
+    out, total = {}, 0.0
+    for name in kern:
+        t = profiled_traffic(workload, name)
+        if t is None:
+            continue
+        total += t
+        out[name] = {"traffic_bytes": t}
+        if name in alg_bytes:
+            out[name]["algorithmic_bytes"] = int(alg_bytes[name])
+            out[name]["traffic_over_algorithmic"] = t / alg_bytes[name]
+    if out and "step" in alg_bytes:
+        out["whole_step"] = {"traffic_bytes": total, "algorithmic_bytes": int(alg_bytes["step"]), "traffic_over_algorithmic": total / alg_bytes["step"]}
+    return out or None
+
+
+def measured_copy_bandwidth(device, gib=1.0, reps=5):
+    """What this box's HBM sustains on a plain device-to-device copy (read + write counted), GB/s: the achievable ceiling
+    SURVEY §8d asks for beside the 8 TB/s of the data sheet (the guide's own figure for the part is ~6.3 TB/s)."""
+    import torch
+
+    n = int(gib * (1 << 30)) // 8
+    a = torch.empty(n, dtype=torch.float64, device=f"cuda:{device}").normal_()
+    b = torch.empty_like(a)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    best = 0.0
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        best = max(best, 2.0 * n * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    del a, b
+    torch.cuda.empty_cache()
+    return best
 
 
 def kernel_matches(short, full):
@@ -347,16 +431,15 @@ def profiled_valu(workload, kern):
         insts += n_inst
         t_ms += ms
         per_kernel[name] = {"valu_wave_instr": n_inst, "ms": ms, "G_wave_instr_per_s": n_inst / (ms * 1e-3) / 1e9,
-                            "frac_of_spec": n_inst / (ms * 1e-3) / FP64_VALU_SPEC, "frac_of_measured": n_inst / (ms * 1e-3) / FP64_VALU_MEASURED}
+                            "frac_of_spec": n_inst / (ms * 1e-3) / FP64_VALU_SPEC}
     extra = [k for k in by_kernel if not any(kernel_matches(n, k) for n in kern)]
     if extra:
         return {"skipped": f"profiles/{os.path.basename(path)} holds kernels this run did not launch ({sorted(extra)[:2]}): re-profile"}
     achieved = insts / (t_ms * 1e-3)
     return {"bound": "fp64-valu-issue", "achieved": achieved / 1e9, "unit": "G wave-instr/s",
             "peak_spec": FP64_VALU_SPEC / 1e9, "frac_of_spec": achieved / FP64_VALU_SPEC,
-            "peak_measured": FP64_VALU_MEASURED / 1e9, "frac_of_measured": achieved / FP64_VALU_MEASURED,
             "valu_wave_instr_per_step": insts, "kernel_ms_per_step": t_ms, "per_kernel": per_kernel, "source": os.path.basename(path),
-            "note": "peak_spec = 256 CU x 4 SIMD x 2.4 GHz / 4 cycles per wave64 fp64 instruction; peak_measured = scripts/fp64_peak.hip on this part"}
+            "note": "peak_spec = 256 CU x 4 SIMD x 2.4 GHz / 4 cycles per wave64 fp64 instruction"}
 
 
 # ------------------------------------------------------------------------------------------------ timed region
@@ -720,6 +803,8 @@ def main():
             "k_raytrace": 16 * nd * count,
         }.get(dom, syn.algorithmic_bytes())
         achieved = alg_bytes / (kern[dom] * 1e-3) / 1e9
+        copy_gbps = measured_copy_bandwidth(local) if world == 1 else None
+        dom_traffic = profiled_traffic(args.workload, dom) if world == 1 else None
         line_ms = kern.get("k_line_all", 0.0) + kern.get("k_line_wide", 0.0) + kern.get("k_line_narrow", 0.0)
         scaling_text = {"weak": "weak (fixed points per GPU: N x the resolving power on the same window)",
                         "strong": "strong (BASELINE's fixed grid split N ways in shards of equal estimated work)"}[args.scaling]
@@ -760,12 +845,18 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": profiled_traffic(args.workload, dom) if world == 1 else None,
+                "peak_measured_copy": copy_gbps,
+                "frac_of_measured_copy": (achieved / copy_gbps) if copy_gbps else None,
+                "traffic": dom_traffic,
+                "traffic_over_algorithmic": (dom_traffic / alg_bytes) if dom_traffic else None,
                 "algorithmic_bytes_per_launch": int(alg_bytes),
                 "avg_kernel_ms": kern,
                 "whole_step": {"algorithmic_bytes": int(syn.algorithmic_bytes()), "achieved": syn.algorithmic_bytes() / (ms_per_step * 1e-3) / 1e9,
                                "frac": syn.algorithmic_bytes() / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS},
-                "note": "path is fp64-VALU bound (Faddeeva evaluations), not HBM bound: see DESIGN.md and roofline_fp64_valu",
+                "per_kernel_traffic": traffic_table(args.workload, kern, {"k_line_all": 8 * (n_l * (1 + 2 * nd + g_cols) + nus.size + nd * count),
+                                                                            "k_raytrace": 16 * nd * count, "step": syn.algorithmic_bytes()}) if world == 1 else None,
+                "note": "path is fp64-VALU bound (Faddeeva evaluations), not HBM bound: see DESIGN.md and roofline_fp64_valu; peak = the data sheet's 8 TB/s, "
+                        "peak_measured_copy = a device-to-device copy timed in this run (read + write)",
                 "voigt_evaluations_per_s": (evals / world) / (line_ms * 1e-3) if line_ms else None,
             },
         }
@@ -776,6 +867,9 @@ def main():
             if n1 is not None:
                 out["n1_same_workload"] = n1
                 out["speedup_vs_n1"] = n1["ms_per_step"] / ms_per_step
+                # the denominator a driver needs for scaling efficiency: `value` at N = 1 is a DIFFERENT workload (S-c2, the 1-GPU
+                # config); this is the N = 1 value of THIS line's workload, measured in this run
+                out["value_n1_same_workload"] = n1["value"]
         valu = profiled_valu(args.workload, kern) if world == 1 else None
         if valu is not None:
             out["roofline_fp64_valu"] = valu

@@ -93,11 +93,7 @@ int sdx_synchronize(sdx_ctx* ctx);
  *       a fixed constant (grids under 3 x 4 x 256 k_raytrace waves take the segmented kernel) — never from the shard's own
  *       width or the device's CU count, so that a frequency shard and the unsharded grid run the same arithmetic and stay
  *       bit-identical; 0: never the segmented kernel; 1: whenever it supports the shape.  The fp32-mixed twins (*_f32mix) that
- *       SURVEY §8b proposed are this library's "mixed_precision" option instead: one set of entry points, two modes.
- *   "wide_hot_depths" (default -1): how many of the first (deepest, hottest) depth points have their wide-window line sums split
- *       over twice the line subsets (two workgroups per (depth, 256-point tile)).  -1: n_depth / 4 — a function of the depth
- *       count only, so that frequency shards and the unsharded grid add every point's terms in the same order; 0: none.
- *       Changes the last bits of the line opacity (the order of summation), nothing else: set it identically on every rank. */
+ *       SURVEY §8b proposed are this library's "mixed_precision" option instead: one set of entry points, two modes. */
 int sdx_set_int_option(sdx_ctx* ctx, const char* name, int64_t value);
 
 /* device memory for callers that do not bring their own (numpy-only users) */
@@ -393,6 +389,9 @@ sdx_ctx* sdx_group_context(sdx_group* group, int rank); /* the rank's context (o
 /* what the last sharded call's collective was: ranks in the communicator, bytes each rank contributed, RCCL's version code
  * (0 in loop-back mode) */
 int sdx_group_last_gather(const sdx_group* group, int* ranks, int64_t* bytes_per_rank, int* rccl_version);
+/* n_evaluations (optional): the number of Voigt evaluations of the whole synthesis — a global figure, counted by the first rank
+ * that owns columns.  Counting needs every window of every line, so that rank runs the full (unculled) pre-pass and becomes the
+ * straggler of the group: a diagnostic, pass NULL in timed loops. */
 int sdx_synthesize_sharded_f64(sdx_group* group, int n_depth, int64_t n_nu, const double* nus, int64_t n_lines,
                                const double* line_nus, const double* doppler_widths, const double* gammas, int gamma_cols,
                                const double* alphas, const sdx_continuum* cont, int n_theta, const double* temperature,

@@ -17,17 +17,24 @@ work = parallel.column_cost(nus, ln, **{k: float(os.environ[e]) for k, e in (("s
 KERNELS = ("k_dnu_partial", "k_classify", "k_prepass_continuum", "k_line_prepass", "k_hlist", "k_gather", "k_line_all", "k_line_wide", "k_line_narrow", "k_raytrace")
 
 
-def rank_time(world, rank, reps=8):
+def rank_time(world, rank, reps=20):
     shard = parallel.balanced_shards(work, world)[rank] if balanced else shard_bounds(nus.size, world, rank)
     syn = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], w["thetas"], w["weights"], w["lines"], w["cont"], shard=shard,
                               track_evaluations=False, keep_line=False)
     ctx = syn.ctx
     syn.capture()
+    # steady state, like bench.py's timed loop: ~0.2 s of untimed replays (clocks settle), then the best of five blocks of replays
     syn.step(); syn.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps): syn.step()
-    syn.synchronize()
-    t = (time.perf_counter() - t0) / reps
+    t_end = time.perf_counter() + 0.2
+    while time.perf_counter() < t_end:
+        for _ in range(reps): syn.step()
+        syn.synchronize()
+    t = 1e9
+    for _ in range(5):
+        t0 = time.perf_counter()
+        for _ in range(reps): syn.step()
+        syn.synchronize()
+        t = min(t, (time.perf_counter() - t0) / reps)
     ctx.call("sdx_profile_enable", 1); ctx.call("sdx_profile_reset")
     for _ in range(3): syn.enqueue()
     ctx.synchronize()

@@ -541,6 +541,8 @@ __global__ __launch_bounds__(kPreBlock) __attribute__((amdgpu_num_sgpr(80))) voi
                                                          int* __restrict__ out_lo_ref, int* __restrict__ out_hi_ref,
                                                          int n_line_blocks, LineParams lp)
 {
+    // (dispatching the pixel and gather blocks of a culled shard BEFORE its line blocks — a rotated grid — was measured in round 4:
+    // 47 against 44 us for this launch on an eighth of S-c3; the order stays [line | pixel | gather])
     prepass_block<GEN, LINES>(blockIdx.x, blockIdx.y, gridDim.y, n_depth, n_nu, nus, dnu_partial, n_partial, n_lines, line_nus, doppler, gammas,
                        gamma_cols, alphas, w, out_lo_ref, out_hi_ref, n_line_blocks, lp);
 }
@@ -620,13 +622,10 @@ __device__ __forceinline__ float2v region1_f32x2(float2v acc, float2v nuh, float
 }
 
 template <int R, bool MIXED>
-__device__ __forceinline__ void line_wide_walk(const int tile_idx, const int split, const int n_split, const int wave, const int n_waves,
-                                               const int d, int64_t n_nu,
+__device__ __forceinline__ void line_wide_walk(const int tile_idx, const int split, const int n_split, const int d, int64_t n_nu,
                                                const double* __restrict__ nus, int64_t nu_begin, int64_t nu_count, int64_t n_lines,
                                                LineWork w, double* __restrict__ plane, int64_t pld, double* __restrict__ lds_all)
 {
-    // split of n_split: the line SUBSET this wave walks (chunk q of 64 candidates belongs to subset q mod n_split);
-    // wave of n_waves: its place in the workgroup, whose waves' sums meet in LDS and are added in wave order
     constexpr int kTile = 64 * R;
     // GLOBAL tiles: tile boundaries are multiples of kTile from grid index 0 whatever the shard, and a tile cut by a shard
     // boundary is classified and evaluated whole (only the stores are masked).  How a (line, depth, tile) is treated — test-free,
@@ -835,7 +834,7 @@ __device__ __forceinline__ void line_wide_walk(const int tile_idx, const int spl
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] += (double)acc32[r >> 1][r & 1];
     }
-    wide_reduce_and_store<R>(wave, n_waves, acc, idx0, s0, s1, lds_all, plane, pld, d);
+    wide_reduce_and_store<R>(split, n_split, acc, idx0, s0, s1, lds_all, plane, pld, d);
 }
 
 // Long line lists: two stable compactions of the per-line classes in two small launches (per-block counts, then every
@@ -853,12 +852,33 @@ __device__ __forceinline__ bool in_xlist(int64_t l, int cls, const int* __restri
     return l >= sel[0] && l < sel[1] && !(sel[3] > sel[2] && l >= ra && l < rb);
 }
 
-__global__ __launch_bounds__(kHlistBlock) void k_hlist_count(int64_t n_lines, const int* __restrict__ whw_max, int* __restrict__ block_cnt,
+// the window half-width of the largest (gamma + dw) alpha of a line (:561-575; NaN or negative: the 10-point floor)
+__device__ __forceinline__ int half_width_of(double m, double d_nu, int64_t n_nu)
+{
+    const double pixels = mul_rn(m / d_nu, 20.0);
+    const double forced = pixels > 10.0 ? pixels : 10.0;
+    return (int)(forced >= (double)n_nu ? n_nu : (int64_t)forced);
+}
+// (culled runs: the class comes from the classification pass's largest (gamma + dw) alpha per line and the grid spacing)
+struct ClassSource {
+    const int* whw_max;       // per line, from a full pre-pass; or nullptr:
+    const double* m_max;      // per line, from k_classify
+    const double* dnu_partial;
+    int n_partial;
+    int64_t n_nu;
+};
+__device__ __forceinline__ int class_of_line(const ClassSource& cs, int64_t l, double d_nu)
+{
+    return line_class(cs.whw_max ? cs.whw_max[l] : half_width_of(cs.m_max[l], d_nu, cs.n_nu));
+}
+__global__ __launch_bounds__(kHlistBlock) void k_hlist_count(int64_t n_lines, ClassSource cs, int* __restrict__ block_cnt,
                                                             const int* __restrict__ sel, int pre_lines)
 {
     __shared__ int s_wave[3][kHlistBlock / 64];
+    __shared__ double s_dnu[kHlistBlock / 64];
+    const double d_nu = cs.whw_max ? 0.0 : block_dnu(cs.dnu_partial, cs.n_partial, s_dnu);
     const int64_t l = (int64_t)blockIdx.x * kHlistBlock + threadIdx.x;
-    const int cls = l < n_lines ? line_class(whw_max[l]) : 0;
+    const int cls = l < n_lines ? class_of_line(cs, l, d_nu) : 0;
     const unsigned long long mh = __ballot(cls == 2), mw = __ballot(cls == 1), mx = __ballot(in_xlist(l, cls, sel, pre_lines));
     if ((threadIdx.x & 63) == 0)
         s_wave[0][threadIdx.x >> 6] = __popcll(mh), s_wave[1][threadIdx.x >> 6] = __popcll(mw), s_wave[2][threadIdx.x >> 6] = __popcll(mx);
@@ -869,19 +889,21 @@ __global__ __launch_bounds__(kHlistBlock) void k_hlist_count(int64_t n_lines, co
         block_cnt[3 * blockIdx.x + threadIdx.x] = tot;
     }
 }
-__global__ __launch_bounds__(kHlistBlock) void k_hlist_scatter(int64_t n_lines, const int* __restrict__ whw_max, const int* __restrict__ block_cnt,
+__global__ __launch_bounds__(kHlistBlock) void k_hlist_scatter(int64_t n_lines, ClassSource cs, const int* __restrict__ block_cnt,
                                                               int* __restrict__ hlist, int* __restrict__ wlist, int* __restrict__ wrank,
                                                               int* __restrict__ hcount, int* __restrict__ xlist, const int* __restrict__ sel,
                                                               int pre_lines)
 {
     __shared__ int s_wave[3][kHlistBlock / 64];
     __shared__ int s_red[3][kHlistBlock / 64];
+    __shared__ double s_dnu[kHlistBlock / 64];
+    const double d_nu = cs.whw_max ? 0.0 : block_dnu(cs.dnu_partial, cs.n_partial, s_dnu);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int bh = 0, bw = 0, bx = 0;
     for (int k = threadIdx.x; k < (int)blockIdx.x; k += kHlistBlock) bh += block_cnt[3 * k], bw += block_cnt[3 * k + 1], bx += block_cnt[3 * k + 2];
     for (int off = 32; off > 0; off >>= 1) bh += __shfl_xor(bh, off), bw += __shfl_xor(bw, off), bx += __shfl_xor(bx, off);
     const int64_t l = (int64_t)blockIdx.x * kHlistBlock + threadIdx.x;
-    const int cls = l < n_lines ? line_class(whw_max[l]) : 0;
+    const int cls = l < n_lines ? class_of_line(cs, l, d_nu) : 0;
     const bool isx = in_xlist(l, cls, sel, pre_lines);
     const unsigned long long mh = __ballot(cls == 2), mw = __ballot(cls == 1), mx = __ballot(isx);
     if (lane == 0) {
@@ -943,72 +965,79 @@ __device__ __forceinline__ void shard_range(int64_t n_nu, const double* __restri
     sel[threadIdx.x] = (int)cnt;
 }
 
-// Frequency-sharded runs of long lists, stage A: the widest window of every line (over all depths), from the window rule
-// alone (:561-575; no centre needed for the half-width) — a streaming pass over the dense inputs that tells which lines can
-// reach any column (whw_max > kMediumHalfWidth -> hlist) or, from just outside the shard's own line range, its edge columns
-// (-> xlist), before the full pre-pass runs on the lines the shard needs.  Block `bid` of `n_blocks` strides over the
-// (line, depth) items.  (Running this stream as a ROLE of the fused pre-pass launch, overlapped with the latency-bound range
-// blocks and the continuum, was measured in round 3: the launch grew from 65 to 94 us and a separate gather launch cost 24 us
-// more — the same 0.600 ms per step of an eighth of S-c3 either way; removed.)
-__device__ __forceinline__ void classify_block(const int bid, const int n_blocks, int n_depth, int64_t n_nu, int64_t n_lines,
-                                               const double* __restrict__ dnu_partial, int n_partial, const double* __restrict__ doppler,
+// Frequency-sharded runs of long lists, stage A: how wide the widest window of every line is (over all depths) — which lines can
+// reach any column (-> hlist) or, from just outside the shard's own line range, its edge columns (-> xlist) — before the full
+// pre-pass runs on the lines the shard needs.  The half-width of the window rule (:561-575), int(max(10, (gamma + dw) alpha / d_nu
+// * 20)), is a non-decreasing function of m = (gamma + dw) alpha, so the widest window of a line is the window of its LARGEST m:
+// this pass streams the dense inputs once and leaves max_d m per line; the list kernels apply the rule (they, not this pass,
+// need the grid spacing — whose partial maxima the FIRST blocks of this launch compute on the side: one launch fewer per step).
+// One wave per line at a time, lane <-> depth: a line's 56 values are one contiguous 448-byte request per array, the maximum is
+// a wave reduction, the result a plain store — no atomics, nothing to clear beforehand.  (Round 3 accumulated integer half-widths
+// with atomicMax behind a pre-filter that needed d_nu: k_dnu_partial had to run, and clear the maxima, before every step.)
+// NaN terms are ignored (their window is the 10-point floor: never the widest).
+constexpr int kClsLinesPerWave = 4;  // lines in flight per wave: 12 independent loads per lane
+__device__ __forceinline__ void classify_block(const int bid, const int n_blocks, int n_depth, int64_t n_lines, const double* __restrict__ doppler,
                                                const double* __restrict__ gammas, int gamma_cols, const double* __restrict__ alphas,
-                                               int* __restrict__ whw_max, double* s_red)
+                                               double* __restrict__ m_max)
 {
-    const double d_nu = block_dnu(dnu_partial, n_partial, s_red);
-    const int64_t n = n_lines * n_depth;
-    const double scale = 20.0 / d_nu;
-    const int64_t bdim = blockDim.x;
-    // a fixed number of blocks strides over the items (the grid-spacing reduction above is paid once per block, not once per
-    // 1024 items); four items per thread and trip, a block apart: twelve independent loads in flight per lane.  (16-byte loads
-    // of item pairs were measured: the same 47 us for 201 MB at 1.5e5 lines — the stream runs at 4.3 TB/s either way.)
-    for (int64_t base = (int64_t)bid * (4 * bdim); base < n; base += (int64_t)n_blocks * (4 * bdim)) {
-        const int64_t k0 = base + threadIdx.x;
-        const int64_t l_first = base / n_depth;  // the line of the trip's first item
-        double dw[4], al[4], g[4];
-        int64_t ls[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    // the block's contiguous run of lines; its waves take consecutive groups of kClsLinesPerWave lines
+    const int64_t per_block = (n_lines + n_blocks - 1) / n_blocks;
+    const int64_t l0 = (int64_t)bid * per_block, l1 = min(l0 + per_block, n_lines);
+    for (int64_t base = l0 + (int64_t)wave * kClsLinesPerWave; base < l1; base += (int64_t)n_waves * kClsLinesPerWave) {
+        double m[kClsLinesPerWave];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int64_t k = k0 + j * bdim;
-            ls[j] = -1;
-            dw[j] = al[j] = g[j] = 0.0;
-            if (k < n) {
-                // line index: one 64-bit division per trip (uniform), a 32-bit one per item (a 64-bit division per item is
-                // ~100 instructions)
-                const unsigned r = (unsigned)(k - l_first * n_depth);
-                const unsigned q = r / (unsigned)n_depth;
-                const int64_t l = l_first + q;
-                ls[j] = l;
-                dw[j] = doppler[k];
-                al[j] = alphas[k];
-                g[j] = gamma_cols > 1 ? gammas[l * gamma_cols + (r - q * (unsigned)n_depth)] : gammas[l];
+        for (int j = 0; j < kClsLinesPerWave; ++j) m[j] = -INFINITY;
+        for (int d = lane; d < n_depth; d += 64) {
+            double dw[kClsLinesPerWave], al[kClsLinesPerWave], g[kClsLinesPerWave];
+#pragma unroll
+            for (int j = 0; j < kClsLinesPerWave; ++j) {
+                const int64_t l = min(base + j, l1 - 1);  // (clamped: a repeated line changes nothing)
+                dw[j] = doppler[l * n_depth + d];
+                al[j] = alphas[l * n_depth + d];
+                g[j] = gamma_cols > 1 ? gammas[l * gamma_cols + d] : gammas[l];
             }
-        }
-        // almost every item is a narrow window: the product with the rounded 20 / d_nu is within 1e-15 of the window rule's
-        // value, so anything below 64.99 needs no exact evaluation (an IEEE division per item)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (ls[j] < 0) continue;
-            if (mul_rn(mul_rn(add_rn(g[j], dw[j]), al[j]), scale) < (double)kNarrowHalfWidth + 0.99) continue;
-            const double pixels = mul_rn(mul_rn(add_rn(g[j], dw[j]), al[j]) / d_nu, 20.0);
-            const double forced = pixels > 10.0 ? pixels : 10.0;
-            const int64_t hw = forced >= (double)n_nu ? n_nu : (int64_t)forced;
-            if (hw > kNarrowHalfWidth) atomicMax(&whw_max[ls[j]], (int)hw);
+            for (int j = 0; j < kClsLinesPerWave; ++j) m[j] = fmax(m[j], mul_rn(add_rn(g[j], dw[j]), al[j]));  // (fmax drops a NaN)
+        }
+#pragma unroll
+        for (int j = 0; j < kClsLinesPerWave; ++j) {
+            for (int off = 32; off > 0; off >>= 1) m[j] = fmax(m[j], __shfl_xor(m[j], off));
+            if (lane == 0 && base + j < l1) m_max[base + j] = m[j];
         }
     }
 }
+// this block's share of max(diff(nus)) -> partial[bid]  (blocks [0, n_dnu) of the classification launches)
+__device__ __forceinline__ void dnu_partial_block(const int bid, const int n_blocks, int64_t n_nu, const double* __restrict__ nus,
+                                                  double* __restrict__ partial, double* s_red)
+{
+    double m = -INFINITY;
+    for (int64_t i = (int64_t)bid * blockDim.x + threadIdx.x; i + 1 < n_nu; i += (int64_t)n_blocks * blockDim.x) m = fmax(m, nus[i + 1] - nus[i]);
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = fmax(m, s_red[w]);
+        partial[bid] = m;
+    }
+}
 
-__global__ __launch_bounds__(kBlock) void k_classify(int n_depth, int64_t n_nu, int64_t n_lines, const double* __restrict__ dnu_partial,
-                                                     int n_partial, const double* __restrict__ doppler, const double* __restrict__ gammas,
-                                                     int gamma_cols, const double* __restrict__ alphas, int* __restrict__ whw_max,
+__global__ __launch_bounds__(kBlock) void k_classify(int n_dnu, int n_depth, int64_t n_nu, int64_t n_lines, double* __restrict__ dnu_partial,
+                                                     const double* __restrict__ doppler, const double* __restrict__ gammas,
+                                                     int gamma_cols, const double* __restrict__ alphas, double* __restrict__ m_max,
                                                      const double* __restrict__ nus, const double* __restrict__ line_nus, int64_t nu_begin,
                                                      int64_t nu_count, int* __restrict__ sel)
 {
     __shared__ double s_red[kBlock / 64];
+    const int b = blockIdx.x;
+    if (b < n_dnu) {
+        dnu_partial_block(b, n_dnu, n_nu, nus, dnu_partial, s_red);
+        return;
+    }
     // four threads of the LAST block find the shard's line ranges on the side (four binary searches: chains of dependent loads
-    // that vanish behind this 50 us stream; on the side of the 5 us k_dnu_partial they doubled its length)
-    if (sel && blockIdx.x == gridDim.x - 1) shard_range(n_nu, nus, n_lines, line_nus, nu_begin, nu_count, sel);
-    classify_block(blockIdx.x, gridDim.x, n_depth, n_nu, n_lines, dnu_partial, n_partial, doppler, gammas, gamma_cols, alphas, whw_max, s_red);
+    // that vanish behind this stream)
+    if (sel && b == (int)gridDim.x - 1) shard_range(n_nu, nus, n_lines, line_nus, nu_begin, nu_count, sel);
+    classify_block(b - n_dnu, (int)gridDim.x - n_dnu, n_depth, n_lines, doppler, gammas, gamma_cols, alphas, m_max);
 }
 
 
@@ -1317,31 +1346,21 @@ __device__ __forceinline__ void line_all_body(int n_wide, int tiles, int n_split
         // take CONTIGUOUS tiles (position p -> tile prefix(p % 8) + p / 8), so neighbouring tiles, whose line ranges
         // overlap, hit the same L2 instead of pulling the same records into all eight.
         const int wg = (roles >> 4) & 15;  // 0: one contiguous eighth of the tiles per XCD; g > 0: groups of g tiles going round the XCDs
-        int tile, row;
+        int tile, d;
         if (wg == 0) {
             const int p = b % tiles;
-            row = b / tiles;
+            d = b / tiles;
             tile = p >> 3;
             for (int f = 0; f < (p & 7); ++f) tile += (tiles - f + 7) >> 3;
         } else {
             // (the host pads the tiles of a depth to whole rounds of 8 g workgroups: b % 8 is then the XCD within every depth)
             const int tiles_pad = (tiles + 8 * wg - 1) / (8 * wg) * (8 * wg);
             const int p = b % tiles_pad, j = p >> 3;
-            row = b / tiles_pad;
+            d = b / tiles_pad;
             tile = ((j / wg) * 8 + (p & 7)) * wg + j % wg;
             if (tile >= tiles) return;
         }
-        // The first `hot` depths — the deepest, hottest layers, whose tiles walk the longest hit lists: the launch cannot end
-        // before its heaviest wave does — are walked by TWICE the line subsets: rows 2 d and 2 d + 1 of the launch are the two
-        // halves of depth d, workgroup h taking subsets h n_split .. h n_split + n_split - 1 of 2 n_split and leaving its sum in
-        // plane 0 (h = 0) or plane 2 (h = 1).  `hot` is a function of the depth count alone: which points' terms meet in
-        // which order stays a property of the grid.
-        const int hot = (roles >> 16) & 0xFFF;
-        const int h = row < 2 * hot ? (row & 1) : 0;
-        const int d = row < 2 * hot ? (row >> 1) : row - hot;
-        const int n_sub = d < hot ? 2 * n_split : n_split;
-        double* __restrict__ wplane = h ? planes + (size_t)2 * n_depth * pld : planes;
-        line_wide_walk<R, MIXED>(tile, h * n_split + wave, n_sub, wave, n_split, d, n_nu, nus, nu_begin, nu_count, n_lines, w, wplane, pld, s_wide);
+        line_wide_walk<R, MIXED>(tile, wave, n_split, d, n_nu, nus, nu_begin, nu_count, n_lines, w, planes, pld, s_wide);
     } else {
         if (!(roles & 2)) return;
         // A wave writes one value into each of the N_d rows of the narrow plane: the waves that fill a 64-byte sector of a
@@ -1399,17 +1418,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(R == 4 ? 6 
 }
 
 // out (+)= sum over the S line subsets, in subset order
-// (plane 2 — the second half of the line subsets — exists for the first `hot` depths only)
 __global__ __launch_bounds__(kBlock) void k_reduce_partials(int n_depth, int64_t nu_count, int n_split,
                                                             const double* __restrict__ partial, int64_t pld,
-                                                            double* __restrict__ out, int64_t out_ld, int accumulate, int hot)
+                                                            double* __restrict__ out, int64_t out_ld, int accumulate)
 {
     const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int d = blockIdx.y;
     if (j >= nu_count) return;
     double v = partial[(size_t)d * pld + j];
-    for (int s = 1; s < n_split; ++s)
-        if (s < 2 || d < hot) v = add_rn(v, partial[((size_t)s * n_depth + d) * pld + j]);
+    for (int s = 1; s < n_split; ++s) v = add_rn(v, partial[((size_t)s * n_depth + d) * pld + j]);
     double* p = out + (size_t)d * out_ld + j;
     *p = accumulate ? add_rn(*p, v) : v;
 }
@@ -2010,24 +2027,32 @@ __global__ __launch_bounds__(kPreBlock) __attribute__((amdgpu_num_sgpr(80))) voi
 }
 
 // Culled shards of the fused step: the classification stream (HBM-bound, vector units idle) and the continuum plane (arithmetic,
-// no traffic to speak of) in ONE launch of 256-thread blocks — blocks [0, n_cls) stream, the rest are continuum tiles.
-__global__ __launch_bounds__(kBlock) void k_classify_continuum(int n_cls, int n_depth, int64_t n_nu, int64_t n_lines, const double* __restrict__ dnu_partial,
-                                                               int n_partial, const double* __restrict__ doppler, const double* __restrict__ gammas,
-                                                               int gamma_cols, const double* __restrict__ alphas, int* __restrict__ whw_max,
+// no traffic to speak of) in ONE launch of 256-thread blocks — blocks [0, n_dnu) the grid-spacing partials, then the continuum
+// tiles, then the n_cls streaming blocks.
+__global__ __launch_bounds__(kBlock) void k_classify_continuum(int n_dnu, int n_cls, int n_depth, int64_t n_nu, int64_t n_lines, double* __restrict__ dnu_partial,
+                                                               const double* __restrict__ doppler, const double* __restrict__ gammas,
+                                                               int gamma_cols, const double* __restrict__ alphas, double* __restrict__ m_max,
                                                                const double* __restrict__ nus, int cont_tiles, int64_t nu_begin, int64_t nu_count,
                                                                ContinuumArgs ca, double* __restrict__ cont_plane, int64_t cont_ld, int stage_table,
                                                                const double* __restrict__ line_nus, int64_t shard_begin, int64_t shard_count,
                                                                int* __restrict__ sel)
 {
+    // order of the roles in the grid = order of dispatch: the continuum tiles — chains of dependent work (coefficients, a barrier,
+    // a table search), eight depths per block so that they are few and long — go first and run behind the stream (round 4, an
+    // eighth of S-c3: this launch 62 us with one depth per block, 46 with eight; tiles first or last: 46 / 47)
+    const int n_cont = (int)gridDim.x - n_dnu - n_cls;
     const int b = blockIdx.x;
-    if (b < n_cls) {
+    if (b < n_dnu) {
         __shared__ double s_red[kBlock / 64];
-        if (sel && b == n_cls - 1) shard_range(n_nu, nus, n_lines, line_nus, shard_begin, shard_count, sel);  // (four threads, on the side)
-        classify_block(b, n_cls, n_depth, n_nu, n_lines, dnu_partial, n_partial, doppler, gammas, gamma_cols, alphas, whw_max, s_red);
-    } else {
-        const int c = b - n_cls;
+        dnu_partial_block(b, n_dnu, n_nu, nus, dnu_partial, s_red);
+    } else if (b < n_dnu + n_cont) {
+        const int c = b - n_dnu;
         continuum_tile_block(c % cont_tiles, c / cont_tiles, (stage_table >> 4) & 15, n_depth, nu_begin, nu_count, nus, ca, cont_plane, cont_ld,
                              (stage_table & 1) != 0);
+    } else {
+        const int k = b - n_dnu - n_cont;
+        if (sel && k == n_cls - 1) shard_range(n_nu, nus, n_lines, line_nus, shard_begin, shard_count, sel);  // (four threads, on the side)
+        classify_block(k, n_cls, n_depth, n_lines, doppler, gammas, gamma_cols, alphas, m_max);
     }
 }
 
@@ -2160,7 +2185,6 @@ struct FusedTotal {
     int64_t cld;
     const double* planes;  // [n_planes][n_depth][pld] partial line-opacity planes, or nullptr (no lines)
     int n_planes;
-    int hot_depths;        // planes beyond the second hold something for depths below this only
     int64_t pld;
     double* total_out;     // [n_depth][out_ld], optional
     double* line_out;      // optional
@@ -2210,21 +2234,12 @@ __global__ __launch_bounds__(kRtBlock) void k_raytrace(int n_depth, int64_t n_nu
     const int64_t ic = i < n_nu ? i : n_nu - 1;
     const int n_gap = n_depth - 1;
     const int col = n_depth;  // LDS row stride per group
-    double* sRD = smem;                       // ray_dist [n_gap][n_theta]
-    double* wbase = sRD + n_gap * n_theta + (size_t)wave * (2 * gpw * col + kBatch * gpw * TH);
+    double* wbase = smem + (size_t)wave * (2 * gpw * col + kBatch * gpw * TH);
     double* sS = wbase;                       // source function  [gpw][col]
     double* sA = sS + gpw * col;              // sqrt(alpha)      [gpw][col]
     double* sX = sA + gpw * col;              // flux terms       [kBatch][gpw][TH]
     const double nu = nus[ic];
 
-    if (theta_stride == n_theta) {
-        for (int k = threadIdx.x; k < n_gap * n_theta; k += kRtBlock) sRD[k] = ray_dist[k];
-    } else {
-        for (int k = threadIdx.x; k < n_gap * n_theta; k += kRtBlock) {
-            const int gp = k / n_theta, t = k - gp * n_theta;
-            sRD[k] = ray_dist[(size_t)gp * theta_stride + t];
-        }
-    }
     if (active) {
         for (int d = g; d < n_depth; d += G) {
             double a;
@@ -2232,8 +2247,7 @@ __global__ __launch_bounds__(kRtBlock) void k_raytrace(int n_depth, int64_t n_nu
                 a = ft.cont[(size_t)d * ft.cld + ic];
                 if (ft.planes) {
                     double line = ft.planes[(size_t)d * ft.pld + ic];
-                    for (int sp = 1; sp < ft.n_planes; ++sp)
-                        if (sp < 2 || d < ft.hot_depths) line = add_rn(line, ft.planes[((size_t)sp * n_depth + d) * ft.pld + ic]);
+                    for (int sp = 1; sp < ft.n_planes; ++sp) line = add_rn(line, ft.planes[((size_t)sp * n_depth + d) * ft.pld + ic]);
                     a = add_rn(a, line);
                     if (valid && ft.line_out) ft.line_out[(size_t)d * ft.out_ld + i] = line;
                 }
@@ -2246,7 +2260,7 @@ __global__ __launch_bounds__(kRtBlock) void k_raytrace(int n_depth, int64_t n_nu
             sS[grp * col + d] = ft.source ? ft.source[(size_t)d * ft.sld + ic] : planck_staged(nu, temps[d]);
         }
     }
-    __syncthreads();
+    wave_sync();  // (nothing is shared between the waves of a block any more: the ray table is read from L1)
 
     const int gi = (active ? grp : 0) * col;  // idle lanes shadow group 0 and never store
     double inten[P], wt[P];
@@ -2270,7 +2284,7 @@ __global__ __launch_bounds__(kRtBlock) void k_raytrace(int n_depth, int64_t n_nu
             const double mg = sA[gi + gap] * sA[gi + gap + 1], mm = sA[gi + gm] * sA[gi + gm + 1];
 #pragma unroll
             for (int k = 0; k < P; ++k) {
-                const double tg = mul_rn(mg, sRD[gap * n_theta + th[k]]), tm = mul_rn(mm, sRD[gm * n_theta + th[k]]);
+                const double tg = mul_rn(mg, ray_dist[(size_t)gap * theta_stride + th[k]]), tm = mul_rn(mm, ray_dist[(size_t)gm * theta_stride + th[k]]);
                 double c, e;
                 rt_coef<false>(tg, tm, s0 - s1, s2 - s1, s1, c, e);
                 inten[k] = tm == 0.0 ? inten[k] : fma(c, inten[k], e);
@@ -2296,12 +2310,20 @@ __global__ __launch_bounds__(kRtBlock) void k_raytrace(int n_depth, int64_t n_nu
         if (valid && g == 0 && F && !accumulate) F[i] = 0.0;
     }
     // rolling state: optical depth of the current gap per angle, source at its two ends, sqrt(alpha) at its far end
-    double tau0[P];
+    // (the ray-length table — 9 KB at 56 depths x 20 angles — is read from global memory, i.e. the L1: a lane needs ONE entry
+    // per gap, requested a gap ahead; staged in LDS it cost every block 9 KB, and with them two of seven workgroups per CU)
+    double tau0[P], rd_next[P];
+    const double* rdp[P];
     double a1 = sA[gi + 1];
     {
         const double mean0 = sA[gi] * a1;
 #pragma unroll
-        for (int k = 0; k < P; ++k) tau0[k] = mul_rn(mean0, sRD[th[k]]);
+        for (int k = 0; k < P; ++k) {
+            rdp[k] = ray_dist + th[k];
+            tau0[k] = mul_rn(mean0, *rdp[k]);
+            rdp[k] += n_gap > 1 ? theta_stride : 0;
+            rd_next[k] = *rdp[k];  // gap 1
+        }
     }
     double s1 = sS[gi + 1], d10 = sS[gi] - s1;
 
@@ -2314,7 +2336,9 @@ __global__ __launch_bounds__(kRtBlock) void k_raytrace(int n_depth, int64_t n_nu
                 const double mean1 = a1 * a2, d21 = s2 - s1;
 #pragma unroll
                 for (int k = 0; k < P; ++k) {
-                    const double t1 = mul_rn(mean1, sRD[(gap + 1) * n_theta + th[k]]);
+                    const double t1 = mul_rn(mean1, rd_next[k]);
+                    rdp[k] += gap + 2 < n_gap ? theta_stride : 0;
+                    rd_next[k] = *rdp[k];  // gap + 2, for the next trip
                     double c, e;
                     rt_coef<false>(tau0[k], t1, d10, d21, s1, c, e);
                     const double inew = fma(c, inten[k], e);
@@ -2429,8 +2453,7 @@ __global__ __launch_bounds__(64 * NS) __attribute__((amdgpu_waves_per_eu(NS >= 8
                 a = ft.cont[(size_t)d * ft.cld + ic];
                 if (ft.planes) {
                     double line = ft.planes[(size_t)d * ft.pld + ic];
-                    for (int sp = 1; sp < ft.n_planes; ++sp)
-                        if (sp < 2 || d < ft.hot_depths) line = add_rn(line, ft.planes[((size_t)sp * n_depth + d) * ft.pld + ic]);
+                    for (int sp = 1; sp < ft.n_planes; ++sp) line = add_rn(line, ft.planes[((size_t)sp * n_depth + d) * ft.pld + ic]);
                     a = add_rn(a, line);
                     if (vq && ft.line_out) ft.line_out[(size_t)d * ft.out_ld + iq] = line;
                 }

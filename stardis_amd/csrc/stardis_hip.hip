@@ -91,7 +91,6 @@ struct sdx_ctx {
     int64_t indexed_min_lines = 8192;  // line lists at least this long: wide lines found by centre range / the huge-line list instead of a full scan
     int64_t mixed_precision = 0;       // 1: fp32 rational for far-wing (region I) evaluations of whole-tile windows
     int64_t segmented_raytrace = -1;   // -1: by the size of the GLOBAL grid; 0 never; 1 whenever the kernel supports the shape
-    int64_t wide_hot_depths = -1;      // -1: the deepest quarter of the depth points get twice the line subsets; >= 0: that many
     // timing
     hipEvent_t t0 = nullptr, t1 = nullptr;
     void* cont_ws = nullptr;  // continuum plane [n_depth][nu_count] of the fused step
@@ -413,10 +412,6 @@ int sdx_set_int_option(sdx_ctx* ctx, const char* name, int64_t value)
     }
     if (std::strcmp(name, "segmented_raytrace") == 0) {
         ctx->segmented_raytrace = value < 0 ? -1 : (value ? 1 : 0);
-        return SDX_OK;
-    }
-    if (std::strcmp(name, "wide_hot_depths") == 0) {
-        ctx->wide_hot_depths = value < 0 ? -1 : value;
         return SDX_OK;
     }
     return fail(SDX_ERR_ARG, std::string("unknown option ") + name);
@@ -752,16 +747,19 @@ static bool use_segmented_raytrace(const sdx_ctx* ctx, int n_depth, int64_t n_nu
 }
 
 // long lists: hlist / wlist / wrank from whw_max (two small launches)
-static void launch_line_lists(sdx_ctx* ctx, int64_t n_lines, LineWork& w, int pre_lines)
+static void launch_line_lists(sdx_ctx* ctx, int64_t n_lines, LineWork& w, int pre_lines, const ClassSource* from_classification = nullptr)
 {
+    ClassSource cs{};
+    if (from_classification) cs = *from_classification;
+    else cs.whw_max = w.whw_max;
     w.hlist = w.whw_max + n_lines;
     w.wlist = w.hlist + n_lines;
     w.wrank = w.wlist + n_lines;
     w.xlist = w.sel ? w.wrank + n_lines + 1 : nullptr;  // culled runs only
     const unsigned hb = (unsigned)((n_lines + kHlistBlock - 1) / kHlistBlock);
     int* block_cnt = w.hcount + 16;  // 3 hb ints behind the counters and sel (reserved in cnt_ws)
-    hipLaunchKernelGGL(k_hlist_count, dim3(hb), dim3(kHlistBlock), 0, ctx->stream, n_lines, (const int*)w.whw_max, block_cnt, w.sel, pre_lines);
-    hipLaunchKernelGGL(k_hlist_scatter, dim3(hb), dim3(kHlistBlock), 0, ctx->stream, n_lines, (const int*)w.whw_max, (const int*)block_cnt, w.hlist,
+    hipLaunchKernelGGL(k_hlist_count, dim3(hb), dim3(kHlistBlock), 0, ctx->stream, n_lines, cs, block_cnt, w.sel, pre_lines);
+    hipLaunchKernelGGL(k_hlist_scatter, dim3(hb), dim3(kHlistBlock), 0, ctx->stream, n_lines, cs, (const int*)block_cnt, w.hlist,
                        w.wlist, w.wrank, w.hcount, w.xlist, w.sel, pre_lines);
 }
 
@@ -786,7 +784,8 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
         if (rc) return rc;
         ctx->cnt_ge_len = (size_t)(n_nu + 2 + 63) / 64 * 64;
         // cnt_ge, then per line: centre, nhw_max, whw_max, hlist, wlist, wrank, xlist; then hcount, sel and the per-block counts
-        rc = ensure(ctx, &ctx->cnt_ws, &ctx->cnt_ws_bytes, (ctx->cnt_ge_len + 8 * (size_t)n_lines + 128 + 3 * ((size_t)n_lines / 1024 + 8)) * sizeof(int));
+        // ... and, behind those, the classification pass's per-line maxima (doubles)
+        rc = ensure(ctx, &ctx->cnt_ws, &ctx->cnt_ws_bytes, (ctx->cnt_ge_len + 10 * (size_t)n_lines + 128 + 3 * ((size_t)n_lines / 1024 + 8) + 8) * sizeof(int));
         if (rc) return rc;
         w = carve(ctx, n_depth, n_lines);
         if (n_depth > kPreDepths) HIP_TRY(hipMemsetAsync(w.nhw_max, 0, (size_t)2 * n_lines * sizeof(int), ctx->stream));  // nhw_max and whw_max
@@ -808,9 +807,10 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
     // change what it computes for them.
     static const bool no_cull = knob("SDX_NO_CULL") != nullptr;
     const bool cull = fill_work && !no_cull && n_lines >= ctx->indexed_min_lines && !count_evals && !gen && !scan_in_block && nu_count < n_nu;
-    // the grid-spacing reduction (a culled run: it also clears whw_max for the classification pass)
+    // the grid-spacing reduction: a launch of its own, or — culled runs — the first blocks of the classification launch
     int* const sel = cull ? w.hcount + 4 : nullptr;
-    if (!scan_in_block && (rc = launch_dnu(ctx, n_nu, nus, &n_partial, cull ? w.whw_max : nullptr, cull ? n_lines : 0))) return rc;
+    if (cull) n_partial = (int)std::min<int64_t>(kDnuPartials, std::max<int64_t>(1, (n_nu + kBlock * 8 - 1) / (kBlock * 8)));
+    else if (!scan_in_block && (rc = launch_dnu(ctx, n_nu, nus, &n_partial))) return rc;
     // continuum blocks of the fused step: one per (frequency tile of `threads` points, group of dgs depths) when the per-depth
     // factors of a group fit LDS (always, for a handful of bound-free levels), else one per (tile, depth) evaluating every point
     // from scratch
@@ -841,6 +841,9 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
         if (tile_shmem <= 48 * 1024 && cont_dgs_env != 0) {
             // depths per block: as many as leave ~2 x 1024 threads of such blocks per CU (one depth per block on small grids)
             int dgs = (int)std::max<int64_t>(1, std::min<int64_t>(kContDepths, ((int64_t)p->cont_tiles * threads / kPreBlock * n_depth) / (2 * (int64_t)ctx->n_cu)));
+            // riding with the classification stream (256-thread blocks) the chip is full anyway: as many depths per block as
+            // there are — the per-frequency work (table search, nu^-3, Rayleigh powers) is then shared by eight points
+            if (threads == kBlock) dgs = kContDepths;
             if (cont_dgs_env > 0) dgs = std::min(cont_dgs_env, kContDepths);
             p->stage_table |= 2 | (dgs << 4);
             p->shmem = tile_shmem;
@@ -856,7 +859,13 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
     bool continuum_done = false;
     if (cull) {
         w.sel = sel;
-        const unsigned n_cls = (unsigned)std::min<int64_t>((n_lines * n_depth + 4 * kBlock - 1) / (4 * kBlock), (int64_t)8 * ctx->n_cu);
+        // classification blocks: contiguous runs of lines, a few blocks per CU (256 threads: 4 waves x 4 lines x 3 arrays in flight)
+        static const int cls_blocks_env = knob("SDX_CLS_BLOCKS") ? std::atoi(knob("SDX_CLS_BLOCKS")) : 0;  // experiment knob
+        const unsigned n_cls = cls_blocks_env > 0 ? (unsigned)cls_blocks_env
+                                                  : (unsigned)std::max<int64_t>(1, std::min<int64_t>((n_lines + 63) / 64, (int64_t)8 * ctx->n_cu));
+        // the per-line maxima: doubles behind the integer lists of cnt_ws (8-byte aligned)
+        double* const m_max = (double*)(((uintptr_t)(w.hcount + 16 + 3 * ((size_t)n_lines / 1024 + 8)) + 7) & ~(uintptr_t)7);
+        double* const dnu_ws = (double*)ctx->small_ws;
         ContPlan cp;
         static const bool no_ride = knob("SDX_NO_CONT_RIDE") != nullptr;  // A/B knob
         if (job && !no_ride) {
@@ -869,18 +878,20 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
                 // half the classification blocks (16 of 32 wave slots per CU: the stream keeps its bytes in flight), the
                 // continuum blocks take the other slots
                 const unsigned n_cls_half = std::max(1u, n_cls / 2);
-                hipLaunchKernelGGL(k_classify_continuum, dim3(n_cls_half + (unsigned)cp.cont_tiles * cp.cont_rows), dim3(kBlock), cp.shmem, ctx->stream, (int)n_cls_half,
-                                   n_depth, n_nu, n_lines, (const double*)ctx->small_ws, n_partial, doppler, gammas, gamma_cols, alphas, w.whw_max, nus,
+                hipLaunchKernelGGL(k_classify_continuum, dim3((unsigned)n_partial + n_cls_half + (unsigned)cp.cont_tiles * cp.cont_rows), dim3(kBlock), cp.shmem, ctx->stream,
+                                   n_partial, (int)n_cls_half, n_depth, n_nu, n_lines, dnu_ws, doppler, gammas, gamma_cols, alphas, m_max, nus,
                                    cp.cont_tiles, job->nu_begin, job->nu_count, cp.ca, job->plane, job->nu_count, cp.stage_table, line_nus, nu_begin, nu_count,
                                    sel);
             } else {
-                hipLaunchKernelGGL(k_classify, dim3(n_cls), dim3(kBlock), 0, ctx->stream, n_depth, n_nu, n_lines, (const double*)ctx->small_ws, n_partial,
-                                   doppler, gammas, gamma_cols, alphas, w.whw_max, nus, line_nus, nu_begin, nu_count, sel);
+                hipLaunchKernelGGL(k_classify, dim3((unsigned)n_partial + n_cls), dim3(kBlock), 0, ctx->stream, n_partial, n_depth, n_nu, n_lines, dnu_ws,
+                                   doppler, gammas, gamma_cols, alphas, m_max, nus, line_nus, nu_begin, nu_count, sel);
             }
         }
         {
             LaunchScope ls(ctx, "k_hlist");
-            launch_line_lists(ctx, n_lines, w, pre_lines);
+            ClassSource cs{};
+            cs.m_max = m_max, cs.dnu_partial = dnu_ws, cs.n_partial = n_partial, cs.n_nu = n_nu;
+            launch_line_lists(ctx, n_lines, w, pre_lines, &cs);
         }
         w.gather = n_line_blocks;  // worst case: every line listed; blocks beyond the lists' end return at once
     }
@@ -953,7 +964,7 @@ static int choose_splits(int n_depth, int64_t n_nu_global, int64_t n_lines, int 
 static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin, int64_t nu_count,
                          int64_t n_lines, const double* line_nus, const double* doppler, const double* gammas, int gamma_cols,
                          const double* alphas, const double** partial_out, int64_t* pld_out, int* n_planes_out, LineWork* w_out,
-                         bool count_evals, const ContinuumJob* job = nullptr, const LineParams* gen = nullptr, int* hot_out = nullptr)
+                         bool count_evals, const ContinuumJob* job = nullptr, const LineParams* gen = nullptr)
 {
     constexpr int R = 4;       // grid points per lane of a wide-role tile (tile = 64 R points)
     constexpr int R_MIXED = 4;  // fp32 far wings (8 — twice the points per fetched record — measured slower: fewer tiles qualify as far wing)
@@ -978,14 +989,12 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
         hipLaunchKernelGGL(k_hscan, dim3(64, (unsigned)n_depth), dim3(kBlock), 0, ctx->stream, n_depth, n_lines, (const int*)w.hlist, (const int*)w.hcount,
                            (const WideScan*)w.wscan, w.hscan);
     }
-    // The deepest quarter of the depth points — the hottest layers, whose tiles walk the longest hit lists — get twice the line
-    // subsets (two workgroups per (depth, tile)): a launch cannot end before its heaviest wave does, and on an eighth of the
-    // grid that wave alone was most of the line kernel's time.  A function of the depth count only (context option
-    // "wide_hot_depths" for experiments): the order of summation stays a property of the grid, not of the shard.
-    const int hot = (int)std::min<int64_t>(n_depth, ctx->wide_hot_depths >= 0 ? ctx->wide_hot_depths : n_depth / 4);
-    // planes: [0] wide windows (the subsets of a workgroup are summed inside it), [1] narrow windows, [2] the second half of the
-    // subsets of the hot depths (rows 0 .. hot - 1 only)
-    rc = ensure(ctx, &ctx->part_ws, &ctx->part_ws_bytes, (size_t)3 * n_depth * nu_count * sizeof(double));
+    // two planes: [0] wide windows (the S subsets are summed inside their workgroup), [1] narrow windows.  (Twice the line subsets
+    // for the deepest, hottest layers — two workgroups per (depth, tile), a third plane for the second halves — was measured in
+    // round 4 at S-c3 and on its eight shards with 0 / 14 / 28 such layers: line kernel 2026 / 2048 / 2092 us unsharded, 332 / 344 /
+    // 346 us on the slowest shard, no change at S-c2 either: the hit lists fall off by only a factor 4 from the deepest to the
+    // shallowest layer, and a launch is bound by its total work, not by its heaviest wave.  Removed.)
+    rc = ensure(ctx, &ctx->part_ws, &ctx->part_ws_bytes, (size_t)2 * n_depth * nu_count * sizeof(double));
     if (rc) return rc;
     double* part = (double*)ctx->part_ws;
     const int64_t pld = nu_count;
@@ -997,7 +1006,7 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
     static const int wide_group_env = knob("SDX_WIDE_GROUP") ? std::atoi(knob("SDX_WIDE_GROUP")) & 15 : -1;
     const int wide_group = wide_group_env >= 0 ? wide_group_env : 0;
     const int64_t tiles_pad = wide_group ? ((int64_t)tiles + 8 * wide_group - 1) / (8 * wide_group) * (8 * wide_group) : tiles;
-    const int64_t n_wide = tiles_pad * (n_depth + hot);
+    const int64_t n_wide = tiles_pad * n_depth;
     // workgroups of n_split waves, rounded up to whole rounds of the XCD-aware order (surplus workgroups return at once)
     // narrow role: F consecutive frequencies per wave (a line's records, loaded once, serve F evaluations) for DENSE lists —
     // at least one line per two grid points, where a frequency visits many lines and the walk is bound by its loads and
@@ -1012,14 +1021,14 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
     const int64_t n_grp = (nu_begin + nu_count + narrow_f - 1) / narrow_f - nu_begin / narrow_f;
     const int64_t n_narrow = (((n_grp * ((n_depth + 63) / 64) + n_split - 1) / n_split + 31) / 32) * 32;
     static const int narrow_order = knob("SDX_NARROW_ORDER") ? atoi(knob("SDX_NARROW_ORDER")) & 3 : 0;
-    REQUIRE(n_wide + n_narrow < ((int64_t)1 << 31) && hot < 4096, "line opacity: grid too large for one launch");
+    REQUIRE(n_wide + n_narrow < ((int64_t)1 << 31), "line opacity: grid too large for one launch");
     static const bool split_launches = knob("SDX_SPLIT_LAUNCHES") != nullptr;  // analysis knob: time the two roles apart
     const size_t shmem = (size_t)n_split * kWideLdsDoubles * sizeof(double);
     const dim3 g((unsigned)(n_wide + n_narrow)), blk((unsigned)(64 * n_split));
     for (int pass = 0; pass < (split_launches ? 2 : 1); ++pass) {
         // (raising the priority of the hot layers' waves with s_setprio was measured in round 4: the instruction has side effects as
         // far as the compiler is concerned, the record fetches of the walk stopped being scalar loads and the kernel ran 37 % slower)
-        const int roles = (split_launches ? (1 << pass) : 3) | (narrow_order << 2) | (wide_group << 4) | (narrow_f << 8) | (hot << 16);
+        const int roles = (split_launches ? (1 << pass) : 3) | (narrow_order << 2) | (wide_group << 4) | (narrow_f << 8);
         LaunchScope ls(ctx, split_launches ? (pass ? "k_line_narrow" : "k_line_wide") : "k_line_all");
 #define SDX_LINE_ARGS (int)n_wide, tiles, n_split, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, part, pld, roles
         if (ctx->mixed_precision && Rm == 8) hipLaunchKernelGGL((k_line_all_mixed<8>), g, blk, shmem, ctx->stream, SDX_LINE_ARGS);
@@ -1029,8 +1038,7 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
     }
     *partial_out = part;
     *pld_out = pld;
-    *n_planes_out = hot > 0 ? 3 : 2;
-    if (hot_out) *hot_out = hot;
+    *n_planes_out = 2;
     if (w_out) *w_out = w;
     return check_launch("line kernels");
 }
@@ -1051,15 +1059,15 @@ static int line_opacity_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, const doub
     }
     const double* part;
     int64_t pld;
-    int n_split, hot = 0;
+    int n_split;
     LineWork w;
     rc = line_partials(ctx, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, &part, &pld,
-                       &n_split, &w, n_evaluations_dev != nullptr, nullptr, gen, &hot);
+                       &n_split, &w, n_evaluations_dev != nullptr, nullptr, gen);
     if (rc) return rc;
     {
         LaunchScope ls(ctx, "k_reduce_partials");
         hipLaunchKernelGGL(k_reduce_partials, grid2(nu_count, n_depth), dim3(kBlock), 0, ctx->stream, n_depth, nu_count, n_split,
-                           part, pld, out, out_ld, accumulate, hot);
+                           part, pld, out, out_ld, accumulate);
     }
     rc = check_launch("k_reduce_partials");
     if (rc) return rc;
@@ -1716,8 +1724,8 @@ static int raytrace_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, c
         }
         const int G = (nth + P - 1) / P;
         const int kbatch = P == 1 ? 4 : 2;
-        auto lds_bytes = [&](int groups) {  // ray table + per wave: source and sqrt(alpha) columns, flux terms of a batch of gaps
-            return ((size_t)(n_depth - 1) * nth + (size_t)(kRtBlock / 64) * (2 * (size_t)groups * n_depth + (size_t)kbatch * groups * P * G)) * sizeof(double);
+        auto lds_bytes = [&](int groups) {  // per wave: source and sqrt(alpha) columns, flux terms of a batch of gaps
+            return ((size_t)(kRtBlock / 64) * (2 * (size_t)groups * n_depth + (size_t)kbatch * groups * P * G)) * sizeof(double);
         };
         int gpw = 64 / G;  // frequencies per wave; lowered (idle lanes) until the staged columns fit 64 KB of LDS
         while (gpw > 1 && lds_bytes(gpw) > 64 * 1024) --gpw;
@@ -1840,7 +1848,7 @@ static int synthesize_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double
     if (rc2) return rc2;
     double* cont_plane = (double*)ctx->cont_ws;
     // the formal solution forms total = continuum + line planes while staging its columns when those fit LDS
-    const size_t lds_columns = ((size_t)(n_depth - 1) * n_theta + (size_t)(kRtBlock / 64) * (2 * (size_t)n_depth + 4 * 64)) * sizeof(double);  // k_raytrace with one frequency per wave
+    const size_t lds_columns = ((size_t)(kRtBlock / 64) * (2 * (size_t)n_depth + 4 * 64)) * sizeof(double);  // k_raytrace with one frequency per wave
     const bool fuse = n_theta <= 64 && lds_columns <= 64 * 1024;
     // spherical geometry (opt->inward_rays): the inward sweep before the outward one, then F_nu *= (r[-1] / reference_r)^2
     // (radiation_field_solvers/base.py:141-198, :340-344)
@@ -1855,11 +1863,11 @@ static int synthesize_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double
     const ContinuumJob job{cont, nu_begin, nu_count, cont_plane};
     const double* part = nullptr;
     int64_t pld = 0;
-    int n_planes = 0, hot = 0;
+    int n_planes = 0;
     if (n_lines > 0) {
         LineWork w;
         rc = line_partials(ctx, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, &part, &pld,
-                           &n_planes, &w, n_evaluations_dev != nullptr, &job, gen, &hot);
+                           &n_planes, &w, n_evaluations_dev != nullptr, &job, gen);
         if (rc) return rc;
         if (n_evaluations_dev)
             HIP_TRY(hipMemcpyAsync(n_evaluations_dev, w.evals, sizeof(int64_t), hipMemcpyDeviceToDevice, ctx->stream));
@@ -1881,9 +1889,9 @@ static int synthesize_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double
             if (part) {
                 if (alpha_line_out)
                     hipLaunchKernelGGL(k_reduce_partials, grid2(nu_count, n_depth), dim3(kBlock), 0, ctx->stream, n_depth, nu_count,
-                                       n_planes, part, pld, alpha_line_out, ld, 0, hot);
+                                       n_planes, part, pld, alpha_line_out, ld, 0);
                 hipLaunchKernelGGL(k_reduce_partials, grid2(nu_count, n_depth), dim3(kBlock), 0, ctx->stream, n_depth, nu_count, n_planes,
-                                   part, pld, total, tld, 1, hot);
+                                   part, pld, total, tld, 1);
             }
         }
         rc = check_launch("k_reduce_partials");
@@ -1903,7 +1911,6 @@ static int synthesize_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double
     ft.cld = nu_count;
     ft.planes = part;
     ft.n_planes = n_planes;
-    ft.hot_depths = hot;
     ft.pld = pld;
     ft.total_out = total_alphas;
     ft.line_out = part ? alpha_line_out : nullptr;
@@ -2423,6 +2430,12 @@ int sdx_synthesize_sharded_f64(sdx_group* g, int n_depth, int64_t n_nu, const do
     std::vector<int> rcs(P, SDX_OK), codes(P, 0);
     std::vector<std::string> errs(P);
     int64_t ev = 0;
+    // the evaluation count (every window of every line: a global figure) is taken from ONE rank — the first that has columns,
+    // not blindly rank 0, whose shard may be empty; asking for it switches that rank's culled pre-pass off (it has to see every
+    // window), which makes it the straggler of the group: a diagnostic, not something to request in a timed loop
+    int ev_rank = -1;
+    for (int r = 0; r < P && ev_rank < 0; ++r)
+        if (begin[r + 1] > begin[r]) ev_rank = r;
     auto work = [&](int r) {
         sdx_ctx* ctx = g->ctx[r];
         io[r].reset(new HostIo(ctx));
@@ -2432,7 +2445,7 @@ int sdx_synthesize_sharded_f64(sdx_group* g, int n_depth, int64_t n_nu, const do
         if (hipSetDevice(ctx->device) != hipSuccess) rr = fail(SDX_ERR_HIP, "hipSetDevice failed");
         if (!rr && cnt > 0)
             rr = synthesize_host_shard(ctx, *io[r], n_depth, n_nu, nus, b, cnt, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, cont, n_theta,
-                                       temps, ray_dist, wts, alpha_line_out, total_alphas, F_nu, (r == 0 && n_evaluations) ? &ev : nullptr, &d_F);
+                                       temps, ray_dist, wts, alpha_line_out, total_alphas, F_nu, (r == ev_rank && n_evaluations) ? &ev : nullptr, &d_F);
         if (!rr && hipMemsetAsync(g->send[r], 0, (size_t)per * sizeof(double), ctx->stream) != hipSuccess) rr = fail(SDX_ERR_HIP, "hipMemsetAsync(send) failed");
         if (!rr && cnt > 0 &&
             hipMemcpyAsync(g->send[r], d_F + (size_t)(n_depth - 1) * cnt, (size_t)cnt * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)

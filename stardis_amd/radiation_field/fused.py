@@ -39,8 +39,9 @@ RAYLEIGH_CUTOFF = 2.3e15  # opacities_solvers/base.py:99
 
 # What this module derives from the plasma's pandas objects (sorted line tables, level tables, density vectors) is kept per
 # OBJECT: the key is the identity of the frames / series it was read from (a strong reference is held, so an id cannot be
-# recycled), a handful of entries, least recently used first out.  A TARDIS plasma hands out fresh objects whenever it is
-# recomputed, which misses the cache as it should; editing a table IN PLACE between two calls is not seen — call clear_cache().
+# recycled) plus a cheap content fingerprint of each (_stamp: an in-place edit between two calls misses the cache, as it
+# should), a handful of entries, least recently used first out.  A TARDIS plasma hands out fresh objects whenever it is
+# recomputed, which misses the cache too.
 _MEMO = {}
 _MEMO_MAX = 16
 
@@ -49,8 +50,24 @@ def clear_cache():
     _MEMO.clear()
 
 
+def _stamp(obj):
+    """A cheap content fingerprint of a pandas object / array next to its identity: shape plus the first, last and summed value
+    of what it holds — an edit IN PLACE between two calls (which the reference and the general path would see) changes it with
+    all but certainty, at the cost of one pass over the values (microseconds next to the sorts the cache saves)."""
+    try:
+        v = np.asarray(obj.to_numpy() if hasattr(obj, "to_numpy") else obj)
+        if v.dtype == object or v.size == 0:
+            return (v.shape,)
+        flat = v.reshape(-1)
+        if flat.dtype.kind in "fiu":
+            return (v.shape, float(flat[0]), float(flat[-1]), float(np.nansum(flat, dtype=np.float64)))
+        return (v.shape,)
+    except Exception:  # noqa: BLE001  (anything exotic: identity only)
+        return None
+
+
 def _memo(tag, objects, extra, build):
-    key = (tag, tuple(id(o) for o in objects), extra)
+    key = (tag, tuple(id(o) for o in objects), tuple(_stamp(o) for o in objects), extra)
     hit = _MEMO.get(key)
     if hit is not None:
         _MEMO[key] = _MEMO.pop(key)  # most recently used last
@@ -122,6 +139,58 @@ class LazyOpacitiesDict(dict):
         return dict.pop(self, key, *default)
 
 
+# Device memory a fused field keeps for its lazy entries (total, line plane, broadening tables, staged inputs, tracked
+# intensities: up to ~1 GB at 1e6 lines) is BOUNDED per process: fields are remembered weakly in creation order, and when the
+# bytes they hold exceed DEVICE_BUDGET_BYTES the oldest ones are released — their entries materialise on the host first (what
+# the reference would hold anyway), then the device twins go back to the context's pool.  A caller that keeps many outputs
+# (model grids, fits) therefore runs out of nothing the reference would not run out of.  release_device() does it by hand.
+DEVICE_BUDGET_BYTES = 8 << 30
+_LIVE = []  # [(weakref to the field, bytes)], oldest first
+
+
+def _enforce_budget(new_bytes):
+    import weakref  # noqa: F401
+
+    alive = [(r, b) for r, b in _LIVE if r() is not None and getattr(r().opacities, "_device_bytes", 0)]
+    _LIVE[:] = alive
+    total = sum(b for _, b in alive) + new_bytes
+    while alive and total > DEVICE_BUDGET_BYTES:
+        ref, b = alive.pop(0)
+        field = ref()
+        if field is not None:
+            release_device(field)
+        total -= b
+    _LIVE[:] = alive
+
+
+def release_device(field, materialize=True):
+    """Drop the device memory a fused RadiationField holds.  materialize=True (default) first forms every lazy entry on the host
+    — opacities_dict, total_alphas, I_nus — so that nothing is lost; False discards what has not been read (the entries then
+    read as the general path would recompute them is NOT attempted: they raise)."""
+    opac = field.opacities
+    if not isinstance(opac, FusedOpacities):
+        return
+    if materialize:
+        opac.opacities_dict._all()
+        opac.total_alphas  # noqa: B018
+        if getattr(field, "_I_dev", None) is not None:
+            field.I_nus  # noqa: B018
+    else:
+        def gone():
+            raise RuntimeError("this entry was released with release_device(materialize=False) before it was read")
+        for key in list(dict.keys(opac.opacities_dict)):
+            if isinstance(dict.__getitem__(opac.opacities_dict, key), _Thunk):
+                dict.__setitem__(opac.opacities_dict, key, _Thunk(gone))
+        opac._discarded = opac._total_host is None
+    opac._total_twin = None
+    opac._total_dev = None
+    opac._resident = {}
+    opac._device_bytes = 0
+    if getattr(field, "_I_dev", None) is not None:
+        field._I_dev = None
+    field._device_blob = None
+
+
 class FusedOpacities(Opacities):
     """Opacities whose `total_alphas` lives on the device until read (opacities/base.py:4-28 keeps a host array)."""
 
@@ -132,11 +201,14 @@ class FusedOpacities(Opacities):
         self._total_host = None
         self._total_twin = None  # device plane written by the fused step
         self._shape = shape
+        self._device_bytes = 0
 
     @property
     def total_alphas(self):
+        if self._total_host is None and getattr(self, "_discarded", False):
+            raise RuntimeError("total_alphas was released with release_device(materialize=False) before it was read")
         if self._total_host is None:
-            self._total_host = self._total_twin.numpy() if self._total_twin is not None else np.zeros(self._shape)
+            self._total_host = self._total_twin.numpy() if self._total_twin is not None else np.zeros(self._shape)  # (no twin: nothing was computed — np.zeros like the reference's constructor)
             if self._total_twin is not None:
                 self._total_dev = (self._total_host.copy(), self._total_twin)
         return self._total_host
@@ -563,6 +635,26 @@ def try_fused(field_cls, tracing_nus, stellar_model, stellar_plasma, config, sou
     if source is not None:
         add("source", source)
     blob, ptrs = _packed_upload(ctx, host)
+    try:
+        return _run_step(locals())
+    except BaseException:
+        # the staging block went up by an asynchronous DMA out of pooled page-locked memory: nothing may hand that block out
+        # again (blob._staging returning to the pool when `blob` dies) while the copy could still be reading it
+        try:
+            ctx.synchronize()
+        except Exception:  # noqa: BLE001
+            pass
+        raise
+
+
+def _run_step(v):
+    """The device part of try_fused (its local variables come in as a dictionary: one function would do, but the guard above
+    has to cover everything from the staging upload to the final download)."""
+    (ctx, host, slot, blob, ptrs, field, opac, nus, nd, temps, tables, table, plane_sources, bf, dv, n_e, line, line_spec, mol, mol_spec,
+     n_lines, n_mol, opacity, config, stellar_plasma, stellar_model, tracked, spherical, correction, source, rayleigh_species, ff_ions) = (
+        v[k] for k in ("ctx", "host", "slot", "blob", "ptrs", "field", "opac", "nus", "nd", "temps", "tables", "table", "plane_sources", "bf", "dv",
+                       "n_e", "line", "line_spec", "mol", "mol_spec", "n_lines", "n_mol", "opacity", "config", "stellar_plasma", "stellar_model",
+                       "tracked", "spherical", "correction", "source", "rayleigh_species", "ff_ions"))
     P = lambda name: ptrs[slot[name]] if name in slot else None  # noqa: E731
 
     file_planes = []
@@ -718,4 +810,11 @@ def try_fused(field_cls, tracing_nus, stellar_model, stellar_plasma, config, sou
             a_ul = mol["a_ul"]
             put("molecule_alpha_line_at_nu_gammas", a_ul[:, np.newaxis].copy() if radiation else np.zeros((n_mol, nd)))
             put("molecule_alpha_line_at_nu_doppler_widths", _Thunk(d_mol_doppler.numpy) if n_mol else np.zeros((0, nd)))
+    # what this field keeps on the device until its entries are read (or it is released): bounded per process
+    import weakref
+
+    held = [d_total, d_line, d_gamma, d_doppler, d_mol, d_mol_doppler, blob, getattr(field, "_I_dev", None), *file_planes]
+    opac._device_bytes = int(sum(int(np.prod(a.shape)) * a.dtype.itemsize for a in held if a is not None))
+    _enforce_budget(opac._device_bytes)
+    _LIVE.append((weakref.ref(field), opac._device_bytes))
     return field

@@ -220,7 +220,7 @@ def make_workload(tag, n_lines=None, seed=SEED, n_nu_override=None):
     )
 
 
-def fake_plasma(nus, atm, n_lines, seed=SEED, vald_broadening=False, table_dir=None):
+def fake_plasma(nus, atm, n_lines, seed=SEED, vald_broadening=False, table_dir=None, n_molecule_lines=0):
     """A pandas stand-in for the TARDIS plasma, the stellar model and the opacity configuration, shaped as the reference's
     calc_alphas / raytrace read them (opacities_solvers/base.py:630-740, radiation_field_solvers/base.py:271-346): the
     continuum state of synth_continuum_state and a VALD-style line list with a dense alpha table (synth_lines' strengths on
@@ -242,7 +242,7 @@ def fake_plasma(nus, atm, n_lines, seed=SEED, vald_broadening=False, table_dir=N
     lines = pd.DataFrame(dict(
         atomic_number=np.asarray(spec.atomic_number), ion_number=np.asarray(spec.ion_number) - 1, nu=spec.nu,
         ionization_energy=spec.ionization_energy, level_energy_upper=spec.upper_energy, level_energy_lower=spec.lower_energy,
-        A_ul=spec.A_ul, stark=spec.stark, waals=spec.waals, e_low=spec.e_low_ev,
+        A_ul=spec.A_ul, stark=spec.stark, waals=spec.waals, e_low=spec.e_low_ev, f_lu=spec.strength, g_lo=spec.g_lo,
     ))
     alpha_table = pd.DataFrame(dense["alphas"], columns=cols)
     alpha_table["nu"] = dense["line_nus"]
@@ -265,7 +265,32 @@ def fake_plasma(nus, atm, n_lines, seed=SEED, vald_broadening=False, table_dir=N
         lines_from_linelist=lines,
         alpha_line_from_linelist=alpha_table,
     )
-    masses = pd.Series(np.array([1.008, 12.011, 24.305, 40.078, 55.845]) * K.AMU_CGS, index=pd.Index([1, 6, 12, 20, 26], name="atomic_number"))
+    # what the per-line-scalar route needs when the dense alpha table is dropped (plasma.alpha_line_from_linelist = None):
+    # number density / partition function per (Z, ion) such that their ratio is the list's population row
+    species = [(z, k) for z in (1, 6, 12, 20, 26) for k in (0, 1)]
+    dens_rows = {key: plasma.ion_number_density.loc[key].to_numpy() for key in plasma.ion_number_density.index}
+    for j, key in enumerate(species):
+        dens_rows.setdefault(key, spec.pop[j])
+    full = pd.MultiIndex.from_tuples(sorted(dens_rows), names=["atomic_number", "ion_number"])
+    plasma.ion_number_density = pd.DataFrame(np.vstack([dens_rows[k] for k in full]), index=full, columns=cols)
+    part = pd.DataFrame(np.ones((len(full), t.size)), index=full, columns=cols)
+    for j, key in enumerate(species):
+        part.loc[key] = plasma.ion_number_density.loc[key].to_numpy() / np.where(spec.pop[j] > 0, spec.pop[j], 1.0)
+    plasma.partition_function = part
+    masses = pd.Series(np.array([1.008, 12.011, 15.999, 24.305, 40.078, 47.867, 55.845]) * K.AMU_CGS,
+                       index=pd.Index([1, 6, 8, 12, 20, 22, 26], name="atomic_number"))
+    if n_molecule_lines:  # a second, molecular list (include_molecules): TiO / H2O style lines, dense table and per-line scalars
+        mol = synth_lines(nus, atm, n_molecule_lines, seed + 1, gamma_per_depth=False, mix=(0.97, 0.03, 0.0))
+        mspec = synth_linelist(nus, atm, n_molecule_lines, seed + 1, vald_broadening=False, mix=(0.97, 0.03, 0.0))
+        names = np.where(np.arange(n_molecule_lines) % 2 == 0, "TiO", "OH")
+        plasma.molecule_lines_from_linelist = pd.DataFrame(dict(nu=mol["line_nus"], molecule=names, A_ul=mspec.A_ul, e_low=mspec.e_low_ev,
+                                                                 f_lu=mspec.strength, g_lo=mspec.g_lo))
+        mtab = pd.DataFrame(mol["alphas"], columns=cols)
+        mtab["nu"] = mol["line_nus"]
+        plasma.molecule_alpha_line_from_linelist = mtab
+        plasma.molecule_ion_map = pd.DataFrame(dict(Ion1=[22, 8], Ion2=[8, 1]), index=["TiO", "OH"])
+        plasma.molecule_number_density = pd.DataFrame(np.vstack([1e-7 * cont["n_h1"], 1e-6 * cont["n_h1"]]), index=["TiO", "OH"], columns=cols)
+        plasma.molecule_partition_function = pd.DataFrame(np.vstack([50.0 + 0.01 * t, 20.0 + 0.005 * t]), index=["TiO", "OH"], columns=cols)
     r = np.asarray(atm["r"], dtype=np.float64)
     model = NS(
         temperatures=t, no_of_depth_points=t.size, spherical=False,

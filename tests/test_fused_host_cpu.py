@@ -56,6 +56,25 @@ def test_memo_is_keyed_on_object_identity():
     assert not fused._MEMO
 
 
+def test_memo_notices_an_edit_in_place():
+    """A table edited IN PLACE between two calls is the same object: the cheap content fingerprint next to the identity (shape,
+    first, last and summed value) makes the cached derivation miss, as the reference — which recomputes everything — would see
+    the edit (round-3 advisor finding)."""
+    fused.clear_cache()
+    table = pd.DataFrame({"nu": [3.0, 1.0, 2.0], "A_ul": [1e7, 2e7, 3e7]})
+    n = []
+    f = lambda: fused._memo("edit", (table,), None, lambda: n.append(1) or float(table["nu"].sum()))  # noqa: E731
+    assert f() == 6.0 and f() == 6.0 and len(n) == 1
+    table.loc[1, "nu"] = 10.0
+    assert f() == 15.0 and len(n) == 2
+    series = pd.Series(np.arange(5.0))
+    g = lambda: fused._memo("edit", (series,), None, lambda: n.append(1) or float(series.iloc[-1]))  # noqa: E731
+    assert g() == 4.0
+    series.iloc[-1] = 9.0
+    assert g() == 9.0
+    fused.clear_cache()
+
+
 def test_sorted_line_tables_follow_pandas_in_grid_order():
     rng = np.random.default_rng(5)
     n, nd = 300, 7
