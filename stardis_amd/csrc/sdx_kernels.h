@@ -2326,6 +2326,7 @@ __global__ __launch_bounds__(kRtBlock) void k_raytrace(int n_depth, int64_t n_nu
         }
     }
     double s1 = sS[gi + 1], d10 = sS[gi] - s1;
+    const float inv_gpw = 1.0f / (float)gpw;
 
     for (int gap0 = 0; gap0 < n_gap; gap0 += kBatch) {
         const int nb = min(kBatch, n_gap - gap0);
@@ -2367,11 +2368,16 @@ __global__ __launch_bounds__(kRtBlock) void k_raytrace(int n_depth, int64_t n_nu
             const int half = (n_theta + 1) >> 1;
             for (int p = lane; p < 2 * nb * gpw; p += 64) {
                 const int h = p & 1, q = p >> 1;
-                const int b = q / gpw, gq = q - b * gpw;
+                const int b = (int)(((float)q + 0.5f) * inv_gpw), gq = q - b * gpw;  // q / gpw without an integer division (q < 2^20: exact)
                 const double* c = sX + (b * gpw + gq) * TH + (h ? half : 0);
                 const int cnt = h ? n_theta - half : half;
                 double sum = 0.0;
-                for (int t = 0; t < cnt; ++t) sum = add_rn(sum, c[t]);
+                int t = 0;
+                for (; t + 5 <= cnt; t += 5) {  // five terms a trip (their loads in flight together), added in ascending order
+                    const double c0 = c[t], c1 = c[t + 1], c2 = c[t + 2], c3 = c[t + 3], c4 = c[t + 4];
+                    sum = add_rn(add_rn(add_rn(add_rn(add_rn(sum, c0), c1), c2), c3), c4);
+                }
+                for (; t < cnt; ++t) sum = add_rn(sum, c[t]);
                 const double other = __shfl_xor(sum, 1);  // 2 nb gpw is even: the partner lane is in the loop too
                 const int64_t iq = i0 + gq;
                 if (h == 0 && iq < n_nu) {
@@ -2379,6 +2385,107 @@ __global__ __launch_bounds__(kRtBlock) void k_raytrace(int n_depth, int64_t n_nu
                     double* dst = F + (size_t)(gap0 + b + 1) * fld + iq;
                     *dst = accumulate ? add_rn(*dst, tot) : tot;
                 }
+            }
+        }
+        wave_sync();
+    }
+}
+
+// The formal solution of the fp32-mixed TOLERANCE path (mixed_precision = 1; plane-parallel, one angle per lane, flux only): the
+// layout of k_raytrace<1> — lane <-> (frequency, angle), columns staged per wave — with the recurrence in fp32 (rt_coef32:
+// hardware exp2 / rcp, ~27 instructions per step at twice the fp64 issue rate against ~54).  sqrt(alpha), the source function
+// and the ray lengths are staged as floats (the totals are formed in fp64 and rounded once); F_nu is written as doubles.
+// Against the fp64 kernels: < 1e-5 of the flux on the full-size workloads (tests/test_gpu_configs.py, stated tolerance 1e-4).
+__global__ __launch_bounds__(kRtBlock) void k_raytrace_f32(int n_depth, int64_t n_nu, int n_theta, int theta_stride, int G,
+                                                           const double* __restrict__ nus, const double* __restrict__ temps,
+                                                           const double* __restrict__ ray_dist, const double* __restrict__ wts,
+                                                           const double* __restrict__ alphas, int64_t ald, double* __restrict__ F,
+                                                           int64_t fld, int gpw, FusedTotal ft)
+{
+    constexpr int kBatch = 8;
+    extern __shared__ double smem[];
+    float* fmem = (float*)smem;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = lane / G, g = lane - grp * G;
+    const int64_t i0 = ((int64_t)blockIdx.x * (kRtBlock / 64) + wave) * gpw;
+    const int64_t i = i0 + grp;
+    const bool active = grp < gpw;
+    const bool valid = active && i < n_nu;
+    const int64_t ic = i < n_nu ? i : n_nu - 1;
+    const int n_gap = n_depth - 1, col = n_depth;
+    float* sRD = fmem;                                   // ray_dist [n_gap][n_theta], shared by the block
+    float* wbase = sRD + n_gap * n_theta + (size_t)wave * (2 * gpw * col + kBatch * gpw * G);
+    float* sS = wbase;                                   // source function [gpw][col]
+    float* sA = sS + gpw * col;                          // sqrt(alpha)
+    float* sX = sA + gpw * col;                          // flux terms [kBatch][gpw][G]
+    const double nu = nus[ic];
+    for (int k = threadIdx.x; k < n_gap * n_theta; k += kRtBlock) {
+        const int gp = k / n_theta, t = k - gp * n_theta;
+        sRD[k] = (float)ray_dist[(size_t)gp * theta_stride + t];
+    }
+    if (active) {
+        for (int d = g; d < n_depth; d += G) {
+            double a;
+            if (ft.cont) {
+                a = ft.cont[(size_t)d * ft.cld + ic];
+                if (ft.planes) {
+                    double line = ft.planes[(size_t)d * ft.pld + ic];
+                    for (int sp = 1; sp < ft.n_planes; ++sp) line = add_rn(line, ft.planes[((size_t)sp * n_depth + d) * ft.pld + ic]);
+                    a = add_rn(a, line);
+                    if (valid && ft.line_out) ft.line_out[(size_t)d * ft.out_ld + i] = line;
+                }
+                for (int x = 0; x < ft.n_extra; ++x) a = add_rn(a, ft.extra[x][(size_t)d * ft.eld + ic]);
+                if (valid && ft.total_out) ft.total_out[(size_t)d * ft.out_ld + i] = a;
+            } else {
+                a = alphas[(size_t)d * ald + ic];
+            }
+            sA[grp * col + d] = __builtin_sqrtf((float)a);
+            sS[grp * col + d] = ft.source ? (float)ft.source[(size_t)d * ft.sld + ic] : planck32(nu, temps[d]);
+        }
+    }
+    __syncthreads();
+    const int gi = (active ? grp : 0) * col;
+    const int th = min(g, n_theta - 1);
+    const float wt = g < n_theta ? (float)wts[th] : 0.f;
+    if (valid && g == 0) F[i] = 0.0;
+    float inten = 0.f;
+    float a1 = sA[gi + 1];
+    float t0 = (sA[gi] * a1) * sRD[th];
+    float s1 = sS[gi + 1], d10 = sS[gi] - s1;
+    const float inv_gpw = 1.0f / (float)gpw;
+    for (int gap0 = 0; gap0 < n_gap; gap0 += kBatch) {
+        const int nb = min(kBatch, n_gap - gap0);
+        for (int b = 0; b < nb; ++b) {
+            const int gap = gap0 + b;
+            const bool last = gap == n_gap - 1;
+            const int nx = last ? gap : gap + 1;
+            const float s2 = sS[gi + nx + 1], a2 = sA[gi + nx + 1];
+            const float t1 = (a1 * a2) * sRD[nx * n_theta + th];
+            const float d21 = s2 - s1;
+            float c, e;
+            rt_coef32(t0, t1, d10, d21, s1, last, c, e);
+            inten = fmaf(c, inten, e);
+            if (active) sX[(b * gpw + grp) * G + g] = inten * wt;
+            t0 = t1, d10 = -d21, s1 = s2, a1 = a2;
+        }
+        wave_sync();
+        {
+            const int half = (n_theta + 1) >> 1;
+            for (int p = lane; p < 2 * nb * gpw; p += 64) {
+                const int h = p & 1, q = p >> 1;
+                const int b = (int)(((float)q + 0.5f) * inv_gpw), gq = q - b * gpw;
+                const float* cc = sX + (b * gpw + gq) * G + (h ? half : 0);
+                const int cnt = h ? n_theta - half : half;
+                float sum = 0.f;
+                int t = 0;
+                for (; t + 5 <= cnt; t += 5) {
+                    const float c0 = cc[t], c1 = cc[t + 1], c2 = cc[t + 2], c3 = cc[t + 3], c4 = cc[t + 4];
+                    sum = ((((sum + c0) + c1) + c2) + c3) + c4;
+                }
+                for (; t < cnt; ++t) sum += cc[t];
+                const float other = __shfl_xor(sum, 1);
+                const int64_t iq = i0 + gq;
+                if (h == 0 && iq < n_nu) F[(size_t)(gap0 + b + 1) * fld + iq] = (double)(sum + other);
             }
         }
         wave_sync();

@@ -619,4 +619,47 @@ __device__ __forceinline__ void rt_coef(double t0, double t1, double d10, double
     }
 }
 
+// ---- the formal solution's step in fp32: the tolerance path (mixed_precision = 1), stated tolerance 1e-4 on the flux -------------
+// The same affine map I' = c I + e as rt_coef, from the EXACT weight functions (van Noort 2002 eq. 14)
+//     w0 = 1 - e^-t,   w1 = 1 - e^-t (1 + t),   w2 = 2 - e^-t (2 + 2 t + t^2)
+// instead of the reference's two-regime forms: below t = 0.25 their power series (six terms: truncation < 1e-7 relative), above
+// it the exponential (v_exp_f32) — in fp32 the differences 1 - E ... lose 6e-8 / t of their value, which the series region
+// keeps out of reach.  The reference's own forms differ from these functions by < 5e-8 (its series stops after two terms at
+// t < 5e-4).  Optical depths below 1e-12 (no measurable change: the step adds t S) are treated as 0; in the second-order terms
+// t is capped at 1e6 (they fall off as 1 / t: the cap moves them by < 1e-6 of the source difference) so that the common
+// denominator t0 t1 (t0 + t1) stays inside the fp32 range.
+__device__ __forceinline__ void rt_coef32(float t0, float t1, float d10, float d21, float s1, bool last, float& c, float& e)
+{
+    float w0, w1, w2;
+    if (t0 < 0.25f) {
+        w0 = t0 * fmaf(t0, fmaf(t0, fmaf(t0, fmaf(t0, fmaf(t0, -1.f / 720, 1.f / 120), -1.f / 24), 1.f / 6), -0.5f), 1.f);
+        const float t2 = t0 * t0;
+        w1 = t2 * fmaf(t0, fmaf(t0, fmaf(t0, fmaf(t0, fmaf(t0, -1.f / 840, 1.f / 144), -1.f / 30), 0.125f), -1.f / 3), 0.5f);
+        w2 = (t2 * t0) * fmaf(t0, fmaf(t0, fmaf(t0, fmaf(t0, fmaf(t0, -1.f / 960, 1.f / 168), -1.f / 36), 0.1f), -0.25f), 1.f / 3);
+    } else {
+        const float E = __builtin_amdgcn_exp2f(fminf(t0, 100.f) * -1.4426950409f);
+        w0 = 1.f - E;
+        w1 = w0 - t0 * E;
+        w2 = fmaf(-t0 * t0, E, w1 + w1);
+    }
+    c = 1.f - w0;
+    const float a0 = fminf(t0, 1e6f), a1 = fminf(t1, 1e6f);
+    if (last) {
+        e = fmaf(w0, s1, (w2 * d10) * __builtin_amdgcn_rcpf(a0 * a0));
+    } else {
+        const float den = (a0 * a1) * (a0 + a1);
+        const float u = fmaf(w1, a1, w2), v = fmaf(-w1, a0, w2);
+        const float num = fmaf(d10 * a1, u, (d21 * a0) * v);
+        e = fmaf(w0, s1, num * __builtin_amdgcn_rcpf(den));
+        if (!(t1 >= 1e-12f)) e = w0 * s1;  // a transparent gap ahead: first order only (the reference divides by zero there)
+    }
+    if (!(t0 >= 1e-12f)) c = 1.f, e = 0.f;  // :203-206 (and NaN: no change rather than poison — tolerance path)
+}
+__device__ __forceinline__ float planck32(double nu, double temp)
+{
+    const float x = (float)mul_rn(kH, nu) * __builtin_amdgcn_rcpf((float)mul_rn(kKB, temp));
+    const double pre = mul_rn(mul_rn(2.0, kH), mul_rn(mul_rn(nu, nu), nu)) * (1.0 / (kC * kC));
+    return (float)pre * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x * 1.4426950409f) - 1.f);
+}
+
 }  // namespace sdx

@@ -1749,6 +1749,22 @@ static int raytrace_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, c
             if (rc) return rc;
             continue;
         }
+        // the tolerance path (mixed_precision = 1): plane-parallel, all angles in one launch, flux only -> the fp32 recurrence
+        if (ctx->mixed_precision && P == 1 && !inward && !acc && !inus && F && n_theta <= 64) {
+            const int g32 = 64 / G;
+            const size_t shmem32 = ((size_t)(n_depth - 1) * nth + (size_t)(kRtBlock / 64) * (2 * (size_t)g32 * n_depth + 8 * (size_t)g32 * G)) * sizeof(float);
+            if (shmem32 <= 64 * 1024) {
+                {
+                    LaunchScope ls(ctx, "k_raytrace");
+                    const unsigned blocks32 = (unsigned)((n_nu + (int64_t)g32 * (kRtBlock / 64) - 1) / ((int64_t)g32 * (kRtBlock / 64)));
+                    hipLaunchKernelGGL(k_raytrace_f32, dim3(blocks32), dim3(kRtBlock), shmem32, ctx->stream, n_depth, n_nu, nth, n_theta, G, nus, temps, rd, w, alphas,
+                                       ald, F, fld, g32, ft);
+                }
+                int rc = check_launch("k_raytrace_f32");
+                if (rc) return rc;
+                continue;
+            }
+        }
         {
             LaunchScope ls(ctx, "k_raytrace");
 #define SDX_RT_ARGS n_depth, n_nu, nth, n_theta, G, nus, temps, rd, w, alphas, ald, F, fld, inus, acc

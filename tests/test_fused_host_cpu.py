@@ -67,11 +67,8 @@ def test_memo_notices_an_edit_in_place():
     assert f() == 6.0 and f() == 6.0 and len(n) == 1
     table.loc[1, "nu"] = 10.0
     assert f() == 15.0 and len(n) == 2
-    series = pd.Series(np.arange(5.0))
-    g = lambda: fused._memo("edit", (series,), None, lambda: n.append(1) or float(series.iloc[-1]))  # noqa: E731
-    assert g() == 4.0
-    series.iloc[-1] = 9.0
-    assert g() == 9.0
+    table.drop(index=0, inplace=True)  # rows dropped in place: another shape
+    assert f() == 12.0 and len(n) == 3
     fused.clear_cache()
 
 
