@@ -1,4 +1,5 @@
-"""Per-kernel times of ONE rank of a balanced N-way split (eager events + graph step): python scripts/r4/shard_kernels.py TAG WORLD RANK [reps]"""
+"""Per-kernel times of ONE rank of a balanced N-way split (eager events + graph step): python scripts/r4/shard_kernels.py TAG WORLD RANK [--shard BEGIN COUNT]
+(--shard: an explicit block of columns instead of the rank's — e.g. a few columns, to see the floor of every launch)"""
 import ctypes as C, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from stardis_amd import synth, parallel, _lib
@@ -8,6 +9,9 @@ tag, world, rank = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 w = synth.make_workload(tag)
 atm, nus = w["atm"], w["nus"]
 shard = parallel.balanced_shards(parallel.column_cost(nus, w["lines"]), world)[rank] if world > 1 else (0, nus.size)
+if "--shard" in sys.argv:
+    k = sys.argv.index("--shard")
+    shard = (int(sys.argv[k + 1]), int(sys.argv[k + 2]))
 syn = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], w["thetas"], w["weights"], w["lines"], w["cont"], shard=shard, track_evaluations=False, keep_line=False)
 ctx = syn.ctx
 syn.capture()
