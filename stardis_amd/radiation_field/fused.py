@@ -44,6 +44,7 @@ RAYLEIGH_CUTOFF = 2.3e15  # opacities_solvers/base.py:99
 # recomputed, which misses the cache too.
 _MEMO = {}
 _MEMO_MAX = 16
+MEMO_MAX_BYTES = 2 << 30  # ... and at most this much derived data (numpy arrays in the cached values; the newest entry always stays)
 
 
 def clear_cache():
@@ -69,6 +70,21 @@ def _stamp(obj):
     return None
 
 
+class _Snapshot:
+    """The named attributes of `obj` as they are now (references, not copies); everything else is read through."""
+
+    def __init__(self, obj, names):
+        self.__dict__["_live"] = obj
+        for name in names:
+            try:
+                self.__dict__[name] = getattr(obj, name)
+            except AttributeError:
+                pass
+
+    def __getattr__(self, name):  # (only reached for names that were not taken)
+        return getattr(self.__dict__["_live"], name)
+
+
 def _memo(tag, objects, extra, build):
     key = (tag, tuple(id(o) for o in objects), tuple(_stamp(o) for o in objects), extra)
     hit = _MEMO.get(key)
@@ -76,10 +92,25 @@ def _memo(tag, objects, extra, build):
         _MEMO[key] = _MEMO.pop(key)  # most recently used last
         return hit[1]
     value = build()
-    _MEMO[key] = (objects, value)
-    while len(_MEMO) > _MEMO_MAX:
+    _MEMO[key] = (objects, value, _nbytes(value))
+    while len(_MEMO) > _MEMO_MAX or (len(_MEMO) > 1 and sum(e[2] for e in _MEMO.values()) > MEMO_MAX_BYTES):
         _MEMO.pop(next(iter(_MEMO)))
     return value
+
+
+def _nbytes(value, depth=0):
+    """numpy bytes reachable from a cached value (tuples, lists, dicts, objects with a __dict__), for the cache's byte bound"""
+    if isinstance(value, np.ndarray):
+        return value.nbytes
+    if depth > 4:
+        return 0
+    if isinstance(value, dict):
+        return sum(_nbytes(v, depth + 1) for v in value.values())
+    if isinstance(value, (tuple, list)):
+        return sum(_nbytes(v, depth + 1) for v in value)
+    if hasattr(value, "__dict__"):
+        return sum(_nbytes(v, depth + 1) for v in vars(value).values())
+    return 0
 
 
 _QUADRATURE = {}
@@ -764,6 +795,12 @@ def _run_step(v):
         return _Thunk(run)
 
     fnus = field.frequencies
+    # The continuum entries are formed on first read from the plasma's tables — the tables of THIS call: the objects are taken now,
+    # so that a plasma whose attributes are replaced afterwards (the next iteration of a fit) still yields entries that belong to
+    # this field's F_nu.  (Tables edited in place are not protected; materialise the entries first — release_device(field).)
+    stellar_plasma = _Snapshot(stellar_plasma, ("ion_number_density", "electron_densities", "h_minus_density", "h2_density", "levels",
+                                                "excitation_energy", "level_number_density", "ionization_data"))
+    stellar_model = _Snapshot(stellar_model, ("temperatures", "no_of_depth_points", "composition"))
     for k, (source, fpath) in enumerate(opacity.file.items()):
         if file_planes:  # the plane the step added is the entry
             put(f"alpha_file_{source}", twin(file_planes[k]))

@@ -56,6 +56,20 @@ def test_memo_is_keyed_on_object_identity():
     assert not fused._MEMO
 
 
+def test_memo_is_bounded_by_bytes_too(monkeypatch):
+    """Sixteen entries of sorted 10^6-line tables would be gigabytes of host memory: the cache also counts the numpy bytes of what
+    it holds and drops the least recently used entries beyond MEMO_MAX_BYTES (the newest always stays)."""
+    fused.clear_cache()
+    monkeypatch.setattr(fused, "MEMO_MAX_BYTES", 3000)
+    keys = [pd.Series([float(k)]) for k in range(5)]
+    for k, obj in enumerate(keys):
+        fused._memo("big", (obj,), None, lambda: {"a": np.zeros(100), "b": (np.zeros(25), [np.zeros(0)])})  # 1000 bytes each
+    assert len(fused._MEMO) == 3 and sum(e[2] for e in fused._MEMO.values()) == 3000
+    fused._memo("huge", (keys[0],), None, lambda: np.zeros(1000))  # larger than the bound on its own: it stays, alone
+    assert len(fused._MEMO) == 1
+    fused.clear_cache()
+
+
 def test_memo_notices_an_edit_in_place():
     """A table edited IN PLACE between two calls is the same object: the cheap content fingerprint next to the identity (shape,
     first, last and summed value) makes the cached derivation miss, as the reference — which recomputes everything — would see

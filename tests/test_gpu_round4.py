@@ -273,3 +273,29 @@ def test_fused_fields_give_their_device_memory_back(ctx, monkeypatch, tmp_path):
     fused.release_device(b, materialize=False)
     with pytest.raises(RuntimeError, match="released"):
         b.opacities.opacities_dict["alpha_line_at_nu"]
+
+
+@pytest.mark.gpu
+def test_lazy_entries_belong_to_the_call_that_made_the_field(ctx, monkeypatch, tmp_path):
+    """The continuum entries of a fused field are formed on first read.  They are formed from the plasma tables of the call
+    (references taken then), not from whatever the plasma holds at the time of the read: replacing the plasma's attributes — the next
+    iteration of a fit — must not give entries that disagree with the field's F_nu (round-3 advisor finding)."""
+    import stardis_amd.radiation_field.base as rf
+    from test_gpu_dropin import rebuild
+
+    g, plasma, model, cfg = rebuild("vald", tmp_path)
+    config = NS(opacity=cfg, no_of_thetas=4, result_options=NS(return_radiation_field=True))
+    monkeypatch.setattr(rf, "FUSED", False)
+    ref = rf.create_stellar_radiation_field(g["nus"].copy(), model, plasma, config)
+    want = {k: np.array(v) for k, v in ref.opacities.opacities_dict.items()}
+    monkeypatch.setattr(rf, "FUSED", True)
+    a = rf.create_stellar_radiation_field(g["nus"].copy(), model, plasma, config)
+    assert type(a.opacities).__name__ == "FusedOpacities"
+    plasma.electron_densities = plasma.electron_densities * 3.0
+    plasma.ion_number_density = plasma.ion_number_density * 0.5
+    plasma.level_number_density = plasma.level_number_density * 2.0
+    for k, v in want.items():
+        assert np.array_equal(np.asarray(a.opacities.opacities_dict[k]), v), k
+    b = rf.create_stellar_radiation_field(g["nus"].copy(), model, plasma, config)  # the edited plasma gives another field
+    assert not np.array_equal(b.F_nu, a.F_nu)
+    assert not np.array_equal(np.asarray(b.opacities.opacities_dict["alpha_electron"]), want["alpha_electron"])
