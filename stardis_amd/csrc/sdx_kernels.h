@@ -143,6 +143,10 @@ constexpr int kMaxTile = 512;           // the widest tile of the wide role (64 
 //   wrec    48 B, read once per (item, tile) that overlaps: line frequency, 1 / doppler and the region-I constants
 //   wslow   16 B, read only by tiles that touch a window edge or the core: y and the amplitude (regions II-IV)
 //   wrec32  32 B, the fp32 twin of wrec for the mixed-precision mode (line frequency as a hi + lo pair)
+#ifdef SDX_WALK_STATS  // analysis build (scripts/r4/walk_stats.sh): what the waves of the line kernel spend their time on
+constexpr int kWalkStatSlots = 1 << 19;  // lower half: wide waves by (depth < 64, tile < 512, subset < 8); upper half: narrow waves by frequency
+__device__ unsigned long long g_walk_stats[(size_t)kWalkStatSlots * 8];
+#endif
 struct alignas(16) WideScan {
     int lo, hi, clo, chi;
 };
@@ -676,6 +680,10 @@ __device__ __forceinline__ void line_wide_walk(const int tile_idx, const int spl
     const WideRec32* __restrict__ rec32_row = MIXED ? w.wrec32 + row : nullptr;
     const int n_h = w.hlist ? __builtin_amdgcn_readfirstlane(*w.hcount) : 0;
     int pending32 = 0;  // fp32 terms accumulated since the last flush into the fp64 sums
+#ifdef SDX_WALK_STATS
+    const unsigned long long st_t0 = wall_clock64();
+    int st_chunks = 0, st_fast = 0, st_general = 0, st_if = 0, st_slow = 0;
+#endif
 
     for (int pass = w.hlist ? 0 : 1; pass < 2; ++pass) {
         // candidate positions [ka, kb) of this pass: hlist positions (pass 0); wlist positions or — short lists — line indices (pass 1)
@@ -725,6 +733,9 @@ __device__ __forceinline__ void line_wide_walk(const int tile_idx, const int spl
             const int clo = sc.clo < 0 ? -sc.clo - 1 : sc.clo;                // sign: core delegated to the narrow role
             const bool fast = hit & (sc.lo <= it0) & (sc.hi >= it1) & ((it1 <= clo) | (it0 >= sc.chi));
             unsigned long long m = __ballot(hit);
+#ifdef SDX_WALK_STATS
+            ++st_chunks;
+#endif
             if (m == 0) continue;
             const unsigned long long mf = __ballot(fast);
             if constexpr (MIXED) pending32 += __popcll(m);
@@ -763,6 +774,9 @@ __device__ __forceinline__ void line_wide_walk(const int tile_idx, const int spl
                         const double c0 = (nu_base_vec - cur.lnu) * cur.inv;
                         region1_add_shared<R>(acc, dnu, cur.inv, c0, k1);
                     }
+#ifdef SDX_WALK_STATS
+                    ++st_fast;
+#endif
                     m = m1;
                 }
                 if (!m) break;
@@ -772,6 +786,9 @@ __device__ __forceinline__ void line_wide_walk(const int tile_idx, const int spl
                 WideRec32 cur32;
                 if (MIXED) cur32 = rec32_row[e];
                 m &= m - 1;
+#ifdef SDX_WALK_STATS
+                ++st_general;
+#endif
                 {
                     // The tile touches a window edge or the core.  Per 64-point block r (scalar tests): outside the window:
                     // nothing; clear of the core: the region-I rational for the whole block, added where the point is
@@ -793,6 +810,9 @@ __device__ __forceinline__ void line_wide_walk(const int tile_idx, const int spl
                         const int a = it0 + 64 * r, z = min(a + 64, it1);
                         if (z <= jlo || a >= jhi || a >= it1) continue;
                         const bool over_core = !(z <= jclo || a >= jchi);
+#ifdef SDX_WALK_STATS
+                        if (!over_core || delegated) ++st_if; else ++st_slow;
+#endif
                         if (!over_core || delegated) {
                             const int ir = idx0 + 64 * r;  // (points beyond the grid's end lie beyond every window: jhi <= N_nu)
                             const bool take = ir >= jlo && ir < jhi && !(over_core && ir >= jclo && ir < jchi);
@@ -834,6 +854,14 @@ __device__ __forceinline__ void line_wide_walk(const int tile_idx, const int spl
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] += (double)acc32[r >> 1][r & 1];
     }
+#ifdef SDX_WALK_STATS
+    if (lane == 0) {  // (a device array read back by sdx_walk_stats_read: printf's host calls slowed the whole launch a thousandfold)
+        const int slot = ((d * 512 + tile_idx) * 8 + split) & (kWalkStatSlots / 2 - 1);
+        unsigned long long* const o = g_walk_stats + (size_t)slot * 8;
+        o[0] = ((unsigned long long)d << 40) | ((unsigned long long)tile_idx << 8) | (unsigned long long)split | (1ull << 63);
+        o[1] = st_t0, o[2] = wall_clock64(), o[3] = st_chunks, o[4] = st_fast, o[5] = st_general, o[6] = st_if, o[7] = st_slow;
+    }
+#endif
     wide_reduce_and_store<R>(split, n_split, acc, idx0, s0, s1, lds_all, plane, pld, d);
 }
 
@@ -1067,6 +1095,10 @@ __device__ __forceinline__ void line_narrow_wave(const int64_t i, const int dept
     const int lb = __builtin_amdgcn_readfirstlane(w.cnt_ge[pa]);
     const double nu_i = nus[i];
     double acc = 0.0;
+#ifdef SDX_WALK_STATS
+    const unsigned long long st_t0 = wall_clock64();
+    int st_chunks = 0, st_rel = 0, st_eval = 0;
+#endif
     for (int base = la; base < lb; base += 64) {
         // lanes test 64 candidate lines at once against this frequency (per-line bound), then the wave visits
         // only the relevant ones, in ascending line order
@@ -1079,8 +1111,14 @@ __device__ __forceinline__ void line_narrow_wave(const int64_t i, const int dept
             rel = hwm > 0 && ii >= c - hwm && ii < c + hwm;
         }
         unsigned long long m = __ballot(rel);
+#ifdef SDX_WALK_STATS
+        ++st_chunks, st_rel += __popcll(m);
+#endif
         // the parameters of the NEXT relevant line are requested before the current one is evaluated (all six loads at
-        // once, used or not): one global-memory round trip per line hides behind the previous line's arithmetic
+        // once, used or not): one global-memory round trip per line hides behind the previous line's arithmetic.  (Two lines in
+        // flight — pairs — and the next chunk's candidates requested ahead were measured in round 4: 24.4 against 24.2 us for the
+        // role alone at S-c2, 37.1 against 37.0 together: a wave's line takes ~1 us because seven waves share the SIMD's
+        // arithmetic, not because it waits for memory.)
         int h = 0, cl = 0;  // this depth's half-width, the line's centre (scalar)
         double y = 0.0, amp = 0.0, inv = 0.0, lnu = 0.0;
         // addresses: a per-line base (uniform: scalar arithmetic) + the lane's depth as an unsigned 32-bit offset
@@ -1102,6 +1140,9 @@ __device__ __forceinline__ void line_narrow_wave(const int64_t i, const int dept
                 cl_n = __builtin_amdgcn_readlane(c, bit);
                 h_n = (w.nhw + ob)[dcu], y_n = (w.n_y + ob)[dcu], amp_n = (w.n_amp + ob)[dcu], inv_n = (w.n_inv + ob)[dcu], lnu_n = line_nus[l];
             }
+#ifdef SDX_WALK_STATS
+            if (__ballot(valid && ii >= cl - h && ii < cl + h)) ++st_eval;
+#endif
             if (valid && ii >= cl - h && ii < cl + h) {  // (h = 0: empty)
                 const RegionI k1 = region1_setup(y, amp);
                 acc = voigt_add(acc, nu_i - lnu, inv, y, amp, k1);
@@ -1109,6 +1150,14 @@ __device__ __forceinline__ void line_narrow_wave(const int64_t i, const int dept
             h = h_n, cl = cl_n, y = y_n, amp = amp_n, inv = inv_n, lnu = lnu_n;
         }
     }
+#ifdef SDX_WALK_STATS
+    if (lane == 0) {
+        const int slot = (int)(kWalkStatSlots / 2 + (i & (kWalkStatSlots / 2 - 1)));
+        unsigned long long* const o = g_walk_stats + (size_t)slot * 8;
+        o[0] = (unsigned long long)i | (3ull << 62);
+        o[1] = st_t0, o[2] = wall_clock64(), o[3] = st_chunks, o[4] = st_rel, o[5] = st_eval, o[6] = 0, o[7] = 0;
+    }
+#endif
     if (valid) plane[(size_t)d * pld + (i - nu_begin)] = acc;
 }
 

@@ -2523,3 +2523,17 @@ int sdx_synthesize_sharded_f64(sdx_group* g, int n_depth, int64_t n_nu, const do
 }
 
 }  // extern "C"
+
+#ifdef SDX_WALK_STATS
+// analysis build only (scripts/r4/walk_stats.sh): the line kernel's wave statistics of the launches so far, then cleared
+extern "C" int sdx_walk_stats_read(unsigned long long* out, long long n_words)
+{
+    const size_t bytes = std::min<size_t>((size_t)n_words * 8, sizeof(unsigned long long) * (size_t)sdx::kWalkStatSlots * 8);
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(sdx::g_walk_stats), bytes) != hipSuccess) return -1;
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(sdx::g_walk_stats)) != hipSuccess) return -1;
+    return hipMemset(p, 0, sizeof(unsigned long long) * (size_t)sdx::kWalkStatSlots * 8) == hipSuccess ? 0 : -1;
+}
+#endif
+
