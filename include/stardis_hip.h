@@ -29,7 +29,8 @@
  *       SDX_RT_P          1, 2, 4: angles per lane of k_raytrace
  *       SDX_R_MIXED       4 / 8: grid points per lane of a mixed-precision tile
  *     scheduling and layout only (same bits): SDX_NARROW_F (1, 2, 4 frequencies per narrow wave), SDX_NARROW_ORDER,
- *       SDX_WIDE_GROUP, SDX_CONT_DGS, SDX_NO_CULL, SDX_NO_CONT_RIDE, SDX_NO_HSCAN, SDX_NO_PINNED_STAGING,
+ *       SDX_WIDE_GROUP, SDX_CONT_DGS, SDX_CLS_BLOCKS (workgroups of a shard's classification stream), SDX_NO_CULL,
+ *       SDX_NO_CONT_RIDE, SDX_NO_HSCAN, SDX_NO_PINNED_STAGING,
  *       SDX_SPLIT_LAUNCHES (the two roles of the line kernel as two launches, for profiling)
  *     test hook: SDX_GROUP_LOOPBACK (see sdx_group_create).
  */
