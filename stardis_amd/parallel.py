@@ -82,7 +82,7 @@ def scan_work(nus, line_nus, half_width=4096):
     return (np.searchsorted(centre, i + half_width, side="left") - np.searchsorted(centre, i - half_width, side="right")).astype(np.float64)
 
 
-def column_cost(nus, lines, indexed_min_lines=8192, scan_weight=0.6, fixed=6000.0, core_weight=14.0):
+def column_cost(nus, lines, indexed_min_lines=8192, scan_weight=0.6, fixed=8000.0, core_weight=14.0):
     """Estimated cost of every grid column in units of one far-wing Voigt evaluation, for balanced_shards: the window
     evaluations (line cores weighted by core_weight), the candidate scan of long lists (scan_weight per line in range) and
     a constant for the continuum and the formal solution — weights measured on MI355X.  A planning estimate on the host: it
