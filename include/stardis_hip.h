@@ -464,7 +464,8 @@ int sdx_alpha_line_levels_dev(sdx_ctx* ctx, int64_t n_lines, int n_depth, int n_
  *                        total = ((continuum + line) + plane 0) + plane 1, what Opacities.calc_total_alphas does with the
  *                        dictionary entries (opacities/base.py:24-28);
  *   linelist             when set, the step's own lines come as per-line scalars (f1, below) and the dense arrays
- *                        (line_nus ... alphas, n_lines) are ignored. */
+ *                        (line_nus ... alphas, n_lines) are ignored.
+ * A zero-initialised description is sdx_synthesize_dev, bit for bit; `options` itself must not be NULL (-1). */
 typedef struct sdx_synthesis_options {
     const double* source;
     int64_t source_ld;

@@ -299,3 +299,57 @@ def test_lazy_entries_belong_to_the_call_that_made_the_field(ctx, monkeypatch, t
     b = rf.create_stellar_radiation_field(g["nus"].copy(), model, plasma, config)  # the edited plasma gives another field
     assert not np.array_equal(b.F_nu, a.F_nu)
     assert not np.array_equal(np.asarray(b.opacities.opacities_dict["alpha_electron"]), want["alpha_electron"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_lines,grid", [(400, (6560.0, 6570.0, dict(step=0.01))), (9000, (4000.0, 4400.0, dict(R=1.0e5)))])
+def test_options_entry_point_equals_its_parts(ctx, n_lines, grid):
+    """sdx_synthesize_opt_dev called directly through the C ABI: with no option set it is sdx_synthesize_dev bit for bit; with extra
+    line planes, the inward sweep and the photospheric correction it equals the same step put together from the individual entry
+    points (line opacity -> total -> accumulate the planes -> sdx_raytrace_spherical_dev); bad arguments are refused with -1."""
+    import ctypes as C
+
+    from stardis_amd import _lib, synth
+    from stardis_amd.engine import SpectralSynthesizer
+
+    atm = synth.solar_atmosphere()
+    cont = synth.synth_continuum_state(atm)
+    th, w = synth.thetas_and_weights(20)
+    nus = synth.tracing_grid(grid[0], grid[1], **grid[2])
+    lines = synth.synth_lines(nus, atm, n_lines, seed=91, mix=(0.7, 0.25, 0.05))
+    syn = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], th, w, lines, cont, ctx=ctx, track_evaluations=False)
+    syn.keep_total = True
+    syn.step()
+    F0, line0, total0 = syn.F_nu().copy(), syn.alpha_line().copy(), syn.total_alphas().copy()
+    nd, n = syn.n_depth, nus.size
+    args = (nd, n, syn.d_nus.ptr, 0, n, syn.n_lines, syn.d_ln.ptr, syn.d_dw.ptr, syn.d_g.ptr, syn.gamma_cols, syn.d_a.ptr, C.byref(syn.cont),
+            syn.n_theta, syn.d_t.ptr, syn.d_ray.ptr, syn.d_w.ptr)
+    d_line, d_total, d_F = ctx.empty((nd, n)), ctx.empty((nd, n)), ctx.empty((nd, n))
+    # 1. no options: the plain fused step
+    opt = _lib.SynthesisOptions()
+    ctx.call("sdx_synthesize_opt_dev", *args, d_line.ptr, d_total.ptr, d_F.ptr, n, C.byref(opt), None)
+    assert np.array_equal(d_F.numpy(), F0) and np.array_equal(d_line.numpy(), line0) and np.array_equal(d_total.numpy(), total0)
+    assert ctx.lib.sdx_synthesize_opt_dev(ctx.handle, *args, d_line.ptr, d_total.ptr, d_F.ptr, n, None, None) == -1  # the description is required
+    # 2. two extra planes, inward rays, correction — against the individual entry points
+    rng = np.random.default_rng(5)
+    extra = [ctx.upload(np.ascontiguousarray(total0 * rng.uniform(0.0, 0.3, size=total0.shape))) for _ in range(2)]
+    opt = _lib.SynthesisOptions()
+    opt.inward_rays, opt.photospheric_correction, opt.n_line_planes, opt.line_plane_ld = 1, 1.21, 2, n
+    opt.line_plane[0], opt.line_plane[1] = extra[0].ptr, extra[1].ptr
+    ctx.call("sdx_synthesize_opt_dev", *args, d_line.ptr, d_total.ptr, d_F.ptr, n, C.byref(opt), None)
+    F1, line1, total1 = d_F.numpy(), d_line.numpy(), d_total.numpy()
+    r_total, r_F = ctx.upload(total0.copy()), ctx.empty((nd, n))
+    for e in extra:
+        ctx.call("sdx_accumulate_dev", nd, n, r_total.ptr, n, e.ptr, n)
+    ctx.call("sdx_raytrace_spherical_dev", nd, n, syn.n_theta, syn.d_nus.ptr, syn.d_t.ptr, syn.d_ray.ptr, syn.d_w.ptr, r_total.ptr, n, r_F.ptr, n, None, 0,
+             C.c_double(1.21))
+    assert np.array_equal(line1, line0) and np.array_equal(total1, r_total.numpy())
+    assert np.array_equal(F1, r_F.numpy()) and np.isfinite(F1).all() and not np.array_equal(F1, F0)
+    # 3. refused: more than two planes, a missing plane, a leading dimension below the shard
+    for bad in (dict(n_line_planes=3), dict(n_line_planes=1, plane0=None), dict(n_line_planes=1, line_plane_ld=n - 1)):
+        o = _lib.SynthesisOptions()
+        o.n_line_planes, o.line_plane_ld = bad["n_line_planes"], bad.get("line_plane_ld", n)
+        o.line_plane[0] = bad.get("plane0", extra[0].ptr)
+        assert ctx.lib.sdx_synthesize_opt_dev(ctx.handle, *args, d_line.ptr, d_total.ptr, d_F.ptr, n, C.byref(o), None) == -1
+        assert b"synthesize" in ctx.lib.sdx_last_error_string()
+    syn.close()
