@@ -1,0 +1,19 @@
+"""GPU experiment: the seeded random long-list configurations of tests/test_gpu_long_random.py beyond the four the suite runs.
+python scripts/fuzz_long_lists.py FIRST LAST"""
+import os, sys, traceback
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
+sys.path.insert(0, os.path.join(root, "tests"))
+import test_gpu_long_random as T
+from stardis_amd._lib import default_context
+
+ctx = default_context()
+bad = 0
+for seed in range(int(sys.argv[1]), int(sys.argv[2])):
+    try:
+        print(f"seed {seed}: ok (n_depth, n_nu, n_lines, n_theta) = {T.check_long_case(ctx, seed)}", flush=True)
+    except Exception:
+        bad += 1
+        print(f"seed {seed}: FAILED", flush=True)
+        traceback.print_exc()
+print("failures:", bad)
