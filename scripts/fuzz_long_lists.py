@@ -1,5 +1,5 @@
 """GPU experiment: the seeded random long-list configurations of tests/test_gpu_long_random.py beyond the four the suite runs.
-python scripts/fuzz_long_lists.py FIRST LAST"""
+python scripts/fuzz_long_lists.py FIRST LAST [--mixed]"""
 import os, sys, traceback
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root)
@@ -9,9 +9,13 @@ from stardis_amd._lib import default_context
 
 ctx = default_context()
 bad = 0
-for seed in range(int(sys.argv[1]), int(sys.argv[2])):
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+for seed in range(int(args[0]), int(args[1])):
     try:
-        print(f"seed {seed}: ok (n_depth, n_nu, n_lines, n_theta) = {T.check_long_case(ctx, seed)}", flush=True)
+        if "--mixed" in sys.argv:
+            print(f"seed {seed}: ok mixed vs fp64 (opacity, flux) = {T.check_long_case_mixed(ctx, seed)}", flush=True)
+        else:
+            print(f"seed {seed}: ok (n_depth, n_nu, n_lines, n_theta) = {T.check_long_case(ctx, seed)}", flush=True)
     except Exception:
         bad += 1
         print(f"seed {seed}: FAILED", flush=True)

@@ -967,8 +967,8 @@ __global__ __launch_bounds__(kBlock) void k_hscan(int n_depth, int64_t n_lines, 
         hscan[(size_t)d * n_lines + k] = wscan[(size_t)d * n_lines + hlist[k]];
 }
 
-// sel[0..1] = [la, lb): the lines whose centre c satisfies begin - H < c < end + H for the shard's columns [begin, end) and
-// H = kMediumHalfWidth; sel[2..3] = [na, nb): the same with H = 2 kNarrowReach
+// sel[0..1] = [la, lb): the lines whose centre c satisfies begin - H < c < end + H for the columns [begin, end) of the shard's
+// tiles and H = kMediumHalfWidth; sel[2..3] = [na, nb): the same for the shard's own columns with H = 2 kNarrowReach
 // (centre_l = #{i : nus[i] >= line_nu_l}; lines ascend in frequency, so centres descend with the line index)
 __device__ __forceinline__ void shard_range(int64_t n_nu, const double* __restrict__ nus, int64_t n_lines, const double* __restrict__ line_nus,
                                             int64_t nu_begin, int64_t nu_count, int* __restrict__ sel)
@@ -976,7 +976,12 @@ __device__ __forceinline__ void shard_range(int64_t n_nu, const double* __restri
     if (threadIdx.x >= 4) return;
     // lines with centre >= p  <=>  line_nu <= nus[p - 1]: their number is cnt_ge[p]
     const int64_t H = threadIdx.x < 2 ? kMediumHalfWidth : 2 * kNarrowReach;
-    const int64_t pa = max(nu_begin - H + 1, (int64_t)0), pb = min(nu_begin + nu_count + H - 1, n_nu);
+    // ... [la, lb) for the shard's columns rounded out to whole TILES of the wide role (kMaxTile covers every tile width): a tile
+    // cut by the shard boundary is walked whole, and its candidate list — with it the points at which the fp32-mixed mode folds its
+    // running sums into the fp64 ones, which count the hits of the whole tile — must be the unsharded run's for the shard to
+    // reproduce that run's bits in BOTH precisions (tests/test_gpu_long_random.py found mixed-mode shards a few 1e-8 apart)
+    const int64_t ext = threadIdx.x < 2 ? kMaxTile - 1 : 0;
+    const int64_t pa = max(nu_begin - ext - H + 1, (int64_t)0), pb = min(nu_begin + nu_count + ext + H - 1, n_nu);
     const int64_t p = (threadIdx.x & 1) == 0 ? pb + 1 : pa;  // sel[0] = cnt_ge[pb + 1], sel[1] = cnt_ge[pa]
     int64_t cnt;
     if (p == 0) cnt = n_lines;
@@ -1257,11 +1262,14 @@ __device__ __forceinline__ void line_narrow_wave32(const int64_t i, const int de
     const double nu_i = nus[i];
     const float nih = (float)nu_i, nil = (float)(nu_i - (double)nih);
     double acc = 0.0;
-    for (int base = la; base < lb; base += 64) {
+    // (chunks of 64 candidates aligned to the LIST — base = 64 k — not to this frequency's first candidate: the fp32 sum of a chunk
+    // is folded into the fp64 sum once per chunk, and which terms share a chunk must not depend on where the candidate range of a
+    // frequency, or of a group of F frequencies, happens to start — F follows the launch's width, a shard's differs from the whole grid's)
+    for (int base = la & ~63; base < lb; base += 64) {
         const int lc = base + lane;
         bool rel = false;
         int c = 0;
-        if (lc < lb) {
+        if (lc >= la && lc < lb) {
             const int hwm = w.nhw_max[lc];
             c = w.centre[lc];
             rel = hwm > 0 && ii >= c - hwm && ii < c + hwm;
@@ -1323,11 +1331,14 @@ __device__ __forceinline__ void line_narrow_group32(const int64_t i0, const int 
         nil[k] = (float)(nu - (double)nih[k]);
         acc[k] = 0.0;
     }
-    for (int base = la; base < lb; base += 64) {
+    // (chunks of 64 candidates aligned to the LIST — base = 64 k — not to this frequency's first candidate: the fp32 sum of a chunk
+    // is folded into the fp64 sum once per chunk, and which terms share a chunk must not depend on where the candidate range of a
+    // frequency, or of a group of F frequencies, happens to start — F follows the launch's width, a shard's differs from the whole grid's)
+    for (int base = la & ~63; base < lb; base += 64) {
         const int lc = base + lane;
         bool rel = false;
         int c = 0;
-        if (lc < lb) {
+        if (lc >= la && lc < lb) {
             const int hwm = w.nhw_max[lc];
             c = w.centre[lc];
             rel = hwm > 0 && ia + (F - 1) >= c - hwm && ia < c + hwm;

@@ -62,6 +62,38 @@ def check_long_case(ctx, seed):
     return nd, nus.size, lines["line_nus"].size, th.size
 
 
+def check_long_case_mixed(ctx, seed):
+    """the fp32-mixed tolerance path on the same configurations: within its stated 1e-4 of the fp64 result, and — like fp64 —
+    the same bits from shards as from the whole grid"""
+    atm, nus, lines, cont, th, w = long_case(seed)
+    ref = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], th, w, lines, cont, ctx=ctx, track_evaluations=False)
+    ref.step()
+    line64, F64 = ref.alpha_line(), ref.F_nu()
+    ref.close()
+    ctx.set_option("mixed_precision", 1)
+    try:
+        syn = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], th, w, lines, cont, ctx=ctx, track_evaluations=False)
+        syn.step()
+        line, F = syn.alpha_line(), syn.F_nu()
+        ea = float(np.max(np.abs(line - line64)) / max(np.abs(line64).max(), 1e-300))
+        ef = float(np.max(np.abs(F - F64) / np.maximum(np.abs(F64).max(axis=0, keepdims=True), 1e-300)))
+        assert ea < 1e-4 and ef < 1e-4, (seed, ea, ef)
+        for b, c in [shard_bounds(nus.size, 3, r) for r in range(3)]:
+            s = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], th, w, lines, cont, ctx=ctx, shard=(b, c), track_evaluations=False)
+            s.step()
+            assert np.array_equal(s.F_nu(), F[:, b:b + c]) and np.array_equal(s.alpha_line(), line[:, b:b + c]), (seed, b, c)
+            s.close()
+        syn.close()
+    finally:
+        ctx.set_option("mixed_precision", 0)
+    return ea, ef
+
+
 @pytest.mark.parametrize("seed", range(4))
 def test_random_long_list_configuration(ctx, seed):
     check_long_case(ctx, seed)
+
+
+@pytest.mark.parametrize("seed", range(2))
+def test_random_long_list_configuration_mixed_precision(ctx, seed):
+    check_long_case_mixed(ctx, seed)
