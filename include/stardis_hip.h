@@ -140,7 +140,8 @@ int sdx_profile_get(sdx_ctx* ctx, const char* kernel, int64_t* launches, double*
  * [n_depth][out_ld] with column 0 = global index nu_begin.  line_nus ascending; doppler/alphas are
  * [n_lines][n_depth]; gammas is [n_lines][gamma_cols], gamma_cols = n_depth or 1 (:547-551).
  * accumulate = 0 overwrites out, 1 adds to it.  n_evaluations_dev (optional, device int64)
- * receives sum(hi - lo) over all (line, depth), i.e. the number of Voigt evaluations of the full grid. */
+ * receives sum(hi - lo) over all (line, depth), i.e. the number of Voigt evaluations of the full grid (0 for an empty list; a call
+ * with nu_count = 0 returns at once and leaves it untouched — sdx_synthesize_sharded_f64 asks its first NON-empty rank). */
 int sdx_line_opacity_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin,
                          int64_t nu_count, int64_t n_lines, const double* line_nus, const double* doppler_widths,
                          const double* gammas, int gamma_cols, const double* alphas, double* out, int64_t out_ld,

@@ -1890,6 +1890,7 @@ static int synthesize_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double
     } else {
         rc = launch_total(ctx, n_depth, nus, nu_begin, nu_count, cont, nullptr, 0, 1, nullptr, 0, cont_plane, nu_count);
         if (rc) return rc;
+        if (n_evaluations_dev) HIP_TRY(hipMemsetAsync(n_evaluations_dev, 0, sizeof(int64_t), ctx->stream));  // (an empty list evaluates nothing)
         if (alpha_line_out)
             HIP_TRY(hipMemset2DAsync(alpha_line_out, ld * sizeof(double), 0, nu_count * sizeof(double), n_depth, ctx->stream));
     }

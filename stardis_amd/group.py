@@ -77,6 +77,11 @@ class DeviceGroup:
         dw = np.ascontiguousarray(lines["doppler_widths"], dtype=f8)
         al = np.ascontiguousarray(lines["alphas"], dtype=f8)
         g = np.ascontiguousarray(lines["gammas"], dtype=f8).reshape(ln.size, -1) if ln.size else np.zeros((0, 1))
+        if ln.size > 1 and np.any(ln[1:] < ln[:-1]):
+            # the library takes the list in ascending frequency (what calc_alpha_line_at_nu passes, base.py:392-397) and refuses anything
+            # else; like the other Python front-ends this one sorts (stably) instead — calc_alan_entries accepts any order
+            order = np.argsort(ln, kind="stable")
+            ln, g, dw, al = (np.ascontiguousarray(a[order]) for a in (ln, g, dw, al))
         keep = []
         cont = host_continuum(continuum, nus, t, keep)
         begins = None

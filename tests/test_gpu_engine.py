@@ -459,3 +459,23 @@ def test_long_list_on_a_deep_model(ctx):
     ref, ref_evals = oracle.calc_alan_entries(130, nus, lines["line_nus"], lines["doppler_widths"], lines["gammas"], lines["alphas"], return_evals=True)
     assert evals == ref_evals and evals == int((hi - lo).clip(min=0).sum())
     assert rel_err(out, ref) < 1e-12
+
+
+def test_an_empty_line_list_counts_zero_evaluations(ctx):
+    """the fused step with no line at all: the evaluation count is written (0), not left as it was (found by
+    scripts/fuzz_group_loopback.py: the sharded entry point returned whatever the scratch held)"""
+    import ctypes as C
+
+    from stardis_amd import synth
+
+    atm = synth.solar_atmosphere()
+    nus = synth.tracing_grid(6560.0, 6562.0, step=0.01)
+    lines = {k: v[:0] for k, v in synth.synth_lines(nus, atm, 4, seed=1).items()}
+    th, w = synth.thetas_and_weights(4)
+    syn = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], th, w, lines, synth.synth_continuum_state(atm), ctx=ctx)
+    d_ev = ctx.upload(np.array([-12345], dtype=np.int64), dtype=np.int64)
+    ctx.call("sdx_synthesize_dev", syn.n_depth, syn.n_nu, syn.d_nus.ptr, 0, syn.n_nu, 0, None, None, None, 1, None, C.byref(syn.cont), syn.n_theta,
+             syn.d_t.ptr, syn.d_ray.ptr, syn.d_w.ptr, None, None, syn.flux_ptr, syn.n_nu, d_ev.ptr)
+    assert int(d_ev.numpy()[0]) == 0 and (syn.F_nu()[-1] > 0).all()
+    syn.close()
+
