@@ -89,7 +89,9 @@ int sdx_synchronize(sdx_ctx* ctx);
  *       (sdx_voigt_term_f32_dev exposes that routine).  Line cores kept by the wide windows, the continuum and the formal
  *       solution stay fp64.  Stated tolerance: 1e-4 relative on the emergent flux (measured: 7e-6 on the line opacity, 7e-6
  *       of Re w per evaluation; tests/test_gpu_configs.py, tests/test_gpu_hot_faddeeva.py).  fp64 remains the default and
- *       the parity path.
+ *       the parity path.  Where the reference divides by zero — an opaque gap with a TRANSPARENT gap ahead of it on the ray
+ *       (radiation_field_solvers/base.py:208-249 with tau[gap + 1] = 0) — the fp64 kernels reproduce its NaN; the fp32 formal
+ *       solution of this mode takes that step to first order and stays finite.
  *   "segmented_raytrace" (default -1): which formal-solution kernel runs.  -1: decided from the size of the GLOBAL grid against
  *       a fixed constant (grids under 3 x 4 x 256 k_raytrace waves take the segmented kernel) — never from the shard's own
  *       width or the device's CU count, so that a frequency shard and the unsharded grid run the same arithmetic and stay
