@@ -30,7 +30,7 @@
  *       SDX_R_MIXED       4 / 8: grid points per lane of a mixed-precision tile
  *     scheduling and layout only (same bits): SDX_NARROW_F (1, 2, 4 frequencies per narrow wave), SDX_NARROW_ORDER,
  *       SDX_WIDE_GROUP, SDX_CONT_DGS, SDX_CLS_BLOCKS (workgroups of a shard's classification stream), SDX_NO_CULL,
- *       SDX_NO_CONT_RIDE, SDX_NO_HSCAN, SDX_NO_PINNED_STAGING,
+ *       SDX_NO_CONT_RIDE, SDX_NO_PREPASS_TICKET, SDX_NO_HSCAN, SDX_NO_PINNED_STAGING,
  *       SDX_SPLIT_LAUNCHES (the two roles of the line kernel as two launches, for profiling)
  *     test hook: SDX_GROUP_LOOPBACK (see sdx_group_create).
  */
@@ -79,6 +79,9 @@ int sdx_synchronize(sdx_ctx* ctx);
  *   "indexed_min_lines" (default 8192): line lists at least this long are not scanned completely by every tile of the wide
  *       role: lines whose widest window exceeds 4096 grid points are listed once and visited by every tile, all others are
  *       found by centre range (the list is sorted); frequency shards of such lists also run a culled pre-pass.
+ *   "prepass_ticket_min_blocks" (default 16384): frequency shards of long lists — from this many 32-line blocks on (5e5 lines) the
+ *       culled pre-pass runs as many workgroups as the chip holds, drawing the blocks that have work from a counter, instead of one
+ *       workgroup per candidate block (most of which return at once).  Scheduling only: the same bits.
  *   "mixed_precision" (default 0): 1 selects the fp32-mixed TOLERANCE path (BASELINE config 5).  Wide windows: far-wing
  *       evaluations — grid tiles wholly inside a line's window and wholly in Faddeeva region I, and window edges — compute
  *       the rational y (q + y^2 + 1/2) / ((q - y^2 - 1/2)^2 + 4 q y^2) in packed fp32, two grid points per instruction:

@@ -215,6 +215,7 @@ struct LineWork {
     int gather;     // gather blocks behind those: block g prepares hlist[g kPreLines ...] (0: none)
     int64_t shard_begin, shard_end;  // the shard's columns (culled runs only need cnt_ge near them)
     unsigned long long* evals;
+    int* ticket;  // culled runs: the pre-pass launch's work counter, one per depth block (zeroed by k_hlist_count), or nullptr
 };
 
 // k / d for 0 <= k < 65536 and 1 <= d < 65536 with the divisor's reciprocal m = small_div_magic(d) = ceil(2^32 / d): one multiply-high
@@ -230,7 +231,7 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
                                                          const double* __restrict__ gammas, int gamma_cols,
                                                          const double* __restrict__ alphas, LineWork w,
                                                          int* __restrict__ out_lo_ref, int* __restrict__ out_hi_ref,
-                                                         int n_line_blocks, const LineParams& lp)
+                                                         int n_line_blocks, const LineParams& lp, const int tid = threadIdx.x)
 {
     int gbx = -1;  // >= 0: a gather block
     if (bx >= n_line_blocks) {
@@ -240,7 +241,7 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
         } else {
             // pixel blocks: cnt_ge[p] = #{l : centre_l >= p} = #{l : line_nu_l <= nus[p-1]}  (centre_l = #{i : nus[i] >= line_nu_l})
             if (by == 0 && w.cnt_ge) {
-                const int64_t pidx = (int64_t)(bx - n_line_blocks) * blockDim.x + threadIdx.x;
+                const int64_t pidx = (int64_t)(bx - n_line_blocks) * blockDim.x + tid;
                 // a shard only reads cnt_ge within kMediumHalfWidth (+ a narrow window) of the TILES that hold its columns: tiles
                 // are aligned to the global grid, so the first and last one reach up to kMaxTile - 1 points beyond the shard
                 const bool needed = !w.sel || (pidx >= w.shard_begin - kMediumHalfWidth - 2 * kNarrowReach - kMaxTile &&
@@ -290,14 +291,14 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
         const int n_g = n_h + (w.xlist ? w.hcount[2] : 0);
         if (l0 >= n_g) return;  // block-uniform
         nl = min(kPreLines, n_g - (int)l0);
-        if (threadIdx.x < kPreLines) {
-            const int k = (int)l0 + threadIdx.x;
-            s_l[threadIdx.x] = threadIdx.x < nl ? (k < n_h ? w.hlist[k] : w.xlist[k - n_h]) : 0;
+        if (tid < kPreLines) {
+            const int k = (int)l0 + tid;
+            s_l[tid] = tid < nl ? (k < n_h ? w.hlist[k] : w.xlist[k - n_h]) : 0;
         }
         __syncthreads();
     } else {
         if (w.sel && (l0 + kPreLines <= w.sel[2] || l0 >= w.sel[3])) return;  // not a block of the shard's own line range
-        if (threadIdx.x < kPreLines) s_l[threadIdx.x] = (int)(l0 + threadIdx.x);
+        if (tid < kPreLines) s_l[tid] = (int)(l0 + tid);
         // (no barrier needed: the non-gather path indexes with l0 + ll directly)
     }
 #define SDX_LINE_OF(ll) (gather ? (int64_t)s_l[ll] : l0 + (ll))
@@ -309,7 +310,7 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
     if constexpr (!GEN) {
 #pragma unroll
         for (int it = 0; it < kPreItems; ++it) {
-            const int k = threadIdx.x + it * kPreBlock;
+            const int k = tid + it * kPreBlock;
             r_dw[it] = r_a[it] = r_g[it] = 0.0;
             if (k < nl * nd) {
                 const int ll = small_div(k, nd_magic), dd = k - ll * nd;
@@ -328,16 +329,16 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
     // load and a ballot — a chain of one or two dependent global loads instead of log2(N_nu / 128)
     __shared__ double s_coarse[128];
     const int64_t cstride = (n_nu + 127) / 128;
-    if (threadIdx.x < 128) {
-        const int64_t j = (int64_t)threadIdx.x * cstride;
-        s_coarse[threadIdx.x] = j < n_nu ? nus[j] : -INFINITY;
-    } else if (threadIdx.x < 128 + kPreLines) {
-        const int ll = threadIdx.x - 128;
+    if (tid < 128) {
+        const int64_t j = (int64_t)tid * cstride;
+        s_coarse[tid] = j < n_nu ? nus[j] : -INFINITY;
+    } else if (tid < 128 + kPreLines) {
+        const int ll = tid - 128;
         s_lnu[ll] = ll < nl ? line_nus[SDX_LINE_OF(ll)] : 0.0;
     }
     __syncthreads();
-    for (int ll = threadIdx.x >> 6; ll < nl; ll += kPreBlock / 64) {
-        const int lane = threadIdx.x & 63;
+    for (int ll = tid >> 6; ll < nl; ll += kPreBlock / 64) {
+        const int lane = tid & 63;
         {
             const double v = s_lnu[ll];
             int a = 0, b = 128;  // first sample strictly below v
@@ -358,7 +359,7 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
             if (lane == 0) s_c[ll] = m ? lo + __builtin_ctzll(m) : hi;
         }
     }
-    if (threadIdx.x < kPreLines) s_hwmax[threadIdx.x] = 0, s_whwmax[threadIdx.x] = 0;
+    if (tid < kPreLines) s_hwmax[tid] = 0, s_whwmax[tid] = 0;
     // d_nu (:524-526): from the partial maxima of k_dnu_partial, or — small grids — scanned here directly
     const double d_nu = dnu_partial ? block_dnu(dnu_partial, n_partial, s_red) : block_max_to_dnu(dnu_local, s_red);
 
@@ -367,10 +368,10 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
         // per-line factors (every pow / tgamma / n_eff) are evaluated once per block column / row and shared through LDS.
         __shared__ GenDepth s_gd[kPreDepths];
         __shared__ GenLine s_gl[kPreLines];
-        if (threadIdx.x < nd) s_gd[threadIdx.x] = gen_depth(lp, d0 + threadIdx.x);
-        else if (threadIdx.x >= 64 && threadIdx.x < 64 + nl) s_gl[threadIdx.x - 64] = gen_line(lp, line_nus[SDX_LINE_OF(threadIdx.x - 64)], SDX_LINE_OF(threadIdx.x - 64));
+        if (tid < nd) s_gd[tid] = gen_depth(lp, d0 + tid);
+        else if (tid >= 64 && tid < 64 + nl) s_gl[tid - 64] = gen_line(lp, line_nus[SDX_LINE_OF(tid - 64)], SDX_LINE_OF(tid - 64));
         __syncthreads();
-        for (int k = threadIdx.x; k < nl * nd; k += nthreads) {
+        for (int k = tid; k < nl * nd; k += nthreads) {
             const int ll = small_div(k, nd_magic), dd = k - ll * nd;
             const int64_t l = SDX_LINE_OF(ll);
             const GenDepth& D = s_gd[dd];  // fields are read from LDS where they are used: copies would cost ~40 VGPRs
@@ -383,7 +384,7 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
         // reference layout in (requested above), line fastest ... depth fastest: coalesced
 #pragma unroll
         for (int it = 0; it < kPreItems; ++it) {
-            const int k = threadIdx.x + it * kPreBlock;
+            const int k = tid + it * kPreBlock;
             if (k < nl * nd) {
                 const int ll = small_div(k, nd_magic), dd = k - ll * nd;
                 s_dw[ll * kStride + dd] = r_dw[it];
@@ -401,7 +402,7 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
     WideScan sc_keep[kPreItems];
 #pragma unroll
     for (int it = 0; it < kPreItems; ++it) {
-        const int k = threadIdx.x + it * kPreBlock;
+        const int k = tid + it * kPreBlock;
         sc_keep[it] = WideScan{0, 0, 0, 0};
         if (k >= nl * nd) continue;
         const int dd = small_div(k, nl_magic), ll = k - dd * nl;
@@ -476,7 +477,7 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
     if (w.wscan) {
 #pragma unroll
         for (int it = 0; it < kPreItems; ++it) {
-            const int k = threadIdx.x + it * kPreBlock;
+            const int k = tid + it * kPreBlock;
             if (k >= nl * nd) continue;
             const int dd = small_div(k, nl_magic), ll = k - dd * nl;
             if (w.skip_unlisted_scan && s_whwmax[ll] == 0) continue;
@@ -484,21 +485,21 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
         }
     }
     // per-line summary for the narrow kernel's candidate test: centre index and the largest narrow half-width
-    if (w.nhw_max && threadIdx.x < nl) {
-        if (gy == 1) w.nhw_max[SDX_LINE_OF(threadIdx.x)] = s_hwmax[threadIdx.x], w.whw_max[SDX_LINE_OF(threadIdx.x)] = s_whwmax[threadIdx.x];
+    if (w.nhw_max && tid < nl) {
+        if (gy == 1) w.nhw_max[SDX_LINE_OF(tid)] = s_hwmax[tid], w.whw_max[SDX_LINE_OF(tid)] = s_whwmax[tid];
         else {  // deep models: several depth blocks per line, both arrays zeroed by the host first
-            atomicMax(&w.nhw_max[SDX_LINE_OF(threadIdx.x)], s_hwmax[threadIdx.x]);
-            atomicMax(&w.whw_max[SDX_LINE_OF(threadIdx.x)], s_whwmax[threadIdx.x]);
+            atomicMax(&w.nhw_max[SDX_LINE_OF(tid)], s_hwmax[tid]);
+            atomicMax(&w.whw_max[SDX_LINE_OF(tid)], s_whwmax[tid]);
         }
-        if (by == 0) w.centre[SDX_LINE_OF(threadIdx.x)] = (int)s_c[threadIdx.x];
+        if (by == 0) w.centre[SDX_LINE_OF(tid)] = (int)s_c[tid];
         if (by == 0 && w.lnu32) {
-            const double lnu = s_lnu[threadIdx.x];
-            w.lnu32[SDX_LINE_OF(threadIdx.x)] = float2v{(float)lnu, (float)(lnu - (double)(float)lnu)};
+            const double lnu = s_lnu[tid];
+            w.lnu32[SDX_LINE_OF(tid)] = float2v{(float)lnu, (float)(lnu - (double)(float)lnu)};
         }
     }
     // line-major outputs: the stashed values, depth fastest so the stores coalesce
     if (w.nhw || out_lo_ref) {
-        for (int k = threadIdx.x; k < nl * nd; k += nthreads) {
+        for (int k = tid; k < nl * nd; k += nthreads) {
             const int ll = small_div(k, nd_magic), dd = k - ll * nd;
             const int sidx = ll * kStride + dd;
             const int lo = s_lo[sidx], hcode = s_hi[sidx];
@@ -525,9 +526,9 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
     }
     if (w.evals) {
         for (int off = 32; off > 0; off >>= 1) ev += __shfl_xor(ev, off);
-        if ((threadIdx.x & 63) == 0) s_ev[threadIdx.x >> 6] = ev;
+        if ((tid & 63) == 0) s_ev[tid >> 6] = ev;
         __syncthreads();
-        if (threadIdx.x == 0) {
+        if (tid == 0) {
             for (int i = 1; i < (nthreads >> 6); ++i) ev += s_ev[i];
             if (ev) atomicAdd(w.evals, ev);
         }
@@ -549,6 +550,37 @@ __global__ __launch_bounds__(kPreBlock) __attribute__((amdgpu_num_sgpr(80))) voi
     // 47 against 44 us for this launch on an eighth of S-c3; the order stays [line | pixel | gather])
     prepass_block<GEN, LINES>(blockIdx.x, blockIdx.y, gridDim.y, n_depth, n_nu, nus, dnu_partial, n_partial, n_lines, line_nus, doppler, gammas,
                        gamma_cols, alphas, w, out_lo_ref, out_hi_ref, n_line_blocks, lp);
+}
+
+// The pre-pass of a CULLED shard.  Which blocks have work is only known on the device (sel, the list counts); one block per
+// candidate is every block of the list twice over — 9 500 blocks for 600 with work at an eighth of S-c3, 62 000 for 5 000 at 1e6
+// lines, each costing a dispatch, 70 KB of LDS and a dependent load before it returns (a third of that launch at 1e6 lines).  Here
+// as many blocks as the chip holds draw the items that exist from a counter — pixel blocks, then the range blocks, then the gather
+// blocks — until none is left.  Which block prepares an item does not matter: every item writes its own outputs.  The thread index
+// goes through an empty asm inside the loop: left visible, everything that depends only on it (a dozen addresses, the grid sample)
+// is hoisted out of the loop and kept in registers — 91 VGPRs instead of 51, one resident block per CU instead of two.
+template <int LINES>
+__global__ __launch_bounds__(kPreBlock) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8))) void k_line_prepass_ticket(
+    int n_depth, int64_t n_nu, const double* __restrict__ nus, const double* __restrict__ dnu_partial, int n_partial, int64_t n_lines,
+    const double* __restrict__ line_nus, const double* __restrict__ doppler, const double* __restrict__ gammas, int gamma_cols,
+    const double* __restrict__ alphas, LineWork w, int n_line_blocks, LineParams lp)
+{
+    __shared__ int s_item;
+    const int first = w.sel[2] / LINES, n_range = max((w.sel[3] + LINES - 1) / LINES - first, 0);
+    const int n_g = w.hcount[0] + (w.xlist ? w.hcount[2] : 0);
+    const int total = w.n_pix + n_range + (n_g + LINES - 1) / LINES;
+    for (;;) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        if (tid == 0) s_item = atomicAdd(w.ticket + blockIdx.y, 1);
+        __syncthreads();
+        const int item = s_item;
+        __syncthreads();  // (s_item is drawn again at the top; the block's LDS arrays serve its next item)
+        if (item >= total) return;
+        const int bx = item < w.n_pix ? n_line_blocks + item : (item < w.n_pix + n_range ? first + (item - w.n_pix) : n_line_blocks + w.n_pix + (item - w.n_pix - n_range));
+        prepass_block<false, LINES>(bx, blockIdx.y, gridDim.y, n_depth, n_nu, nus, dnu_partial, n_partial, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, w,
+                                    nullptr, nullptr, n_line_blocks, lp, tid);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -900,10 +932,11 @@ __device__ __forceinline__ int class_of_line(const ClassSource& cs, int64_t l, d
     return line_class(cs.whw_max ? cs.whw_max[l] : half_width_of(cs.m_max[l], d_nu, cs.n_nu));
 }
 __global__ __launch_bounds__(kHlistBlock) void k_hlist_count(int64_t n_lines, ClassSource cs, int* __restrict__ block_cnt,
-                                                            const int* __restrict__ sel, int pre_lines)
+                                                            const int* __restrict__ sel, int pre_lines, int* __restrict__ ticket)
 {
     __shared__ int s_wave[3][kHlistBlock / 64];
     __shared__ double s_dnu[kHlistBlock / 64];
+    if (ticket && blockIdx.x == 0 && threadIdx.x < 8) ticket[threadIdx.x] = 0;  // (the work counters of the pre-pass launch that follows)
     const double d_nu = cs.whw_max ? 0.0 : block_dnu(cs.dnu_partial, cs.n_partial, s_dnu);
     const int64_t l = (int64_t)blockIdx.x * kHlistBlock + threadIdx.x;
     const int cls = l < n_lines ? class_of_line(cs, l, d_nu) : 0;

@@ -89,6 +89,7 @@ struct sdx_ctx {
     size_t cnt_ge_len = 0;
     // tuning options (sdx_set_int_option)
     int64_t indexed_min_lines = 8192;  // line lists at least this long: wide lines found by centre range / the huge-line list instead of a full scan
+    int64_t prepass_ticket_min_blocks = 16384;  // culled shards: from this many line blocks on the pre-pass draws its work from a counter
     int64_t mixed_precision = 0;       // 1: fp32 rational for far-wing (region I) evaluations of whole-tile windows
     int64_t segmented_raytrace = -1;   // -1: by the size of the GLOBAL grid; 0 never; 1 whenever the kernel supports the shape
     // timing
@@ -404,6 +405,10 @@ int sdx_set_int_option(sdx_ctx* ctx, const char* name, int64_t value)
     REQUIRE(ctx && name, "sdx_set_int_option: null pointer");
     if (std::strcmp(name, "indexed_min_lines") == 0) {
         ctx->indexed_min_lines = value;
+        return SDX_OK;
+    }
+    if (std::strcmp(name, "prepass_ticket_min_blocks") == 0) {
+        ctx->prepass_ticket_min_blocks = value;
         return SDX_OK;
     }
     if (std::strcmp(name, "mixed_precision") == 0) {
@@ -758,7 +763,7 @@ static void launch_line_lists(sdx_ctx* ctx, int64_t n_lines, LineWork& w, int pr
     w.xlist = w.sel ? w.wrank + n_lines + 1 : nullptr;  // culled runs only
     const unsigned hb = (unsigned)((n_lines + kHlistBlock - 1) / kHlistBlock);
     int* block_cnt = w.hcount + 16;  // 3 hb ints behind the counters and sel (reserved in cnt_ws)
-    hipLaunchKernelGGL(k_hlist_count, dim3(hb), dim3(kHlistBlock), 0, ctx->stream, n_lines, cs, block_cnt, w.sel, pre_lines);
+    hipLaunchKernelGGL(k_hlist_count, dim3(hb), dim3(kHlistBlock), 0, ctx->stream, n_lines, cs, block_cnt, w.sel, pre_lines, w.ticket);
     hipLaunchKernelGGL(k_hlist_scatter, dim3(hb), dim3(kHlistBlock), 0, ctx->stream, n_lines, cs, (const int*)block_cnt, w.hlist,
                        w.wlist, w.wrank, w.hcount, w.xlist, w.sel, pre_lines);
 }
@@ -795,6 +800,7 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
     }
     w.sel = nullptr;
     w.gather = 0;
+    w.ticket = nullptr;
     // long lists find their wide lines through hlist / wlist: the scan words of a line without a wide window anywhere are never
     // read (needs the line's widest window inside one block: one depth block per line)
     w.skip_unlisted_scan = (fill_work && n_lines >= ctx->indexed_min_lines && n_depth <= kPreDepths) ? 1 : 0;
@@ -887,6 +893,12 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
                                    doppler, gammas, gamma_cols, alphas, m_max, nus, line_nus, nu_begin, nu_count, sel);
             }
         }
+        static const bool no_ticket = knob("SDX_NO_PREPASS_TICKET") != nullptr;  // A/B knob: one block per candidate instead
+        // the pre-pass launch that follows draws its items from a counter (k_line_prepass_ticket); the list launch zeroes it
+        // (worth it where the candidates are many: at 1e6 lines 57 000 of 62 000 candidate blocks are empty and the launch takes 245
+        // instead of 292 us on an eighth of the grid; at 1.5e5 lines 9 500 candidates cost less than the counter's round trips)
+        const bool ticket = !no_ticket && !(job && !continuum_done) && !gen && !lo_ref && n_line_blocks >= ctx->prepass_ticket_min_blocks;
+        if (ticket) w.ticket = (int*)((char*)ctx->small_ws + 2064);
         {
             LaunchScope ls(ctx, "k_hlist");
             ClassSource cs{};
@@ -918,7 +930,14 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
         LaunchScope ls(ctx, job ? "k_prepass_continuum" : "k_line_prepass");
 #define SDX_PRE_ARGS n_depth, n_nu, nus, scan_in_block ? (const double*)nullptr : (const double*)ctx->small_ws, n_partial, n_lines, line_nus, doppler, \
                      gammas, gamma_cols, alphas, w, (int*)lo_ref, (int*)hi_ref, n_line_blocks, lp
-        if (gen && pre_lines == 16) hipLaunchKernelGGL((k_line_prepass<true, 16>), grid, dim3(kPreBlock), 0, ctx->stream, SDX_PRE_ARGS);
+        if (w.ticket) {
+            const dim3 pgrid(std::min<unsigned>(grid.x, 2u * (unsigned)ctx->n_cu), grid.y);
+            const double* dnu_arg = scan_in_block ? (const double*)nullptr : (const double*)ctx->small_ws;
+            if (pre_lines == 16) hipLaunchKernelGGL((k_line_prepass_ticket<16>), pgrid, dim3(kPreBlock), 0, ctx->stream, n_depth, n_nu, nus, dnu_arg, n_partial, n_lines,
+                                                    line_nus, doppler, gammas, gamma_cols, alphas, w, n_line_blocks, lp);
+            else hipLaunchKernelGGL((k_line_prepass_ticket<32>), pgrid, dim3(kPreBlock), 0, ctx->stream, n_depth, n_nu, nus, dnu_arg, n_partial, n_lines, line_nus, doppler,
+                                    gammas, gamma_cols, alphas, w, n_line_blocks, lp);
+        } else if (gen && pre_lines == 16) hipLaunchKernelGGL((k_line_prepass<true, 16>), grid, dim3(kPreBlock), 0, ctx->stream, SDX_PRE_ARGS);
         else if (gen) hipLaunchKernelGGL((k_line_prepass<true, 32>), grid, dim3(kPreBlock), 0, ctx->stream, SDX_PRE_ARGS);
         else if (pre_lines == 16) hipLaunchKernelGGL((k_line_prepass<false, 16>), grid, dim3(kPreBlock), 0, ctx->stream, SDX_PRE_ARGS);
         else hipLaunchKernelGGL((k_line_prepass<false, 32>), grid, dim3(kPreBlock), 0, ctx->stream, SDX_PRE_ARGS);

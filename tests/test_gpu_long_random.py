@@ -97,3 +97,17 @@ def test_random_long_list_configuration(ctx, seed):
 @pytest.mark.parametrize("seed", range(2))
 def test_random_long_list_configuration_mixed_precision(ctx, seed):
     check_long_case_mixed(ctx, seed)
+
+
+def test_culled_prepass_drawing_its_work_from_a_counter(ctx):
+    """Lists of >= 5e5 lines prepare a shard's lines with as many workgroups as the chip holds, each drawing the blocks that have
+    work from a device counter (k_line_prepass_ticket) instead of one workgroup per candidate block.  Forced here on a small long
+    list: shards — equal and balanced, fp64 and mixed — still reproduce the unsharded bits."""
+    ctx.set_option("prepass_ticket_min_blocks", 0)
+    try:
+        for seed in (1, 2):
+            check_long_case(ctx, seed)
+        check_long_case_mixed(ctx, 3)
+    finally:
+        ctx.set_option("prepass_ticket_min_blocks", 16384)
+
