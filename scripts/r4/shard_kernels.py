@@ -14,6 +14,8 @@ if "--shard" in sys.argv:
     shard = (int(sys.argv[k + 1]), int(sys.argv[k + 2]))
 syn = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], w["thetas"], w["weights"], w["lines"], w["cont"], shard=shard, track_evaluations=False, keep_line=False)
 ctx = syn.ctx
+if os.environ.get("TICKET_MIN_BLOCKS"):
+    ctx.set_option("prepass_ticket_min_blocks", int(os.environ["TICKET_MIN_BLOCKS"]))
 syn.capture()
 for _ in range(10): syn.step()
 syn.synchronize()

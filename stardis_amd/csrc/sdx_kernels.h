@@ -555,8 +555,8 @@ __global__ __launch_bounds__(kPreBlock) __attribute__((amdgpu_num_sgpr(80))) voi
 // The pre-pass of a CULLED shard.  Which blocks have work is only known on the device (sel, the list counts); one block per
 // candidate is every block of the list twice over — 9 500 blocks for 600 with work at an eighth of S-c3, 62 000 for 5 000 at 1e6
 // lines, each costing a dispatch, 70 KB of LDS and a dependent load before it returns (a third of that launch at 1e6 lines).  Here
-// as many blocks as the chip holds draw the items that exist from a counter — pixel blocks, then the range blocks, then the gather
-// blocks — until none is left.  Which block prepares an item does not matter: every item writes its own outputs.  The thread index
+// as many blocks as the chip holds draw the items that exist from a counter — the range blocks, then the gather blocks, then the
+// pixel blocks — until none is left.  Which block prepares an item does not matter: every item writes its own outputs.  The thread index
 // goes through an empty asm inside the loop: left visible, everything that depends only on it (a dozen addresses, the grid sample)
 // is hoisted out of the loop and kept in registers — 91 VGPRs instead of 51, one resident block per CU instead of two.
 template <int LINES>
@@ -577,7 +577,9 @@ __global__ __launch_bounds__(kPreBlock) __attribute__((amdgpu_num_sgpr(80), amdg
         const int item = s_item;
         __syncthreads();  // (s_item is drawn again at the top; the block's LDS arrays serve its next item)
         if (item >= total) return;
-        const int bx = item < w.n_pix ? n_line_blocks + item : (item < w.n_pix + n_range ? first + (item - w.n_pix) : n_line_blocks + w.n_pix + (item - w.n_pix - n_range));
+        // (the long items first, the pixel blocks — a binary search per thread — last: they fill the launch's tail)
+        const int n_long = total - w.n_pix;
+        const int bx = item < n_range ? first + item : (item < n_long ? n_line_blocks + w.n_pix + (item - n_range) : n_line_blocks + (item - n_long));
         prepass_block<false, LINES>(bx, blockIdx.y, gridDim.y, n_depth, n_nu, nus, dnu_partial, n_partial, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, w,
                                     nullptr, nullptr, n_line_blocks, lp, tid);
     }
