@@ -184,7 +184,9 @@ int sdx_calc_gamma_dev(sdx_ctx* ctx, int64_t n_lines, int n_depth, const int32_t
 /* calc_doppler_width :32-71 broadcast as at :723-730 / :814-819 */
 int sdx_doppler_widths_dev(sdx_ctx* ctx, int64_t n_lines, int n_depth, const double* line_nus, const double* mass,
                            const double* temperature, double microturbulence, double* doppler_widths);
-/* calc_vald_gamma :1009-1085 (stark :880-890, van der Waals :893-1006) */
+/* calc_vald_gamma :1009-1085 (stark :880-890, van der Waals :893-1006).  flags: 1 linear Stark (hydrogen lines), 2 VALD Stark,
+ * 4 van der Waals, 8 radiation; + 16 = the sum is NOT halved: the VALD branch of calculate_molecule_broadening (:771-799), which adds
+ * A_ul, calc_vald_stark_gamma when linear OR quadratic Stark is configured (pass 2, never 1) and calc_vald_vdW and skips :1084. */
 int sdx_calc_vald_gamma_dev(sdx_ctx* ctx, int64_t n_lines, int n_depth, const int32_t* atomic_number,
                             const int32_t* ion_number, const double* ionization_energy,
                             const double* upper_level_energy, const double* lower_level_energy, const double* A_ul,

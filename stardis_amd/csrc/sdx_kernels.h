@@ -1705,7 +1705,7 @@ __global__ __launch_bounds__(kBlock) void k_calc_vald_gamma(int64_t n_lines, int
     }
     if (flags & 2) g = add_rn(g, vald_stark(ne[d], stark[l], temps[d]));
     if (flags & 4) g = add_rn(g, vald_vdw(waals[l], temps[d], mass[l], e_up[l], e_lo[l], nh[d], ion[l], e_ion[l]));
-    out[k] = g / 2;  // broadening.py:1084
+    out[k] = (flags & 16) ? g : g / 2;  // broadening.py:1084; the molecular branch (:771-799) does not halve
 }
 
 // ------------------------------------------------------------------------------------------------

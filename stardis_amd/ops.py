@@ -163,8 +163,8 @@ def doppler_widths(line_nus, atomic_mass, temperature, microturbulence, ctx=None
 
 def calc_vald_gamma_arrays(atomic_number, ion_number, ionization_energy, upper_level_energy, lower_level_energy, A_ul,
                            stark, waals, atomic_mass, electron_density, temperature, h_density, linear_stark,
-                           quadratic_stark, van_der_waals, radiation, ctx=None):
-    """opacities/opacities_solvers/broadening.py:1009-1085 on plain arrays"""
+                           quadratic_stark, van_der_waals, radiation, ctx=None, halve=True):
+    """opacities/opacities_solvers/broadening.py:1009-1085 on plain arrays (halve=False: the sum as :771-799 leaves it)"""
     ctx = ctx or default_context()
     z = _host(atomic_number, np.int32).reshape(-1)
     ion = _host(ion_number, np.int32).reshape(-1)
@@ -174,7 +174,7 @@ def calc_vald_gamma_arrays(atomic_number, ion_number, ionization_energy, upper_l
     d = [ctx.upload(z, np.int32), ctx.upload(ion, np.int32)] + [ctx.upload(x) for x in per_line + per_depth]
     out = ctx.empty((z.size, nd))
     ctx.call("sdx_calc_vald_gamma_dev", z.size, nd, *[x.ptr for x in d],
-             _flags(linear_stark, quadratic_stark, van_der_waals, radiation), out.ptr)
+             _flags(linear_stark, quadratic_stark, van_der_waals, radiation) | (0 if halve else 16), out.ptr)
     return out.numpy()
 
 

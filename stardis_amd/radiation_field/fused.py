@@ -38,61 +38,127 @@ F8 = np.float64
 RAYLEIGH_CUTOFF = 2.3e15  # opacities_solvers/base.py:99
 
 # What this module derives from the plasma's pandas objects (sorted line tables, level tables, density vectors) is kept per
-# OBJECT: the key is the identity of the frames / series it was read from (a strong reference is held, so an id cannot be
-# recycled) plus, for line tables, a cheap content fingerprint (_stamp: an in-place edit between two calls misses the cache, as
-# it should), a handful of entries, least recently used first out.  A TARDIS plasma hands out fresh objects whenever it is
-# recomputed, which misses the cache too.
+# OBJECT and VERIFIED BY CONTENT: an entry is found by the identity of the frames / series it was read from (a strong
+# reference is held, so an id cannot be recycled) and served only if a 128-bit digest of the values it was derived from
+# (_witness: xxh3 over the objects' value blocks, ~40 us per MB) still matches — a table edited in place between two calls
+# is derived again, as the reference (radiation_field/base.py:71-117 recomputes everything per call) would see the edit.
+# Cached values are private copies (nothing in them aliases the plasma's memory).  A handful of entries, least recently used
+# first out.  CACHE = False derives everything on every call.
+CACHE = True
 _MEMO = {}
 _MEMO_MAX = 16
 MEMO_MAX_BYTES = 2 << 30  # ... and at most this much derived data (numpy arrays in the cached values; the newest entry always stays)
+
+try:
+    import xxhash as _xx
+
+    def _digest(buf):
+        return _xx.xxh3_128_digest(buf)
+except ImportError:  # (no xxhash: correct, ~1 GB/s instead of ~20)
+    import hashlib as _hl
+
+    def _digest(buf):
+        return _hl.blake2b(buf, digest_size=16).digest()
 
 
 def clear_cache():
     _MEMO.clear()
 
 
-def _stamp(obj):
-    """A cheap content fingerprint next to the identity, for the objects whose cached derivations are worth protecting — the line
-    tables (frames with a `nu` column: sorted copies of 10^3 .. 10^6 rows hang on them): shape and three frequencies (first,
-    middle, last).  A table edited IN PLACE between two calls — rows added, dropped, reordered, rescaled — then misses the cache,
-    as the reference (which recomputes everything) would see the edit; a change that leaves the shape and those three values
-    alone does not (clear_cache()).  Small per-depth objects (densities, level data) are keyed by identity only: a TARDIS plasma
-    hands out fresh ones whenever it is recomputed.  O(1): ~10 us per table (summing the values as well, as first tried, doubled
-    the 0.33 ms of a whole fused call)."""
+class _Same:
+    """Compares equal only to a wrapper of the very same object: the immutable parts of a pandas object (its Index objects,
+    which pandas replaces rather than edits) inside a witness tuple."""
+
+    __slots__ = ("obj",)
+
+    def __init__(self, obj):
+        self.obj = obj
+
+    def __eq__(self, other):
+        return type(other) is _Same and other.obj is self.obj
+
+    __hash__ = None
+
+
+class _Never:
+    """A witness that matches nothing (an object whose content cannot be read as arrays): derived again on every call."""
+
+    def __eq__(self, other):
+        return False
+
+    __hash__ = None
+
+
+def _hash_array(a):
+    if not isinstance(a, np.ndarray):
+        a = np.asarray(a)  # (pandas extension arrays)
+    if a.dtype.kind == "O":  # strings / mixed objects: pandas' value hash per element (a buffer of pointers says nothing)
+        import pandas as pd
+
+        return (a.shape, "O", _digest(np.ascontiguousarray(pd.util.hash_array(a.reshape(-1), categorize=False))))
+    if a.flags.c_contiguous:
+        d = _digest(a)
+    elif a.flags.f_contiguous:  # a DataFrame block made from a row-major table
+        d = _digest(a.T)
+    else:
+        d = _digest(np.ascontiguousarray(a))
+    return (a.shape, a.dtype.str, d)
+
+
+def _witness(obj):
+    """What a cached derivation of `obj` is checked against: a digest of every value it holds (+ the identity of its axes).
+    ~1 us for a per-depth vector, ~40 us per MB of table."""
+    if isinstance(obj, np.ndarray):
+        return _hash_array(obj)
+    kind = type(obj).__name__
     try:
-        if type(obj).__name__ == "DataFrame" and "nu" in obj.columns:  # (hasattr on a pandas Series walks its __getattr__: 7 us a miss)
-            f = obj["nu"].to_numpy()
-            if f.size and f.dtype.kind in "fiu":
-                return (obj.shape, float(f[0]), float(f[f.size // 2]), float(f[-1]))
-            return (obj.shape,)
-    except Exception:  # noqa: BLE001  (anything exotic: identity only)
+        if kind in ("DataFrame", "Series"):
+            mgr = getattr(obj, "_mgr", None)
+            arrays = getattr(mgr, "arrays", None)
+            if arrays is None:
+                arrays = (obj.to_numpy(),)
+            parts = [_Same(obj.index)]
+            if kind == "DataFrame":
+                parts.append(_Same(obj.columns))
+                for name in ("blknos", "blklocs"):  # which column sits where in which block
+                    loc = getattr(mgr, name, None)
+                    if loc is not None:
+                        parts.append(_hash_array(np.asarray(loc)))
+            parts.extend(_hash_array(a) for a in arrays)
+            return tuple(parts)
+        if hasattr(obj, "is_unique") and hasattr(obj, "get_indexer"):  # a pandas Index: immutable
+            return (_Same(obj),)
+    except Exception:  # noqa: BLE001  (anything exotic: not cacheable)
         pass
-    return None
+    return _Never()
 
 
-class _Snapshot:
-    """The named attributes of `obj` as they are now (references, not copies); everything else is read through."""
-
-    def __init__(self, obj, names):
-        self.__dict__["_live"] = obj
-        for name in names:
-            try:
-                self.__dict__[name] = getattr(obj, name)
-            except AttributeError:
-                pass
-
-    def __getattr__(self, name):  # (only reached for names that were not taken)
-        return getattr(self.__dict__["_live"], name)
+_SEEN = None  # {id(object): witness} for the duration of ONE try_fused call (several derivations read the same tables), else None
 
 
-def _memo(tag, objects, extra, build):
-    key = (tag, tuple(id(o) for o in objects), tuple(_stamp(o) for o in objects), extra)
+def _witness_once(obj):
+    if _SEEN is None:
+        return _witness(obj)
+    w = _SEEN.get(id(obj))
+    if w is None:
+        w = _SEEN[id(obj)] = _witness(obj)
+    return w
+
+
+def _memo(tag, objects, extra, build, private=()):
+    """build() for these source objects, or the value kept from an earlier call if the objects are the same AND hold the same
+    values.  `private`: positions in `objects` of values this module made itself (cached derivations handed on): identity only."""
+    if not CACHE:
+        return build()
+    key = (tag, tuple(id(o) for o in objects), extra)
+    now = tuple(_Same(o) if i in private else _witness_once(o) for i, o in enumerate(objects))
     hit = _MEMO.get(key)
-    if hit is not None:
+    if hit is not None and hit[3] == now:
         _MEMO[key] = _MEMO.pop(key)  # most recently used last
         return hit[1]
+    _MEMO.pop(key, None)
     value = build()
-    _MEMO[key] = (objects, value, _nbytes(value))
+    _MEMO[key] = (objects, value, _nbytes(value), now)
     while len(_MEMO) > _MEMO_MAX or (len(_MEMO) > 1 and sum(e[2] for e in _MEMO.values()) > MEMO_MAX_BYTES):
         _MEMO.pop(next(iter(_MEMO)))
     return value
@@ -381,7 +447,8 @@ def _line_arrays(stellar_plasma, stellar_model, nus, cfg):
     vald_broadening = bool(vald.use_vald_broadening and vald.use_linelist)
     masses = stellar_model.composition.nuclide_masses
     tab = _memo("line_tables", (lines, alpha_table, masses), vald_broadening,
-                lambda: _sorted_line_tables(lines, alpha_table, masses, vald_broadening))
+                lambda: _sorted_line_tables(lines, alpha_table, masses, vald_broadening),
+                private=() if vald.use_linelist else (0,))  # (the joined TARDIS table is this module's own, verified above)
     if tab is None:
         return None
     # nu.between(min, max) (:393-395) on sorted columns is a slice
@@ -409,19 +476,20 @@ def _depth_vectors(stellar_plasma, opacity, file_source, rayleigh_species):
 
     def build():
         ions = p.ion_number_density
-        out = {"n_e": np.ascontiguousarray(plain(p.electron_densities), dtype=F8).reshape(-1)}
+        own = lambda a: np.array(plain(a), dtype=F8)  # noqa: E731  (a copy: cached values must not alias the plasma's memory)
+        out = {"n_e": own(p.electron_densities).reshape(-1)}
         if file_source is not None:
-            out["file"] = np.asarray(plain(get_number_density(p, file_source)[0]), dtype=F8)
+            out["file"] = own(get_number_density(p, file_source)[0])
         ff_ions, ff_dens = [], []
         for spec in ff_species:
             number_density, _, ion_number = get_number_density(p, spec + "_ff")
-            ff_ions.append(ion_number), ff_dens.append(np.asarray(plain(number_density), dtype=F8))
+            ff_ions.append(ion_number), ff_dens.append(own(number_density))
         out["ff_ions"], out["ff_dens"] = ff_ions, ff_dens
-        out["n_h"] = np.asarray(plain(ions.loc[1, 0]), dtype=F8)  # neutral hydrogen: van der Waals broadening and Rayleigh scattering
+        out["n_h"] = own(ions.loc[1, 0])  # neutral hydrogen: van der Waals broadening and Rayleigh scattering
         if "He" in rayleigh_species:
-            out["n_he"] = np.asarray(plain(ions.loc[2, 0]), dtype=F8)
+            out["n_he"] = own(ions.loc[2, 0])
         if "H2" in rayleigh_species:
-            out["n_h2"] = np.asarray(plain(p.h2_density), dtype=F8)
+            out["n_h2"] = own(p.h2_density)
         return out
 
     objs = [p.ion_number_density, p.electron_densities]
@@ -436,6 +504,14 @@ def _fingerprint(a):
     return (a.shape, hash(a.tobytes()))
 
 
+def _owned(spec):
+    """`spec` (a LineList) with every array its own copy: nothing in a cached list may alias the plasma's or the model's memory."""
+    for name, a in list(vars(spec).items()):
+        if isinstance(a, np.ndarray):  # (owndata says nothing: ascontiguousarray hands a conforming caller's array back as it is)
+            setattr(spec, name, a.copy())
+    return spec
+
+
 def _deferred_atomic(stellar_plasma, stellar_model, nus, cfg):
     """The LineList calc_alpha_line_at_nu builds when the plasma carries no dense alpha table (base.py mirror, f1), kept per
     set of plasma objects, grid range, model temperatures and broadening configuration."""
@@ -447,7 +523,7 @@ def _deferred_atomic(stellar_plasma, stellar_model, nus, cfg):
                                      stellar_model.composition.nuclide_masses),
                  (float(nus.min()), float(nus.max()), tuple(cfg.broadening), bool(vald.use_vald_broadening), _fingerprint(temps),
                   _microturbulence_cgs(stellar_model)),
-                 lambda: deferred_line_list(p.lines_from_linelist, nus, stellar_model, p, cfg.broadening, vald.use_vald_broadening))
+                 lambda: _owned(deferred_line_list(p.lines_from_linelist, nus, stellar_model, p, cfg.broadening, vald.use_vald_broadening)))
 
 
 def _deferred_molecules(stellar_plasma, stellar_model, nus, cfg):
@@ -458,7 +534,7 @@ def _deferred_molecules(stellar_plasma, stellar_model, nus, cfg):
     return _memo("deferred_molecules", (p.molecule_lines_from_linelist, p.molecule_number_density, p.molecule_partition_function, p.molecule_ion_map,
                                         stellar_model.composition.nuclide_masses),
                  (float(nus.min()), float(nus.max()), tuple(cfg.broadening), _fingerprint(temps), _microturbulence_cgs(stellar_model)),
-                 lambda: deferred_molecule_line_list(p.molecule_lines_from_linelist, nus, stellar_model, p, cfg.broadening))
+                 lambda: _owned(deferred_molecule_line_list(p.molecule_lines_from_linelist, nus, stellar_model, p, cfg.broadening)))
 
 
 def _sorted_molecule_tables(lines, alpha_table, ion_map, nuclide_masses):
@@ -523,6 +599,15 @@ def _linelist_struct(spec, tag, P):
 
 def try_fused(field_cls, tracing_nus, stellar_model, stellar_plasma, config, source_function):
     """-> RadiationField computed by one fused device pass, or None when the configuration needs the general path."""
+    global _SEEN
+    _SEEN = {}  # (witnesses are per call: the tables may be edited before the next one)
+    try:
+        return _try_fused(field_cls, tracing_nus, stellar_model, stellar_plasma, config, source_function)
+    finally:
+        _SEEN = None
+
+
+def _try_fused(field_cls, tracing_nus, stellar_model, stellar_plasma, config, source_function):
     opacity = config.opacity
     spherical = bool(getattr(stellar_model, "spherical", False))
     tracked = bool(config.result_options.return_radiation_field)
@@ -794,23 +879,35 @@ def _run_step(v):
             return value
         return _Thunk(run)
 
-    fnus = field.frequencies
-    # The continuum entries are formed on first read from the plasma's tables — the tables of THIS call: the objects are taken now,
-    # so that a plasma whose attributes are replaced afterwards (the next iteration of a fit) still yields entries that belong to
-    # this field's F_nu.  (Tables edited in place are not protected; materialise the entries first — release_device(field).)
-    stellar_plasma = _Snapshot(stellar_plasma, ("ion_number_density", "electron_densities", "h_minus_density", "h2_density", "levels",
-                                                "excitation_energy", "level_number_density", "ionization_data"))
-    stellar_model = _Snapshot(stellar_model, ("temperatures", "no_of_depth_points", "composition"))
+    # The continuum entries are formed on first read by the per-source entry points the general path calls (the same device
+    # functions: bit-identical planes) — from the arrays THIS call derived and sent up (private copies: `bf`, `dv`, `nus`, `temps`),
+    # never from the plasma again: whatever happens to the plasma's tables afterwards, replaced or edited in place, the entries
+    # belong to this field's F_nu, as the reference's eagerly computed ones do.
+    nus_own, temps_own = nus.copy(), temps.copy()
+    ff_plane = np.vstack(dv["ff_dens"]) if dv["ff_dens"] else np.zeros((0, nd))
+
+    def rayleigh_plane():
+        picks = {}
+        if "H" in rayleigh_species:
+            picks["n_h"] = dv["n_h"]
+        if "He" in rayleigh_species:
+            picks["n_he"] = dv["n_he"]
+        if "H2" in rayleigh_species:
+            picks["n_h2"] = dv["n_h2"]
+        return B._download(ops.alpha_rayleigh(nus_own.copy(), nd, **picks)[0])  # (no frequency above the cut-off here: nothing to clip)
+
     for k, (source, fpath) in enumerate(opacity.file.items()):
         if file_planes:  # the plane the step added is the entry
             put(f"alpha_file_{source}", twin(file_planes[k]))
-        else:
-            put(f"alpha_file_{source}", remembered(f"alpha_file_{source}", lambda s=source, f=fpath: B.calc_alpha_file(stellar_plasma, stellar_model, fnus, s, f)))
-    put("alpha_bf", remembered("alpha_bf", lambda: B.calc_alpha_bf(stellar_plasma, stellar_model, fnus, opacity.bf)))
-    put("alpha_ff", remembered("alpha_ff", lambda: B.calc_alpha_ff(stellar_plasma, stellar_model, fnus, opacity.ff)))
-    put("alpha_rayleigh", remembered("alpha_rayleigh", lambda: B.calc_alpha_rayleigh(stellar_plasma, stellar_model, fnus, opacity.rayleigh)))
+        else:  # one 1-D table, interpolated inside the step
+            put(f"alpha_file_{source}", remembered(f"alpha_file_{source}", lambda: B._download(
+                ops.alpha_file_1d(K.nu_to_angstrom(nus_own), table[1], table[2], dv["file"]))))
+    put("alpha_bf", remembered("alpha_bf", lambda: B._download(ops.alpha_bf(nus_own, bf[0], bf[1], bf[2], bf[3], nd))))
+    put("alpha_ff", remembered("alpha_ff", lambda: B._download(ops.alpha_ff(nus_own, temps_own, ff_ions, ff_plane))))
+    put("alpha_rayleigh", remembered("alpha_rayleigh", rayleigh_plane))
     put("alpha_electron", 0 if opacity.disable_electron_scattering else remembered(
-        "alpha_electron", lambda: B.calc_alpha_electron(stellar_plasma, stellar_model, fnus, False)))
+        "alpha_electron", lambda: B._download(ops.alpha_electron(nus_own.size, n_e))))
+
     def tables_of(spec):
         """gammas / doppler_widths of a deferred list, formed the way the general path forms them (sdx_line_params_dev) on
         first read of either entry."""

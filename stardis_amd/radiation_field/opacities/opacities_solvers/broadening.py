@@ -95,11 +95,21 @@ def calculate_broadening(lines, stellar_model, stellar_plasma, broadening_line_o
 
 def calculate_molecule_broadening(lines, stellar_model, stellar_plasma, broadening_line_opacity_config, use_vald_broadening=False):
     """Molecular lines: gamma = A_ul as an (N_l, 1) column when "radiation" is configured (:800-801), Doppler
-    width with the summed mass of the two constituent nuclides (:808-819)."""
-    if use_vald_broadening:
-        raise NotImplementedError("VALD broadening for molecules is not reachable in the reference either (:444-474)")
+    width with the summed mass of the two constituent nuclides (:808-819).  use_vald_broadening (:771-799; not reachable from
+    calc_molecular_alpha_line_at_nu, callable by a user whose molecular table carries the VALD columns): gamma (N_l, N_d) =
+    A_ul + calc_vald_stark_gamma (when linear OR quadratic Stark is configured) + calc_vald_vdW, NOT halved — the terms of
+    k_calc_vald_gamma without its hydrogen linear-Stark term and without :1084."""
     n_depth = stellar_model.no_of_depth_points if hasattr(stellar_model, "no_of_depth_points") else len(plain(stellar_model.temperatures))
-    if "radiation" in broadening_line_opacity_config:
+    if use_vald_broadening:
+        lin, quad, vdw, rad = _switches(broadening_line_opacity_config)
+        n_e, temps, n_h = _depth_state(stellar_model, stellar_plasma)
+        gammas = ops.calc_vald_gamma_arrays(
+            lines.atomic_number.values, lines.ion_number.values + 1, lines.ionization_energy.values, lines.level_energy_upper.values,
+            lines.level_energy_lower.values, lines.A_ul.values, lines.stark.values, lines.waals.values,
+            stellar_model.composition.nuclide_masses.loc[lines.atomic_number].values, n_e, temps, n_h,
+            False, lin or quad, vdw, rad, halve=False,
+        )
+    elif "radiation" in broadening_line_opacity_config:
         gammas = np.asarray(lines.A_ul.values, dtype=float)[:, np.newaxis]
     else:
         gammas = np.zeros((len(lines), n_depth), dtype=float)

@@ -354,6 +354,22 @@ def g3_broadening(rng, atm, cont):
             + NUCLIDE_MASSES.loc[plasma.molecule_ion_map.loc[mol_lines.molecule].Ion2].values
         ),
     )
+    # molecules, VALD branch (broadening.py:771-799: A_ul + calc_vald_stark_gamma when linear OR quadratic Stark is configured +
+    # calc_vald_vdW, NOT halved).  calc_molecular_alpha_line_at_nu never asks for it, a caller can: the atomic table above with a
+    # `molecule` column stands in for a molecular list that carries the VALD columns.  (Drawn last: the arrays above keep their values.)
+    molv = lines.copy()
+    molv["molecule"] = rng.choice(["CH", "MgH"], len(molv))
+    for tag, cfg in {
+        "all": ["linear_stark", "quadratic_stark", "van_der_waals", "radiation"],
+        "lin": ["linear_stark"],
+        "quad": ["quadratic_stark"],
+        "vdw_rad": ["van_der_waals", "radiation"],
+        "none": [],
+    }.items():
+        mg, md = R.br.calculate_molecule_broadening(molv, model, plasma, cfg, use_vald_broadening=True)
+        out["molv_gammas_" + tag] = np.asarray(mg, dtype=np.float64)
+    out["molv_doppler"] = np.asarray(md, dtype=np.float64)
+    out["molv_molecule_is_MgH"] = (molv.molecule.values == "MgH").astype(np.int32)
     inputs = {("line_" + c): lines[c].values for c in lines.columns}
     inputs["line_mass"] = NUCLIDE_MASSES.loc[lines.atomic_number].values
     save("g3_broadening", temperatures=t, n_e=n_e, n_h1=n_h1, microturbulence=np.float64(1.0e5), **inputs, **out)

@@ -71,19 +71,59 @@ def test_memo_is_bounded_by_bytes_too(monkeypatch):
 
 
 def test_memo_notices_an_edit_in_place():
-    """A table edited IN PLACE between two calls is the same object: the cheap content fingerprint next to the identity (shape,
-    first, last and summed value) makes the cached derivation miss, as the reference — which recomputes everything — would see
-    the edit (round-3 advisor finding)."""
+    """A table edited IN PLACE between two calls is the same object: the digest of its values kept beside the identity makes the
+    cached derivation miss, as the reference — which recomputes everything (radiation_field/base.py:71-117) — would see the edit.
+    ANY value counts (round-4 review: the three sampled frequencies of the earlier fingerprint let most edits through)."""
     fused.clear_cache()
     table = pd.DataFrame({"nu": [3.0, 1.0, 2.0], "A_ul": [1e7, 2e7, 3e7]})
     n = []
-    f = lambda: fused._memo("edit", (table,), None, lambda: n.append(1) or float(table["nu"].sum()))  # noqa: E731
-    assert f() == 6.0 and f() == 6.0 and len(n) == 1
+    f = lambda: fused._memo("edit", (table,), None, lambda: n.append(1) or float(table["nu"].sum() + table["A_ul"].sum()))  # noqa: E731
+    assert f() == 6.0 + 6e7 and f() == 6.0 + 6e7 and len(n) == 1
     table.loc[1, "nu"] = 10.0
-    assert f() == 15.0 and len(n) == 2
+    assert f() == 15.0 + 6e7 and len(n) == 2
+    table.iloc[1, 1] *= 2.0  # a value the old fingerprint never looked at
+    assert f() == 15.0 + 8e7 and f() == 15.0 + 8e7 and len(n) == 3
     table.drop(index=0, inplace=True)  # rows dropped in place: another shape
-    assert f() == 12.0 and len(n) == 3
+    assert f() == 12.0 + 7e7 and len(n) == 4
+    dens = pd.Series(np.arange(5.0))
+    g = lambda: fused._memo("series", (dens,), None, lambda: n.append(1) or float(dens.sum()))  # noqa: E731
+    assert g() == 10.0 and g() == 10.0
+    dens *= 2.0
+    assert g() == 20.0
+    dens.iloc[2] = 0.0
+    assert g() == 16.0
+    frame = pd.DataFrame(np.ones((4, 3)))
+    h = lambda: fused._memo("frame", (frame,), None, lambda: float(frame.to_numpy().sum()))  # noqa: E731
+    assert h() == 12.0
+    frame.iloc[:, 0] *= 2.0
+    assert h() == 16.0
+    frame[1] = 5.0  # a column replaced
+    assert h() == 32.0
     fused.clear_cache()
+
+
+def test_memo_private_objects_are_identity_only_and_cache_can_be_switched_off(monkeypatch):
+    fused.clear_cache()
+    own = pd.Series([1.0, 2.0])
+    n = []
+    f = lambda: fused._memo("own", (own,), None, lambda: n.append(1) or float(own.sum()), private=(0,))  # noqa: E731
+    assert f() == 3.0
+    own.iloc[0] = 5.0  # this module's own derivations are never edited; if one were, it would not be looked at
+    assert f() == 3.0 and len(n) == 1
+    monkeypatch.setattr(fused, "CACHE", False)
+    assert f() == 7.0 and f() == 7.0 and len(n) == 3
+    fused.clear_cache()
+
+
+def test_witness_of_object_columns_and_unknown_objects():
+    a = pd.DataFrame({"molecule": ["TiO", "H2O", "TiO"], "nu": [1.0, 2.0, 3.0]})
+    w0 = fused._witness(a)
+    assert w0 == fused._witness(a)
+    a.loc[1, "molecule"] = "CO"
+    assert w0 != fused._witness(a)
+    assert fused._witness(object()) != fused._witness(object())  # nothing to read: never a hit
+    idx = pd.MultiIndex.from_tuples([(1, 0), (2, 0)])
+    assert fused._witness(idx) == fused._witness(idx) and fused._witness(idx) != fused._witness(idx.copy())
 
 
 def test_sorted_line_tables_follow_pandas_in_grid_order():

@@ -153,6 +153,28 @@ def test_broadening_golden(ctx):
     va = base[:6] + (g["line_stark"], g["line_waals"], g["line_mass"]) + base[6:]
     assert rel_err(ops.calc_vald_gamma_arrays(*va, True, True, True, True), g["vald_gamma_all"]) < 1e-13
     assert rel_err(ops.calc_vald_gamma_arrays(*va, False, False, True, True), g["vald_gamma_rad_vdw"]) < 1e-13
+    # calculate_molecule_broadening(use_vald_broadening=True) (:771-799) on the reference's own call: a molecular table with the
+    # VALD columns (the fixture's atomic table + a `molecule` column), five broadening configurations
+    import pandas as pd
+    from types import SimpleNamespace as NS
+    from stardis_amd.radiation_field.opacities.opacities_solvers.broadening import calculate_molecule_broadening
+
+    molv = pd.DataFrame({k[len("line_"):]: g[k] for k in g.files if k.startswith("line_") and k != "line_mass"})
+    molv["molecule"] = np.where(g["molv_molecule_is_MgH"] == 1, "MgH", "CH")
+    masses = pd.Series(np.array([1.008, 4.0026, 12.011, 24.305, 40.078, 55.845]) * K.AMU_CGS, index=pd.Index([1, 2, 6, 12, 20, 26], name="atomic_number"))
+    assert np.array_equal(masses.loc[g["line_atomic_number"]].values, g["line_mass"])
+    cols = np.arange(g["temperatures"].size)
+    model = NS(temperatures=g["temperatures"], no_of_depth_points=cols.size, microturbulence=float(g["microturbulence"]),
+               composition=NS(nuclide_masses=masses))
+    plasma = NS(electron_densities=pd.Series(g["n_e"], index=cols),
+                ion_number_density=pd.DataFrame(g["n_h1"][None, :], index=pd.MultiIndex.from_tuples([(1, 0)]), columns=cols),
+                molecule_ion_map=pd.DataFrame(dict(Ion1=[6, 12], Ion2=[1, 1]), index=["CH", "MgH"]))
+    for tag, cfg in dict(all=["linear_stark", "quadratic_stark", "van_der_waals", "radiation"], lin=["linear_stark"], quad=["quadratic_stark"],
+                         vdw_rad=["van_der_waals", "radiation"], none=[]).items():
+        gam, dop = calculate_molecule_broadening(molv, model, plasma, cfg, use_vald_broadening=True)
+        ref = g["molv_gammas_" + tag]
+        assert gam.shape == ref.shape and np.array_equal(gam == 0, ref == 0) and rel_err(gam, ref) < 1e-13, tag
+    assert rel_err(dop, g["molv_doppler"]) < 1e-15
     # element-wise ufunc counterparts (reference test_broadening.py known answers)
     from stardis_amd.radiation_field.opacities.opacities_solvers import broadening as B
 

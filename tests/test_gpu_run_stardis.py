@@ -216,9 +216,11 @@ def test_fused_path_declines_what_it_does_not_cover(ctx, monkeypatch, tmp_path):
     assert np.array_equal(quiet.F_nu, plain_field.F_nu)
 
 
-def test_plasma_tables_are_cached_per_object_not_per_value(ctx, monkeypatch, tmp_path):
-    """The fused path keeps what it derives from the plasma's pandas objects keyed on their IDENTITY: the same objects hit the
-    cache, a replaced table (what a recomputed plasma hands out) misses it, an in-place edit needs clear_cache()."""
+def test_plasma_tables_are_cached_per_object_and_verified_by_value(ctx, monkeypatch, tmp_path):
+    """The fused path keeps what it derives from the plasma's pandas objects per object AND checks a digest of their values on
+    every call: the same objects with the same values hit the cache, a replaced table (what a recomputed plasma hands out) misses
+    it, and so does ANY edit in place — the call returns what the reference, which recomputes everything per call
+    (radiation_field/base.py:71-117), returns for the same call sequence.  No clear_cache() anywhere."""
     import stardis_amd.radiation_field.base as rf
     from stardis_amd.radiation_field import fused
     from test_gpu_dropin import rebuild
@@ -228,7 +230,9 @@ def test_plasma_tables_are_cached_per_object_not_per_value(ctx, monkeypatch, tmp
 
     def run(use_fused=True):
         monkeypatch.setattr(rf, "FUSED", use_fused)
-        return rf.create_stellar_radiation_field(g["nus"].copy(), model, plasma, config).F_nu
+        field = rf.create_stellar_radiation_field(g["nus"].copy(), model, plasma, config)
+        assert (type(field.opacities).__name__ == "FusedOpacities") == use_fused
+        return field.F_nu
 
     fused.clear_cache()
     first = run()
@@ -242,8 +246,39 @@ def test_plasma_tables_are_cached_per_object_not_per_value(ctx, monkeypatch, tmp
     assert not np.array_equal(changed, first) and np.array_equal(changed, run(use_fused=False))
     plasma.electron_densities = plasma.electron_densities * 1.0  # new object, same values
     assert np.array_equal(run(), changed)
-    stronger.iloc[:, 0] *= 2.0  # in place: not seen until the cache is cleared
-    fused.clear_cache()
+    # ---- edits IN PLACE: seen by the very next call
+    stronger.iloc[:, 0] *= 2.0  # one depth column of the dense alpha table (none of the values a sampled fingerprint would read)
+    edited = run()
+    assert not np.array_equal(edited, changed) and np.array_equal(edited, run(use_fused=False))
+    stronger.iloc[stronger.shape[0] // 3, 5] *= 50.0  # ONE element
+    one = run()
+    assert not np.array_equal(one, edited) and np.array_equal(one, run(use_fused=False))
+    plasma.electron_densities *= 1.5  # Thomson scattering, the Stark widths
+    ne = run()
+    assert not np.array_equal(ne, one) and np.array_equal(ne, run(use_fused=False))
+    plasma.ion_number_density.iloc[:, :] = plasma.ion_number_density.to_numpy() * 0.7  # free-free, Rayleigh, van der Waals, H-
+    ions = run()
+    assert not np.array_equal(ions, ne) and np.array_equal(ions, run(use_fused=False))
+    plasma.level_number_density.iloc[0, :] *= 4.0  # bound-free
+    lev = run()
+    assert not np.array_equal(lev, ions) and np.array_equal(lev, run(use_fused=False))
+    plasma.lines_from_linelist["A_ul"] *= 30.0  # a per-line scalar: radiation damping
+    aul = run()
+    assert not np.array_equal(aul, lev) and np.array_equal(aul, run(use_fused=False))
+    # ---- the dictionary entries of a field belong to ITS call, whatever happens to the plasma afterwards (the reference forms
+    # them eagerly): read late, after another edit, they are the planes of the call that made the field
+    monkeypatch.setattr(rf, "FUSED", False)
+    eager = rf.create_stellar_radiation_field(g["nus"].copy(), model, plasma, config)
+    monkeypatch.setattr(rf, "FUSED", True)
+    lazy = rf.create_stellar_radiation_field(g["nus"].copy(), model, plasma, config)
+    plasma.electron_densities *= 2.0
+    plasma.level_number_density.iloc[:, :] = 0.0
+    plasma.ion_number_density.iloc[:, :] = plasma.ion_number_density.to_numpy() * 3.0
+    for key, value in eager.opacities.opacities_dict.items():
+        assert np.array_equal(np.asarray(lazy.opacities.opacities_dict[key]), np.asarray(value)), key
+    assert np.array_equal(lazy.opacities.total_alphas, eager.opacities.total_alphas)
+    # ---- and with the cache switched off altogether: the same answers
+    monkeypatch.setattr(fused, "CACHE", False)
     assert np.array_equal(run(), run(use_fused=False))
 
 

@@ -58,6 +58,12 @@ def test_broadening_golden():
     # numpy evaluates 10**x and x**0.38 with its own SIMD pow: 1e-15 level differences from libm
     assert rel_err(oracle.calc_vald_gamma(*va, flags=15), g["vald_gamma_all"]) < 5e-15
     assert rel_err(oracle.calc_vald_gamma(*va, flags=12), g["vald_gamma_rad_vdw"]) < 5e-15
+    # calculate_molecule_broadening(use_vald_broadening=True) (:771-799): Stark when linear OR quadratic is configured, not halved (16)
+    for tag, flags in dict(all=8 | 2 | 4, lin=2, quad=2, vdw_rad=4 | 8, none=0).items():
+        ref = g["molv_gammas_" + tag]
+        got = oracle.calc_vald_gamma(*va, flags=flags | 16)
+        assert np.array_equal(got == 0, ref == 0) and rel_err(got, ref) < 5e-15, tag
+    assert rel_err(2 * oracle.calc_vald_gamma(*va, flags=14), g["molv_gammas_all"]) < 5e-15  # the same sum through the halving path
     assert np.array_equal(oracle.doppler_widths(g["mol_nu"], g["mol_mass"], g["temperatures"], 1e5), g["mol_doppler"])
 
 
