@@ -484,6 +484,7 @@ typedef struct sdx_synthesis_options {
     const double* line_plane[2];
     int64_t line_plane_ld;
     const sdx_linelist* linelist;
+    const double* line_m_max; /* two-collective mode (below): the gathered per-line maxima [n_lines], or NULL */
 } sdx_synthesis_options;
 int sdx_synthesize_opt_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin, int64_t nu_count,
                            int64_t n_lines, const double* line_nus, const double* doppler_widths, const double* gammas,
@@ -491,6 +492,24 @@ int sdx_synthesize_opt_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double
                            const double* temperatures, const double* ray_dist, const double* weights, double* alpha_line_out,
                            double* total_alphas, double* F_nu, int64_t ld, const sdx_synthesis_options* options,
                            int64_t* n_evaluations_dev);
+
+/* Frequency shards of long lists in TWO collectives (optional; SURVEY §8e plans one).  A shard's step begins by classifying EVERY
+ * line of the replicated list — the largest (gamma + doppler_width) alpha over the depths, from which the window rule
+ * (opacities_solvers/base.py:561-575) gives the line's widest window: which lines can reach the shard from anywhere — a stream of
+ * 8 n_lines (2 n_depth + gamma_cols) bytes that every rank repeats and that does not shrink with the number of ranks.  Here each
+ * rank classifies a SHARE of the lines and the ranks exchange the shares (an all-gather of 8 n_lines bytes):
+ *   1. sdx_synthesize_classify_dev(...)       m_max[line_begin .. line_begin + line_count) = this rank's share; the same launch
+ *                                             leaves the grid spacing, the shard's line ranges and the continuum plane of the step
+ *                                             in the context's scratch;
+ *   2. the caller gathers m_max [n_lines]      (RCCL / torch.distributed; stardis_amd.parallel.ClassificationGatherer);
+ *   3. sdx_synthesize_opt_dev(..., options->line_m_max = m_max)   the rest of the step — same context, same grid, shard, lists.
+ * Results are bit-identical to the one-call step (the classes of the lines follow from the same numbers).  Only for culled
+ * shards: dense lists of >= `indexed_min_lines` lines, grids of more than 16384 points, nu_count < n_nu, no evaluation count;
+ * anything else is SDX_ERR_ARG (-1), as is step 3 without step 1. */
+int sdx_synthesize_classify_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin, int64_t nu_count,
+                                int64_t n_lines, const double* line_nus, const double* doppler_widths, const double* gammas,
+                                int gamma_cols, const double* alphas, const sdx_continuum* cont, int64_t line_begin,
+                                int64_t line_count, double* m_max);
 
 /* sdx_line_opacity_dev / sdx_synthesize_dev with the line parameters generated in the pre-pass. */
 int sdx_line_opacity_linelist_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin,

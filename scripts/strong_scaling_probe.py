@@ -1,7 +1,9 @@
 """GPU experiment: strong scaling of one workload by frequency sharding, emulated on one GPU — each rank's step is timed
 alone (ranks are independent: no data-path exchange; the flux gather overlaps the next step), the projected speed-up is
 t(1) / max_r t_r(P).  Steps are replayed as hipGraphs, like bench.py; the slowest rank's per-kernel times are printed.
-python scripts/strong_scaling_probe.py [TAG] [WORLD ...] [--balanced] [--all-ranks] [--verbose]"""
+python scripts/strong_scaling_probe.py [TAG] [WORLD ...] [--balanced] [--all-ranks] [--verbose] [--two-collectives]
+--two-collectives: every rank classifies 1 / WORLD of the line list and reads the other shares from a buffer filled beforehand (what
+the all-gather of m_max would deliver; its cost is NOT in the time printed — profiles/README.md models it)."""
 import ctypes as C, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stardis_amd import synth, parallel, _lib
@@ -19,24 +21,41 @@ KERNELS = ("k_dnu_partial", "k_classify", "k_prepass_continuum", "k_line_prepass
 
 def rank_time(world, rank, reps=20):
     shard = parallel.balanced_shards(work, world)[rank] if balanced else shard_bounds(nus.size, world, rank)
+    two = "--two-collectives" in sys.argv and world > 1
+    extra = {}
+    if two:
+        n_l = int(ln["line_nus"].size)
+        per = -(-n_l // world)
+        m_full = _lib.default_context().empty((n_l,))
+        extra = dict(classify_share=(0, n_l), m_max=m_full)
     syn = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], w["thetas"], w["weights"], w["lines"], w["cont"], shard=shard,
-                              track_evaluations=False, keep_line=False)
+                              track_evaluations=False, keep_line=False, **extra)
     ctx = syn.ctx
+    if two:  # every share once (the other ranks' part of the gathered array), then this rank's own from now on
+        syn.enqueue_classify(); ctx.synchronize()
+        syn.classify_share = (min(rank * per, n_l), max(0, min(per, n_l - rank * per)))
     syn.capture()
+
+    def one():
+        if two: syn.step_classify()
+        syn.step()
+
     # steady state, like bench.py's timed loop: ~0.2 s of untimed replays (clocks settle), then the best of five blocks of replays
-    syn.step(); syn.synchronize()
+    one(); syn.synchronize()
     t_end = time.perf_counter() + 0.2
     while time.perf_counter() < t_end:
-        for _ in range(reps): syn.step()
+        for _ in range(reps): one()
         syn.synchronize()
     t = 1e9
     for _ in range(5):
         t0 = time.perf_counter()
-        for _ in range(reps): syn.step()
+        for _ in range(reps): one()
         syn.synchronize()
         t = min(t, (time.perf_counter() - t0) / reps)
     ctx.call("sdx_profile_enable", 1); ctx.call("sdx_profile_reset")
-    for _ in range(3): syn.enqueue()
+    for _ in range(3):
+        if two: syn.enqueue_classify()
+        syn.enqueue()
     ctx.synchronize()
     kern = {}
     for k in KERNELS:

@@ -94,6 +94,7 @@ class SynthesisOptions(C.Structure):
         ("line_plane", _vp * 2),
         ("line_plane_ld", _i64),
         ("linelist", C.POINTER(LineListStruct)),
+        ("line_m_max", _vp),
     ]
 
 
@@ -170,6 +171,7 @@ PROTOTYPES = {
                                      _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp]),
     "sdx_synthesize_opt_dev": (_int, [_vp, _int, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _int, _vp, C.POINTER(Continuum), _int,
                                       _vp, _vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(SynthesisOptions), _vp]),
+    "sdx_synthesize_classify_dev": (_int, [_vp, _int, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _int, _vp, C.POINTER(Continuum), _i64, _i64, _vp]),
     "sdx_synthesize_f64": (_int, [_vp, _int, _i64, _vp, _i64, _vp, _vp, _vp, _int, _vp, C.POINTER(Continuum), _int, _vp, _vp, _vp, _vp, _vp,
                                   _vp, _vp]),
     "sdx_continuum_f64": (_int, [_vp, _int, _i64, _vp, C.POINTER(Continuum), _vp, _vp, _vp, _vp, _vp, _vp]),

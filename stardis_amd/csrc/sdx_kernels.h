@@ -216,6 +216,7 @@ struct LineWork {
     int64_t shard_begin, shard_end;  // the shard's columns (culled runs only need cnt_ge near them)
     unsigned long long* evals;
     int* ticket;  // culled runs: the pre-pass launch's work counter, one per depth block (zeroed by k_hlist_count), or nullptr
+    int front;    // culled runs: the blocks with work are the FIRST blocks of the pre-pass grid (k_line_prepass maps its block index)
 };
 
 // k / d for 0 <= k < 65536 and 1 <= d < 65536 with the divisor's reciprocal m = small_div_magic(d) = ceil(2^32 / d): one multiply-high
@@ -548,7 +549,22 @@ __global__ __launch_bounds__(kPreBlock) __attribute__((amdgpu_num_sgpr(80))) voi
 {
     // (dispatching the pixel and gather blocks of a culled shard BEFORE its line blocks — a rotated grid — was measured in round 4:
     // 47 against 44 us for this launch on an eighth of S-c3; the order stays [line | pixel | gather])
-    prepass_block<GEN, LINES>(blockIdx.x, blockIdx.y, gridDim.y, n_depth, n_nu, nus, dnu_partial, n_partial, n_lines, line_nus, doppler, gammas,
+    int bx = blockIdx.x;
+    if (w.sel && w.front) {
+        // A culled shard's grid is one block per CANDIDATE (every block of consecutive lines twice over, 9 500 at S-c3) of which a
+        // few hundred have work — somewhere in the middle of the range for most ranks, behind thousands of blocks that only look at
+        // `sel` and leave, each holding a block slot (70 KB of LDS) for a round trip.  Here the blocks that have work are the FIRST of
+        // the grid, whatever the rank: block index -> item by the counts the list launch left (range blocks, gather blocks, pixel
+        // blocks; the long items first), and everything behind them returns.  Which block prepares an item does not matter.
+        const int first = w.sel[2] / LINES, n_range = max((w.sel[3] + LINES - 1) / LINES - first, 0);
+        const int n_g = (w.hcount[0] + (w.xlist ? w.hcount[2] : 0) + LINES - 1) / LINES;
+        const int item = bx;
+        if (item < n_range) bx = first + item;
+        else if (item < n_range + n_g) bx = n_line_blocks + w.n_pix + (item - n_range);
+        else if (item < n_range + n_g + w.n_pix) bx = n_line_blocks + (item - n_range - n_g);
+        else return;
+    }
+    prepass_block<GEN, LINES>(bx, blockIdx.y, gridDim.y, n_depth, n_nu, nus, dnu_partial, n_partial, n_lines, line_nus, doppler, gammas,
                        gamma_cols, alphas, w, out_lo_ref, out_hi_ref, n_line_blocks, lp);
 }
 
@@ -1044,14 +1060,15 @@ __device__ __forceinline__ void shard_range(int64_t n_nu, const double* __restri
 // with atomicMax behind a pre-filter that needed d_nu: k_dnu_partial had to run, and clear the maxima, before every step.)
 // NaN terms are ignored (their window is the 10-point floor: never the widest).
 constexpr int kClsLinesPerWave = 4;  // lines in flight per wave: 12 independent loads per lane
-__device__ __forceinline__ void classify_block(const int bid, const int n_blocks, int n_depth, int64_t n_lines, const double* __restrict__ doppler,
-                                               const double* __restrict__ gammas, int gamma_cols, const double* __restrict__ alphas,
-                                               double* __restrict__ m_max)
+__device__ __forceinline__ void classify_block(const int bid, const int n_blocks, int n_depth, const int64_t cls_begin, const int64_t cls_end,
+                                               const double* __restrict__ doppler, const double* __restrict__ gammas, int gamma_cols,
+                                               const double* __restrict__ alphas, double* __restrict__ m_max)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
-    // the block's contiguous run of lines; its waves take consecutive groups of kClsLinesPerWave lines
-    const int64_t per_block = (n_lines + n_blocks - 1) / n_blocks;
-    const int64_t l0 = (int64_t)bid * per_block, l1 = min(l0 + per_block, n_lines);
+    // the lines [cls_begin, cls_end) — the whole list, or this rank's share of it (two-collective mode: the ranks exchange their
+    // shares of m_max) — in contiguous runs per block; a block's waves take consecutive groups of kClsLinesPerWave lines
+    const int64_t per_block = (cls_end - cls_begin + n_blocks - 1) / n_blocks;
+    const int64_t l0 = cls_begin + (int64_t)bid * per_block, l1 = min(l0 + per_block, cls_end);
     for (int64_t base = l0 + (int64_t)wave * kClsLinesPerWave; base < l1; base += (int64_t)n_waves * kClsLinesPerWave) {
         double m[kClsLinesPerWave];
 #pragma unroll
@@ -1094,7 +1111,7 @@ __global__ __launch_bounds__(kBlock) void k_classify(int n_dnu, int n_depth, int
                                                      const double* __restrict__ doppler, const double* __restrict__ gammas,
                                                      int gamma_cols, const double* __restrict__ alphas, double* __restrict__ m_max,
                                                      const double* __restrict__ nus, const double* __restrict__ line_nus, int64_t nu_begin,
-                                                     int64_t nu_count, int* __restrict__ sel)
+                                                     int64_t nu_count, int* __restrict__ sel, int64_t cls_begin, int64_t cls_end)
 {
     __shared__ double s_red[kBlock / 64];
     const int b = blockIdx.x;
@@ -1105,7 +1122,7 @@ __global__ __launch_bounds__(kBlock) void k_classify(int n_dnu, int n_depth, int
     // four threads of the LAST block find the shard's line ranges on the side (four binary searches: chains of dependent loads
     // that vanish behind this stream)
     if (sel && b == (int)gridDim.x - 1) shard_range(n_nu, nus, n_lines, line_nus, nu_begin, nu_count, sel);
-    classify_block(b - n_dnu, (int)gridDim.x - n_dnu, n_depth, n_lines, doppler, gammas, gamma_cols, alphas, m_max);
+    classify_block(b - n_dnu, (int)gridDim.x - n_dnu, n_depth, cls_begin, cls_end, doppler, gammas, gamma_cols, alphas, m_max);
 }
 
 
@@ -2130,7 +2147,7 @@ __global__ __launch_bounds__(kBlock) void k_classify_continuum(int n_dnu, int n_
                                                                const double* __restrict__ nus, int cont_tiles, int64_t nu_begin, int64_t nu_count,
                                                                ContinuumArgs ca, double* __restrict__ cont_plane, int64_t cont_ld, int stage_table,
                                                                const double* __restrict__ line_nus, int64_t shard_begin, int64_t shard_count,
-                                                               int* __restrict__ sel)
+                                                               int* __restrict__ sel, int64_t cls_begin, int64_t cls_end)
 {
     // order of the roles in the grid = order of dispatch: the continuum tiles — chains of dependent work (coefficients, a barrier,
     // a table search), eight depths per block so that they are few and long — go first and run behind the stream (round 4, an
@@ -2147,7 +2164,7 @@ __global__ __launch_bounds__(kBlock) void k_classify_continuum(int n_dnu, int n_
     } else {
         const int k = b - n_dnu - n_cont;
         if (sel && k == n_cls - 1) shard_range(n_nu, nus, n_lines, line_nus, shard_begin, shard_count, sel);  // (four threads, on the side)
-        classify_block(k, n_cls, n_depth, n_lines, doppler, gammas, gamma_cols, alphas, m_max);
+        classify_block(k, n_cls, n_depth, cls_begin, cls_end, doppler, gammas, gamma_cols, alphas, m_max);
     }
 }
 
@@ -2335,6 +2352,11 @@ __global__ __launch_bounds__(kRtBlock) void k_raytrace(int n_depth, int64_t n_nu
     double* sX = sA + gpw * col;              // flux terms       [kBatch][gpw][TH]
     const double nu = nus[ic];
 
+    // (Staging the columns a batch of G depth points AHEAD of the recurrence — the loads of batch b + 1 requested when batch b is
+    // committed, so that a shard's single generation of workgroups does not wait for all its planes before any wave computes — was
+    // built and measured in round 5: k_raytrace 60 - 91 us instead of 55 - 84 on the eighths of S-c3 and 428 instead of 377 on the
+    // whole grid.  The commit inside the gap loop needs the loop's registers: 46 spilled VGPRs at seven waves per SIMD, and a lone
+    // generation is bound by the 55-step chain of each wave, not by its staging.  Removed.)
     if (active) {
         for (int d = g; d < n_depth; d += G) {
             double a;

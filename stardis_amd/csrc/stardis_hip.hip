@@ -111,6 +111,14 @@ struct sdx_ctx {
     size_t free_block_bytes = 0;
     // bumped whenever a scratch buffer is reallocated: hipGraphs captured earlier hold the old device pointers
     uint64_t ws_generation = 0;
+    // two-collective mode: what sdx_synthesize_classify_dev left in the scratch (grid spacing, the shard's line ranges, the
+    // continuum plane) and for which problem; the synthesis that follows with options->line_m_max checks and consumes it
+    struct {
+        bool valid = false;
+        int n_depth = 0;
+        int64_t n_nu = 0, nu_begin = 0, nu_count = 0, n_lines = 0;
+        uint64_t generation = 0;
+    } classified;
     bool profile = false;
     std::vector<ProfileRecord> records;
     std::vector<hipEvent_t> event_pool;
@@ -161,7 +169,7 @@ LineWork carve(sdx_ctx* ctx, int n_depth, int64_t n_lines)
 {
     const size_t n = (size_t)n_depth * (size_t)n_lines;
     char* p = (char*)ctx->line_ws;
-    LineWork w;
+    LineWork w{};
     w.wrec = (WideRec*)p;                    // 48 n, 16-byte aligned
     w.wscan = (WideScan*)(w.wrec + n);       // 16 n
     w.wslow = (WideSlow*)(w.wscan + n);      // 16 n
@@ -723,6 +731,15 @@ struct ContinuumJob {  // continuum plane computed by the trailing blocks of the
     int64_t nu_begin, nu_count;
     double* plane;
 };
+// Frequency shards of long lists, two-collective mode: the classification stream of a culled pre-pass (the largest (gamma + dw) alpha
+// of every line, 8 N_l (2 N_d + G) bytes read by EVERY rank) split over the ranks — phase 1 classifies a share of the lines into the
+// caller's m_max array (and does everything else of that launch: grid spacing, the shard's line ranges, the continuum plane), the
+// caller exchanges the shares (an all-gather of 8 N_l bytes), phase 2 is the rest of the step on the gathered array.
+struct ClassifyPhase {
+    int phase;             // 1 or 2
+    int64_t begin, count;  // phase 1: the lines to classify
+    double* m_max;         // [n_lines]: phase 1 writes [begin, begin + count), phase 2 reads everything
+};
 
 // The segmented formal solution (k_raytrace_seg: the gaps of a ray over the 8 waves of a workgroup) pays ~40 % more
 // instructions for eight times the waves: it wins where k_raytrace would leave the chip under three waves per SIMD.
@@ -771,7 +788,8 @@ static void launch_line_lists(sdx_ctx* ctx, int64_t n_lines, LineWork& w, int pr
 static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t n_lines, const double* line_nus,
                         const double* doppler, const double* gammas, int gamma_cols, const double* alphas, bool fill_work,
                         int32_t* lo_ref, int32_t* hi_ref, LineWork* w_out, bool count_evals = true,
-                        const ContinuumJob* job = nullptr, const LineParams* gen = nullptr, int64_t nu_begin = 0, int64_t nu_count = -1)
+                        const ContinuumJob* job = nullptr, const LineParams* gen = nullptr, int64_t nu_begin = 0, int64_t nu_count = -1,
+                        const ClassifyPhase* ph = nullptr)
 {
     if (nu_count < 0) nu_count = n_nu;
     const LineParams lp = gen ? *gen : LineParams{};
@@ -801,6 +819,7 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
     w.sel = nullptr;
     w.gather = 0;
     w.ticket = nullptr;
+    w.front = 0;
     // long lists find their wide lines through hlist / wlist: the scan words of a line without a wide window anywhere are never
     // read (needs the line's widest window inside one block: one depth block per line)
     w.skip_unlisted_scan = (fill_work && n_lines >= ctx->indexed_min_lines && n_depth <= kPreDepths) ? 1 : 0;
@@ -813,6 +832,8 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
     // change what it computes for them.
     static const bool no_cull = knob("SDX_NO_CULL") != nullptr;
     const bool cull = fill_work && !no_cull && n_lines >= ctx->indexed_min_lines && !count_evals && !gen && !scan_in_block && nu_count < n_nu;
+    REQUIRE(!ph || cull, "two-collective mode is for frequency shards of long dense line lists (>= indexed_min_lines lines, a grid of more than "
+                         "16384 points, nu_count < n_nu, no evaluation count)");
     // the grid-spacing reduction: a launch of its own, or — culled runs — the first blocks of the classification launch
     int* const sel = cull ? w.hcount + 4 : nullptr;
     if (cull) n_partial = (int)std::min<int64_t>(kDnuPartials, std::max<int64_t>(1, (n_nu + kBlock * 8 - 1) / (kBlock * 8)));
@@ -867,10 +888,11 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
         w.sel = sel;
         // classification blocks: contiguous runs of lines, a few blocks per CU (256 threads: 4 waves x 4 lines x 3 arrays in flight)
         static const int cls_blocks_env = knob("SDX_CLS_BLOCKS") ? std::atoi(knob("SDX_CLS_BLOCKS")) : 0;  // experiment knob
+        const int64_t cls_begin = ph && ph->phase == 1 ? ph->begin : 0, cls_end = ph && ph->phase == 1 ? ph->begin + ph->count : n_lines;
         const unsigned n_cls = cls_blocks_env > 0 ? (unsigned)cls_blocks_env
-                                                  : (unsigned)std::max<int64_t>(1, std::min<int64_t>((n_lines + 63) / 64, (int64_t)8 * ctx->n_cu));
-        // the per-line maxima: doubles behind the integer lists of cnt_ws (8-byte aligned)
-        double* const m_max = (double*)(((uintptr_t)(w.hcount + 16 + 3 * ((size_t)n_lines / 1024 + 8)) + 7) & ~(uintptr_t)7);
+                                                  : (unsigned)std::max<int64_t>(1, std::min<int64_t>((cls_end - cls_begin + 63) / 64, (int64_t)8 * ctx->n_cu));
+        // the per-line maxima: doubles behind the integer lists of cnt_ws (8-byte aligned), or the caller's array (two-collective mode)
+        double* const m_max = ph ? ph->m_max : (double*)(((uintptr_t)(w.hcount + 16 + 3 * ((size_t)n_lines / 1024 + 8)) + 7) & ~(uintptr_t)7);
         double* const dnu_ws = (double*)ctx->small_ws;
         ContPlan cp;
         static const bool no_ride = knob("SDX_NO_CONT_RIDE") != nullptr;  // A/B knob
@@ -878,7 +900,16 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
             if ((rc = plan_continuum(kBlock, &cp))) return rc;
             continuum_done = cp.tiled;
         }
-        {
+        if (ph && ph->phase == 2) {
+            // the classification launch ran in phase 1 (sdx_synthesize_classify_dev) and left the grid spacing, `sel` and the
+            // continuum plane in this context's scratch — for THIS problem, and no buffer has moved since
+            const auto& c = ctx->classified;
+            REQUIRE(c.valid && c.n_depth == n_depth && c.n_nu == n_nu && c.nu_begin == nu_begin && c.nu_count == nu_count && c.n_lines == n_lines,
+                    "synthesize: options->line_m_max needs sdx_synthesize_classify_dev on this context first, for the same grid, shard and line list");
+            REQUIRE(c.generation == ctx->ws_generation, "synthesize: the context's scratch was reallocated between sdx_synthesize_classify_dev and the synthesis");
+            REQUIRE(!job || continuum_done, "synthesize: two-collective mode needs the tiled continuum");
+        } else {
+            REQUIRE(!ph || !job || continuum_done, "synthesize: two-collective mode needs the tiled continuum (at most 4096 bound-free levels)");
             LaunchScope ls(ctx, "k_classify");
             if (continuum_done) {
                 // half the classification blocks (16 of 32 wave slots per CU: the stream keeps its bytes in flight), the
@@ -887,11 +918,17 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
                 hipLaunchKernelGGL(k_classify_continuum, dim3((unsigned)n_partial + n_cls_half + (unsigned)cp.cont_tiles * cp.cont_rows), dim3(kBlock), cp.shmem, ctx->stream,
                                    n_partial, (int)n_cls_half, n_depth, n_nu, n_lines, dnu_ws, doppler, gammas, gamma_cols, alphas, m_max, nus,
                                    cp.cont_tiles, job->nu_begin, job->nu_count, cp.ca, job->plane, job->nu_count, cp.stage_table, line_nus, nu_begin, nu_count,
-                                   sel);
+                                   sel, cls_begin, cls_end);
             } else {
                 hipLaunchKernelGGL(k_classify, dim3((unsigned)n_partial + n_cls), dim3(kBlock), 0, ctx->stream, n_partial, n_depth, n_nu, n_lines, dnu_ws,
-                                   doppler, gammas, gamma_cols, alphas, m_max, nus, line_nus, nu_begin, nu_count, sel);
+                                   doppler, gammas, gamma_cols, alphas, m_max, nus, line_nus, nu_begin, nu_count, sel, cls_begin, cls_end);
             }
+        }
+        if (ph && ph->phase == 1) {
+            auto& c = ctx->classified;
+            c.valid = true, c.n_depth = n_depth, c.n_nu = n_nu, c.nu_begin = nu_begin, c.nu_count = nu_count, c.n_lines = n_lines;
+            c.generation = ctx->ws_generation;
+            return check_launch("k_classify");
         }
         static const bool no_ticket = knob("SDX_NO_PREPASS_TICKET") != nullptr;  // A/B knob: one block per candidate instead
         // the pre-pass launch that follows draws its items from a counter (k_line_prepass_ticket); the list launch zeroes it
@@ -906,6 +943,8 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
             launch_line_lists(ctx, n_lines, w, pre_lines, &cs);
         }
         w.gather = n_line_blocks;  // worst case: every line listed; blocks beyond the lists' end return at once
+        static const bool no_front = knob("SDX_NO_PREPASS_FRONT") != nullptr;  // A/B knob
+        w.front = no_front ? 0 : 1;
     }
     const dim3 grid((unsigned)(n_line_blocks + n_pixel_blocks + w.gather), (unsigned)((n_depth + kPreDepths - 1) / kPreDepths));
     if (job && !continuum_done) {
@@ -983,13 +1022,13 @@ static int choose_splits(int n_depth, int64_t n_nu_global, int64_t n_lines, int 
 static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin, int64_t nu_count,
                          int64_t n_lines, const double* line_nus, const double* doppler, const double* gammas, int gamma_cols,
                          const double* alphas, const double** partial_out, int64_t* pld_out, int* n_planes_out, LineWork* w_out,
-                         bool count_evals, const ContinuumJob* job = nullptr, const LineParams* gen = nullptr)
+                         bool count_evals, const ContinuumJob* job = nullptr, const LineParams* gen = nullptr, const ClassifyPhase* ph = nullptr)
 {
     constexpr int R = 4;       // grid points per lane of a wide-role tile (tile = 64 R points)
     constexpr int R_MIXED = 4;  // fp32 far wings (8 — twice the points per fetched record — measured slower: fewer tiles qualify as far wing)
     LineWork w;
     int rc = line_prepass(ctx, n_depth, n_nu, nus, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, true, nullptr, nullptr, &w,
-                          count_evals, job, gen, nu_begin, nu_count);
+                          count_evals, job, gen, nu_begin, nu_count, ph);
     if (rc) return rc;
     static const int r_mixed_env = knob("SDX_R_MIXED") ? std::atoi(knob("SDX_R_MIXED")) : R_MIXED;  // experiment knob: 4 or 8
     const int Rm = ctx->mixed_precision ? (r_mixed_env == 8 ? 8 : R_MIXED) : R;
@@ -1899,10 +1938,13 @@ static int synthesize_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double
     const double* part = nullptr;
     int64_t pld = 0;
     int n_planes = 0;
+    // two-collective mode: the classification launch ran already (sdx_synthesize_classify_dev), the per-line maxima were gathered
+    const ClassifyPhase second{2, 0, 0, opt ? const_cast<double*>(opt->line_m_max) : nullptr};
+    REQUIRE(!second.m_max || (n_lines > 0 && !gen), "synthesize: options->line_m_max goes with a dense line list");
     if (n_lines > 0) {
         LineWork w;
         rc = line_partials(ctx, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, &part, &pld,
-                           &n_planes, &w, n_evaluations_dev != nullptr, &job, gen);
+                           &n_planes, &w, n_evaluations_dev != nullptr, &job, gen, second.m_max ? &second : nullptr);
         if (rc) return rc;
         if (n_evaluations_dev)
             HIP_TRY(hipMemcpyAsync(n_evaluations_dev, w.evals, sizeof(int64_t), hipMemcpyDeviceToDevice, ctx->stream));
@@ -2020,6 +2062,29 @@ int sdx_synthesize_opt_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double
     return synthesize_impl(ctx, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, cont, n_theta,
                            temps, ray_dist, wts, alpha_line_out, total_alphas, F_nu, ld, n_evaluations_dev, nullptr, opt->I_nus, opt->source,
                            opt->source_ld, opt);
+}
+
+// Phase 1 of the two-collective mode (include/stardis_hip.h): the classification launch of a culled shard's step on a SHARE of the
+// lines.  Everything else that launch does for the step — the grid-spacing partials, the shard's line ranges, the continuum plane —
+// stays in the context's scratch for the synthesis that follows with options->line_m_max.
+int sdx_synthesize_classify_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin, int64_t nu_count, int64_t n_lines,
+                                const double* line_nus, const double* doppler, const double* gammas, int gamma_cols, const double* alphas,
+                                const sdx_continuum* cont, int64_t line_begin, int64_t line_count, double* m_max)
+{
+    int rc = check_line_args(ctx, n_depth, n_nu, nus, n_lines, line_nus, doppler, gammas, gamma_cols, alphas);
+    if (rc) return rc;
+    REQUIRE(cont && m_max && n_lines > 0, "classify: null pointer or empty line list");
+    REQUIRE(nu_begin >= 0 && nu_count > 0 && nu_begin + nu_count <= n_nu, "classify: shard outside the grid");
+    REQUIRE(line_begin >= 0 && line_count >= 0 && line_begin + line_count <= n_lines, "classify: line share outside the list");
+    if ((rc = check_file_planes(cont, n_nu))) return rc;
+    if ((rc = ensure(ctx, &ctx->cont_ws, &ctx->cont_ws_bytes, (size_t)n_depth * nu_count * sizeof(double)))) return rc;
+    // (the partial planes of the line kernels: reserved here so that the synthesis that follows moves nothing)
+    if ((rc = ensure(ctx, &ctx->part_ws, &ctx->part_ws_bytes, (size_t)2 * n_depth * nu_count * sizeof(double)))) return rc;
+    const ContinuumJob job{cont, nu_begin, nu_count, (double*)ctx->cont_ws};
+    const ClassifyPhase first{1, line_begin, line_count, m_max};
+    ctx->classified.valid = false;
+    return line_prepass(ctx, n_depth, n_nu, nus, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, true, nullptr, nullptr, nullptr, false, &job,
+                        nullptr, nu_begin, nu_count, &first);
 }
 
 // The fused synthesis for a caller that holds everything in host memory (C, or numpy through ctypes): uploads, runs

@@ -25,12 +25,18 @@ def shard_bounds(n_nu, world_size, rank):
 
 class SpectralSynthesizer:
     def __init__(self, nus, temperatures, dist, thetas, theta_weights, lines, continuum=None, ctx=None, shard=None,
-                 flux_out=None, track_evaluations=True, keep_line=True, keep_total=True):
+                 flux_out=None, track_evaluations=True, keep_line=True, keep_total=True, classify_share=None, m_max=None, m_share_out=None):
         """nus: global grid (descending).  lines: dict(line_nus, doppler_widths, gammas, alphas) in the
         reference layout (N_l, N_d), or a stardis_amd.linelist.LineList (per-line scalars; the pre-pass generates the
         three values per (line, depth) itself).  continuum: dict as produced by synth.synth_continuum_state or None.
         shard: (begin, count) of the global frequency index computed here (default: everything).
-        flux_out: optional contiguous CUDA tensor (N_d, count) to receive F_nu (e.g. for an RCCL gather)."""
+        flux_out: optional contiguous CUDA tensor (N_d, count) to receive F_nu (e.g. for an RCCL gather).
+        classify_share, m_max: the two-collective mode of frequency shards of long lists (include/stardis_hip.h,
+        sdx_synthesize_classify_dev) — classify_share = (first line, number of lines) this rank classifies, m_max = a device
+        buffer of n_lines doubles (DeviceArray or CUDA tensor) that holds every rank's share once the caller has gathered it.
+        m_share_out: optional device buffer that receives the share's values from its index 0 (the send buffer of the all-gather;
+        default: they are written in place, m_max[first line ...]).
+        A step is then enqueue_classify() [-> the caller's all-gather of m_max] -> enqueue()."""
         self.ctx = ctx or default_context()
         c = self.ctx
         nus = np.ascontiguousarray(nus, dtype=np.float64)
@@ -90,6 +96,12 @@ class SpectralSynthesizer:
         self._keep_total = keep_total  # also write total_alphas (the reference keeps it on Opacities; the flux does not need it in HBM)
         self.count_evaluations = track_evaluations  # sum(hi - lo) per step costs a memset + copy: switch off when timing
         self.graph = None
+        self.graph_classify = None
+        self.classify_share, self.m_max, self.m_share_out = classify_share, m_max, m_share_out
+        if (classify_share is None) != (m_max is None):
+            raise ValueError("classify_share and m_max go together")
+        if m_max is not None and (self.linelist is not None or track_evaluations):
+            raise ValueError("the two-collective mode takes dense line lists and no evaluation count")
         c.call("sdx_reserve_line_workspace", self.n_depth, self.n_lines)
 
     # -- set-up ---------------------------------------------------------------------------------
@@ -149,9 +161,27 @@ class SpectralSynthesizer:
         return ptr_of(self._flux_tensor) if self._flux_tensor is not None else self.d_F.ptr
 
     # -- one step: everything from resident inputs to F_nu -----------------------------------------
+    def enqueue_classify(self):
+        """Two-collective mode, phase 1: this rank's share of the classification stream (+ grid spacing, line ranges and continuum
+        plane of the step) -> m_max[share]; the caller gathers m_max before enqueue()."""
+        c = self.ctx
+        b, n = self.classify_share
+        # (the library writes m_max[l] for the lines l of the share: with a send buffer, entry l lands at index l - b of it)
+        base = ptr_of(self.m_max) if self.m_share_out is None else ptr_of(self.m_share_out) - 8 * int(b)
+        c.call("sdx_synthesize_classify_dev", self.n_depth, self.n_nu, self.d_nus.ptr, self.begin, self.count, self.n_lines, self.d_ln.ptr,
+               self.d_dw.ptr, self.d_g.ptr, self.gamma_cols, self.d_a.ptr, C.byref(self.cont), int(b), int(n), base)
+
     def enqueue(self):
         """One fused step on the context's stream: sdx_synthesize_dev (pre-pass, line gather, total, raytrace)."""
         c = self.ctx
+        if self.m_max is not None:  # phase 2 of the two-collective mode: everything behind the classification launch
+            opt = _lib.SynthesisOptions()
+            opt.line_m_max = ptr_of(self.m_max)
+            c.call("sdx_synthesize_opt_dev", self.n_depth, self.n_nu, self.d_nus.ptr, self.begin, self.count, self.n_lines,
+                   self.d_ln.ptr, self.d_dw.ptr, self.d_g.ptr, self.gamma_cols, self.d_a.ptr, C.byref(self.cont), self.n_theta,
+                   self.d_t.ptr, self.d_ray.ptr, self.d_w.ptr, self.d_line.ptr if self.keep_line else None,
+                   self.d_total.ptr if self.keep_total else None, self.flux_ptr, self.count, C.byref(opt), None)
+            return
         if self.linelist is not None:
             c.call("sdx_synthesize_linelist_dev", self.n_depth, self.n_nu, self.d_nus.ptr, self.begin, self.count,
                    self.linelist.byref(), C.byref(self.cont), self.n_theta, self.d_t.ptr, self.d_ray.ptr, self.d_w.ptr,
@@ -181,18 +211,43 @@ class SpectralSynthesizer:
                self.d_total.ptr, cnt, self.flux_ptr, cnt, None, 0)
 
     def capture(self):
-        """Record one step into a hipGraph (after one eager step has sized the scratch)."""
+        """Record one step into a hipGraph (after one eager step has sized the scratch).  Two-collective mode: two graphs, the
+        classification launch and the rest — the caller's all-gather of m_max goes between step_classify() and step(); m_max must
+        hold every rank's share when capture() is called (the eager pass reads it)."""
         c = self.ctx
+
+        def record(enqueue):
+            c.call("sdx_graph_begin")
+            try:
+                enqueue()
+            finally:
+                handle = C.c_void_p()
+                _lib.check(c.lib.sdx_graph_end(c.handle, C.byref(handle)))
+            return handle
+
+        if self.m_max is not None:
+            self.enqueue_classify()
+            self.enqueue()
+            c.synchronize()
+            self.graph_classify = record(self.enqueue_classify)
+            self.graph = record(self.enqueue)
+            return self
         self.enqueue()
         c.synchronize()
-        c.call("sdx_graph_begin")
-        try:
-            self.enqueue()
-        finally:
-            handle = C.c_void_p()
-            _lib.check(c.lib.sdx_graph_end(c.handle, C.byref(handle)))
-        self.graph = handle
+        self.graph = record(self.enqueue)
         return self
+
+    def step_classify(self):
+        if self.graph_classify is not None:
+            try:
+                self.ctx.call("sdx_graph_launch", self.graph_classify)
+                return
+            except _lib.StaleGraphError:
+                self.close()
+                self.capture()
+                self.ctx.call("sdx_graph_launch", self.graph_classify)
+                return
+        self.enqueue_classify()
 
     def step(self):
         if self.graph is not None:
@@ -242,6 +297,9 @@ class SpectralSynthesizer:
         if self.graph is not None:
             self.ctx.call("sdx_graph_destroy", self.graph)
             self.graph = None
+        if self.graph_classify is not None:
+            self.ctx.call("sdx_graph_destroy", self.graph_classify)
+            self.graph_classify = None
 
 
 class SynthesisPool:

@@ -214,6 +214,47 @@ class FluxGatherer:
         return self._assemble()
 
 
+class ClassificationGatherer:
+    """The optional SECOND collective of a strong-scaled step (include/stardis_hip.h, sdx_synthesize_classify_dev): every rank
+    classifies an equal share of the replicated line list — the largest (gamma + doppler_width) alpha of each of its lines — and
+    the shares are exchanged by one all-gather of 8 N_l bytes, instead of every rank streaming the whole list (8 N_l (2 N_d + G)
+    bytes per rank and step, which does not shrink with the number of ranks).  Buffers are allocated once.
+
+        g = ClassificationGatherer(n_lines, world, rank, device)
+        syn = SpectralSynthesizer(..., classify_share=g.share, m_max=g.full, m_share_out=g.send)
+        per step:  syn.step_classify(); g.gather(); syn.step()
+    """
+
+    def __init__(self, n_lines, world_size, rank, device):
+        import torch
+
+        self.n_lines, self.world, self.rank = int(n_lines), int(world_size), int(rank)
+        self.per = -(-self.n_lines // self.world)
+        begin = min(self.rank * self.per, self.n_lines)
+        self.share = (begin, max(0, min(self.per, self.n_lines - begin)))
+        self.send = torch.zeros(self.per, dtype=torch.float64, device=device)
+        self.full = torch.zeros(self.per * self.world, dtype=torch.float64, device=device)  # rank r's lines at [r per, r per + per)
+        self.host = None
+
+    def gather(self):
+        """All-gather the shares behind the work already on the current stream; the stream waits for the result (RCCL) — with
+        the gloo backend and device tensors the collective runs on host copies (tests, one device)."""
+        import torch
+        import torch.distributed as dist
+
+        if self.world == 1:
+            self.full[: self.per].copy_(self.send)
+            return self.full
+        if dist.get_backend() == "gloo" and self.send.is_cuda:
+            if self.host is None:
+                self.host = torch.empty(self.per * self.world, dtype=torch.float64)
+            dist.all_gather_into_tensor(self.host, self.send.cpu())
+            self.full.copy_(self.host)
+        else:
+            dist.all_gather_into_tensor(self.full, self.send)
+        return self.full
+
+
 def gather_flux(local_flux, n_nu, world_size, shards=None):
     """All-gather per-rank emergent-flux shards (1-D tensors of this rank's `count` columns, on the device the
     backend wants) into the full (n_nu,) spectrum on every rank.  shards: (begin, count) per rank when unequal."""

@@ -26,6 +26,7 @@ WORKLOADS = {
     "S-c1": dict(lam0=6560.0, lam1=6570.0, step=0.01, n_lines=2000, gamma_per_depth=True),
     "S-c2": dict(lam0=6500.0, lam1=6600.0, R=5.0e5, n_lines=2000, gamma_per_depth=True),
     "S-c3": dict(lam0=3000.0, lam1=10000.0, R=1.0e5, n_lines=150000, gamma_per_depth=True),
+    "S-c3-R5e5": dict(lam0=3000.0, lam1=10000.0, R=5.0e5, n_lines=150000, gamma_per_depth=True),  # S-c3's list at five times the resolving power
     "S-c4": dict(lam0=3000.0, lam1=10000.0, R=1.0e5, n_lines=1000000, gamma_per_depth=False),
     "S-big": dict(lam0=3000.0, lam1=10000.0, R=1.0e6, n_lines=1000000, gamma_per_depth=False),
     # BASELINE config 5: the full solar spectrum of config 3, synthesised with the fp32-mixed tolerance path and followed on

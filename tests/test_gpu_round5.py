@@ -1,0 +1,94 @@
+"""Round 5: the optional SECOND collective of strong-scaled long lists (every rank classifies a share of the line list, the shares
+are exchanged: include/stardis_hip.h, sdx_synthesize_classify_dev), and the culled pre-pass whose blocks with work come first
+in the grid.  Both are pure scheduling: the bits of the one-call step."""
+import numpy as np
+import pytest
+
+from stardis_amd import parallel, synth
+from stardis_amd.engine import SpectralSynthesizer, shard_bounds
+
+pytestmark = pytest.mark.gpu
+
+
+def long_list_case(seed=3, n_nu=30000, n_lines=20000):
+    atm = synth.solar_atmosphere()
+    nus = synth.tracing_grid(5000.0, 5000.0 * (1.0 + 1.02 * n_nu / 1.0e5), R=1.0e5)[:n_nu]
+    lines = synth.synth_lines(nus, atm, n_lines, seed=seed, mix=(0.85, 0.12, 0.03))
+    th, w = synth.thetas_and_weights(8)
+    return atm, nus, lines, synth.synth_continuum_state(atm), th, w
+
+
+@pytest.mark.parametrize("world", [3, 8])
+def test_two_collective_mode_reproduces_the_one_call_step(ctx, world):
+    """Each rank classifies 1 / world of the lines, the shares are 'gathered' (here: every share written into one array), the rest
+    of the step runs on the gathered array: F_nu, total and line opacity of every shard equal the one-call shard and the unsharded
+    run bit for bit — eagerly and as two captured graphs, shares written in place or through a send buffer."""
+    atm, nus, lines, cont, th, w = long_list_case()
+    args = (nus, atm["temperatures"], atm["dist"], th, w, lines, cont)
+    whole = SpectralSynthesizer(*args, ctx=ctx, track_evaluations=False)
+    whole.step()
+    F, total, line = whole.F_nu(), whole.total_alphas(), whole.alpha_line()
+    whole.close()
+    n_l = lines["line_nus"].size
+    per = -(-n_l // world)
+    shares = [(min(r * per, n_l), max(0, min(per, n_l - r * per))) for r in range(world)]
+    shards = parallel.balanced_shards(parallel.column_cost(nus, lines), world)
+    for rank in (0, world // 2, world - 1):
+        b, c = shards[rank]
+        m_full = ctx.zeros((per * world,))
+        send = ctx.zeros((per,))
+        syn = SpectralSynthesizer(*args, ctx=ctx, shard=(b, c), track_evaluations=False, classify_share=shares[rank], m_max=m_full)
+        # the "gather": every share, computed on this rank's shard (what a line's largest (gamma + dw) alpha is does not depend on the shard)
+        for q in range(world):
+            if q != rank:
+                syn.classify_share = shares[q]
+                syn.enqueue_classify()
+        syn.classify_share = shares[rank]
+        syn.enqueue_classify()
+        syn.enqueue()
+        assert np.array_equal(syn.F_nu(), F[:, b:b + c]), (world, rank)
+        assert np.array_equal(syn.total_alphas(), total[:, b:b + c]) and np.array_equal(syn.alpha_line(), line[:, b:b + c])
+        m_host = m_full.numpy()[:n_l]
+        dw, g, al = lines["doppler_widths"], lines["gammas"].reshape(n_l, -1), lines["alphas"]
+        assert np.array_equal(m_host, np.max((g + dw) * al, axis=1))  # the reference's operations (:561-575), one rounding each
+        # through a send buffer (the all-gather's input): the share lands at its index 0
+        syn.m_share_out = send
+        syn.enqueue_classify()
+        lo, n = shares[rank]
+        assert np.array_equal(send.numpy()[:n], m_host[lo:lo + n])
+        syn.m_share_out = None
+        # two graphs, replayed
+        syn.capture()
+        for _ in range(3):
+            syn.step_classify()
+            syn.step()
+        assert np.array_equal(syn.F_nu(), F[:, b:b + c])
+        syn.close()
+
+
+def test_two_collective_mode_refuses_what_it_does_not_cover(ctx):
+    atm, nus, lines, cont, th, w = long_list_case(n_nu=20000, n_lines=9000)
+    args = (nus, atm["temperatures"], atm["dist"], th, w, lines, cont)
+    n_l = lines["line_nus"].size
+    m = ctx.zeros((n_l,))
+    b, c = shard_bounds(nus.size, 4, 1)
+    syn = SpectralSynthesizer(*args, ctx=ctx, shard=(b, c), track_evaluations=False, classify_share=(0, n_l), m_max=m)
+    with pytest.raises(ValueError, match="sdx_synthesize_classify_dev"):
+        syn.enqueue()  # phase 2 without phase 1
+    syn.enqueue_classify()
+    syn.enqueue()
+    other = SpectralSynthesizer(*args, ctx=ctx, shard=shard_bounds(nus.size, 4, 2), track_evaluations=False, classify_share=(0, n_l), m_max=m)
+    with pytest.raises(ValueError, match="same grid, shard"):
+        other.enqueue()  # phase 1 ran for another shard
+    unsharded = SpectralSynthesizer(*args, ctx=ctx, track_evaluations=False, classify_share=(0, n_l), m_max=m)
+    with pytest.raises(ValueError, match="two-collective mode is for frequency shards"):
+        unsharded.enqueue_classify()
+    short = synth.synth_lines(nus, atm, 500, seed=1)
+    few = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], th, w, short, cont, ctx=ctx, shard=(b, c), track_evaluations=False,
+                              classify_share=(0, 500), m_max=ctx.zeros((500,)))
+    with pytest.raises(ValueError, match="two-collective mode is for frequency shards"):
+        few.enqueue_classify()
+    with pytest.raises(ValueError):
+        SpectralSynthesizer(*args, ctx=ctx, shard=(b, c), classify_share=(0, n_l))  # share without the array
+    for s in (syn, other, unsharded, few):
+        s.close()

@@ -259,7 +259,7 @@ def test_plasma_tables_are_cached_per_object_and_verified_by_value(ctx, monkeypa
     plasma.ion_number_density.iloc[:, :] = plasma.ion_number_density.to_numpy() * 0.7  # free-free, Rayleigh, van der Waals, H-
     ions = run()
     assert not np.array_equal(ions, ne) and np.array_equal(ions, run(use_fused=False))
-    plasma.level_number_density.iloc[0, :] *= 4.0  # bound-free
+    plasma.level_number_density.iloc[2, :] *= 4.0  # bound-free (n = 3: its edge, 3.65e14 Hz, lies below the grid's frequencies)
     lev = run()
     assert not np.array_equal(lev, ions) and np.array_equal(lev, run(use_fused=False))
     plasma.lines_from_linelist["A_ul"] *= 30.0  # a per-line scalar: radiation damping
