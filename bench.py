@@ -102,6 +102,21 @@ def synth_desc(tag):
     return f"{tag}: {star} MARCS structure, {c['lam0']:.0f}-{c['lam1']:.0f} A at {grid}, {c['n_lines']} lines, fp64"
 
 
+def kernel_variant(ctx, stage):
+    """which device kernel ran under a stage name in the last profiled pass (k_raytrace -> k_raytrace_seg<8,7> | k_raytrace<1> | ...)"""
+    import ctypes as C
+
+    buf = C.create_string_buffer(64)
+    ctx.call("sdx_profile_variant", stage.encode(), buf, 64)
+    return buf.value.decode() or stage
+
+
+def sha16(a):
+    import hashlib
+
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+
+
 def kernel_times(ctx, syn, n=10):
     """Average duration of every kernel of one step, HIP events on the launch stream (eager launches)."""
     import ctypes as C
@@ -455,7 +470,7 @@ def profiled_valu(workload, kern):
 class Runner:
     """One rank's synthesizer(s) + flux gather for a workload: step(), drain()."""
 
-    def __init__(self, w, world, rank, local, ctx, scaling, use_graph, overlap):
+    def __init__(self, w, world, rank, local, ctx, scaling, use_graph, overlap, two_collectives=False):
         import torch
 
         from stardis_amd import parallel
@@ -469,37 +484,69 @@ class Runner:
         self.begin, self.count = self.shards[rank] if self.shards else shard_bounds(nus.size, world, rank)
         self.world, self.overlap = world, overlap and world > 1
         dev = f"cuda:{local}"
+        # the optional SECOND collective (--two-collectives): each rank classifies 1 / N of the line list, the shares of the per-line
+        # maxima are all-gathered, the rest of the step runs on the gathered array (stardis_amd.parallel.ClassificationGatherer)
+        self.classes = None
+        if two_collectives and world > 1 and scaling == "strong" and isinstance(w["lines"], dict):
+            self.classes = parallel.ClassificationGatherer(int(np.asarray(w["lines"]["line_nus"]).size), world, rank, dev)
         self.lanes = []
         for k in range(2 if self.overlap else 1):
             flux = torch.zeros((self.nd, self.count), dtype=torch.float64, device=dev)
+            extra = {}
+            if self.classes is not None:
+                extra = dict(classify_share=self.classes.share, m_max=self.classes.full, m_share_out=self.classes.send)
             syn = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], w["thetas"], w["weights"], w["lines"], w["cont"], ctx=ctx,
-                                      shard=(self.begin, self.count), flux_out=flux, track_evaluations=(k == 0), keep_line=False)
+                                      shard=(self.begin, self.count), flux_out=flux, track_evaluations=(k == 0 and self.classes is None),
+                                      keep_line=False, **extra)
             self.lanes.append([syn, flux, parallel.FluxGatherer(nus.size, world, flux.device, shards=self.shards)])
         self.syn, self.flux = self.lanes[0][0], self.lanes[0][1]
+        if self.classes is not None:
+            self.syn.enqueue_classify()
+            self.classes.gather()
+            self.evals = None  # (the counting pre-pass is the unculled one: not part of this mode)
         self.syn.step()
         ctx.synchronize()
-        self.evals = self.syn.evaluations()
-        self.syn.count_evaluations = False  # known now; the counter costs a memset + a copy per step
+        if self.classes is None:
+            self.evals = self.syn.evaluations()
+            self.syn.count_evaluations = False  # known now; the counter costs a memset + a copy per step
         if use_graph:
             for lane in self.lanes:
                 lane[0].capture()
         self.counter = 0
+        self.last = None
+
+    def _run(self, syn):
+        if self.classes is not None:
+            syn.step_classify()
+            self.classes.gather()
+        syn.step()
 
     def step(self):
         syn, flux, gather = self.lanes[self.counter % len(self.lanes)]
         self.counter += 1
+        self.last = gather
         if self.overlap:
             gather.finish()  # the gather that last read this lane's flux buffer
-            syn.step()
+            self._run(syn)
             gather.start(flux[-1])
             return None
-        syn.step()
+        self._run(syn)
         return gather(flux[-1])
 
     def drain(self):
         if self.overlap:
             for _, _, gather in self.lanes:
                 gather.finish()
+
+    def last_spectrum(self):
+        """the emergent flux the last step gathered (every rank holds it), as a host array"""
+        if self.last is None:
+            return None
+        self.drain()
+        import torch
+
+        torch.cuda.synchronize()
+        return self.last._assemble().cpu().numpy() if self.world > 1 else None
 
     def close(self):
         for syn, _, _ in self.lanes:
@@ -549,6 +596,9 @@ def timed(runner, steps, warmup, world, local, settle_s=0.5, cold=True):
         runner.step()
     runner.drain()
     fence()
+    if settle_s <= 0:  # a long run: the W warm-up steps are all that precedes the timed region
+        elapsed, t_local = run(steps)
+        return dict(elapsed=elapsed, local=t_local, cold=elapsed, settle=0)
     # the K steps right after the W requested warm-up steps: clocks still ramping (reported as ms_per_step_cold)
     t_cold = run(steps)[0] if cold else None
     # clocks and caches settle over the first tenths of a second of work: a short --steps run would otherwise time the ramp
@@ -593,10 +643,11 @@ def n1_same_workload(w, local, steps, use_graph):
         syn.step()
     ctx.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
+    spectrum_hash = sha16(syn.F_nu()[-1])
     syn.close()
     ctx.close()
     torch.cuda.synchronize()
-    return {"ms_per_step": ms, "value": nus.size * atm["temperatures"].size / (ms * 1e-3), "steps": steps,
+    return {"ms_per_step": ms, "value": nus.size * atm["temperatures"].size / (ms * 1e-3), "steps": steps, "spectrum_sha256_16": spectrum_hash,
             "how": "the unsharded grid on rank 0's GPU, same process, after the timed region (other ranks wait at a barrier)"}
 
 
@@ -608,6 +659,9 @@ def collective_info(world, runner):
         return None
     info = {"op": "all_gather_into_tensor of the zero-padded F_nu[-1] shards", "backend": dist.get_backend(), "world_size_seen_by_dist": dist.get_world_size(),
             "bytes_per_rank": int(runner.lanes[0][2].per * 8), "overlapped_with_next_step": bool(runner.overlap)}
+    if runner.classes is not None:
+        info["second_collective"] = {"op": "all_gather_into_tensor of the per-line maxima (each rank classifies 1 / N of the line list), between the "
+                                           "classification launch and the rest of the step", "bytes_per_rank": int(runner.classes.per * 8)}
     if dist.get_backend() == "nccl":
         try:
             info["nccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
@@ -720,6 +774,9 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default=None,
                     help="what `value` measures at N > 1. strong (default): the workload's grid split across the GPUs in shards of equal "
                          "estimated work (stardis_amd.parallel.balanced_shards); weak: fixed grid points per GPU (N x the resolving power)")
+    ap.add_argument("--two-collectives", action="store_true",
+                    help="N > 1, strong scaling: every rank classifies 1 / N of the line list and the per-line maxima are all-gathered "
+                         "(a second collective of 8 N_l bytes per step) instead of every rank streaming the whole list")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip every leg that runs the CPU oracle (baseline and parity checks)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the S-c3 / S-c4m / S-c5 / drop-in blocks")
@@ -758,11 +815,15 @@ def main():
     # N > 1: two flux buffers alternate so that the all-gather of step k (RCCL, its own stream) overlaps the kernels
     # of step k+1; a buffer is reused only after its gather has been waited for.  SDX_BENCH_SYNC_GATHER=1: blocking gather.
     overlap = os.environ.get("SDX_BENCH_SYNC_GATHER") != "1"
-    runner = Runner(w, world, rank, local, ctx, args.scaling, not args.no_graph, overlap)
-    tm = timed(runner, args.steps, args.warmup, world, local)
+    runner = Runner(w, world, rank, local, ctx, args.scaling, not args.no_graph, overlap, args.two_collectives)
+    # a run of >= 200 timed steps is long enough for the clocks to have settled within its first few percent: the W warm-up steps
+    # the driver asked for are then ALL that precedes the timed region; shorter runs get ~0.5 s of untimed settling (disclosed)
+    tm = timed(runner, args.steps, args.warmup, world, local, settle_s=0.0 if args.steps >= 200 else 0.5, cold=args.steps < 200)
     elapsed, settle = tm["elapsed"], tm["settle"]
     syn, flux, count, evals = runner.syn, runner.flux, runner.count, runner.evals
+    spectrum = runner.last_spectrum()
     kern = kernel_times(ctx, syn, 20)
+    rt_variant = kernel_variant(ctx, "k_raytrace")
 
     # N > 1: what every rank did (shard, its own time for the timed steps, per-kernel times), gathered on rank 0, and the
     # one-GPU step of the same workload on rank 0's GPU
@@ -826,6 +887,10 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "ms_per_step_cold": (tm["cold"] / args.steps * 1e3) if tm["cold"] is not None else None,
+            "untimed_settle_steps_after_warmup": settle,
+            "timed_region": ("the K steps follow the W warm-up steps directly" if settle == 0 else
+                             f"K steps after W warm-up steps + {settle} untimed settling steps (~0.5 s: clocks; runs of >= 200 steps skip it); "
+                             "ms_per_step_cold = the same K steps timed right after the W warm-up steps"),
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
@@ -839,17 +904,16 @@ def main():
                 "n_depth": int(nd),
                 "n_lines": int(n_l),
                 "n_theta": int(len(w["thetas"])),
-                "voigt_evaluations_global": int(evals),
+                "voigt_evaluations_global": int(evals) if evals is not None else None,
                 "parallelism": f"nu-shard x{world}" + (", 1 all-gather of F_nu[-1] per step" + (" overlapped with the next step" if runner.overlap else "") if world > 1 else ""),
                 "hip_graph": not args.no_graph,
                 "line_inputs": args.inputs,
                 "outputs": "F_nu and total_alphas (N_d, N_nu); the optional alpha_line plane is not written",
-                "untimed_settle_steps_after_warmup": settle,
-                "ms_per_step_cold": "the same K steps timed right after the W requested warm-up steps, before the untimed settling (clocks still ramping)",
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": dom,
+                "kernel": rt_variant if dom == "k_raytrace" else dom,
+                "stage": dom,
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
@@ -866,11 +930,15 @@ def main():
                                                                             "k_raytrace": 16 * nd * count, "step": syn.algorithmic_bytes()}) if world == 1 else None,
                 "note": "path is fp64-VALU bound (Faddeeva evaluations), not HBM bound: see DESIGN.md and roofline_fp64_valu; peak = the data sheet's 8 TB/s, "
                         "peak_measured_copy = a device-to-device copy timed in this run (read + write)",
-                "voigt_evaluations_per_s": (evals / world) / (line_ms * 1e-3) if line_ms else None,
+                "voigt_evaluations_per_s": (evals / world) / (line_ms * 1e-3) if (line_ms and evals is not None) else None,
             },
         }
         if world > 1:
             out["collective"] = collective_info(world, runner)
+            if spectrum is not None:
+                out["gathered_spectrum_sha256_16"] = sha16(spectrum)
+                if n1 is not None:
+                    out["gathered_spectrum_equals_n1_bit_for_bit"] = bool(n1.get("spectrum_sha256_16") == sha16(spectrum))
             out["per_rank"] = per_rank
             out["config"]["shards"] = [[int(b), int(c)] for b, c in (runner.shards or [])] or "equal blocks of ceil(N_nu / N)"
             if n1 is not None:

@@ -136,6 +136,9 @@ int sdx_timer_stop(sdx_ctx* ctx, double* elapsed_ms);
 int sdx_profile_enable(sdx_ctx* ctx, int on); /* bracket every kernel launch with events */
 int sdx_profile_reset(sdx_ctx* ctx);
 int sdx_profile_get(sdx_ctx* ctx, const char* kernel, int64_t* launches, double* total_ms);
+/* which device kernel last ran under the stage name `kernel` while profiling was on ("k_raytrace" -> "k_raytrace_seg<8,7>",
+ * "k_raytrace<1>", "k_raytrace_f32", ...); "" when the stage has one kernel only or did not run */
+int sdx_profile_variant(sdx_ctx* ctx, const char* kernel, char* out, int out_len);
 
 /* ---- line opacity ---------------------------------------------------------------------------
  * Replaces calc_alan_entries (radiation_field/opacities/opacities_solvers/base.py:487-592):

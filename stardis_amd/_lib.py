@@ -136,6 +136,7 @@ PROTOTYPES = {
     "sdx_timer_stop": (_int, [_vp, c_dp]),
     "sdx_profile_enable": (_int, [_vp, _int]),
     "sdx_profile_reset": (_int, [_vp]),
+    "sdx_profile_variant": (_int, [_vp, C.c_char_p, C.c_char_p, _int]),
     "sdx_profile_get": (_int, [_vp, C.c_char_p, C.POINTER(_i64), c_dp]),
     "sdx_line_opacity_dev": (_int, [_vp, _int, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _int, _vp, _vp, _i64, _int, _vp]),
     "sdx_line_opacity_f64": (_int, [_vp, _int, _i64, _vp, _i64, _vp, _vp, _vp, _int, _vp, _vp, C.POINTER(_i64)]),

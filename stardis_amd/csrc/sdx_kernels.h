@@ -1024,29 +1024,38 @@ __global__ __launch_bounds__(kBlock) void k_hscan(int n_depth, int64_t n_lines, 
 __device__ __forceinline__ void shard_range(int64_t n_nu, const double* __restrict__ nus, int64_t n_lines, const double* __restrict__ line_nus,
                                             int64_t nu_begin, int64_t nu_count, int* __restrict__ sel)
 {
-    if (threadIdx.x >= 4) return;
+    // one WAVE per bound (the first four waves of the block), each a 64-ary search: three round trips to memory for 1.5e5 lines
+    // where a thread's bisection makes seventeen — in the two-collective mode the classification launch is a few microseconds of
+    // streaming, and the four chains of dependent loads were what it waited for (24 - 29 us on an eighth of S-c3)
+    const int which = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (which >= 4) return;
     // lines with centre >= p  <=>  line_nu <= nus[p - 1]: their number is cnt_ge[p]
-    const int64_t H = threadIdx.x < 2 ? kMediumHalfWidth : 2 * kNarrowReach;
+    const int64_t H = which < 2 ? kMediumHalfWidth : 2 * kNarrowReach;
     // ... [la, lb) for the shard's columns rounded out to whole TILES of the wide role (kMaxTile covers every tile width): a tile
     // cut by the shard boundary is walked whole, and its candidate list — with it the points at which the fp32-mixed mode folds its
     // running sums into the fp64 ones, which count the hits of the whole tile — must be the unsharded run's for the shard to
     // reproduce that run's bits in BOTH precisions (tests/test_gpu_long_random.py found mixed-mode shards a few 1e-8 apart)
-    const int64_t ext = threadIdx.x < 2 ? kMaxTile - 1 : 0;
+    const int64_t ext = which < 2 ? kMaxTile - 1 : 0;
     const int64_t pa = max(nu_begin - ext - H + 1, (int64_t)0), pb = min(nu_begin + nu_count + ext + H - 1, n_nu);
-    const int64_t p = (threadIdx.x & 1) == 0 ? pb + 1 : pa;  // sel[0] = cnt_ge[pb + 1], sel[1] = cnt_ge[pa]
+    const int64_t p = (which & 1) == 0 ? pb + 1 : pa;  // sel[0] = cnt_ge[pb + 1], sel[1] = cnt_ge[pa]
     int64_t cnt;
     if (p == 0) cnt = n_lines;
     else if (p >= n_nu + 1) cnt = 0;
     else {
         const double v = nus[p - 1];
-        int64_t lo = 0, hi = n_lines;
-        while (lo < hi) {
-            const int64_t mid = lo + ((hi - lo) >> 1);
-            if (line_nus[mid] <= v) lo = mid + 1; else hi = mid;
+        int64_t lo = 0, hi = n_lines;  // the first l with line_nus[l] > v lies in [lo, hi]
+        while (hi > lo) {
+            const int64_t step = (hi - lo + 63) / 64;
+            const int64_t idx = lo + (int64_t)lane * step;  // the lanes' probes ascend: `le` is true on a prefix of them
+            const bool le = idx < hi && line_nus[idx] <= v;
+            const int k = __popcll(__ballot(le));
+            const int64_t base = lo;
+            lo = k > 0 ? base + (int64_t)(k - 1) * step + 1 : base;
+            hi = min(base + (int64_t)k * step, hi);
         }
         cnt = lo;
     }
-    sel[threadIdx.x] = (int)cnt;
+    if (lane == 0) sel[which] = (int)cnt;
 }
 
 // Frequency-sharded runs of long lists, stage A: how wide the widest window of every line is (over all depths) — which lines can

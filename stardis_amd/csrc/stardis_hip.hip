@@ -64,6 +64,7 @@ int fail(int code, const std::string& msg)
 
 struct ProfileRecord {
     const char* name;
+    const char* variant;  // which device kernel ran under this name (k_raytrace: "k_raytrace<1>", "k_raytrace_seg<8,7>", ...), or nullptr
     hipEvent_t start, stop;
 };
 
@@ -218,10 +219,11 @@ struct LaunchScope {
     sdx_ctx* ctx;
     ProfileRecord rec{};
     bool on;
-    LaunchScope(sdx_ctx* c, const char* name) : ctx(c), on(c->profile)
+    LaunchScope(sdx_ctx* c, const char* name, const char* variant = nullptr) : ctx(c), on(c->profile)
     {
         if (on) {
             rec.name = name;
+            rec.variant = variant;
             rec.start = take_event(ctx);
             rec.stop = take_event(ctx);
             hipEventRecord(rec.start, ctx->stream);
@@ -725,6 +727,15 @@ int sdx_profile_get(sdx_ctx* ctx, const char* kernel, int64_t* launches, double*
     return SDX_OK;
 }
 
+int sdx_profile_variant(sdx_ctx* ctx, const char* kernel, char* out, int out_len)
+{
+    REQUIRE(ctx && kernel && out && out_len > 0, "sdx_profile_variant: null pointer");
+    out[0] = 0;
+    for (auto& r : ctx->records)
+        if (std::strcmp(r.name, kernel) == 0 && r.variant) std::snprintf(out, (size_t)out_len, "%s", r.variant);
+    return SDX_OK;
+}
+
 // ================================================================================================ line opacity
 struct ContinuumJob {  // continuum plane computed by the trailing blocks of the pre-pass launch
     const sdx_continuum* cont;
@@ -889,8 +900,13 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
         // classification blocks: contiguous runs of lines, a few blocks per CU (256 threads: 4 waves x 4 lines x 3 arrays in flight)
         static const int cls_blocks_env = knob("SDX_CLS_BLOCKS") ? std::atoi(knob("SDX_CLS_BLOCKS")) : 0;  // experiment knob
         const int64_t cls_begin = ph && ph->phase == 1 ? ph->begin : 0, cls_end = ph && ph->phase == 1 ? ph->begin + ph->count : n_lines;
+        // (a SHARE of the list — two-collective mode — is a few microseconds of streaming: sixteen lines per block, one trip of each
+        // wave's loop, so that the launch is as long as one round trip and not as a chain of nine; the whole list is a stream that
+        // wants its bytes in flight, not short chains)
+        const bool share = ph && ph->phase == 1;
+        const int64_t cls_per_block = share ? 16 : 64;
         const unsigned n_cls = cls_blocks_env > 0 ? (unsigned)cls_blocks_env
-                                                  : (unsigned)std::max<int64_t>(1, std::min<int64_t>((cls_end - cls_begin + 63) / 64, (int64_t)8 * ctx->n_cu));
+                                                  : (unsigned)std::max<int64_t>(1, std::min<int64_t>((cls_end - cls_begin + cls_per_block - 1) / cls_per_block, (int64_t)8 * ctx->n_cu));
         // the per-line maxima: doubles behind the integer lists of cnt_ws (8-byte aligned), or the caller's array (two-collective mode)
         double* const m_max = ph ? ph->m_max : (double*)(((uintptr_t)(w.hcount + 16 + 3 * ((size_t)n_lines / 1024 + 8)) + 7) & ~(uintptr_t)7);
         double* const dnu_ws = (double*)ctx->small_ws;
@@ -914,7 +930,7 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
             if (continuum_done) {
                 // half the classification blocks (16 of 32 wave slots per CU: the stream keeps its bytes in flight), the
                 // continuum blocks take the other slots
-                const unsigned n_cls_half = std::max(1u, n_cls / 2);
+                const unsigned n_cls_half = share ? n_cls : std::max(1u, n_cls / 2);
                 hipLaunchKernelGGL(k_classify_continuum, dim3((unsigned)n_partial + n_cls_half + (unsigned)cp.cont_tiles * cp.cont_rows), dim3(kBlock), cp.shmem, ctx->stream,
                                    n_partial, (int)n_cls_half, n_depth, n_nu, n_lines, dnu_ws, doppler, gammas, gamma_cols, alphas, m_max, nus,
                                    cp.cont_tiles, job->nu_begin, job->nu_count, cp.ca, job->plane, job->nu_count, cp.stage_table, line_nus, nu_begin, nu_count,
@@ -1796,7 +1812,7 @@ static int raytrace_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, c
         const size_t seg_doubles = seg_lds_doubles(n_depth, nth);
         if (use_segmented_raytrace(ctx, n_depth, nu_global, n_theta, P == 1 && !inward && !acc)) {
             {
-                LaunchScope ls(ctx, "k_raytrace");
+                LaunchScope ls(ctx, "k_raytrace", kSegWaves == 4 ? "k_raytrace_seg<4,14>" : "k_raytrace_seg<8,7>");
                 const unsigned seg_blocks = (unsigned)(((n_nu + seg_gpw - 1) / seg_gpw + 7) / 8 * 8);  // whole rounds of the XCD-aware order
 #define SDX_SEG_ARGS n_depth, n_nu, nth, n_theta, nus, temps, rd, w, alphas, ald, F, fld, inus, seg_gpw, ft
                 if (kSegWaves == 4) hipLaunchKernelGGL((k_raytrace_seg<4, 14>), dim3(seg_blocks), dim3(256), seg_doubles * sizeof(double), ctx->stream, SDX_SEG_ARGS);
@@ -1813,7 +1829,7 @@ static int raytrace_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, c
             const size_t shmem32 = ((size_t)(n_depth - 1) * nth + (size_t)(kRtBlock / 64) * (2 * (size_t)g32 * n_depth + 8 * (size_t)g32 * G)) * sizeof(float);
             if (shmem32 <= 64 * 1024) {
                 {
-                    LaunchScope ls(ctx, "k_raytrace");
+                    LaunchScope ls(ctx, "k_raytrace", "k_raytrace_f32");
                     const unsigned blocks32 = (unsigned)((n_nu + (int64_t)g32 * (kRtBlock / 64) - 1) / ((int64_t)g32 * (kRtBlock / 64)));
                     hipLaunchKernelGGL(k_raytrace_f32, dim3(blocks32), dim3(kRtBlock), shmem32, ctx->stream, n_depth, n_nu, nth, n_theta, G, nus, temps, rd, w, alphas,
                                        ald, F, fld, g32, ft);
@@ -1824,7 +1840,7 @@ static int raytrace_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, c
             }
         }
         {
-            LaunchScope ls(ctx, "k_raytrace");
+            LaunchScope ls(ctx, "k_raytrace", shmem <= 64 * 1024 ? (P == 1 ? "k_raytrace<1>" : (P == 2 ? "k_raytrace<2>" : "k_raytrace<4>")) : "k_raytrace_basic");
 #define SDX_RT_ARGS n_depth, n_nu, nth, n_theta, G, nus, temps, rd, w, alphas, ald, F, fld, inus, acc
             if (shmem <= 64 * 1024) {
                 if (P == 1) hipLaunchKernelGGL(k_raytrace<1>, dim3(blocks), dim3(kRtBlock), shmem, ctx->stream, SDX_RT_ARGS, inward, gpw, ft);

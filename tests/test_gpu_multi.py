@@ -74,3 +74,37 @@ def test_bench_self_launches_two_ranks():
     assert out["n1_same_workload"]["ms_per_step"] > 0
     assert abs(out["speedup_vs_n1"] - out["n1_same_workload"]["ms_per_step"] / out["ms_per_step"]) < 1e-9
     assert out["ms_per_step_cold"] > 0
+
+
+@pytest.mark.parametrize("two_collectives", [False, True])
+def test_bench_eight_ranks_on_one_device_rehearse_the_scale_run(two_collectives):
+    """The closest thing to the driver's 8-GPU SCALE run a one-GPU box allows: `bench.py --gpus 8` (all ranks on device 0, gloo) —
+    eight per-rank entries, shards that tile the 120 398-point grid of configs[2], and the gathered spectrum bit-equal to the
+    one-GPU run of the same workload in the same process; with --two-collectives every rank classifies an eighth of the list."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(SDX_BENCH_BACKEND="gloo", SDX_BENCH_SINGLE_DEVICE="1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+    proc = subprocess.run(cmd + (["--two-collectives"] if two_collectives else []), env=env, capture_output=True, text=True, timeout=1800)
+    assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-3000:]
+    out = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 8 and out["scaling"] == "strong" and out["config"]["n_nu_global"] == 120398
+    shards = out["config"]["shards"]
+    assert len(shards) == 8 and sum(c for _, c in shards) == 120398
+    assert all(shards[r + 1][0] == shards[r][0] + shards[r][1] for r in range(7)) and shards[0][0] == 0
+    assert [r["rank"] for r in out["per_rank"]] == list(range(8)) and [r["shard"] for r in out["per_rank"]] == shards
+    assert all(r["avg_kernel_ms"]["k_line_all"] > 0 and r["avg_kernel_ms"]["k_classify"] > 0 for r in out["per_rank"])  # culled pre-pass on every rank
+    assert out["collective"]["world_size_seen_by_dist"] == 8 and out["collective"]["bytes_per_rank"] == 8 * max(c for _, c in shards)
+    assert ("second_collective" in out["collective"]) == two_collectives
+    if two_collectives:
+        assert out["collective"]["second_collective"]["bytes_per_rank"] == 8 * -(-150000 // 8)
+    assert out["gathered_spectrum_equals_n1_bit_for_bit"] is True
+    assert out["n1_same_workload"]["ms_per_step"] > 0 and out["speedup_vs_n1"] > 0
+
+
+def test_shards_of_the_million_line_workload_reproduce_the_unsharded_bits():
+    """scripts/r4/big_shard_check.py as a test: ranks 0, 3 and 7 of a balanced 8-way split of S-c4m (1e6 lines: the culled pre-pass
+    with its classification stream, counter-driven blocks and gather lists at full size) against the unsharded run, bit for bit."""
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "r4", "big_shard_check.py"), "S-c4m", "8", "0", "3", "7"],
+                          capture_output=True, text=True, timeout=1800)
+    assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-3000:]
+    assert proc.stdout.count("identical to the unsharded run") == 3
