@@ -266,12 +266,16 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
             return;
         }
     }
-    constexpr int kStride = kPreDepths + 1;  // odd row stride: conflict-free transposed LDS reads
-    constexpr int kPreItems = kPreLines * kPreDepths / kPreBlock;  // items per thread
-    static_assert(kPreLines * kPreDepths == kPreItems * kPreBlock && kPreLines <= 32, "whole items per thread");
+    // Round 5: every thread keeps its (line, depth) items in REGISTERS, depth fastest — the order of the reference layout it reads
+    // and of the line-major narrow arrays it writes: loads and narrow stores coalesce as they are, and nothing is staged through
+    // LDS (rounds 1 - 4 transposed the block through 70 KB of it so that the depth-major wide records were written line-fastest:
+    // three arrays written, read transposed, the derived constants written back and read again by a second pass, two more barriers).
+    // The depth-major records of WIDE items — a few per cent of a list — and the scan words go out as scattered 16 / 48-byte stores;
+    // the lines of a block are neighbours in those rows, so the pieces of a 64-byte sector meet in the L2 of the XCD the block runs
+    // on before it is written back.  3 KB of LDS per block instead of 70: the size of a block is its threads and registers alone.
+    constexpr int kPreItems = (kPreLines * kPreDepths + kPreBlock - 1) / kPreBlock;  // items per thread
+    static_assert(kPreLines <= 64, "lines per pre-pass block");
     constexpr int kMaxWaves = kPreBlock / 64;
-    __shared__ double s_dw[kPreLines * kStride], s_g[kPreLines * kStride], s_a[kPreLines * kStride];
-    __shared__ int s_lo[kPreLines * kStride], s_hi[kPreLines * kStride];
     __shared__ int64_t s_c[kPreLines];
     __shared__ double s_red[kMaxWaves];
     __shared__ unsigned long long s_ev[kMaxWaves];
@@ -304,8 +308,19 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
     }
 #define SDX_LINE_OF(ll) (gather ? (int64_t)s_l[ll] : l0 + (ll))
     const int nd = min(kPreDepths, n_depth - d0);
-    const unsigned nd_magic = small_div_magic(nd), nl_magic = small_div_magic(nl);  // (items k < kPreLines kPreDepths = 2048)
-    // The block's dense inputs are requested first (kPreItems per thread), so their latency hides behind the centre search
+    const unsigned nd_magic = small_div_magic(nd);  // (items k < kPreLines kPreDepths = 4096)
+    // line centres first: a 128-entry sample of the grid in LDS brackets the answer (requested before everything else: the
+    // block's first barrier waits for these loads only)
+    __shared__ double s_coarse[128];
+    const int64_t cstride = (n_nu + 127) / 128;
+    if (tid < 128) {
+        const int64_t j = (int64_t)tid * cstride;
+        s_coarse[tid] = j < n_nu ? nus[j] : -INFINITY;
+    } else if (tid < 128 + kPreLines) {
+        const int ll = tid - 128;
+        s_lnu[ll] = ll < nl ? line_nus[SDX_LINE_OF(ll)] : 0.0;
+    }
+    // The block's dense inputs are requested next (kPreItems per thread), so their latency hides behind the centre search
     // below instead of following it.
     double r_dw[kPreItems], r_a[kPreItems], r_g[kPreItems];
     if constexpr (!GEN) {
@@ -325,19 +340,9 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
     }
     // small grids: this thread's part of the d_nu scan is requested now, its loads travel while the centres are searched
     const double dnu_local = dnu_partial ? 0.0 : dnu_scan_local(nus, n_nu);
-    // line centres: a 128-entry sample of the grid in LDS brackets the answer; wave ll then narrows the bracket of line
-    // ll to 64 points by bisection (none needed when the grid has <= 8192 points) and resolves it with ONE coalesced
-    // load and a ballot — a chain of one or two dependent global loads instead of log2(N_nu / 128)
-    __shared__ double s_coarse[128];
-    const int64_t cstride = (n_nu + 127) / 128;
-    if (tid < 128) {
-        const int64_t j = (int64_t)tid * cstride;
-        s_coarse[tid] = j < n_nu ? nus[j] : -INFINITY;
-    } else if (tid < 128 + kPreLines) {
-        const int ll = tid - 128;
-        s_lnu[ll] = ll < nl ? line_nus[SDX_LINE_OF(ll)] : 0.0;
-    }
     __syncthreads();
+    // wave ll narrows the bracket of line ll to 64 points by bisection (none needed when the grid has <= 8192 points) and resolves
+    // it with ONE coalesced load and a ballot — a chain of one or two dependent global loads instead of log2(N_nu / 128)
     for (int ll = tid >> 6; ll < nl; ll += kPreBlock / 64) {
         const int lane = tid & 63;
         {
@@ -362,6 +367,7 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
     }
     if (tid < kPreLines) s_hwmax[tid] = 0, s_whwmax[tid] = 0;
     // d_nu (:524-526): from the partial maxima of k_dnu_partial, or — small grids — scanned here directly
+    // (its barriers also publish the centres and the cleared maxima)
     const double d_nu = dnu_partial ? block_dnu(dnu_partial, n_partial, s_red) : block_max_to_dnu(dnu_local, s_red);
 
     if constexpr (GEN) {
@@ -372,75 +378,63 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
         if (tid < nd) s_gd[tid] = gen_depth(lp, d0 + tid);
         else if (tid >= 64 && tid < 64 + nl) s_gl[tid - 64] = gen_line(lp, line_nus[SDX_LINE_OF(tid - 64)], SDX_LINE_OF(tid - 64));
         __syncthreads();
-        for (int k = tid; k < nl * nd; k += nthreads) {
-            const int ll = small_div(k, nd_magic), dd = k - ll * nd;
-            const int64_t l = SDX_LINE_OF(ll);
-            const GenDepth& D = s_gd[dd];  // fields are read from LDS where they are used: copies would cost ~40 VGPRs
-            const GenLine& L = s_gl[ll];
-            s_dw[ll * kStride + dd] = gen_doppler(lp, L, D, l);
-            s_a[ll * kStride + dd] = gen_alpha(lp, D, line_nus[l], l, d0 + dd, n_depth);
-            s_g[ll * kStride + dd] = gen_gamma(lp, L, D, l);
-        }
-    } else {
-        // reference layout in (requested above), line fastest ... depth fastest: coalesced
 #pragma unroll
         for (int it = 0; it < kPreItems; ++it) {
             const int k = tid + it * kPreBlock;
+            r_dw[it] = r_a[it] = r_g[it] = 0.0;
             if (k < nl * nd) {
                 const int ll = small_div(k, nd_magic), dd = k - ll * nd;
-                s_dw[ll * kStride + dd] = r_dw[it];
-                s_a[ll * kStride + dd] = r_a[it];
-                s_g[ll * kStride + dd] = r_g[it];
+                const int64_t l = SDX_LINE_OF(ll);
+                const GenDepth& D = s_gd[dd];  // fields are read from LDS where they are used: copies would cost ~40 VGPRs
+                const GenLine& L = s_gl[ll];
+                r_dw[it] = gen_doppler(lp, L, D, l);
+                r_a[it] = gen_alpha(lp, D, line_nus[l], l, d0 + dd, n_depth);
+                r_g[it] = gen_gamma(lp, L, D, l);
             }
         }
     }
-    __syncthreads();
 
-    // ONE arithmetic pass, line fastest (depth-major stores coalesce).  The derived constants replace the inputs in
-    // LDS so that the line-major stores below need no second evaluation.
+    // ONE arithmetic pass, depth fastest; every output of an item leaves from its thread
     unsigned long long ev = 0;
-    __shared__ unsigned char s_h[kPreLines * kStride];
-    WideScan sc_keep[kPreItems];
+    // what the scan word of an item is rebuilt from after the barrier (two registers per item instead of the word's four: three
+    // items per thread have to fit 64 VGPRs — two resident blocks per CU): the half-width of a WIDE window (0: the word is empty) and
+    // the core's half-width, negative when the core is delegated to the narrow role
+    int keep_hw[kPreItems], keep_chw[kPreItems];
 #pragma unroll
     for (int it = 0; it < kPreItems; ++it) {
         const int k = tid + it * kPreBlock;
-        sc_keep[it] = WideScan{0, 0, 0, 0};
+        keep_hw[it] = 0, keep_chw[it] = 0;
         if (k >= nl * nd) continue;
-        const int dd = small_div(k, nl_magic), ll = k - dd * nl;
-        const int sidx = ll * kStride + dd;
-        const double dw = s_dw[sidx], g = s_g[sidx], a = s_a[sidx];
+        const int ll = small_div(k, nd_magic), dd = k - ll * nd;
+        const int64_t l = SDX_LINE_OF(ll);
+        const double dw = r_dw[it], g = r_g[it], a = r_a[it];
+        const int64_t c = s_c[ll];
         int lo, hi;
-        const int64_t hw = window_rule(s_c[ll], n_nu, d_nu, g, dw, a, lo, hi);
+        const int64_t hw = window_rule(c, n_nu, d_nu, g, dw, a, lo, hi);
         const bool narrow = hw <= kNarrowHalfWidth;
         const double inv = 1.0 / dw;
         const double yy = (g / mul_rn(kSqrtPi, kPi)) / dw;  // voigt.py:148
         const double amp = a / mul_rn(kSqrtPi, dw);         // voigt.py:149 x base.py:627
-        // (forming y and the amplitude through 1 / dw instead — two IEEE divisions fewer — and leaving out the scan words of
-        // lines with no wide window anywhere — 0.9 of 2.8 GB of writes at 1e6 lines — were both measured: no change in the
-        // time of this launch, 16 us at 2000 lines and 1.2 ms at 1e6, where it issues 460 G instructions/s)
-        s_dw[sidx] = inv;
-        s_g[sidx] = yy;
-        s_a[sidx] = amp;
-        int core_lo = 0, core_hi = 0, core_hw = 0;
+        int core_hw = 0;
         bool delegated = false;
         if (w.wscan) {
-            const size_t o = (size_t)(d0 + dd) * n_lines + SDX_LINE_OF(ll);  // depth-major (wide kernel)
+            const size_t o = (size_t)(d0 + dd) * n_lines + l;  // depth-major (wide kernel)
             WideScan sc = {0, 0, 0, 0};
             if (!narrow && hi > lo) {
-                const int64_t c = s_c[ll];
                 // core: grid points with |x| + y <= 15 lie within (15 - y) doppler widths of the line, i.e. within
                 // floor(that / d_nu) + 1 points of the centre (d_nu is the SMALLEST spacing of the grid, :524-526).  A margin
                 // (15.001, + 2 points) covers the rounding of x = delta_nu * (1 / dw); a superset costs nothing but speed.
                 const double reach = mul_rn(15.001 - yy, dw) / d_nu;
                 const int64_t chw = yy < 15.001 ? (reach >= (double)n_nu ? n_nu : (int64_t)reach + 2) : 0;
+                keep_chw[it] = (int)min(chw, (int64_t)2147483647);
                 sc.lo = lo;
                 sc.hi = hi;
                 sc.clo = max((int)max(c - chw, (int64_t)0), lo);
                 sc.chi = chw > 0 ? min((int)min(c + chw, n_nu), hi) : sc.clo;
                 // A core no wider than a narrow window is DELEGATED to the narrow role (lanes <-> depth: all depths of a line
                 // sit in the same Faddeeva regions at one frequency, where a 64-point tile holds a few core points of one
-                // depth): the narrow arrays below get [clo, chi) as this item's window and the wide role leaves those points out.
-                core_lo = sc.clo, core_hi = sc.chi;
+                // depth): the narrow arrays below get the core's half-width as this item's window and the wide role leaves
+                // those points out.
                 delegated = chw > 0 && chw <= kNarrowReach && sc.chi > sc.clo;
                 core_hw = (int)min(chw, hw);  // the core is clipped by the window (64 < hw < chw happens)
                 if (delegated) {
@@ -459,16 +453,32 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
             } else if (narrow) {
                 atomicMax(&s_hwmax[ll], (int)hw);
             }
-            sc_keep[it] = sc;  // stored below, once the line's widest window is known
+            if (!narrow && hi > lo) keep_hw[it] = (int)hw, keep_chw[it] = delegated ? -keep_chw[it] : keep_chw[it];  // (the word is stored below, once the line's widest window is known)
             // a gather block knows its lines' positions in hlist: the list-ordered copy of the scan word is written here
             // (culled runs; otherwise k_hscan makes it once the list exists)
             if (gather && w.hscan && l0 + ll < n_h) w.hscan[(size_t)(d0 + dd) * n_lines + l0 + ll] = sc;
         }
-        // the second pass writes the NARROW arrays: a narrow item's window, or the delegated core of a wide item; the sign
-        // bit of the stashed upper bound tells the two apart from "nothing for the narrow role"
-        s_lo[sidx] = delegated ? core_lo : lo;
-        s_hi[sidx] = narrow ? hi : (delegated ? core_hi : -hi - 1);
-        s_h[sidx] = (unsigned char)(narrow ? (int)hw : (delegated ? core_hw : 0));
+        // line-major outputs, depth fastest: the stores coalesce
+        const size_t o = (size_t)l * n_depth + (d0 + dd);
+        if (out_lo_ref) {  // sdx_line_windows_dev (no wide records there: the window itself)
+            out_lo_ref[o] = lo;
+            out_hi_ref[o] = hi;
+        }
+        if (w.nhw) {
+            // the narrow role's window: a narrow item's own half-width, the delegated core's, or nothing
+            w.nhw[o] = (unsigned char)(narrow ? (int)hw : (delegated ? core_hw : 0));
+            if (narrow || delegated) {
+                if (w.n_inv32) {
+                    w.n_inv32[o] = (float)inv;
+                    w.n_y32[o] = (float)yy;
+                    w.n_amp32[o] = (float)amp;
+                } else {
+                    w.n_inv[o] = inv;
+                    w.n_y[o] = yy;
+                    w.n_amp[o] = amp;
+                }
+            }
+        }
         if (hi > lo) ev += (unsigned long long)(hi - lo);
     }
     __syncthreads();
@@ -480,9 +490,19 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
         for (int it = 0; it < kPreItems; ++it) {
             const int k = tid + it * kPreBlock;
             if (k >= nl * nd) continue;
-            const int dd = small_div(k, nl_magic), ll = k - dd * nl;
+            const int ll = small_div(k, nd_magic), dd = k - ll * nd;
             if (w.skip_unlisted_scan && s_whwmax[ll] == 0) continue;
-            w.wscan[(size_t)(d0 + dd) * n_lines + SDX_LINE_OF(ll)] = sc_keep[it];
+            WideScan sc = {0, 0, 0, 0};
+            if (keep_hw[it] > 0) {  // the word of the arithmetic pass, from the same integers
+                const int64_t c = s_c[ll], hw = keep_hw[it], chw = keep_chw[it] < 0 ? -(int64_t)keep_chw[it] : (int64_t)keep_chw[it];
+                const int64_t lw = c - hw, hw_end = c + hw;
+                sc.lo = (int)(lw < 0 ? 0 : lw);
+                sc.hi = (int)(hw_end > n_nu ? n_nu : hw_end);
+                sc.clo = max((int)max(c - chw, (int64_t)0), sc.lo);
+                sc.chi = chw > 0 ? min((int)min(c + chw, n_nu), sc.hi) : sc.clo;
+                if (keep_chw[it] < 0) sc.clo = -sc.clo - 1;
+            }
+            w.wscan[(size_t)(d0 + dd) * n_lines + SDX_LINE_OF(ll)] = sc;
         }
     }
     // per-line summary for the narrow kernel's candidate test: centre index and the largest narrow half-width
@@ -498,33 +518,6 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
             w.lnu32[SDX_LINE_OF(tid)] = float2v{(float)lnu, (float)(lnu - (double)(float)lnu)};
         }
     }
-    // line-major outputs: the stashed values, depth fastest so the stores coalesce
-    if (w.nhw || out_lo_ref) {
-        for (int k = tid; k < nl * nd; k += nthreads) {
-            const int ll = small_div(k, nd_magic), dd = k - ll * nd;
-            const int sidx = ll * kStride + dd;
-            const int lo = s_lo[sidx], hcode = s_hi[sidx];
-            const bool narrow = hcode >= 0;
-            const int hi = narrow ? hcode : -hcode - 1;
-            const size_t o = (size_t)SDX_LINE_OF(ll) * n_depth + (d0 + dd);
-            if (out_lo_ref) {  // sdx_line_windows_dev
-                out_lo_ref[o] = lo;
-                out_hi_ref[o] = hi;
-            }
-            if (w.nhw) {
-                w.nhw[o] = s_h[sidx];
-                if (narrow && w.n_inv32) {
-                    w.n_inv32[o] = (float)s_dw[sidx];
-                    w.n_y32[o] = (float)s_g[sidx];
-                    w.n_amp32[o] = (float)s_a[sidx];
-                } else if (narrow) {
-                    w.n_inv[o] = s_dw[sidx];
-                    w.n_y[o] = s_g[sidx];
-                    w.n_amp[o] = s_a[sidx];
-                }
-            }
-        }
-    }
     if (w.evals) {
         for (int off = 32; off > 0; off >>= 1) ev += __shfl_xor(ev, off);
         if ((tid & 63) == 0) s_ev[tid >> 6] = ev;
@@ -538,7 +531,7 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
 }
 
 template <bool GEN, int LINES>
-__global__ __launch_bounds__(kPreBlock) __attribute__((amdgpu_num_sgpr(80))) void k_line_prepass(int n_depth, int64_t n_nu, const double* __restrict__ nus,
+__global__ __launch_bounds__(kPreBlock) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(LINES >= 48 ? 8 : 4, 8))) void k_line_prepass(int n_depth, int64_t n_nu, const double* __restrict__ nus,
                                                          const double* __restrict__ dnu_partial, int n_partial,
                                                          int64_t n_lines, const double* __restrict__ line_nus,
                                                          const double* __restrict__ doppler,
@@ -675,10 +668,13 @@ __device__ __forceinline__ float2v region1_f32x2(float2v acc, float2v nuh, float
     return __builtin_elementwise_fma(num, r, acc);
 }
 
-template <int R, bool MIXED>
+// DEFER: the partial sums of this wave are handed back (acc_out) instead of being reduced and stored here — the kernel of dense
+// long lists has ONE reduction for both roles (line_all_body)
+template <int R, bool MIXED, bool DEFER = false>
 __device__ __forceinline__ void line_wide_walk(const int tile_idx, const int split, const int n_split, const int d, int64_t n_nu,
                                                const double* __restrict__ nus, int64_t nu_begin, int64_t nu_count, int64_t n_lines,
-                                               LineWork w, double* __restrict__ plane, int64_t pld, double* __restrict__ lds_all)
+                                               LineWork w, double* __restrict__ plane, int64_t pld, double* __restrict__ lds_all,
+                                               double* __restrict__ acc_out = nullptr)
 {
     constexpr int kTile = 64 * R;
     // GLOBAL tiles: tile boundaries are multiples of kTile from grid index 0 whatever the shard, and a tile cut by a shard
@@ -912,7 +908,12 @@ __device__ __forceinline__ void line_wide_walk(const int tile_idx, const int spl
         o[1] = st_t0, o[2] = wall_clock64(), o[3] = st_chunks, o[4] = st_fast, o[5] = st_general, o[6] = st_if, o[7] = st_slow;
     }
 #endif
-    wide_reduce_and_store<R>(split, n_split, acc, idx0, s0, s1, lds_all, plane, pld, d);
+    if constexpr (DEFER) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc_out[r] = acc[r];
+    } else {
+        wide_reduce_and_store<R>(split, n_split, acc, idx0, s0, s1, lds_all, plane, pld, d);
+    }
 }
 
 // Long line lists: two stable compactions of the per-line classes in two small launches (per-block counts, then every
@@ -1105,8 +1106,17 @@ __device__ __forceinline__ void classify_block(const int bid, const int n_blocks
 __device__ __forceinline__ void dnu_partial_block(const int bid, const int n_blocks, int64_t n_nu, const double* __restrict__ nus,
                                                   double* __restrict__ partial, double* s_red)
 {
-    double m = -INFINITY;
-    for (int64_t i = (int64_t)bid * blockDim.x + threadIdx.x; i + 1 < n_nu; i += (int64_t)n_blocks * blockDim.x) m = fmax(m, nus[i + 1] - nus[i]);
+    // four independent pairs of loads in flight per thread: the scan is a chain of round trips, not a stream (the grid sits in L2)
+    double m0 = -INFINITY, m1 = -INFINITY, m2 = -INFINITY, m3 = -INFINITY;
+    const int64_t step = (int64_t)n_blocks * blockDim.x;
+    int64_t i = (int64_t)bid * blockDim.x + threadIdx.x;
+    for (; i + 3 * step + 1 < n_nu; i += 4 * step) {
+        const double a0 = nus[i], b0 = nus[i + 1], a1 = nus[i + step], b1 = nus[i + step + 1];
+        const double a2 = nus[i + 2 * step], b2 = nus[i + 2 * step + 1], a3 = nus[i + 3 * step], b3 = nus[i + 3 * step + 1];
+        m0 = fmax(m0, b0 - a0), m1 = fmax(m1, b1 - a1), m2 = fmax(m2, b2 - a2), m3 = fmax(m3, b3 - a3);
+    }
+    for (; i + 1 < n_nu; i += step) m0 = fmax(m0, nus[i + 1] - nus[i]);
+    double m = fmax(fmax(m0, m1), fmax(m2, m3));
     for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
     if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = m;
     __syncthreads();
@@ -1303,6 +1313,86 @@ __device__ __forceinline__ void line_narrow_group(const int64_t i0, const int de
         if (valid && act[k]) plane[(size_t)d * pld + (i0 + k - nu_begin)] = acc[k];
 }
 
+// The narrow role of DENSE long lists (at least one line per two grid points, four line subsets): the four waves of a workgroup
+// share ONE group of F consecutive frequencies and split its candidate lines — wave s takes the lines l with (l / 16) % 4 == s,
+// sixteen-line runs of the LIST going round the waves, so every wave gets a quarter of every stretch of the list — and the four
+// partial sums meet in LDS, where wave 0 adds them in subset order.  A wave still fetches a visited line's records once for up to
+// F evaluations (what F = 4 frequencies per wave saved: a third of the role's instructions and three quarters of its fetch), but
+// there are as many waves as with one frequency per wave: a frequency SHARD of 11 000 - 21 000 columns fills the chip (round 4 had
+// to fall back to one frequency per wave there: 3 000 four-times-longer waves are a launch's tail).  Which lines share a partial
+// sum is a property of the list (the run index of a line), so shards reproduce the unsharded bits; the sums differ from the
+// sequential walk's in the last bits (four partial sums instead of one).
+template <int F>
+__device__ __forceinline__ void line_narrow_subsets(const int64_t i0, const int depth_chunk, const int subset, int n_depth, int64_t n_nu,
+                                                    const double* __restrict__ nus, int64_t nu_begin, int64_t nu_count,
+                                                    const double* __restrict__ line_nus, LineWork w, double* __restrict__ acc_out)
+{
+    const int lane = threadIdx.x & 63;
+    const int d = depth_chunk * 64 + lane;
+    const bool valid = d < n_depth;
+    const int dc = valid ? d : n_depth - 1;
+    const unsigned dcu = (unsigned)dc;
+    const int ia = (int)i0;
+    // lines with centre c in [i0 - H + 1, i0 + F - 1 + H]
+    const int64_t pa = max(i0 - kNarrowReach + 1, (int64_t)0);
+    const int64_t pb = min(i0 + F - 1 + kNarrowReach, n_nu);
+    const int la = __builtin_amdgcn_readfirstlane(w.cnt_ge[pb + 1]);
+    const int lb = __builtin_amdgcn_readfirstlane(w.cnt_ge[pa]);
+    double nu_k[F], acc[F];
+    bool act[F];  // the frequency belongs to this launch's columns (wave-uniform)
+#pragma unroll
+    for (int k = 0; k < F; ++k) {
+        act[k] = i0 + k >= nu_begin && i0 + k < nu_begin + nu_count;
+        nu_k[k] = nus[min(i0 + k, n_nu - 1)];
+        acc[k] = 0.0;
+    }
+    // lane -> candidate: 64 lines of this subset per trip, out of a stretch of 256 aligned to the LIST (lanes ascend with the line index)
+    const int lane_off = ((lane >> 4) << 6) + (subset << 4) + (lane & 15);
+    for (int base = la & ~255; base < lb; base += 256) {
+        const int lc = base + lane_off;
+        bool rel = false;
+        int c = 0;
+        if (lc >= la && lc < lb) {
+            const int hwm = w.nhw_max[lc];
+            c = w.centre[lc];
+            rel = hwm > 0 && ia + (F - 1) >= c - hwm && ia < c + hwm;
+        }
+        unsigned long long m = __ballot(rel);
+        // the parameters of the NEXT relevant line are requested before the current one is evaluated
+        int h = 0, cl = 0;
+        double y = 0.0, amp = 0.0, inv = 0.0, lnu = 0.0;
+        if (m) {
+            const int bit = __builtin_ctzll(m);
+            const int l = base + ((bit >> 4) << 6) + (subset << 4) + (bit & 15);
+            const size_t ob = (size_t)l * n_depth;
+            cl = __builtin_amdgcn_readlane(c, bit);
+            h = (w.nhw + ob)[dcu], y = (w.n_y + ob)[dcu], amp = (w.n_amp + ob)[dcu], inv = (w.n_inv + ob)[dcu], lnu = line_nus[l];
+        }
+        while (m) {
+            m &= m - 1;
+            int h_n = 0, cl_n = 0;
+            double y_n = 0.0, amp_n = 0.0, inv_n = 0.0, lnu_n = 0.0;
+            if (m) {
+                const int bit = __builtin_ctzll(m);
+                const int l = base + ((bit >> 4) << 6) + (subset << 4) + (bit & 15);
+                const size_t ob = (size_t)l * n_depth;
+                cl_n = __builtin_amdgcn_readlane(c, bit);
+                h_n = (w.nhw + ob)[dcu], y_n = (w.n_y + ob)[dcu], amp_n = (w.n_amp + ob)[dcu], inv_n = (w.n_inv + ob)[dcu], lnu_n = line_nus[l];
+            }
+            const int lo = cl - h, hi = cl + h;  // (h = 0: empty; the clamp to the grid is implied by ia + k being a grid index)
+            if (valid && ia + (F - 1) >= lo && ia < hi) {
+                const RegionI k1 = region1_setup(y, amp);
+#pragma unroll
+                for (int k = 0; k < F; ++k)
+                    if (act[k] && ia + k >= lo && ia + k < hi) acc[k] = voigt_add(acc[k], nu_k[k] - lnu, inv, y, amp, k1);
+            }
+            h = h_n, cl = cl_n, y = y_n, amp = amp_n, inv = inv_n, lnu = lnu_n;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < F; ++k) acc_out[k] = acc[k];  // (the four subsets of a group meet in the kernel's common reduction)
+}
+
 // The narrow role of the mixed-precision mode: the same walk, every term evaluated by voigt_add32 (packed fp32, all four
 // regions) from fp32 records; the frequency difference comes from the hi + lo float pairs of both frequencies (exact to
 // 2^-48 of the frequency, i.e. ~1e-7 of a narrow window's reach), the terms of one 64-candidate chunk gather in an fp32
@@ -1446,13 +1536,91 @@ __device__ __forceinline__ void line_narrow_group32(const int64_t i0, const int 
         if (valid && act[k]) plane[(size_t)d * pld + (i0 + k - nu_begin)] = acc[k];
 }
 
+// ... and the subset walk of dense long lists (line_narrow_subsets) in the mixed-precision mode: the fp32 terms of one trip — the 64
+// candidates a wave takes out of a 256-line stretch of the list — gather in an fp32 sum that goes into the fp64 sum once per trip.
+template <int F>
+__device__ __forceinline__ void line_narrow_subsets32(const int64_t i0, const int depth_chunk, const int subset, int n_depth, int64_t n_nu,
+                                                      const double* __restrict__ nus, int64_t nu_begin, int64_t nu_count, LineWork w,
+                                                      double* __restrict__ acc_out)
+{
+    const int lane = threadIdx.x & 63;
+    const int d = depth_chunk * 64 + lane;
+    const bool valid = d < n_depth;
+    const int dc = valid ? d : n_depth - 1;
+    const int ia = (int)i0;
+    const int64_t pa = max(i0 - kNarrowReach + 1, (int64_t)0);
+    const int64_t pb = min(i0 + F - 1 + kNarrowReach, n_nu);
+    const int la = __builtin_amdgcn_readfirstlane(w.cnt_ge[pb + 1]);
+    const int lb = __builtin_amdgcn_readfirstlane(w.cnt_ge[pa]);
+    float nih[F], nil[F];
+    double acc[F];
+    bool act[F];
+#pragma unroll
+    for (int k = 0; k < F; ++k) {
+        act[k] = i0 + k >= nu_begin && i0 + k < nu_begin + nu_count;
+        const double nu = nus[min(i0 + k, n_nu - 1)];
+        nih[k] = (float)nu;
+        nil[k] = (float)(nu - (double)nih[k]);
+        acc[k] = 0.0;
+    }
+    const int lane_off = ((lane >> 4) << 6) + (subset << 4) + (lane & 15);
+    for (int base = la & ~255; base < lb; base += 256) {
+        const int lc = base + lane_off;
+        bool rel = false;
+        int c = 0;
+        if (lc >= la && lc < lb) {
+            const int hwm = w.nhw_max[lc];
+            c = w.centre[lc];
+            rel = hwm > 0 && ia + (F - 1) >= c - hwm && ia < c + hwm;
+        }
+        unsigned long long m = __ballot(rel);
+        float acc32[F];
+#pragma unroll
+        for (int k = 0; k < F; ++k) acc32[k] = 0.f;
+        int h = 0, cl = 0;
+        float y = 0.f, amp = 0.f, inv = 0.f;
+        float2v lnu = {0.f, 0.f};
+        if (m) {
+            const int bit = __builtin_ctzll(m);
+            const int l = base + ((bit >> 4) << 6) + (subset << 4) + (bit & 15);
+            const size_t o = (size_t)l * n_depth + dc;
+            cl = __builtin_amdgcn_readlane(c, bit);
+            h = w.nhw[o], y = w.n_y32[o], amp = w.n_amp32[o], inv = w.n_inv32[o], lnu = w.lnu32[l];
+        }
+        while (m) {
+            m &= m - 1;
+            int h_n = 0, cl_n = 0;
+            float y_n = 0.f, amp_n = 0.f, inv_n = 0.f;
+            float2v lnu_n = {0.f, 0.f};
+            if (m) {
+                const int bit = __builtin_ctzll(m);
+                const int l = base + ((bit >> 4) << 6) + (subset << 4) + (bit & 15);
+                const size_t o = (size_t)l * n_depth + dc;
+                cl_n = __builtin_amdgcn_readlane(c, bit);
+                h_n = w.nhw[o], y_n = w.n_y32[o], amp_n = w.n_amp32[o], inv_n = w.n_inv32[o], lnu_n = w.lnu32[l];
+            }
+            const int lo = cl - h, hi = cl + h;
+            if (valid && ia + (F - 1) >= lo && ia < hi) {
+#pragma unroll
+                for (int k = 0; k < F; ++k)
+                    if (act[k] && ia + k >= lo && ia + k < hi) acc32[k] = voigt_add32(acc32[k], ((nih[k] - lnu.x) + (nil[k] - lnu.y)) * inv, y, amp);
+            }
+            h = h_n, cl = cl_n, y = y_n, amp = amp_n, inv = inv_n, lnu = lnu_n;
+        }
+#pragma unroll
+        for (int k = 0; k < F; ++k) acc[k] += (double)acc32[k];
+    }
+#pragma unroll
+    for (int k = 0; k < F; ++k) acc_out[k] = acc[k];  // (the four subsets of a group meet in the kernel's common reduction)
+}
+
 // Both line kernels in ONE launch of workgroups of S waves (S = number of line subsets): workgroups [0, n_wide) take the
 // wide role — one (depth, tile) each, wave s walks subset s — depth slowest, hottest layers first; the rest take the narrow
 // role, one frequency per wave.  The two roles only share the pre-pass, and each leaves issue slots idle on its own; a
 // cross-stream fork/join would cost two ~12 us inter-queue edges per step, one grid costs nothing.
 // roles: bit 0 wide, bit 1 narrow (both by default; one at a time for split-launch profiling, SDX_SPLIT_LAUNCHES=1).
 // Output planes: [0] the wide windows (all subsets summed), [1] the narrow windows.
-template <int R, bool MIXED>
+template <int R, bool MIXED, bool SUBSETS>
 __device__ __forceinline__ void line_all_body(int n_wide, int tiles, int n_split, int n_depth, int64_t n_nu,
                                                    const double* __restrict__ nus, int64_t nu_begin, int64_t nu_count,
                                                    int64_t n_lines, const double* __restrict__ line_nus, LineWork w,
@@ -1461,6 +1629,13 @@ __device__ __forceinline__ void line_all_body(int n_wide, int tiles, int n_split
     extern __shared__ double s_wide[];  // n_split x kWideLdsDoubles
     const int b = blockIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform, which the compiler cannot see: chunk and frequency indices stay scalar
+    // SUBSETS (the kernel of dense long lists): both roles end in ONE reduction — every wave of a workgroup brings R partial sums per
+    // lane (a wide wave: R points of its tile; a narrow wave: the R = F frequencies of the workgroup's group), they meet in LDS
+    // and wave 0 adds them in subset order and writes.  One barrier in the kernel: with a second one in the narrow branch the
+    // compiler spilled the WIDE walk's registers, and a kernel that touches scratch at all ran a third slower (round 5).
+    [[maybe_unused]] double part[R];
+    [[maybe_unused]] int out_row = 0, out_col = 0;      // where lane's sums go: row (depth), first column; columns step 64 (wide) or 1 (narrow)
+    [[maybe_unused]] bool out_wide = true, out_valid = true;
     if (b < n_wide) {
         if (!(roles & 1)) return;
         // XCD-aware tile order: workgroup i runs on XCD i % 8, each with its own L2.  Within a depth the workgroups of one XCD
@@ -1481,7 +1656,13 @@ __device__ __forceinline__ void line_all_body(int n_wide, int tiles, int n_split
             tile = ((j / wg) * 8 + (p & 7)) * wg + j % wg;
             if (tile >= tiles) return;
         }
-        line_wide_walk<R, MIXED>(tile, wave, n_split, d, n_nu, nus, nu_begin, nu_count, n_lines, w, planes, pld, s_wide);
+        if constexpr (SUBSETS) {
+            line_wide_walk<R, MIXED, true>(tile, wave, n_split, d, n_nu, nus, nu_begin, nu_count, n_lines, w, planes, pld, s_wide, part);
+            out_row = d;
+            out_col = (int)((nu_begin / (64 * R) + (int64_t)tile) * (64 * R)) + (int)(threadIdx.x & 63);
+        } else {
+            line_wide_walk<R, MIXED>(tile, wave, n_split, d, n_nu, nus, nu_begin, nu_count, n_lines, w, planes, pld, s_wide);
+        }
     } else {
         if (!(roles & 2)) return;
         // A wave writes one value into each of the N_d rows of the narrow plane: the waves that fill a 64-byte sector of a
@@ -1493,22 +1674,34 @@ __device__ __forceinline__ void line_all_body(int n_wide, int tiles, int n_split
         // F consecutive frequencies per wave (roles bits 8-11: 1, 2 or 4 — 8 was measured slower), groups aligned
         // to the global grid
         const int F = max(1, (roles >> 8) & 15);
+        // dense long lists (a kernel of their own — SUBSETS — so that neither walk pays for the other's registers: with both narrow
+        // walks in one kernel the WIDE role spilled, and a kernel that touches scratch memory ran a third slower): the workgroup's
+        // four waves share one group of F = 4 frequencies
+        constexpr bool subsets = SUBSETS;
         const int64_t g0 = nu_begin / F;
         const int64_t n_grp = (nu_begin + nu_count + F - 1) / F - g0;
         const int64_t n_narrow = n_grp * ((n_depth + 63) / 64);
-        const int64_t n_nb = (n_narrow + n_split - 1) / n_split;
+        const int64_t n_nb = subsets ? n_narrow : (n_narrow + n_split - 1) / n_split;
         const int64_t p = b - n_wide, j = p >> 3;
         const int order = (roles >> 2) & 3;  // analysis knob (SDX_NARROW_ORDER): 0 grouped (default), 1 plain, 2 one block per XCD
         int64_t wg = ((j / kNarrowGroup) * 8 + (p & 7)) * kNarrowGroup + j % kNarrowGroup;
         if (order == 1) wg = p;
         if (order == 2) wg = (p & 7) * ((n_nb + 7) / 8) + j;
         if ((order == 2 && j >= (n_nb + 7) / 8) || wg >= n_nb) return;
-        const int64_t c = wg * n_split + wave;
-        if (c >= n_narrow) return;
+        const int64_t c = subsets ? wg : wg * n_split + wave;
+        if (c >= n_narrow) return;  // (subsets: the whole workgroup)
         const int64_t i0 = (g0 + c % n_grp) * F;
         const int chunk = (int)(c / n_grp);
         double* __restrict__ nplane = planes + (size_t)n_depth * pld;
-        if constexpr (MIXED) {
+        if constexpr (SUBSETS) {
+            static_assert(!SUBSETS || R == 4, "the common reduction: R points per wide lane = F frequencies per narrow group");
+            if constexpr (MIXED) line_narrow_subsets32<4>(i0, chunk, wave, n_depth, n_nu, nus, nu_begin, nu_count, w, part);
+            else line_narrow_subsets<4>(i0, chunk, wave, n_depth, n_nu, nus, nu_begin, nu_count, line_nus, w, part);
+            out_wide = false;
+            out_row = chunk * 64 + (int)(threadIdx.x & 63);
+            out_valid = out_row < n_depth;
+            out_col = (int)i0;
+        } else if constexpr (MIXED) {
             if (F == 4) line_narrow_group32<4>(i0, chunk, n_depth, n_nu, nus, nu_begin, nu_count, w, nplane, pld);
             else if (F == 2) line_narrow_group32<2>(i0, chunk, n_depth, n_nu, nus, nu_begin, nu_count, w, nplane, pld);
             else line_narrow_wave32(i0, chunk, n_depth, n_nu, nus, nu_begin, nu_count, w, nplane, pld);
@@ -1518,24 +1711,48 @@ __device__ __forceinline__ void line_all_body(int n_wide, int tiles, int n_split
             else line_narrow_wave(i0, chunk, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, nplane, pld);
         }
     }
+    if constexpr (SUBSETS) {
+        const int lane = threadIdx.x & 63;
+        if (wave > 0) {
+            double* mine = s_wide + (size_t)wave * kWideLdsDoubles;
+#pragma unroll
+            for (int r = 0; r < R; ++r) mine[r * 64 + lane] = part[r];
+        }
+        __syncthreads();
+        if (wave == 0) {
+            for (int s = 1; s < n_split; ++s) {
+                const double* other = s_wide + (size_t)s * kWideLdsDoubles;
+#pragma unroll
+                for (int r = 0; r < R; ++r) part[r] = add_rn(part[r], other[r * 64 + lane]);
+            }
+            const int64_t s0 = nu_begin, s1 = nu_begin + nu_count;  // the columns this launch stores
+            double* __restrict__ dst = planes + (out_wide ? (size_t)0 : (size_t)n_depth * pld) + (size_t)out_row * pld;
+            const int stride = out_wide ? 64 : 1;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int64_t col = (int64_t)out_col + (int64_t)r * stride;
+                if (out_valid && col >= s0 && col < s1) dst[col - s0] = part[r];
+            }
+        }
+    }
 }
 
-template <int R>
+template <int R, bool SUBSETS = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_line_all(int n_wide, int tiles, int n_split, int n_depth, int64_t n_nu,
                                                    const double* __restrict__ nus, int64_t nu_begin, int64_t nu_count,
                                                    int64_t n_lines, const double* __restrict__ line_nus, LineWork w,
                                                    double* __restrict__ planes, int64_t pld, int roles)
 {
-    line_all_body<R, false>(n_wide, tiles, n_split, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, planes, pld, roles);
+    line_all_body<R, false, SUBSETS>(n_wide, tiles, n_split, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, planes, pld, roles);
 }
 // the mixed-precision variant: 512-point tiles; the register budget is capped at 128 (4 waves per SIMD) — what exceeds it
 // sits in the rarely taken fp64 general path
-template <int R>
+template <int R, bool SUBSETS = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(R == 4 ? 6 : 4, 8))) void k_line_all_mixed(
     int n_wide, int tiles, int n_split, int n_depth, int64_t n_nu, const double* __restrict__ nus, int64_t nu_begin, int64_t nu_count,
     int64_t n_lines, const double* __restrict__ line_nus, LineWork w, double* __restrict__ planes, int64_t pld, int roles)
 {
-    line_all_body<R, true>(n_wide, tiles, n_split, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, planes, pld, roles);
+    line_all_body<R, true, SUBSETS>(n_wide, tiles, n_split, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, planes, pld, roles);
 }
 
 // out (+)= sum over the S line subsets, in subset order

@@ -810,7 +810,16 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
     const bool scan_in_block = n_nu <= 16384;  // every pre-pass block re-scans a small grid instead of a separate launch
     LineWork w{};
     // 16 lines per block while all such blocks are resident at once (two 1024-thread blocks per CU), else 32
-    const int pre_lines = ((n_lines + 15) / 16) * ((n_depth + kPreDepths - 1) / kPreDepths) <= 2 * (int64_t)ctx->n_cu ? 16 : 32;  // (culled runs: long lists, 32)
+    int pre_lines = ((n_lines + 15) / 16) * ((n_depth + kPreDepths - 1) / kPreDepths) <= 2 * (int64_t)ctx->n_cu ? 16 : 32;
+    // A culled shard (decided below from the same quantities) prepares its own line range + the listed lines: at an eighth of 1.5e5
+    // lines ~22 000 lines, 690 blocks of 32 on the chip's 512 slots of 1024 threads — a whole second round of the block's chain of
+    // round trips for a third of a round's work.  48 lines per block (three items per thread, registers only) are 470 blocks:
+    // ONE round, a chain one item longer.
+    static const bool no_cull_early = knob("SDX_NO_CULL") != nullptr;
+    static const int pre_lines_env = knob("SDX_PRE_LINES") ? std::atoi(knob("SDX_PRE_LINES")) : 0;  // experiment knob: 32, 48 or 64 on culled shards
+    const bool will_cull = fill_work && !no_cull_early && n_lines >= ctx->indexed_min_lines && !count_evals && !gen && n_nu > 16384 && nu_count < n_nu;
+    // (lists long enough for the counter-driven launch keep 32: its looping kernel has no registers to spare for a third item)
+    if (will_cull && !lo_ref && (n_lines + 31) / 32 < ctx->prepass_ticket_min_blocks) pre_lines = (pre_lines_env == 32 || pre_lines_env == 48) ? pre_lines_env : 48;
     const int n_line_blocks = (int)((n_lines + pre_lines - 1) / pre_lines);
     int n_pixel_blocks = 0;
     if (fill_work) {
@@ -847,7 +856,8 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
                          "16384 points, nu_count < n_nu, no evaluation count)");
     // the grid-spacing reduction: a launch of its own, or — culled runs — the first blocks of the classification launch
     int* const sel = cull ? w.hcount + 4 : nullptr;
-    if (cull) n_partial = (int)std::min<int64_t>(kDnuPartials, std::max<int64_t>(1, (n_nu + kBlock * 8 - 1) / (kBlock * 8)));
+    // (grid-spacing blocks of a classification launch: four pairs of loads per thread — one trip of their loop — up to 256 blocks)
+    if (cull) n_partial = (int)std::min<int64_t>(kDnuPartials, std::max<int64_t>(1, (n_nu + kBlock * 4 - 1) / (kBlock * 4)));
     else if (!scan_in_block && (rc = launch_dnu(ctx, n_nu, nus, &n_partial))) return rc;
     // continuum blocks of the fused step: one per (frequency tile of `threads` points, group of dgs depths) when the per-depth
     // factors of a group fit LDS (always, for a handful of bound-free levels), else one per (tile, depth) evaluating every point
@@ -978,6 +988,7 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
         if (gen && pre_lines == 16) hipLaunchKernelGGL((k_prepass_continuum<true, 16>), dim3(total_blocks), dim3(kPreBlock), shmem, ctx->stream, SDX_PRE_ARGS);
         else if (gen) hipLaunchKernelGGL((k_prepass_continuum<true, 32>), dim3(total_blocks), dim3(kPreBlock), shmem, ctx->stream, SDX_PRE_ARGS);
         else if (pre_lines == 16) hipLaunchKernelGGL((k_prepass_continuum<false, 16>), dim3(total_blocks), dim3(kPreBlock), shmem, ctx->stream, SDX_PRE_ARGS);
+        else if (pre_lines == 48) hipLaunchKernelGGL((k_prepass_continuum<false, 48>), dim3(total_blocks), dim3(kPreBlock), shmem, ctx->stream, SDX_PRE_ARGS);
         else hipLaunchKernelGGL((k_prepass_continuum<false, 32>), dim3(total_blocks), dim3(kPreBlock), shmem, ctx->stream, SDX_PRE_ARGS);
 #undef SDX_PRE_ARGS
         }
@@ -988,11 +999,13 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
         if (w.ticket) {
             const dim3 pgrid(std::min<unsigned>(grid.x, 2u * (unsigned)ctx->n_cu), grid.y);
             const double* dnu_arg = scan_in_block ? (const double*)nullptr : (const double*)ctx->small_ws;
-            if (pre_lines == 16) hipLaunchKernelGGL((k_line_prepass_ticket<16>), pgrid, dim3(kPreBlock), 0, ctx->stream, n_depth, n_nu, nus, dnu_arg, n_partial, n_lines,
-                                                    line_nus, doppler, gammas, gamma_cols, alphas, w, n_line_blocks, lp);
-            else hipLaunchKernelGGL((k_line_prepass_ticket<32>), pgrid, dim3(kPreBlock), 0, ctx->stream, n_depth, n_nu, nus, dnu_arg, n_partial, n_lines, line_nus, doppler,
-                                    gammas, gamma_cols, alphas, w, n_line_blocks, lp);
-        } else if (gen && pre_lines == 16) hipLaunchKernelGGL((k_line_prepass<true, 16>), grid, dim3(kPreBlock), 0, ctx->stream, SDX_PRE_ARGS);
+#define SDX_TICKET_ARGS n_depth, n_nu, nus, dnu_arg, n_partial, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, w, n_line_blocks, lp
+            if (pre_lines == 16) hipLaunchKernelGGL((k_line_prepass_ticket<16>), pgrid, dim3(kPreBlock), 0, ctx->stream, SDX_TICKET_ARGS);
+            else if (pre_lines == 48) hipLaunchKernelGGL((k_line_prepass_ticket<48>), pgrid, dim3(kPreBlock), 0, ctx->stream, SDX_TICKET_ARGS);
+            else hipLaunchKernelGGL((k_line_prepass_ticket<32>), pgrid, dim3(kPreBlock), 0, ctx->stream, SDX_TICKET_ARGS);
+#undef SDX_TICKET_ARGS
+        } else if (pre_lines == 48) hipLaunchKernelGGL((k_line_prepass<false, 48>), grid, dim3(kPreBlock), 0, ctx->stream, SDX_PRE_ARGS);
+        else if (gen && pre_lines == 16) hipLaunchKernelGGL((k_line_prepass<true, 16>), grid, dim3(kPreBlock), 0, ctx->stream, SDX_PRE_ARGS);
         else if (gen) hipLaunchKernelGGL((k_line_prepass<true, 32>), grid, dim3(kPreBlock), 0, ctx->stream, SDX_PRE_ARGS);
         else if (pre_lines == 16) hipLaunchKernelGGL((k_line_prepass<false, 16>), grid, dim3(kPreBlock), 0, ctx->stream, SDX_PRE_ARGS);
         else hipLaunchKernelGGL((k_line_prepass<false, 32>), grid, dim3(kPreBlock), 0, ctx->stream, SDX_PRE_ARGS);
@@ -1092,8 +1105,20 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
     int narrow_f = 1;
     if (2 * n_lines >= n_nu) narrow_f = nu_count >= 32768 ? 4 : (nu_count >= 16384 ? 2 : 1);
     if (narrow_f_env == 1 || narrow_f_env == 2 || narrow_f_env == 4) narrow_f = narrow_f_env;
+    // VERY dense long lists (>= 4 lines per grid point, four line subsets): the four waves of a narrow-role workgroup share one group
+    // of four frequencies and split its candidate lines (line_narrow_subsets) — the record sharing of F = 4 with the wave count of
+    // F = 1, whatever the width of the launch.  Decided from the global list and grid: it changes the order of a sum.  Measured in
+    // round 5: 1e6 lines on 120 398 points (8.3 per point) 10.2 -> 9.9 ms for the whole grid and 1.52 -> 1.36 ms on an eighth; 1.5e5
+    // lines (1.25 per point: ~17 lines per wave, less than the wave's start-up and the workgroup's reduction) 2.03 -> 2.20 ms and
+    // 311 -> 320 us — hence the density in the rule.
+    static const bool no_narrow_subsets = knob("SDX_NO_NARROW_SUBSETS") != nullptr;  // A/B knob
+    static const int sub_density_env = knob("SDX_NARROW_SUBSETS_DENSITY") ? std::atoi(knob("SDX_NARROW_SUBSETS_DENSITY")) : -1;  // experiment knob: halves of a line per grid point
+    const int64_t sub_density = sub_density_env >= 0 ? sub_density_env : 8;
+    const int narrow_sub = (!no_narrow_subsets && 2 * n_lines >= sub_density * n_nu && n_split == 4 && Rm != 8) ? 4 : 0;
+    if (narrow_sub) narrow_f = 4;
     const int64_t n_grp = (nu_begin + nu_count + narrow_f - 1) / narrow_f - nu_begin / narrow_f;
-    const int64_t n_narrow = (((n_grp * ((n_depth + 63) / 64) + n_split - 1) / n_split + 31) / 32) * 32;
+    const int64_t n_narrow_units = n_grp * ((n_depth + 63) / 64);
+    const int64_t n_narrow = (((narrow_sub ? n_narrow_units : (n_narrow_units + n_split - 1) / n_split) + 31) / 32) * 32;
     static const int narrow_order = knob("SDX_NARROW_ORDER") ? atoi(knob("SDX_NARROW_ORDER")) & 3 : 0;
     REQUIRE(n_wide + n_narrow < ((int64_t)1 << 31), "line opacity: grid too large for one launch");
     static const bool split_launches = knob("SDX_SPLIT_LAUNCHES") != nullptr;  // analysis knob: time the two roles apart
@@ -1102,11 +1127,13 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
     for (int pass = 0; pass < (split_launches ? 2 : 1); ++pass) {
         // (raising the priority of the hot layers' waves with s_setprio was measured in round 4: the instruction has side effects as
         // far as the compiler is concerned, the record fetches of the walk stopped being scalar loads and the kernel ran 37 % slower)
-        const int roles = (split_launches ? (1 << pass) : 3) | (narrow_order << 2) | (wide_group << 4) | (narrow_f << 8);
+        const int roles = (split_launches ? (1 << pass) : 3) | (narrow_order << 2) | (wide_group << 4) | (narrow_f << 8) | (narrow_sub << 12);
         LaunchScope ls(ctx, split_launches ? (pass ? "k_line_narrow" : "k_line_wide") : "k_line_all");
 #define SDX_LINE_ARGS (int)n_wide, tiles, n_split, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, part, pld, roles
         if (ctx->mixed_precision && Rm == 8) hipLaunchKernelGGL((k_line_all_mixed<8>), g, blk, shmem, ctx->stream, SDX_LINE_ARGS);
+        else if (ctx->mixed_precision && narrow_sub) hipLaunchKernelGGL((k_line_all_mixed<R_MIXED, true>), g, blk, shmem, ctx->stream, SDX_LINE_ARGS);
         else if (ctx->mixed_precision) hipLaunchKernelGGL((k_line_all_mixed<R_MIXED>), g, blk, shmem, ctx->stream, SDX_LINE_ARGS);
+        else if (narrow_sub) hipLaunchKernelGGL((k_line_all<R, true>), g, blk, shmem, ctx->stream, SDX_LINE_ARGS);
         else hipLaunchKernelGGL((k_line_all<R>), g, blk, shmem, ctx->stream, SDX_LINE_ARGS);
 #undef SDX_LINE_ARGS
     }
