@@ -28,6 +28,19 @@ __device__ __forceinline__ void wave_sync()
 // ------------------------------------------------------------------------------------------------
 // d_nu = -max(diff(nus))  (opacities_solvers/base.py:524-526): partial maxima, finished by consumers.
 constexpr int kDnuPartials = 256;
+// ... and, 4096 bytes behind the partial maxima, a SAMPLE of the grid: kGridSample frequencies at a stride of ceil(N_nu / kGridSample)
+// points, written by the launch that computes the partial maxima and read — 16 contiguous KB — by every pre-pass block that
+// looks for line centres (a block sampling the grid itself touches one 64-byte line per sample)
+constexpr int kGridSample = 2048;
+constexpr int kGridSampleOffset = 512;  // doubles
+__device__ __forceinline__ void grid_sample_block(const int bid, const int n_blocks, int64_t n_nu, const double* __restrict__ nus, double* __restrict__ sample)
+{
+    const int64_t cstride = (n_nu + kGridSample - 1) / kGridSample;
+    for (int q = bid * (int)blockDim.x + (int)threadIdx.x; q < kGridSample; q += n_blocks * (int)blockDim.x) {
+        const int64_t j = (int64_t)q * cstride;
+        sample[q] = j < n_nu ? nus[j] : -INFINITY;
+    }
+}
 
 __device__ __forceinline__ void shard_range(int64_t n_nu, const double* __restrict__ nus, int64_t n_lines, const double* __restrict__ line_nus,
                                             int64_t nu_begin, int64_t nu_count, int* __restrict__ sel);
@@ -37,6 +50,7 @@ __global__ __launch_bounds__(kBlock) void k_dnu_partial(int64_t n_nu, const doub
 {
     // (culled pre-pass: the per-line maxima the classification pass accumulates into are cleared here, not by a memset node)
     for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < n_zero; k += (int64_t)gridDim.x * kBlock) zero[k] = 0;
+    grid_sample_block(blockIdx.x, gridDim.x, n_nu, nus, partial + kGridSampleOffset);
     double m = -INFINITY;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i + 1 < n_nu; i += (int64_t)gridDim.x * kBlock)
         m = fmax(m, nus[i + 1] - nus[i]);
@@ -146,6 +160,13 @@ constexpr int kMaxTile = 512;           // the widest tile of the wide role (64 
 #ifdef SDX_WALK_STATS  // analysis build (scripts/r4/walk_stats.sh): what the waves of the line kernel spend their time on
 constexpr int kWalkStatSlots = 1 << 19;  // lower half: wide waves by (depth < 64, tile < 512, subset < 8); upper half: narrow waves by frequency
 __device__ unsigned long long g_walk_stats[(size_t)kWalkStatSlots * 8];
+#endif
+#ifdef SDX_PRE_STATS  // analysis build (scripts/r5/pre_stats.sh): when the phases of a pre-pass block begin (100 MHz device clock)
+constexpr int kPreStatSlots = 1 << 14;
+__device__ unsigned long long g_pre_stats[(size_t)kPreStatSlots * 8];
+#define SDX_PRE_STAMP(n) do { if (tid == 0) pst[n] = wall_clock64(); } while (0)
+#else
+#define SDX_PRE_STAMP(n) do { } while (0)
 #endif
 struct alignas(16) WideScan {
     int lo, hi, clo, chi;
@@ -273,8 +294,14 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
     // The depth-major records of WIDE items — a few per cent of a list — and the scan words go out as scattered 16 / 48-byte stores;
     // the lines of a block are neighbours in those rows, so the pieces of a 64-byte sector meet in the L2 of the XCD the block runs
     // on before it is written back.  3 KB of LDS per block instead of 70: the size of a block is its threads and registers alone.
-    constexpr int kPreItems = (kPreLines * kPreDepths + kPreBlock - 1) / kPreBlock;  // items per thread
+    // (54 lines per block: models of at most 56 depth points — every MARCS model has 56 — where 54 x 56 items are three per thread)
+    constexpr int kItemDepths = kPreLines == 54 ? 56 : kPreDepths;
+    constexpr int kPreItems = (kPreLines * kItemDepths + kPreBlock - 1) / kPreBlock;  // items per thread
     static_assert(kPreLines <= 64, "lines per pre-pass block");
+#ifdef SDX_PRE_STATS
+    unsigned long long pst[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    SDX_PRE_STAMP(0);
     constexpr int kMaxWaves = kPreBlock / 64;
     __shared__ int64_t s_c[kPreLines];
     __shared__ double s_red[kMaxWaves];
@@ -309,19 +336,33 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
 #define SDX_LINE_OF(ll) (gather ? (int64_t)s_l[ll] : l0 + (ll))
     const int nd = min(kPreDepths, n_depth - d0);
     const unsigned nd_magic = small_div_magic(nd);  // (items k < kPreLines kPreDepths = 4096)
-    // line centres first: a 128-entry sample of the grid in LDS brackets the answer (requested before everything else: the
-    // block's first barrier waits for these loads only)
-    __shared__ double s_coarse[128];
-    const int64_t cstride = (n_nu + 127) / 128;
-    if (tid < 128) {
+    // line centres first: a sample of the grid in LDS brackets the answer — 128 points read from the grid itself where the block
+    // also scans the grid spacing (<= 16384 points), otherwise the 2048 points the grid-spacing launch left (kGridSample): a
+    // bracket of at most 64 points up to 131 072 grid points, i.e. no dependent global load before the one that resolves it
+    // (rounds 1 - 4 sampled 128 points whatever the grid, and at 120 398 points a block spent 5.9 of its 26 us on four bisection
+    // steps in global memory — device time stamps, scripts/r5/pre_stats.sh)
+    __shared__ double s_coarse[kGridSample];
+    const int n_samp = dnu_partial ? kGridSample : 128;  // (the launch that left the partial maxima also left the sample)
+    const int64_t cstride = (n_nu + n_samp - 1) / n_samp;
+    if (dnu_partial) {
+        for (int q = tid; q < kGridSample; q += kPreBlock) s_coarse[q] = dnu_partial[kGridSampleOffset + q];
+    } else if (tid < 128) {
         const int64_t j = (int64_t)tid * cstride;
         s_coarse[tid] = j < n_nu ? nus[j] : -INFINITY;
-    } else if (tid < 128 + kPreLines) {
-        const int ll = tid - 128;
+    }
+    if (tid >= kPreBlock - kPreLines) {
+        const int ll = tid - (kPreBlock - kPreLines);
         s_lnu[ll] = ll < nl ? line_nus[SDX_LINE_OF(ll)] : 0.0;
     }
-    // The block's dense inputs are requested next (kPreItems per thread), so their latency hides behind the centre search
-    // below instead of following it.
+
+    // this thread's share of max(diff(nus)), requested now — its loads travel while the centres are searched: one of the partial
+    // maxima a launch before this one left (long grids: n_partial <= kDnuPartials < the block's threads), or its part of the scan
+    const double dnu_local = dnu_partial ? (tid < n_partial ? dnu_partial[tid] : -INFINITY) : dnu_scan_local(nus, n_nu);
+    __syncthreads();
+    SDX_PRE_STAMP(1);  // the grid sample and the line frequencies are in LDS
+    // The block's dense inputs are requested now (kPreItems per thread): their latency hides behind the centre search below —
+    // whose one global load they precede in the queue — instead of following it; requested before the barrier above they only
+    // held eighteen registers through the sample's hand-over.
     double r_dw[kPreItems], r_a[kPreItems], r_g[kPreItems];
     if constexpr (!GEN) {
 #pragma unroll
@@ -338,16 +379,13 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
             }
         }
     }
-    // small grids: this thread's part of the d_nu scan is requested now, its loads travel while the centres are searched
-    const double dnu_local = dnu_partial ? 0.0 : dnu_scan_local(nus, n_nu);
-    __syncthreads();
     // wave ll narrows the bracket of line ll to 64 points by bisection (none needed when the grid has <= 8192 points) and resolves
     // it with ONE coalesced load and a ballot — a chain of one or two dependent global loads instead of log2(N_nu / 128)
     for (int ll = tid >> 6; ll < nl; ll += kPreBlock / 64) {
         const int lane = tid & 63;
         {
             const double v = s_lnu[ll];
-            int a = 0, b = 128;  // first sample strictly below v
+            int a = 0, b = n_samp;  // first sample strictly below v
             while (a < b) {
                 const int mid = (a + b) >> 1;
                 if (s_coarse[mid] >= v) a = mid + 1; else b = mid;
@@ -366,9 +404,11 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
         }
     }
     if (tid < kPreLines) s_hwmax[tid] = 0, s_whwmax[tid] = 0;
+    SDX_PRE_STAMP(2);  // this wave's centres are found
     // d_nu (:524-526): from the partial maxima of k_dnu_partial, or — small grids — scanned here directly
     // (its barriers also publish the centres and the cleared maxima)
-    const double d_nu = dnu_partial ? block_dnu(dnu_partial, n_partial, s_red) : block_max_to_dnu(dnu_local, s_red);
+    const double d_nu = block_max_to_dnu(dnu_local, s_red);
+    SDX_PRE_STAMP(3);  // grid spacing known
 
     if constexpr (GEN) {
         // line parameters from per-line scalars and per-depth state (f1): nothing dense to read.  The per-depth and the
@@ -395,7 +435,8 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
     }
 
     // ONE arithmetic pass, depth fastest; every output of an item leaves from its thread
-    unsigned long long ev = 0;
+    constexpr bool kCountEvals = kPreLines < 48;  // (48 lines per block: culled shards only, which never count — two registers the block needs)
+    [[maybe_unused]] unsigned long long ev = 0;
     // what the scan word of an item is rebuilt from after the barrier (two registers per item instead of the word's four: three
     // items per thread have to fit 64 VGPRs — two resident blocks per CU): the half-width of a WIDE window (0: the word is empty) and
     // the core's half-width, negative when the core is delegated to the narrow role
@@ -479,9 +520,13 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
                 }
             }
         }
-        if (hi > lo) ev += (unsigned long long)(hi - lo);
+        if constexpr (kCountEvals) {
+            if (hi > lo) ev += (unsigned long long)(hi - lo);
+        }
     }
+    SDX_PRE_STAMP(4);  // arithmetic and per-item stores issued
     __syncthreads();
+    SDX_PRE_STAMP(5);
     // the scan words (depth-major): every tile of the wide role scans the word of a line it considers — all lines of a short
     // list, the hlist / wlist lines of a long one.  A line of a long list without a wide window at any depth is in neither
     // list: its 16 bytes per depth (0.9 of 2.8 GB of pre-pass writes at 1e6 lines) are not written.
@@ -518,20 +563,30 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
             w.lnu32[SDX_LINE_OF(tid)] = float2v{(float)lnu, (float)(lnu - (double)(float)lnu)};
         }
     }
-    if (w.evals) {
-        for (int off = 32; off > 0; off >>= 1) ev += __shfl_xor(ev, off);
-        if ((tid & 63) == 0) s_ev[tid >> 6] = ev;
-        __syncthreads();
-        if (tid == 0) {
-            for (int i = 1; i < (nthreads >> 6); ++i) ev += s_ev[i];
-            if (ev) atomicAdd(w.evals, ev);
+    if constexpr (kCountEvals) {
+        if (w.evals) {
+            for (int off = 32; off > 0; off >>= 1) ev += __shfl_xor(ev, off);
+            if ((tid & 63) == 0) s_ev[tid >> 6] = ev;
+            __syncthreads();
+            if (tid == 0) {
+                for (int i = 1; i < (nthreads >> 6); ++i) ev += s_ev[i];
+                if (ev) atomicAdd(w.evals, ev);
+            }
         }
     }
+#ifdef SDX_PRE_STATS
+    if (tid == 0) {
+        unsigned long long* const o = g_pre_stats + (size_t)((bx * 2 + (gather ? 1 : 0)) & (kPreStatSlots - 1)) * 8;
+        o[0] = ((unsigned long long)bx << 8) | (gather ? 2 : 0) | 1;
+        for (int q = 0; q < 6; ++q) o[1 + q] = pst[q];
+        o[7] = wall_clock64();
+    }
+#endif
 #undef SDX_LINE_OF
 }
 
 template <bool GEN, int LINES>
-__global__ __launch_bounds__(kPreBlock) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(LINES >= 48 ? 8 : 4, 8))) void k_line_prepass(int n_depth, int64_t n_nu, const double* __restrict__ nus,
+__global__ __launch_bounds__(kPreBlock) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8))) void k_line_prepass(int n_depth, int64_t n_nu, const double* __restrict__ nus,
                                                          const double* __restrict__ dnu_partial, int n_partial,
                                                          int64_t n_lines, const double* __restrict__ line_nus,
                                                          const double* __restrict__ doppler,
@@ -670,7 +725,8 @@ __device__ __forceinline__ float2v region1_f32x2(float2v acc, float2v nuh, float
 
 // DEFER: the partial sums of this wave are handed back (acc_out) instead of being reduced and stored here — the kernel of dense
 // long lists has ONE reduction for both roles (line_all_body)
-template <int R, bool MIXED, bool DEFER = false>
+// STAGED (fp32-mixed mode, the kernel of very dense lists): the records of a chunk's hits reach the lanes through LDS (below)
+template <int R, bool MIXED, bool DEFER = false, bool STAGED = false>
 __device__ __forceinline__ void line_wide_walk(const int tile_idx, const int split, const int n_split, const int d, int64_t n_nu,
                                                const double* __restrict__ nus, int64_t nu_begin, int64_t nu_count, int64_t n_lines,
                                                LineWork w, double* __restrict__ plane, int64_t pld, double* __restrict__ lds_all,
@@ -785,6 +841,86 @@ __device__ __forceinline__ void line_wide_walk(const int tile_idx, const int spl
             if (m == 0) continue;
             const unsigned long long mf = __ballot(fast);
             if constexpr (MIXED) pending32 += __popcll(m);
+            if constexpr (MIXED && STAGED) {
+                // fp32-mixed mode, lists whose tiles find most of a chunk's candidates hitting (1e6 lines: 10 000 lines wider than
+                // 4096 points, every tile walks them all): the hits of the chunk are COMPACTED — one wave permutation puts hit j's line index, lane and
+                // test-free flag into lane j — and lane j fetches hit j's 32-byte fp32 record and stages it in LDS.  The walk is
+                // then over hit ordinals: a run of test-free hits is a counted loop whose records arrive by broadcast LDS reads,
+                // two per trip — no mask arithmetic, no address arithmetic, no scalar load per hit.  (Round 4's walk fetched every
+                // record with scalar loads: ~20 scalar instructions per hit — lowest set bit, read-lane, 64-bit address, two
+                // s_load, the test for the next hit — next to ~19 vector ones.)  Same records, same order, same pairing of the fp32
+                // sums: the bits of the scalar walk.  Measured in round 5 (two builds, alternating): the line kernel of the 1e6-line
+                // list 7.59 -> 6.70 ms, that of the 1.5e5-line list 1.60 -> 1.69 ms (a few hits per chunk: the staging of a chunk —
+                // three permutations, a gathered load, two hand-overs through LDS — costs more than its scalar fetches) — hence only
+                // in the kernel that very dense lists run.
+                WideRec32* const stage = reinterpret_cast<WideRec32*>(lds_all + (size_t)split * kWideLdsDoubles);  // 64 x 32 B of this wave's LDS
+                const int n_hits = __popcll(m);
+                const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));  // hit lanes below this one
+                const int dst = (hit ? below : n_hits + (lane - below)) << 2;  // a permutation: the hits first, in order
+                const int line_c = __builtin_amdgcn_ds_permute(dst, line);
+                const int lane_c = __builtin_amdgcn_ds_permute(dst, lane);
+                const int fast_c = __builtin_amdgcn_ds_permute(dst, fast ? 1 : 0);
+                const unsigned long long fast_o = __ballot(fast_c != 0);  // bit j: hit j is test-free
+                if (lane < n_hits) stage[lane] = rec32_row[line_c];
+                wave_sync();
+                int k = 0;
+                while (k < n_hits) {
+                    const unsigned long long rest = ~(fast_o >> k);
+                    const int run = rest ? __builtin_ctzll(rest) : 64;  // test-free hits from ordinal k on
+                    for (int j = 0; j < run; j += 2) {
+                        // two hits per trip; an odd last one runs a second time with a zero amplitude (adds exactly 0)
+                        const bool two = j + 1 < run;
+                        const WideRec32 ra = stage[k + j];
+                        WideRec32 rb = stage[k + j + (two ? 1 : 0)];
+                        rb.yk = two ? rb.yk : 0.f;
+#pragma unroll
+                        for (int r = 0; r < R / 2; ++r) {
+                            acc32[r] = region1_f32x2(acc32[r], nu_h[r], nu_l[r], ra);
+                            acc32[r] = region1_f32x2(acc32[r], nu_h[r], nu_l[r], rb);
+                        }
+                    }
+                    k += run;
+                    if (k >= n_hits) break;
+                    // hit k touches a window edge or the core (the fp64 branch below has the commentary)
+                    const int b = __builtin_amdgcn_readlane(lane_c, k);
+                    const int e = __builtin_amdgcn_readlane(line_c, k);
+                    ++k;
+                    const WideRec cur = rec_row[e];
+                    const WideRec32 cur32 = rec32_row[e];
+                    const int jlo = __builtin_amdgcn_readlane(sc.lo, b), jhi = __builtin_amdgcn_readlane(sc.hi, b);
+                    const int jc = __builtin_amdgcn_readlane(sc.clo, b), jchi = __builtin_amdgcn_readlane(sc.chi, b);
+                    const bool delegated = jc < 0;
+                    const int jclo = delegated ? -jc - 1 : jc;
+                    const RegionI k1 = {cur.yk, cur.cv, cur.cd};
+                    float2v term32[R / 2];  // sum + fp32 rational of every point pair, once per hit
+#pragma unroll
+                    for (int p = 0; p < R / 2; ++p) term32[p] = region1_f32x2(acc32[p], nu_h[p], nu_l[p], cur32);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const int a = it0 + 64 * r, z = min(a + 64, it1);
+                        if (z <= jlo || a >= jhi || a >= it1) continue;
+                        const bool over_core = !(z <= jclo || a >= jchi);
+                        if (!over_core || delegated) {
+                            const int ir = idx0 + 64 * r;
+                            const bool take = ir >= jlo && ir < jhi && !(over_core && ir >= jclo && ir < jchi);
+                            acc32[r >> 1][r & 1] = take ? term32[r >> 1][r & 1] : acc32[r >> 1][r & 1];
+                        } else {
+                            const WideSlow sl = slow_row[e];
+                            if (idx0 + 64 * r >= jlo && idx0 + 64 * r < jhi) {
+                                const double nu_r = (double)nu_h[r >> 1][r & 1] + (double)nu_l[r >> 1][r & 1];
+                                acc[r] = voigt_add(acc[r], nu_r - cur.lnu, cur.inv, sl.y, sl.amp, k1);
+                            }
+                        }
+                    }
+                }
+                wave_sync();  // (the next chunk's records go into the same LDS)
+                if (pending32 >= 48) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) acc[r] += (double)acc32[r >> 1][r & 1], acc32[r >> 1][r & 1] = 0.f;
+                    pending32 = 0;
+                }
+                continue;
+            }
             // walk the hits in ascending order.  The record is fetched with scalar loads straight into SGPRs, which the fp64
             // instructions take as operands (one each): no copy, no vector registers.  Its latency is not hidden by a
             // software prefetch — carrying a record across iterations makes the compiler park it in 12 VGPRs and move it
@@ -1106,6 +1242,7 @@ __device__ __forceinline__ void classify_block(const int bid, const int n_blocks
 __device__ __forceinline__ void dnu_partial_block(const int bid, const int n_blocks, int64_t n_nu, const double* __restrict__ nus,
                                                   double* __restrict__ partial, double* s_red)
 {
+    grid_sample_block(bid, n_blocks, n_nu, nus, partial + kGridSampleOffset);
     // four independent pairs of loads in flight per thread: the scan is a chain of round trips, not a stream (the grid sits in L2)
     double m0 = -INFINITY, m1 = -INFINITY, m2 = -INFINITY, m3 = -INFINITY;
     const int64_t step = (int64_t)n_blocks * blockDim.x;
@@ -1657,7 +1794,7 @@ __device__ __forceinline__ void line_all_body(int n_wide, int tiles, int n_split
             if (tile >= tiles) return;
         }
         if constexpr (SUBSETS) {
-            line_wide_walk<R, MIXED, true>(tile, wave, n_split, d, n_nu, nus, nu_begin, nu_count, n_lines, w, planes, pld, s_wide, part);
+            line_wide_walk<R, MIXED, true, MIXED>(tile, wave, n_split, d, n_nu, nus, nu_begin, nu_count, n_lines, w, planes, pld, s_wide, part);
             out_row = d;
             out_col = (int)((nu_begin / (64 * R) + (int64_t)tile) * (64 * R)) + (int)(threadIdx.x & 63);
         } else {
@@ -2338,7 +2475,7 @@ constexpr int kContPoints = 1;
 // Pre-pass and continuum in ONE launch: the pre-pass is a few latency-bound blocks (binary searches, a grid scan);
 // the continuum plane depends on nothing and fills the rest of the chip meanwhile.
 template <bool GEN, int LINES>
-__global__ __launch_bounds__(kPreBlock) __attribute__((amdgpu_num_sgpr(80))) void k_prepass_continuum(int n_pre_x, int n_pre_y, int cont_tiles, int n_depth, int64_t n_nu,
+__global__ __launch_bounds__(kPreBlock) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8))) void k_prepass_continuum(int n_pre_x, int n_pre_y, int cont_tiles, int n_depth, int64_t n_nu,
                                                               const double* __restrict__ nus,
                                                               const double* __restrict__ dnu_partial, int n_partial,
                                                               int64_t n_lines, const double* __restrict__ line_nus,
@@ -2355,12 +2492,23 @@ __global__ __launch_bounds__(kPreBlock) __attribute__((amdgpu_num_sgpr(80))) voi
                            gammas, gamma_cols, alphas, w, nullptr, nullptr, n_line_blocks, lp);
     } else {
         const int c = b - n_pre;
+#ifdef SDX_PRE_STATS
+        const unsigned long long st0 = wall_clock64();
+#endif
         if (stage_table & 2)  // bit 1: depth-group blocks (the per-depth factors of a group fit LDS); bits 4..7: depths per block
             continuum_tile_block(c % cont_tiles, c / cont_tiles, (stage_table >> 4) & 15, n_depth, nu_begin, nu_count, nus, ca, cont_plane, cont_ld,
                                  (stage_table & 1) != 0);
         else
             total_alphas_block<kContPoints>(c % cont_tiles, c / cont_tiles, n_depth, nu_begin, nu_count, nus, ca, nullptr, 0, 1, nullptr, 0,
                                             cont_plane, cont_ld, (stage_table & 1) != 0);
+#ifdef SDX_PRE_STATS
+        if (threadIdx.x == 0) {
+            unsigned long long* const o = g_pre_stats + (size_t)((kPreStatSlots / 2 + c) & (kPreStatSlots - 1)) * 8;
+            o[0] = ((unsigned long long)c << 8) | 4 | 1;
+            o[1] = st0;
+            o[7] = wall_clock64();
+        }
+#endif
     }
 }
 

@@ -127,7 +127,7 @@ struct sdx_ctx {
 
 namespace {
 
-constexpr size_t kSmallHeader = 4096;  // [0,2048): d_nu partials; [2048,2056): evaluation counter
+constexpr size_t kSmallHeader = 4096 + 8 * (size_t)sdx::kGridSample;  // [0,2048): d_nu partials; [2048,2056): evaluation counter; [2064, ..): ticket counters; [4096, ..): grid sample
 
 int ensure(sdx_ctx* ctx, void** buf, size_t* have, size_t need)
 {
@@ -819,7 +819,9 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
     static const int pre_lines_env = knob("SDX_PRE_LINES") ? std::atoi(knob("SDX_PRE_LINES")) : 0;  // experiment knob: 32, 48 or 64 on culled shards
     const bool will_cull = fill_work && !no_cull_early && n_lines >= ctx->indexed_min_lines && !count_evals && !gen && n_nu > 16384 && nu_count < n_nu;
     // (lists long enough for the counter-driven launch keep 32: its looping kernel has no registers to spare for a third item)
-    if (will_cull && !lo_ref && (n_lines + 31) / 32 < ctx->prepass_ticket_min_blocks) pre_lines = (pre_lines_env == 32 || pre_lines_env == 48) ? pre_lines_env : 48;
+    // (54 when the model has at most 56 depth points — every MARCS model — and three items per thread still cover the block)
+    if (will_cull && !lo_ref && (n_lines + 31) / 32 < ctx->prepass_ticket_min_blocks)
+        pre_lines = (pre_lines_env == 32 || pre_lines_env == 48) ? pre_lines_env : (n_depth <= 56 ? 54 : 48);
     const int n_line_blocks = (int)((n_lines + pre_lines - 1) / pre_lines);
     int n_pixel_blocks = 0;
     if (fill_work) {
@@ -889,6 +891,14 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
         if (tile_shmem <= 48 * 1024 && cont_dgs_env != 0) {
             // depths per block: as many as leave ~2 x 1024 threads of such blocks per CU (one depth per block on small grids)
             int dgs = (int)std::max<int64_t>(1, std::min<int64_t>(kContDepths, ((int64_t)p->cont_tiles * threads / kPreBlock * n_depth) / (2 * (int64_t)ctx->n_cu)));
+            if (threads == kPreBlock) {
+                // ... next to the launch's pre-pass blocks: ALL blocks of the launch in one round of the chip's 2 x n_cu slots of 1024
+                // threads (S-c2: 133 pre-pass blocks + 448 one-depth tiles were 581 on 512 slots — the 69 of the second round ended
+                // the launch at 15.6 us where two depths per tile end it at 12.0; device time stamps, scripts/r5/pre_stats.sh)
+                const int64_t slots = std::max<int64_t>(1, 2 * (int64_t)ctx->n_cu - ((int64_t)n_line_blocks + n_pixel_blocks) * ((n_depth + kPreDepths - 1) / kPreDepths));
+                const int64_t fit = ((int64_t)p->cont_tiles * n_depth + slots - 1) / slots;
+                dgs = (int)std::max<int64_t>(dgs, std::min<int64_t>(kContDepths, fit));
+            }
             // riding with the classification stream (256-thread blocks) the chip is full anyway: as many depths per block as
             // there are — the per-frequency work (table search, nu^-3, Rayleigh powers) is then shared by eight points
             if (threads == kBlock) dgs = kContDepths;
@@ -989,6 +999,7 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
         else if (gen) hipLaunchKernelGGL((k_prepass_continuum<true, 32>), dim3(total_blocks), dim3(kPreBlock), shmem, ctx->stream, SDX_PRE_ARGS);
         else if (pre_lines == 16) hipLaunchKernelGGL((k_prepass_continuum<false, 16>), dim3(total_blocks), dim3(kPreBlock), shmem, ctx->stream, SDX_PRE_ARGS);
         else if (pre_lines == 48) hipLaunchKernelGGL((k_prepass_continuum<false, 48>), dim3(total_blocks), dim3(kPreBlock), shmem, ctx->stream, SDX_PRE_ARGS);
+        else if (pre_lines == 54) hipLaunchKernelGGL((k_prepass_continuum<false, 54>), dim3(total_blocks), dim3(kPreBlock), shmem, ctx->stream, SDX_PRE_ARGS);
         else hipLaunchKernelGGL((k_prepass_continuum<false, 32>), dim3(total_blocks), dim3(kPreBlock), shmem, ctx->stream, SDX_PRE_ARGS);
 #undef SDX_PRE_ARGS
         }
@@ -1002,9 +1013,11 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
 #define SDX_TICKET_ARGS n_depth, n_nu, nus, dnu_arg, n_partial, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, w, n_line_blocks, lp
             if (pre_lines == 16) hipLaunchKernelGGL((k_line_prepass_ticket<16>), pgrid, dim3(kPreBlock), 0, ctx->stream, SDX_TICKET_ARGS);
             else if (pre_lines == 48) hipLaunchKernelGGL((k_line_prepass_ticket<48>), pgrid, dim3(kPreBlock), 0, ctx->stream, SDX_TICKET_ARGS);
+            else if (pre_lines == 54) hipLaunchKernelGGL((k_line_prepass_ticket<54>), pgrid, dim3(kPreBlock), 0, ctx->stream, SDX_TICKET_ARGS);
             else hipLaunchKernelGGL((k_line_prepass_ticket<32>), pgrid, dim3(kPreBlock), 0, ctx->stream, SDX_TICKET_ARGS);
 #undef SDX_TICKET_ARGS
         } else if (pre_lines == 48) hipLaunchKernelGGL((k_line_prepass<false, 48>), grid, dim3(kPreBlock), 0, ctx->stream, SDX_PRE_ARGS);
+        else if (pre_lines == 54) hipLaunchKernelGGL((k_line_prepass<false, 54>), grid, dim3(kPreBlock), 0, ctx->stream, SDX_PRE_ARGS);
         else if (gen && pre_lines == 16) hipLaunchKernelGGL((k_line_prepass<true, 16>), grid, dim3(kPreBlock), 0, ctx->stream, SDX_PRE_ARGS);
         else if (gen) hipLaunchKernelGGL((k_line_prepass<true, 32>), grid, dim3(kPreBlock), 0, ctx->stream, SDX_PRE_ARGS);
         else if (pre_lines == 16) hipLaunchKernelGGL((k_line_prepass<false, 16>), grid, dim3(kPreBlock), 0, ctx->stream, SDX_PRE_ARGS);
@@ -2651,6 +2664,19 @@ int sdx_synthesize_sharded_f64(sdx_group* g, int n_depth, int64_t n_nu, const do
 }
 
 }  // extern "C"
+
+#ifdef SDX_PRE_STATS
+// analysis build only (scripts/r5/pre_stats.sh): the phase time stamps of the pre-pass blocks of the launches so far, then cleared
+extern "C" int sdx_pre_stats_read(unsigned long long* out, long long n_words)
+{
+    const size_t bytes = std::min<size_t>((size_t)n_words * 8, sizeof(unsigned long long) * (size_t)sdx::kPreStatSlots * 8);
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(sdx::g_pre_stats), bytes) != hipSuccess) return -1;
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(sdx::g_pre_stats)) != hipSuccess) return -1;
+    return hipMemset(p, 0, sizeof(unsigned long long) * (size_t)sdx::kPreStatSlots * 8) == hipSuccess ? 0 : -1;
+}
+#endif
 
 #ifdef SDX_WALK_STATS
 // analysis build only (scripts/r4/walk_stats.sh): the line kernel's wave statistics of the launches so far, then cleared
