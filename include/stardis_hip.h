@@ -28,9 +28,12 @@
  *       SDX_RT_NS         4: segmented kernel with 4 waves x 14 gaps instead of 8 x 7
  *       SDX_RT_P          1, 2, 4: angles per lane of k_raytrace
  *       SDX_R_MIXED       4 / 8: grid points per lane of a mixed-precision tile
+ *       SDX_NO_NARROW_SUBSETS, SDX_NARROW_SUBSETS_DENSITY (halves of a line per grid point from which the narrow role of a long
+ *                         list splits its candidate lines over the four waves of a workgroup; default 8 = four lines per point)
  *     scheduling and layout only (same bits): SDX_NARROW_F (1, 2, 4 frequencies per narrow wave), SDX_NARROW_ORDER,
  *       SDX_WIDE_GROUP, SDX_CONT_DGS, SDX_CLS_BLOCKS (workgroups of a shard's classification stream), SDX_NO_CULL,
- *       SDX_NO_CONT_RIDE, SDX_NO_PREPASS_TICKET, SDX_NO_HSCAN, SDX_NO_PINNED_STAGING,
+ *       SDX_NO_CONT_RIDE, SDX_NO_PREPASS_TICKET, SDX_NO_PREPASS_FRONT, SDX_PRE_LINES (32 / 48 lines per pre-pass block of a
+ *       culled shard), SDX_NO_HSCAN, SDX_NO_PINNED_STAGING,
  *       SDX_SPLIT_LAUNCHES (the two roles of the line kernel as two launches, for profiling)
  *     test hook: SDX_GROUP_LOOPBACK (see sdx_group_create).
  */

@@ -365,7 +365,9 @@ class PinnedPool:
         ptr = self._take(cap)
         if ptr is None:
             return None
-        block = (C.c_char * nbytes).from_address(ptr)
+        # (the ctypes array type is made per size CLASS — ctypes keeps every array type it ever built — and the numpy view is cut
+        # from it: a caller that asks for many different sizes does not grow that cache without bound)
+        block = (C.c_char * cap).from_address(ptr)
         weakref.finalize(block, self._give_back, ptr, cap)  # every view of the array keeps `block` alive through .base
         return np.frombuffer(block, dtype=dtype, count=count).reshape(shape)
 

@@ -706,12 +706,18 @@ __device__ __forceinline__ void wide_reduce_and_store(const int split, const int
 
 // fp32 evaluation of the region-I rational for the mixed-precision mode, TWO grid points per instruction (v_pk_add / mul /
 // fma_f32: a packed instruction issues like one fp64 instruction and does two evaluations; only the reciprocal is per
-// point).  x comes from the hi / lo split of both frequencies (nu_i - nu_l is exact to ~1e-7 relative whatever their
-// distance), everything else is plain fp32 (v_rcp_f32 is good to 1 ulp).
-__device__ __forceinline__ float2v region1_f32x2(float2v acc, float2v nuh, float2v nul, const WideRec32& k)
+// point).  x = fma(dq, inv, c0) like the fp64 walk's: dq = the lane's frequencies as OFFSETS from the tile's base frequency
+// (formed in fp64, rounded once: 1.2e4 Hz at the far end of a tile, 1e-5 of a Doppler width) and c0 = (base - nu_l) * inv from
+// the hi / lo split of the line frequency, formed once per (line, tile) — ONE packed instruction per pair of points where rounds
+// 2 - 4 spent three on the hi / lo split of both frequencies (round 5: 18 -> 14 packed instructions per line and lane).
+// Everything else is plain fp32 (v_rcp_f32 is good to 1 ulp).
+__device__ __forceinline__ float region1_c0(float base_h, const WideRec32& k)
 {
-    // x = ((nuh - k.nuh) + (nul - k.nul)) * inv in three packed instructions
-    const float2v x = __builtin_elementwise_fma(nul, (float2v)(k.inv), __builtin_elementwise_fma(nuh - k.nuh, (float2v)(k.inv), (float2v)(k.ncl)));
+    return fmaf(base_h - k.nuh, k.inv, k.ncl);  // ((base_h - nuh) - nul) * inv: the difference of two fp32 frequencies is exact
+}
+__device__ __forceinline__ float2v region1_f32x2(float2v acc, float2v dq, float c0, const WideRec32& k)
+{
+    const float2v x = __builtin_elementwise_fma(dq, (float2v)(k.inv), (float2v)(c0));
     const float2v v = __builtin_elementwise_fma(x, x, (float2v)(k.cv));
     const float2v den = __builtin_elementwise_fma(v, v, (float2v)(k.cd));
     const float2v num = __builtin_elementwise_fma((float2v)(k.yk), v, (float2v)(k.yk));
@@ -749,7 +755,7 @@ __device__ __forceinline__ void line_wide_walk(const int tile_idx, const int spl
     // (the fp64 value is their exact sum to 2^-48, rebuilt on the rare general path), so that R = 8 points per lane fit the
     // register budget
     double dnu[MIXED ? 1 : R], acc[R];
-    float2v nu_h[MIXED ? R / 2 : 1], nu_l[MIXED ? R / 2 : 1], acc32[MIXED ? R / 2 : 1];  // pairs of points (r, r + 1)
+    float2v dq[MIXED ? R / 2 : 1], acc32[MIXED ? R / 2 : 1];  // pairs of points (r, r + 1): offsets from the tile's base frequency, fp32 sums
     // (grid index of point r of this lane: it0 + lane + 64 r, formed where it is needed — an edge test, the final store —
     // instead of living in registers through the walk)
     const int idx0 = it0 + lane;
@@ -760,15 +766,16 @@ __device__ __forceinline__ void line_wide_walk(const int tile_idx, const int spl
     // instruction reads one SGPR pair), otherwise the compiler moves nu_l into vector registers for every line it walks
     double nu_base_vec = nu_base;
     asm("" : "+v"(nu_base_vec));
+    // mixed mode: the base frequency as an fp32 number (in a VGPR: it meets the record's scalar operands in one instruction)
+    float base_h = (float)nu_base;
+    asm("" : "+v"(base_h));
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int64_t i = t0 + lane + r * 64;
         const double nu = i < t1 ? nus[i] : nu_base;
         acc[r] = 0.0;
         if constexpr (MIXED) {
-            const float h = (float)nu;
-            nu_h[r >> 1][r & 1] = h;
-            nu_l[r >> 1][r & 1] = (float)(nu - (double)h);
+            dq[r >> 1][r & 1] = (float)(nu - (double)base_h);  // (exact in fp64, rounded once)
             acc32[r >> 1][r & 1] = 0.f;
         } else {
             dnu[r] = nu - nu_base;
@@ -873,10 +880,11 @@ __device__ __forceinline__ void line_wide_walk(const int tile_idx, const int spl
                         const WideRec32 ra = stage[k + j];
                         WideRec32 rb = stage[k + j + (two ? 1 : 0)];
                         rb.yk = two ? rb.yk : 0.f;
+                        const float ca = region1_c0(base_h, ra), cb = region1_c0(base_h, rb);
 #pragma unroll
                         for (int r = 0; r < R / 2; ++r) {
-                            acc32[r] = region1_f32x2(acc32[r], nu_h[r], nu_l[r], ra);
-                            acc32[r] = region1_f32x2(acc32[r], nu_h[r], nu_l[r], rb);
+                            acc32[r] = region1_f32x2(acc32[r], dq[r], ca, ra);
+                            acc32[r] = region1_f32x2(acc32[r], dq[r], cb, rb);
                         }
                     }
                     k += run;
@@ -893,8 +901,9 @@ __device__ __forceinline__ void line_wide_walk(const int tile_idx, const int spl
                     const int jclo = delegated ? -jc - 1 : jc;
                     const RegionI k1 = {cur.yk, cur.cv, cur.cd};
                     float2v term32[R / 2];  // sum + fp32 rational of every point pair, once per hit
+                    const float c32 = region1_c0(base_h, cur32);
 #pragma unroll
-                    for (int p = 0; p < R / 2; ++p) term32[p] = region1_f32x2(acc32[p], nu_h[p], nu_l[p], cur32);
+                    for (int p = 0; p < R / 2; ++p) term32[p] = region1_f32x2(acc32[p], dq[p], c32, cur32);
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
                         const int a = it0 + 64 * r, z = min(a + 64, it1);
@@ -907,7 +916,7 @@ __device__ __forceinline__ void line_wide_walk(const int tile_idx, const int spl
                         } else {
                             const WideSlow sl = slow_row[e];
                             if (idx0 + 64 * r >= jlo && idx0 + 64 * r < jhi) {
-                                const double nu_r = (double)nu_h[r >> 1][r & 1] + (double)nu_l[r >> 1][r & 1];
+                                const double nu_r = nus[(int64_t)idx0 + 64 * r];  // (a core kept by the wide role: rare; the exact frequency)
                                 acc[r] = voigt_add(acc[r], nu_r - cur.lnu, cur.inv, sl.y, sl.amp, k1);
                             }
                         }
@@ -943,10 +952,11 @@ __device__ __forceinline__ void line_wide_walk(const int tile_idx, const int spl
                         const WideRec32 ra = rec32_row[e];
                         WideRec32 rb = rec32_row[e1];
                         rb.yk = two ? rb.yk : 0.f;
+                        const float ca = region1_c0(base_h, ra), cb = region1_c0(base_h, rb);
 #pragma unroll
                         for (int r = 0; r < R / 2; ++r) {
-                            acc32[r] = region1_f32x2(acc32[r], nu_h[r], nu_l[r], ra);
-                            acc32[r] = region1_f32x2(acc32[r], nu_h[r], nu_l[r], rb);
+                            acc32[r] = region1_f32x2(acc32[r], dq[r], ca, ra);
+                            acc32[r] = region1_f32x2(acc32[r], dq[r], cb, rb);
                         }
                         m = two ? (m1 & (m1 - 1)) : m1;
                         continue;
@@ -984,8 +994,9 @@ __device__ __forceinline__ void line_wide_walk(const int tile_idx, const int spl
                     const double c0 = (nu_base_vec - cur.lnu) * cur.inv;
                     float2v term32[MIXED ? R / 2 : 1];  // mixed mode: sum + fp32 rational of every point pair, once per hit
                     if constexpr (MIXED) {
+                        const float c32 = region1_c0(base_h, cur32);
 #pragma unroll
-                        for (int p = 0; p < R / 2; ++p) term32[p] = region1_f32x2(acc32[p], nu_h[p], nu_l[p], cur32);
+                        for (int p = 0; p < R / 2; ++p) term32[p] = region1_f32x2(acc32[p], dq[p], c32, cur32);
                     }
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
@@ -1007,7 +1018,7 @@ __device__ __forceinline__ void line_wide_walk(const int tile_idx, const int spl
                             const WideSlow sl = slow_row[e];
                             if (idx0 + 64 * r >= jlo && idx0 + 64 * r < jhi) {
                                 if constexpr (MIXED) {
-                                    const double nu_r = (double)nu_h[MIXED ? r >> 1 : 0][r & 1] + (double)nu_l[MIXED ? r >> 1 : 0][r & 1];
+                                    const double nu_r = nus[(int64_t)idx0 + 64 * r];  // (a core kept by the wide role: rare; the exact frequency)
                                     acc[r] = voigt_add(acc[r], nu_r - cur.lnu, cur.inv, sl.y, sl.amp, k1);
                                 } else {
                                     // x from the tile offsets like every other point of the tile (a core kept here is wider than 128
@@ -1807,7 +1818,9 @@ __device__ __forceinline__ void line_all_body(int n_wide, int tiles, int n_split
         // its own.  Workgroups p, p + 8, ... (one XCD) therefore take GROUPS of kNarrowGroup consecutive workgroups' worth
         // of frequencies, the groups going round the XCDs.  (Giving each XCD one contiguous eighth of the grid was measured
         // 45 % slower: the lines per grid point follow the frequency, so one XCD gets several times the work of another.)
-        constexpr int kNarrowGroup = 4;
+        // (SUBSETS: a workgroup is ONE group of frequencies, not four — sixteen workgroups keep the 64 consecutive frequencies per XCD
+        // whose lines' records then meet in one L2)
+        constexpr int kNarrowGroup = SUBSETS ? 16 : 4;
         // F consecutive frequencies per wave (roles bits 8-11: 1, 2 or 4 — 8 was measured slower), groups aligned
         // to the global grid
         const int F = max(1, (roles >> 8) & 15);

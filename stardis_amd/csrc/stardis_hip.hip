@@ -1131,7 +1131,9 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
     if (narrow_sub) narrow_f = 4;
     const int64_t n_grp = (nu_begin + nu_count + narrow_f - 1) / narrow_f - nu_begin / narrow_f;
     const int64_t n_narrow_units = n_grp * ((n_depth + 63) / 64);
-    const int64_t n_narrow = (((narrow_sub ? n_narrow_units : (n_narrow_units + n_split - 1) / n_split) + 31) / 32) * 32;
+    // (whole rounds of the XCD-aware order: 8 XCDs x groups of 4 workgroups, 16 in the subsets kernel)
+    const int64_t narrow_round = narrow_sub ? 128 : 32;
+    const int64_t n_narrow = (((narrow_sub ? n_narrow_units : (n_narrow_units + n_split - 1) / n_split) + narrow_round - 1) / narrow_round) * narrow_round;
     static const int narrow_order = knob("SDX_NARROW_ORDER") ? atoi(knob("SDX_NARROW_ORDER")) & 3 : 0;
     REQUIRE(n_wide + n_narrow < ((int64_t)1 << 31), "line opacity: grid too large for one launch");
     static const bool split_launches = knob("SDX_SPLIT_LAUNCHES") != nullptr;  // analysis knob: time the two roles apart

@@ -192,3 +192,46 @@ def test_bench_starts_its_own_ranks_when_no_rendezvous_is_set(tmp_path):
     assert proc.returncode != 0
     assert "launch with torch.distributed.run" not in text
     assert text.count("no HIP device") >= 1 or "Found no NVIDIA driver" in text or "HIP" in text, text[-2000:]
+
+
+def _worker_classes(rank, world, port, n_lines, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch
+
+    from stardis_amd import parallel
+
+    parallel.init_from_env("gloo")
+    g = parallel.ClassificationGatherer(n_lines, world, rank, "cpu")
+    begin, count = g.share
+    m_max = np.arange(n_lines, dtype=np.float64) ** 1.5 + 0.25  # stands for the per-line maxima
+    g.send[:count] = torch.from_numpy(m_max[begin : begin + count])
+    full = g.gather()
+    np.save(os.path.join(out_dir, f"classes{rank}.npy"), np.concatenate([[begin, count, g.per], full.numpy()]))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_lines", [150000, 9001])
+def test_two_ranks_exchange_their_classification_shares(tmp_path, n_lines):
+    """The optional second collective of strong-scaled long lists (parallel.ClassificationGatherer): each rank owns an equal share of
+    the line list, and after ONE all-gather every rank holds the per-line maxima of the whole list at index = line."""
+    import torch.multiprocessing as mp
+
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_worker_classes, args=(r, 2, port, n_lines, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    want = np.arange(n_lines, dtype=np.float64) ** 1.5 + 0.25
+    shares = []
+    for r in range(2):
+        got = np.load(tmp_path / f"classes{r}.npy")
+        begin, count, per = (int(x) for x in got[:3])
+        assert per == -(-n_lines // 2) and begin == r * per and got[3:].size == 2 * per
+        assert np.array_equal(got[3 : 3 + n_lines], want)
+        shares.append((begin, count))
+    assert shares[0][1] + shares[1][1] == n_lines and shares[1][0] == shares[0][1]
