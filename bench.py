@@ -916,6 +916,9 @@ def main():
             "timed_region": ("the K steps follow the W warm-up steps directly" if settle == 0 else
                              f"K steps after W warm-up steps + {settle} untimed settling steps (~0.5 s: clocks; runs of >= 200 steps skip it); "
                              "ms_per_step_cold = the same K steps timed right after the W warm-up steps"),
+            "counters_from": "instruction counts (roofline_fp64_valu) and HBM traffic (roofline.traffic, hbm_traffic) are read from the committed "
+                             "rocprofv3 PMC passes under profiles/ (newest round), not counted in this run; every time in this line is "
+                             "measured in this run; a figure is refused when the committed pass does not hold exactly the kernels that ran",
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
