@@ -1,10 +1,11 @@
 // sdx_kernels.h — HIP kernels of the STARDIS hot path for gfx950.  Included once by stardis_hip.hip.
 //
-// Data layout in HBM
+// Data layout in HBM (DESIGN.md section 3 has the table)
 //   inputs   reference layout: line arrays [N_l][N_d] (doppler, alpha, gamma[N_l][N_d|1]), grid nus[N_nu] descending.
-//   pre-pass depth-major SoA  [N_d][N_l]: inv_dw, y, amp (f64) and lo, hi (i32 window bounds); so that a
-//            (depth, line-range) read in the line kernel is contiguous.  32 B per (line, depth).
-//   outputs  [N_d][ld] with the frequency index contiguous: every kernel has lane <-> nu, coalesced.
+//   pre-pass WIDE items (half-width > 64 points) depth-major [N_d][N_l], split by use: scan words 16 B, records 48 B, slow part
+//            16 B (+ 32 B fp32 records in the mixed mode); NARROW items line-major [N_l][N_d]: a one-byte half-width and three
+//            f64 (1 / doppler, y, amplitude) — struct LineWork below.
+//   outputs  [N_d][ld] with the frequency index contiguous.
 #pragma once
 #include <type_traits>
 
@@ -136,10 +137,10 @@ __device__ __forceinline__ int64_t window_rule(int64_t c, int64_t n_nu, double d
 }
 
 // ------------------------------------------------------------------------------------------------
-// Pre-pass: one block = 32 lines x up to 64 depths.  Reads the reference layout coalesced into LDS,
-// writes the depth-major SoA coalesced.
-// lines per pre-pass block: 16 (one (line, depth) item per thread) for short lists whose blocks all fit the chip at once, 32 (two
-// items per thread: the block's latency chain is paid once for twice the items) for long ones — a template parameter
+// Pre-pass: one block = kPreLines lines x up to 64 depths, 1024 threads, the (line, depth) items in registers (prepass_block).
+// lines per pre-pass block — a template parameter: 16 (one item per thread) for short lists whose blocks all fit the chip at once,
+// 32 (two items per thread: the block's latency chain is paid once for twice the items) for long ones, 48 / 54 (three) for the
+// culled pre-pass of a frequency shard, whose blocks then fit ONE round of the chip
 constexpr int kPreDepths = 64;
 constexpr int kPreBlock = 1024;  // threads per pre-pass block: one (line, depth) item per thread, 16 waves to hide latency
 
