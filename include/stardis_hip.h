@@ -25,6 +25,7 @@
  *     changes kernel choice or summation order (last bits of a result; shards of one spectrum must agree on them):
  *       SDX_WIDE_BLOCKS   target number of wide-role workgroups -> line subsets per (depth, tile)
  *       SDX_RT_SEG        0 / 1: never / always the segmented formal-solution kernel (the option "segmented_raytrace" wins)
+ *       SDX_FAR           0 / 1: never / always the far field of the line kernels (the option "far_field" wins); SDX_FAR_RF 1 / 2 / 4
  *       SDX_RT_NS         4: segmented kernel with 4 waves x 14 gaps instead of 8 x 7
  *       SDX_RT_P          1, 2, 4: angles per lane of k_raytrace
  *       SDX_R_MIXED       4 / 8: grid points per lane of a mixed-precision tile
@@ -102,7 +103,18 @@ int sdx_synchronize(sdx_ctx* ctx);
  *       a fixed constant (grids under 3 x 4 x 256 k_raytrace waves take the segmented kernel) — never from the shard's own
  *       width or the device's CU count, so that a frequency shard and the unsharded grid run the same arithmetic and stay
  *       bit-identical; 0: never the segmented kernel; 1: whenever it supports the shape.  The fp32-mixed twins (*_f32mix) that
- *       SURVEY §8b proposed are this library's "mixed_precision" option instead: one set of entry points, two modes. */
+ *       SURVEY §8b proposed are this library's "mixed_precision" option instead: one set of entry points, two modes.
+ *   "far_field" (default -1): the far field of the line opacity.  A (line, depth) item whose window (base.py:561-575) contains a whole
+ *       256-point tile of the GLOBAL grid, clear of the line's core range (every point of the tile in Faddeeva region I) and with the
+ *       line's centre at least three tile widths (6 half-widths, measured in frequency) from the tile's centre, is not evaluated at
+ *       the tile's 256 grid points but at its 16 Chebyshev nodes — the same region-I rational, fp64 — and the summed node values are
+ *       carried to the grid points by the degree-15 interpolant (k_line_far; a third partial plane).  Nine tenths of the window
+ *       evaluations of the 3000 - 10000 A workloads are such triples.  Interpolation error <= 11.9^-16 = 6e-18 of an item's value;
+ *       measured against the direct sum: <= 7e-15 relative on the line opacity, 7e-13 on the flux (tolerances 1e-12 / 1e-10).
+ *       Which triples are far is a property of the grid and the list, not of the shard: shards stay bit-identical to the unsharded
+ *       run.  -1: grids of at least 32768 frequencies (decided from the GLOBAL grid); 0: never — every window point is evaluated
+ *       where it lies, as the reference does; 1: whenever the line kernel runs 256-point tiles (always, unless an experiment knob
+ *       says otherwise). */
 int sdx_set_int_option(sdx_ctx* ctx, const char* name, int64_t value);
 
 /* device memory for callers that do not bring their own (numpy-only users) */

@@ -32,6 +32,8 @@ a = a_all[(a_all[:, 0] >> np.uint64(62)) == 2]
 key = a[:, 0]
 d = ((key >> np.uint64(40)) & np.uint64(0xFFFF)).astype(float); tile = ((key >> np.uint64(8)) & np.uint64(0xFFFFFF)).astype(float); split = (key & np.uint64(0xFF)).astype(float)
 t0, t1 = a[:, 1].astype(float), a[:, 2].astype(float)
+flush_us = (a[:, 3] >> np.uint64(32)).astype(float) / 100.0  # (queued walks of the far-field kernels: time spent evaluating queued hits)
+a[:, 3] &= np.uint64(0xFFFFFFFF)
 chunks, fast, general, b_if, b_slow = (a[:, k].astype(float) for k in range(3, 8))
 dur = (t1 - t0) / 100.0
 start, end = (t0 - t0.min()) / 100.0, (t1 - t0.min()) / 100.0
@@ -39,6 +41,7 @@ print(f"{tag} shard {shard}: {len(a)} wide waves; launch span {end.max():.1f} us
 X = np.stack([np.ones_like(dur), chunks, fast, general, b_if, b_slow], axis=1)
 coef, *_ = np.linalg.lstsq(X, dur, rcond=None)
 print("fit [us]: const %.2f, per scan chunk %.3f, per test-free hit %.3f, per general hit %.3f, per region-I block %.3f, per full-Voigt block %.3f" % tuple(coef))
+print("queued evaluation: mean %.1f us per wave of %.1f" % (flush_us.mean(), ((t1 - t0) / 100.0).mean()))
 print("mean per wave: chunks %.1f fast %.1f general %.1f blocks_if %.1f blocks_slow %.1f" % (chunks.mean(), fast.mean(), general.mean(), b_if.mean(), b_slow.mean()))
 print("share of the summed wave time: const %.0f%% chunks %.0f%% fast %.0f%% general %.0f%% if %.0f%% slow %.0f%%" % tuple(100 * coef * X.sum(axis=0) / dur.sum()))
 depths = sorted(set(d.astype(int)))

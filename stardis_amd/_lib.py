@@ -283,6 +283,12 @@ class Context:
     def call(self, name, *args):
         check(getattr(self.lib, name)(self.handle, *args))
 
+    def profile(self, kernel):
+        """(launches, milliseconds) recorded under `kernel` since sdx_profile_reset (sdx_profile_enable(1) switches recording on)."""
+        cnt, ms = C.c_int64(), C.c_double()
+        check(self.lib.sdx_profile_get(self.handle, kernel.encode(), C.byref(cnt), C.byref(ms)))
+        return cnt.value, ms.value
+
     @property
     def pinned(self):
         """The context's pool of page-locked host arrays (PinnedPool)."""

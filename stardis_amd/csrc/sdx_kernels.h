@@ -11,6 +11,7 @@
 
 #include "sdx_math.h"
 #include "sdx_broadening.h"
+#include "sdx_cheb.h"
 
 namespace sdx {
 
@@ -239,6 +240,11 @@ struct LineWork {
     unsigned long long* evals;
     int* ticket;  // culled runs: the pre-pass launch's work counter, one per depth block (zeroed by k_hlist_count), or nullptr
     int front;    // culled runs: the blocks with work are the FIRST blocks of the pre-pass grid (k_line_prepass maps its block index)
+    // far field (k_line_far): the (line, depth, tile) triples that far_eligible() accepts are left to k_line_far — the wide role
+    // skips them — and their sum reaches the grid through the tile's 16 Chebyshev nodes (a third plane).
+    // far_range[2 T], [2 T + 1] (k_far_ranges): a line is far from global tile T when its centre index is < the first or > the second
+    // (0 and INT_MAX: tile T has no far field); nullptr = no far field in this launch
+    const int* far_range;
 };
 
 // k / d for 0 <= k < 65536 and 1 <= d < 65536 with the divisor's reciprocal m = small_div_magic(d) = ceil(2^32 / d): one multiply-high
@@ -675,9 +681,77 @@ __global__ __launch_bounds__(kPreBlock) __attribute__((amdgpu_num_sgpr(80), amdg
 // point — does not depend on the tile or on how the grid is sharded.
 // The S subsets of a (depth, tile) are the S waves of one workgroup: their partial sums meet in LDS and wave 0 adds them in
 // subset order and writes the tile — one line-opacity plane, no atomics, bit-stable results.
-constexpr int kWideLdsDoubles = 64 * 8;  // per wave: R <= 8 partial sums per lane
+// ------------------------------------------------------------------------------------------------
+// FAR FIELD.  The reference's window of a strong line spans thousands of grid points ((gamma + doppler) alpha / d_nu * 20 pixels,
+// base.py:561-575): nine tenths of all window evaluations of the 3000 - 10000 A workloads lie more than two tiles away from
+// the line's centre, where the profile is the region-I rational — a smooth function of frequency whose nearest singularity is
+// the line itself.  For a full tile [i0, i1) of 64 R points with end frequencies nu_a > nu_b, centre c = (nu_a + nu_b) / 2 and
+// half-width h = (nu_a - nu_b) / 2, a (line, depth) item is FAR when the tile lies wholly inside its window, clear of its core
+// range (every point in region I) and |c - nu_l| >= 6 h (decided in index space, k_far_ranges).  The sum of the far items of a tile is then evaluated at the tile's
+// kFarNodes = 16 Chebyshev nodes c + h cos(pi (j + 1/2) / 16) — the same rational, the same records, fp64 — and carried to
+// the tile's grid points by the degree-15 interpolant (k_line_far): 16 evaluations per (item, tile) instead of 64 R.  The
+// interpolation error of a function analytic inside the ellipse through a pole at distance D from the centre is
+// ~ (D/h + sqrt((D/h)^2 - 1))^-16 <= 11.9^-16 = 6e-18 of the item's value; measured against 80-bit sums of the far items of
+// S-c3's tiles: 2.5e-14 relative, rounding included (the direct fp64 sum: 4e-15).  The opacity tolerance is 1e-12, the flux's 1e-10.
+// Which triples are far is a property of the grid and the list (global tiles), not of the shard or the launch geometry; both
+// kernels decide it with THIS function on the same operands, so every triple is evaluated exactly once.
+constexpr double kFarRatio = 6.0;
+constexpr int kFarTile = 256;  // the far field lives on the 256-point tiles of the fp64 line kernel (R = 4)
+constexpr int kFarWaveLdsDoubles = 64 * 6 + 64;  // per wave of k_line_far: 64 staged records, the queue's line indices and tile masks
+// centre and half-width of a tile from its end frequencies (exact halvings of one rounded sum / difference each)
+__device__ __forceinline__ void far_tile_geometry(double nu_a, double nu_b, double& c, double& h)
+{
+    c = mul_rn(0.5, add_rn(nu_a, nu_b));
+    h = mul_rn(0.5, sub_rn(nu_a, nu_b));
+}
+// The distance test in INDEX space, once per tile (one thread each): a line's centre index is cidx = #{i : nus[i] >= nu_l}
+// (closest_index, the reference's own quantity), so with ihi = #{i : nus[i] >= c + 6 h} and ilo = #{i : nus[i] >= c - 6 h}
+//   cidx < ihi  =>  nu_l > nus[ihi - 1] >= c + 6 h        cidx > ilo  =>  nu_l <= nus[ilo] < c - 6 h
+// — rigorous on any descending grid, whatever its spacing does, and the kernels compare integers per candidate instead of
+// carrying its frequency.  Tiles without a far field (cut by the grid's end, or of zero width) get (0, INT_MAX): never far.
+__global__ __launch_bounds__(kBlock) void k_far_ranges(int64_t n_nu, const double* __restrict__ nus, int64_t tile_first, int64_t tile_count,
+                                                        int* __restrict__ far_range)
+{
+    const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (k >= tile_count) return;
+    const int64_t T = tile_first + k, i0 = T * kFarTile;
+    int ihi = 0, ilo = 0x7FFFFFFF;
+    if (i0 + kFarTile <= n_nu) {
+        double c, h;
+        far_tile_geometry(nus[i0], nus[i0 + kFarTile - 1], c, h);
+        if (h > 0.0) {
+            const double reach = mul_rn(kFarRatio, h);
+            ihi = (int)closest_index(nus, n_nu, add_rn(c, reach));
+            ilo = (int)closest_index(nus, n_nu, sub_rn(c, reach));
+        }
+    }
+    far_range[2 * T] = ihi;
+    far_range[2 * T + 1] = ilo;
+}
+// The centre index itself is not needed: the core range of a scan word always holds it (prepass_block: clo <= c <= chi, both equal
+// to c where the core is empty), so chi < ihi or clo > ilo decide the same thing from the 16 bytes every candidate test reads anyway
+// — conservatively where a core is wide, which only leaves a few more tiles to the direct sum.
+__device__ __forceinline__ bool far_eligible(const WideScan& sc, int i0, int i1, int ihi, int ilo)
+{
+    const int clo = sc.clo < 0 ? -sc.clo - 1 : sc.clo;
+    return (sc.lo <= i0) & (sc.hi >= i1) & ((i1 <= clo) | (i0 >= sc.chi)) & ((sc.chi < ihi) | (clo > ilo));
+}
 
-template <int R>
+constexpr int kWideLdsDoubles = 64 * 8;  // per wave: R <= 8 partial sums per lane
+// ... and in the fp64 kernels with a far field, whose wide role queues its hits (line_wide_walk): 64 staged records (48 B), their
+// scan words (16 B) and the queue itself (64 ints)
+constexpr int kWideFarLdsDoubles = 64 * 6 + 64 * 2 + 32;
+#ifndef SDX_WIDE_QUEUED  // (A/B builds: 0 = the direct walk in the far-field kernels too)
+#define SDX_WIDE_QUEUED 1
+#endif
+#ifndef SDX_SCAN_BATCH   // (A/B builds: chunks of candidates requested together by a queued walk)
+#define SDX_SCAN_BATCH 1
+#endif
+#ifndef SDX_FAR_WAVES    // (A/B builds: waves per SIMD the fp64 far-field line kernels are compiled for)
+#define SDX_FAR_WAVES 6
+#endif
+
+template <int R, int STRIDE = kWideLdsDoubles>
 __device__ __forceinline__ void wide_reduce_and_store(const int split, const int n_split, double (&acc)[R], const int idx0, const int64_t s0,
                                                       const int64_t s1, double* __restrict__ lds_all, double* __restrict__ plane, int64_t pld,
                                                       const int d)
@@ -685,14 +759,14 @@ __device__ __forceinline__ void wide_reduce_and_store(const int split, const int
     const int lane = threadIdx.x & 63;
     if (n_split > 1) {
         if (split > 0) {
-            double* mine = lds_all + (size_t)split * kWideLdsDoubles;
+            double* mine = lds_all + (size_t)split * STRIDE;
 #pragma unroll
             for (int r = 0; r < R; ++r) mine[r * 64 + lane] = acc[r];
         }
         __syncthreads();
         if (split == 0) {
             for (int s = 1; s < n_split; ++s) {
-                const double* other = lds_all + (size_t)s * kWideLdsDoubles;
+                const double* other = lds_all + (size_t)s * STRIDE;
 #pragma unroll
                 for (int r = 0; r < R; ++r) acc[r] = add_rn(acc[r], other[r * 64 + lane]);
             }
@@ -733,7 +807,7 @@ __device__ __forceinline__ float2v region1_f32x2(float2v acc, float2v dq, float 
 // DEFER: the partial sums of this wave are handed back (acc_out) instead of being reduced and stored here — the kernel of dense
 // long lists has ONE reduction for both roles (line_all_body)
 // STAGED (fp32-mixed mode, the kernel of very dense lists): the records of a chunk's hits reach the lanes through LDS (below)
-template <int R, bool MIXED, bool DEFER = false, bool STAGED = false>
+template <int R, bool MIXED, bool DEFER = false, bool STAGED = false, bool FAR = false>
 __device__ __forceinline__ void line_wide_walk(const int tile_idx, const int split, const int n_split, const int d, int64_t n_nu,
                                                const double* __restrict__ nus, int64_t nu_begin, int64_t nu_count, int64_t n_lines,
                                                LineWork w, double* __restrict__ plane, int64_t pld, double* __restrict__ lds_all,
@@ -782,6 +856,15 @@ __device__ __forceinline__ void line_wide_walk(const int tile_idx, const int spl
             dnu[r] = nu - nu_base;
         }
     }
+    // far field: the triples k_line_far evaluates at the tile's Chebyshev nodes are no hits here (full tiles only)
+    // (FAR is a kernel of its own: the candidate's centre index is one more register carried through the walk, and the walk's
+    // budget has none to spare — with the test in the one kernel its sums spilled to scratch)
+    static_assert(!FAR || kTile == kFarTile, "the far field lives on 256-point tiles");
+    [[maybe_unused]] int far_ihi = 0, far_ilo = 0x7FFFFFFF;  // (never far)
+    if constexpr (FAR) {
+        far_ihi = __builtin_amdgcn_readfirstlane(w.far_range[2 * (t0 / kTile)]);
+        far_ilo = __builtin_amdgcn_readfirstlane(w.far_range[2 * (t0 / kTile) + 1]);
+    }
     const size_t row = (size_t)d * n_lines;
     const WideScan* __restrict__ scan_row = w.wscan + row;
     const WideScan* __restrict__ hscan_row = w.hscan + row;
@@ -792,8 +875,75 @@ __device__ __forceinline__ void line_wide_walk(const int tile_idx, const int spl
     int pending32 = 0;  // fp32 terms accumulated since the last flush into the fp64 sums
 #ifdef SDX_WALK_STATS
     const unsigned long long st_t0 = wall_clock64();
-    int st_chunks = 0, st_fast = 0, st_general = 0, st_if = 0, st_slow = 0;
+    int st_chunks = 0, st_fast = 0, st_general = 0, st_if = 0, st_slow = 0, st_flush = 0;  // (st_flush: ticks spent evaluating queued hits)
 #endif
+
+    // With a far field the hits that remain are few (the near zone of a line, window edges, cores: ~1 per chunk of 64 candidates
+    // at S-c3 where the direct walk met 14), and a wave that fetches the record of every hit where it meets it is one dependent
+    // round trip after the other (measured: 3.4 us per chunk).  The fp64 kernels with a far field therefore QUEUE their hits in LDS —
+    // line index + test-free flag, list order — and evaluate a full queue (64 hits) at once: lane j fetches hit j's record and scan
+    // word, all in one round trip, into LDS; the wave then goes through them with broadcast reads.  Same hits, same order, same
+    // arithmetic as the direct walk.
+    constexpr bool QUEUED = FAR && !MIXED && SDX_WIDE_QUEUED;
+    constexpr int kLdsStride = QUEUED ? kWideFarLdsDoubles : kWideLdsDoubles;
+    [[maybe_unused]] WideRec* const q_rec = reinterpret_cast<WideRec*>(lds_all + (size_t)split * kLdsStride);  // 64 x 48 B
+    [[maybe_unused]] WideScan* const q_sc = reinterpret_cast<WideScan*>(lds_all + (size_t)split * kLdsStride + 64 * 6);
+    [[maybe_unused]] int* const q_ent = reinterpret_cast<int*>(lds_all + (size_t)split * kLdsStride + 64 * 8);
+    [[maybe_unused]] int q_count = 0;
+    [[maybe_unused]] auto q_flush = [&](int cnt) {
+      if constexpr (QUEUED) {
+        if (cnt == 0) return;
+        wave_sync();
+        const bool mine = lane < cnt;
+        const int ent = mine ? q_ent[lane] : 0;
+        const int ql = ent & 0x7FFFFFFF;
+        if (mine) {
+            q_rec[lane] = rec_row[ql];
+            q_sc[lane] = scan_row[ql];
+        }
+        const unsigned long long mfq = __ballot(mine && ent < 0);
+        wave_sync();
+        for (int k = 0; k < cnt; ++k) {
+            const WideRec cur = q_rec[k];  // (one address for the whole wave: a broadcast read)
+            const RegionI k1 = {cur.yk, cur.cv, cur.cd};
+            const double c0 = (nu_base_vec - cur.lnu) * cur.inv;
+            if ((mfq >> k) & 1) {
+                region1_add_shared<R>(acc, dnu, cur.inv, c0, k1);
+#ifdef SDX_WALK_STATS
+                ++st_fast;
+#endif
+                continue;
+            }
+#ifdef SDX_WALK_STATS
+            ++st_general;
+#endif
+            // the tile touches a window edge or the core (the direct walk below has the commentary)
+            const WideScan hs = q_sc[k];
+            const int jlo = __builtin_amdgcn_readfirstlane(hs.lo), jhi = __builtin_amdgcn_readfirstlane(hs.hi);
+            const int jc = __builtin_amdgcn_readfirstlane(hs.clo), jchi = __builtin_amdgcn_readfirstlane(hs.chi);
+            const bool delegated = jc < 0;
+            const int jclo = delegated ? -jc - 1 : jc;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int a = it0 + 64 * r, z = min(a + 64, it1);
+                if (z <= jlo || a >= jhi || a >= it1) continue;
+                const bool over_core = !(z <= jclo || a >= jchi);
+#ifdef SDX_WALK_STATS
+                if (!over_core || delegated) ++st_if; else ++st_slow;
+#endif
+                if (!over_core || delegated) {
+                    const int ir = idx0 + 64 * r;
+                    const bool take = ir >= jlo && ir < jhi && !(over_core && ir >= jclo && ir < jchi);
+                    acc[r] = region1_add_if(acc[r], fma(dnu[MIXED ? 0 : r], cur.inv, c0), k1, take);
+                } else {
+                    const WideSlow sl = slow_row[__builtin_amdgcn_readlane(ql, k)];
+                    if (idx0 + 64 * r >= jlo && idx0 + 64 * r < jhi) acc[r] = voigt_add_x(acc[r], fma(dnu[MIXED ? 0 : r], cur.inv, c0), sl.y, sl.amp, k1);
+                }
+            }
+        }
+        wave_sync();  // (the queue and the staged records are written again)
+      }
+    };
 
     for (int pass = w.hlist ? 0 : 1; pass < 2; ++pass) {
         // candidate positions [ka, kb) of this pass: hlist positions (pass 0); wlist positions or — short lists — line indices (pass 1)
@@ -832,6 +982,45 @@ __device__ __forceinline__ void line_wide_walk(const int tile_idx, const int spl
                 }
             }
         };
+        if constexpr (QUEUED) {
+            // the scan of a queued walk has nothing to wait for but its own loads: kScanBatch chunks are requested together (a chunk is
+            // two dependent loads in the wlist pass), tested, and their hits appended in list order
+            constexpr int kScanBatch = SDX_SCAN_BATCH;
+            for (; q <= q_last; q += kScanBatch * n_split) {
+                int bl[kScanBatch];
+                WideScan bs[kScanBatch];
+#pragma unroll
+                for (int u = 0; u < kScanBatch; ++u) fetch(q + u * n_split, bl[u], bs[u]);
+#pragma unroll
+                for (int u = 0; u < kScanBatch; ++u) {
+                    const int line = bl[u];
+                    const WideScan sc = bs[u];
+                    const bool far = far_eligible(sc, it0, it1, far_ihi, far_ilo);  // k_line_far's
+                    const bool hit = (line >= 0) & (sc.lo < it1) & (sc.hi > it0) & !far;
+                    const int clo = sc.clo < 0 ? -sc.clo - 1 : sc.clo;
+                    const bool fast = hit & (sc.lo <= it0) & (sc.hi >= it1) & ((it1 <= clo) | (it0 >= sc.chi));
+                    const unsigned long long m = __ballot(hit);
+#ifdef SDX_WALK_STATS
+                    if (q + u * n_split <= q_last) ++st_chunks;
+#endif
+                    if (m == 0) continue;
+                    const int n = __popcll(m);
+                    if (q_count + n > 64) {
+#ifdef SDX_WALK_STATS
+                        const unsigned long long tq = wall_clock64();
+#endif
+                        q_flush(q_count);
+#ifdef SDX_WALK_STATS
+                        st_flush += (int)(wall_clock64() - tq);
+#endif
+                        q_count = 0;
+                    }
+                    if (hit) q_ent[q_count + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = line | (fast ? (int)0x80000000 : 0);
+                    q_count += n;
+                }
+            }
+            continue;
+        }
         int line_next;
         WideScan sc_next;
         fetch(q, line_next, sc_next);
@@ -839,7 +1028,8 @@ __device__ __forceinline__ void line_wide_walk(const int tile_idx, const int spl
             const int line = line_next;
             const WideScan sc = sc_next;
             fetch(q + n_split, line_next, sc_next);
-            const bool hit = (line >= 0) & (sc.lo < it1) & (sc.hi > it0);  // narrow / empty items have lo = hi = 0
+            const bool far = FAR && far_eligible(sc, it0, it1, far_ihi, far_ilo);  // k_line_far's
+            const bool hit = (line >= 0) & (sc.lo < it1) & (sc.hi > it0) & !far;  // narrow / empty items have lo = hi = 0
             const int clo = sc.clo < 0 ? -sc.clo - 1 : sc.clo;                // sign: core delegated to the narrow role
             const bool fast = hit & (sc.lo <= it0) & (sc.hi >= it1) & ((it1 <= clo) | (it0 >= sc.chi));
             unsigned long long m = __ballot(hit);
@@ -1044,6 +1234,13 @@ __device__ __forceinline__ void line_wide_walk(const int tile_idx, const int spl
             }
         }
     }
+#ifdef SDX_WALK_STATS
+    const unsigned long long tq_last = wall_clock64();
+#endif
+    if constexpr (QUEUED) q_flush(q_count);
+#ifdef SDX_WALK_STATS
+    st_flush += (int)(wall_clock64() - tq_last);
+#endif
     if constexpr (MIXED) {
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] += (double)acc32[r >> 1][r & 1];
@@ -1053,14 +1250,14 @@ __device__ __forceinline__ void line_wide_walk(const int tile_idx, const int spl
         const int slot = ((d * 512 + tile_idx) * 8 + split) & (kWalkStatSlots / 2 - 1);
         unsigned long long* const o = g_walk_stats + (size_t)slot * 8;
         o[0] = ((unsigned long long)d << 40) | ((unsigned long long)tile_idx << 8) | (unsigned long long)split | (1ull << 63);
-        o[1] = st_t0, o[2] = wall_clock64(), o[3] = st_chunks, o[4] = st_fast, o[5] = st_general, o[6] = st_if, o[7] = st_slow;
+        o[1] = st_t0, o[2] = wall_clock64(), o[3] = (unsigned long long)st_chunks | ((unsigned long long)(unsigned)st_flush << 32), o[4] = st_fast, o[5] = st_general, o[6] = st_if, o[7] = st_slow;
     }
 #endif
     if constexpr (DEFER) {
 #pragma unroll
         for (int r = 0; r < R; ++r) acc_out[r] = acc[r];
     } else {
-        wide_reduce_and_store<R>(split, n_split, acc, idx0, s0, s1, lds_all, plane, pld, d);
+        wide_reduce_and_store<R, kLdsStride>(split, n_split, acc, idx0, s0, s1, lds_all, plane, pld, d);
     }
 }
 
@@ -1769,7 +1966,7 @@ __device__ __forceinline__ void line_narrow_subsets32(const int64_t i0, const in
 // cross-stream fork/join would cost two ~12 us inter-queue edges per step, one grid costs nothing.
 // roles: bit 0 wide, bit 1 narrow (both by default; one at a time for split-launch profiling, SDX_SPLIT_LAUNCHES=1).
 // Output planes: [0] the wide windows (all subsets summed), [1] the narrow windows.
-template <int R, bool MIXED, bool SUBSETS>
+template <int R, bool MIXED, bool SUBSETS, bool FAR = false>
 __device__ __forceinline__ void line_all_body(int n_wide, int tiles, int n_split, int n_depth, int64_t n_nu,
                                                    const double* __restrict__ nus, int64_t nu_begin, int64_t nu_count,
                                                    int64_t n_lines, const double* __restrict__ line_nus, LineWork w,
@@ -1806,11 +2003,11 @@ __device__ __forceinline__ void line_all_body(int n_wide, int tiles, int n_split
             if (tile >= tiles) return;
         }
         if constexpr (SUBSETS) {
-            line_wide_walk<R, MIXED, true, MIXED>(tile, wave, n_split, d, n_nu, nus, nu_begin, nu_count, n_lines, w, planes, pld, s_wide, part);
+            line_wide_walk<R, MIXED, true, MIXED, FAR>(tile, wave, n_split, d, n_nu, nus, nu_begin, nu_count, n_lines, w, planes, pld, s_wide, part);
             out_row = d;
             out_col = (int)((nu_begin / (64 * R) + (int64_t)tile) * (64 * R)) + (int)(threadIdx.x & 63);
         } else {
-            line_wide_walk<R, MIXED>(tile, wave, n_split, d, n_nu, nus, nu_begin, nu_count, n_lines, w, planes, pld, s_wide);
+            line_wide_walk<R, MIXED, false, false, FAR>(tile, wave, n_split, d, n_nu, nus, nu_begin, nu_count, n_lines, w, planes, pld, s_wide);
         }
     } else {
         if (!(roles & 2)) return;
@@ -1863,16 +2060,17 @@ __device__ __forceinline__ void line_all_body(int n_wide, int tiles, int n_split
         }
     }
     if constexpr (SUBSETS) {
+        constexpr int kLdsStride = (FAR && !MIXED && SDX_WIDE_QUEUED) ? kWideFarLdsDoubles : kWideLdsDoubles;  // (the wide walk's)
         const int lane = threadIdx.x & 63;
         if (wave > 0) {
-            double* mine = s_wide + (size_t)wave * kWideLdsDoubles;
+            double* mine = s_wide + (size_t)wave * kLdsStride;
 #pragma unroll
             for (int r = 0; r < R; ++r) mine[r * 64 + lane] = part[r];
         }
         __syncthreads();
         if (wave == 0) {
             for (int s = 1; s < n_split; ++s) {
-                const double* other = s_wide + (size_t)s * kWideLdsDoubles;
+                const double* other = s_wide + (size_t)s * kLdsStride;
 #pragma unroll
                 for (int r = 0; r < R; ++r) part[r] = add_rn(part[r], other[r * 64 + lane]);
             }
@@ -1888,22 +2086,259 @@ __device__ __forceinline__ void line_all_body(int n_wide, int tiles, int n_split
     }
 }
 
-template <int R, bool SUBSETS = false>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_line_all(int n_wide, int tiles, int n_split, int n_depth, int64_t n_nu,
+template <int R, bool SUBSETS = false, bool FAR = false>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FAR ? SDX_FAR_WAVES : 7, 8))) void k_line_all(int n_wide, int tiles, int n_split, int n_depth, int64_t n_nu,
                                                    const double* __restrict__ nus, int64_t nu_begin, int64_t nu_count,
                                                    int64_t n_lines, const double* __restrict__ line_nus, LineWork w,
                                                    double* __restrict__ planes, int64_t pld, int roles)
 {
-    line_all_body<R, false, SUBSETS>(n_wide, tiles, n_split, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, planes, pld, roles);
+    line_all_body<R, false, SUBSETS, FAR>(n_wide, tiles, n_split, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, planes, pld, roles);
 }
 // the mixed-precision variant: 512-point tiles; the register budget is capped at 128 (4 waves per SIMD) — what exceeds it
 // sits in the rarely taken fp64 general path
-template <int R, bool SUBSETS = false>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(R == 4 ? 6 : 4, 8))) void k_line_all_mixed(
+template <int R, bool SUBSETS = false, bool FAR = false>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(R == 4 ? (FAR ? 5 : 6) : 4, 8))) void k_line_all_mixed(
     int n_wide, int tiles, int n_split, int n_depth, int64_t n_nu, const double* __restrict__ nus, int64_t nu_begin, int64_t nu_count,
     int64_t n_lines, const double* __restrict__ line_nus, LineWork w, double* __restrict__ planes, int64_t pld, int roles)
 {
-    line_all_body<R, true, SUBSETS>(n_wide, tiles, n_split, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, planes, pld, roles);
+    line_all_body<R, true, SUBSETS, FAR>(n_wide, tiles, n_split, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, planes, pld, roles);
+}
+
+// FAR FIELD of the line opacity (far_eligible above): the third plane of the line kernels.  One workgroup owns (depth d, a unit of
+// 4 RF consecutive global tiles); lane <-> (tile 4 r + lane / 16 of the unit, Chebyshev node lane % 16), r < RF.  Its n_split waves go
+// through the candidate lists exactly as the wide role does (hlist, then the wlist range around the unit; chunk q of 64 candidates
+// belongs to wave q mod n_split): each lane tests ONE candidate against every tile of the unit (tile geometry is wave-uniform) and
+// keeps the mask of the tiles it is far from; the hits are walked in ascending order with scalar record fetches and evaluated at the
+// lanes' nodes with the wide role's own arithmetic (x = fma(dnu, inv, c0), region1_add) — test-free when the candidate is far from
+// every tile of the unit.  The waves' node sums meet in LDS (subset order), wave 0 turns the 16 node values of a tile into the
+// coefficients of its Chebyshev series (kFarCoef), and every wave evaluates the series of its share of the tiles at their grid
+// points (Clenshaw) and writes the plane — zeros where a tile has no far field.  The sum of a (tile, node) adds its lines in list
+// order within a subset and the subsets in order, whatever RF and whatever the shard: RF is pure scheduling.
+template <int R, int RF>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_line_far(int units, int n_split, int n_depth, int64_t n_nu,
+                                                                                           const double* __restrict__ nus, int64_t nu_begin, int64_t nu_count,
+                                                                                           int64_t n_lines, LineWork w, double* __restrict__ plane, int64_t pld)
+{
+    constexpr int kTile = 64 * R, kUnitTiles = 4 * RF;
+    extern __shared__ double s_far[];  // [n_split][64 RF] partial node sums, [64 RF] node values, [64 RF] coefficients, [n_split][kFarWaveLdsDoubles]
+    const int lane = threadIdx.x & 63;
+    const int split = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int d = blockIdx.x / units, u = blockIdx.x - d * units;
+    const int64_t T_first = nu_begin / kTile, T_last = (nu_begin + nu_count - 1) / kTile;  // the global tiles that hold the shard's columns
+    const int64_t Tu = (T_first / kUnitTiles + u) * kUnitTiles;                          // units are aligned to the global tiles too
+    const int64_t Ta = max(Tu, T_first), Tb = min(Tu + kUnitTiles - 1, T_last);
+    if (Ta > Tb) return;
+    const int64_t g0 = Ta * kTile, g1 = min((Tb + 1) * kTile, n_nu);  // the grid points of the tiles this workgroup handles
+    const int64_t s0 = nu_begin, s1 = nu_begin + nu_count;
+
+    // the tiles' far ranges, wave-uniform (scalar loads): the candidate tests below
+    static_assert(kTile == kFarTile, "the far field lives on 256-point tiles");
+    int ihi[kUnitTiles], ilo[kUnitTiles];
+    unsigned all_mask = 0;
+#pragma unroll
+    for (int t = 0; t < kUnitTiles; ++t) {
+        const int64_t T = Tu + t;
+        const bool mine = T >= Ta && T <= Tb;
+        ihi[t] = mine ? w.far_range[2 * T] : 0;
+        ilo[t] = mine ? w.far_range[2 * T + 1] : 0x7FFFFFFF;
+        all_mask |= (ihi[t] != 0 || ilo[t] != 0x7FFFFFFF) ? (1u << t) : 0u;  // (0, INT_MAX): no far field
+    }
+    if (all_mask == 0) {  // nothing but a partial last tile: zeros
+        for (int t = split; t < kUnitTiles; t += n_split) {
+            const int64_t T = Tu + t;
+            if (T < Ta || T > Tb) continue;
+            for (int p = 0; p < R; ++p) {
+                const int64_t i = T * kTile + lane + 64 * p;
+                if (i < n_nu && i >= s0 && i < s1) plane[(size_t)d * pld + (i - s0)] = 0.0;
+            }
+        }
+        return;
+    }
+    // the lane's nodes as offsets from a base frequency (the wide role's form of x) that depends on neither the shard nor RF: the
+    // first frequency of the block of 16 global tiles the unit lies in
+    const double nu_base_v = nus[(Tu / 16) * 16 * kTile];
+    const double nu_base = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(nu_base_v)), __builtin_amdgcn_readfirstlane(__double2loint(nu_base_v)));
+    double nu_base_vec = nu_base;
+    asm("" : "+v"(nu_base_vec));
+    double dnu[RF], acc[RF];
+    const int tg = lane >> 4;
+    const double node = kFarNode[lane & 15];
+#pragma unroll
+    for (int r = 0; r < RF; ++r) {
+        const int64_t T = Tu + 4 * r + tg, i0 = T * kTile;
+        acc[r] = 0.0;
+        dnu[r] = 0.0;
+        if (T >= Ta && T <= Tb && i0 + kTile <= n_nu) {
+            double c, h;
+            far_tile_geometry(nus[i0], nus[i0 + kTile - 1], c, h);
+            dnu[r] = fma(h, node, c - nu_base);
+        }
+    }
+    const size_t row = (size_t)d * n_lines;
+    const WideScan* __restrict__ scan_row = w.wscan + row;
+    const WideScan* __restrict__ hscan_row = w.hscan + row;
+    const WideRec* __restrict__ rec_row = w.wrec + row;
+    const int n_h = w.hlist ? __builtin_amdgcn_readfirstlane(*w.hcount) : 0;
+
+    // Scan and evaluation are decoupled: a wave that fetched the record of every hit when it met it spent its time waiting for one
+    // dependent load after the other (~500 hits, a microsecond each).  The hits of the chunks are QUEUED in LDS instead — line index
+    // and tile mask, in list order — and a full queue (64 hits) is evaluated at once: lane j fetches hit j's 48-byte record, all 64
+    // in ONE round trip, into LDS, and the wave goes through them with broadcast reads.
+    double* const wave_lds = s_far + (size_t)(n_split + 2) * RF * 64 + (size_t)split * kFarWaveLdsDoubles;
+    WideRec* const stage = reinterpret_cast<WideRec*>(wave_lds);  // 64 x 48 B
+    int* const q_line = reinterpret_cast<int*>(wave_lds + 64 * 6);
+    int* const q_mask = q_line + 64;
+    int count = 0;
+    auto flush = [&](int cnt) {
+        if (cnt == 0) return;
+        wave_sync();
+        const bool mine = lane < cnt;
+        const unsigned qm = mine ? (unsigned)q_mask[lane] : 0u;
+        if (mine) stage[lane] = rec_row[q_line[lane]];
+        const unsigned long long mfull = __ballot(mine && qm == all_mask);
+        wave_sync();
+        for (int k = 0; k < cnt; ++k) {
+            const WideRec cur = stage[k];  // (one address for the whole wave: a broadcast read)
+            const RegionI k1 = {cur.yk, cur.cv, cur.cd};
+            const double c0 = (nu_base_vec - cur.lnu) * cur.inv;
+            if ((mfull >> k) & 1) {  // far from every tile of the unit: no per-lane tests
+#pragma unroll
+                for (int r = 0; r < RF; ++r) acc[r] = region1_add(acc[r], fma(dnu[r], cur.inv, c0), k1);
+            } else {
+                const unsigned tm = (unsigned)__builtin_amdgcn_readlane((int)qm, k);
+#pragma unroll
+                for (int r = 0; r < RF; ++r) {
+                    if (((tm >> (4 * r)) & 15u) == 0) continue;  // (scalar)
+                    const bool take = (tm >> (4 * r + tg)) & 1u;
+                    acc[r] = region1_add_if(acc[r], fma(dnu[r], cur.inv, c0), k1, take);
+                }
+            }
+        }
+        wave_sync();  // (the queue and the staged records are written again)
+    };
+
+    for (int pass = w.hlist ? 0 : 1; pass < 2; ++pass) {
+        int ka = 0, kb = n_h;
+        if (pass == 1) {
+            kb = (int)n_lines;
+            if (w.hlist) {  // (the wide role's candidate range, around the unit instead of a tile)
+                const int64_t pa = max(g0 - kMediumHalfWidth + 1, (int64_t)0), pb = min(g1 + kMediumHalfWidth - 1, n_nu);
+                ka = __builtin_amdgcn_readfirstlane(w.wrank[w.cnt_ge[pb + 1]]);
+                kb = __builtin_amdgcn_readfirstlane(w.wrank[w.cnt_ge[pa]]);
+                if (w.sel) {
+                    ka = max(ka, __builtin_amdgcn_readfirstlane(w.wrank[w.sel[0]]));
+                    kb = min(kb, __builtin_amdgcn_readfirstlane(w.wrank[w.sel[1]]));
+                }
+            }
+        }
+        if (kb <= ka) continue;
+        const int q_first = ka >> 6, q_last = (kb - 1) >> 6;
+        int q = q_first + ((split - q_first % n_split) + n_split) % n_split;
+        auto fetch = [&](int qq, int& line, WideScan& sc) {
+            const int k = qq * 64 + lane;
+            line = -1;
+            sc = WideScan{0, 0, 0, 0};
+            if (qq <= q_last && k >= ka && k < kb) {
+                if (pass == 0) {
+                    line = w.hlist[k];
+                    sc = w.hscan ? hscan_row[k] : scan_row[line];
+                } else {
+                    line = w.hlist ? w.wlist[k] : k;
+                    sc = scan_row[line];
+                }
+            }
+        };
+        int line_next;
+        WideScan sc_next;
+        fetch(q, line_next, sc_next);
+        for (; q <= q_last; q += n_split) {
+            const int line = line_next;
+            const WideScan sc = sc_next;
+            fetch(q + n_split, line_next, sc_next);
+            unsigned tmask = 0;
+#pragma unroll
+            for (int t = 0; t < kUnitTiles; ++t) {
+                const int i0 = (int)min((Tu + t) * kTile, n_nu);  // (tiles beyond the grid: never far)
+                tmask |= far_eligible(sc, i0, i0 + kTile, ihi[t], ilo[t]) ? (1u << t) : 0u;
+            }
+            if (line < 0) tmask = 0;
+            // the hits join the wave's queue (list order); a full queue is evaluated (flush)
+            const unsigned long long m = __ballot(tmask != 0);
+            const int n = __popcll(m);
+            if (n == 0) continue;
+            if (count + n > 64) {
+                flush(count);
+                count = 0;
+            }
+            if (tmask != 0) {
+                const int at = count + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                q_line[at] = line;
+                q_mask[at] = (int)tmask;
+            }
+            count += n;
+        }
+    }
+    flush(count);
+
+    // the subsets' node sums, in subset order
+    double* red = s_far;
+    double* sV = s_far + (size_t)n_split * RF * 64;
+    double* sC = sV + RF * 64;
+    if (split > 0) {
+#pragma unroll
+        for (int r = 0; r < RF; ++r) red[((size_t)split * RF + r) * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (split == 0) {
+        for (int s = 1; s < n_split; ++s) {
+#pragma unroll
+            for (int r = 0; r < RF; ++r) acc[r] = add_rn(acc[r], red[((size_t)s * RF + r) * 64 + lane]);
+        }
+#pragma unroll
+        for (int r = 0; r < RF; ++r) sV[r * 64 + lane] = acc[r];
+        wave_sync();
+        // node values -> Chebyshev coefficients: lane <-> (tile, k)
+        const int k = lane & 15;
+#pragma unroll
+        for (int r = 0; r < RF; ++r) {
+            const double* v = sV + r * 64 + (lane & 48);
+            double c = 0.0;
+#pragma unroll
+            for (int j = 0; j < kFarNodes; ++j) c = fma(kFarCoef[k][j], v[j], c);
+            sC[r * 64 + lane] = c;  // = sC[(4 r + tg) * 16 + k]
+        }
+    }
+    __syncthreads();
+    // the series at the grid points of the tiles (Clenshaw), one tile at a time per wave
+    for (int t = split; t < kUnitTiles; t += n_split) {
+        const int64_t T = Tu + t, i0 = T * kTile;
+        if (T < Ta || T > Tb) continue;
+        bool okt = i0 + kTile <= n_nu;
+        double c = 0.0, h = 1.0;
+        if (okt) {
+            far_tile_geometry(nus[i0], nus[i0 + kTile - 1], c, h);
+            okt = h > 0.0;
+        }
+        const double rh = okt ? 1.0 / h : 0.0;
+        const double* cf = sC + t * kFarNodes;
+#pragma unroll
+        for (int p = 0; p < R; ++p) {
+            const int64_t i = i0 + lane + 64 * p;
+            if (i >= n_nu) continue;
+            double val = 0.0;
+            if (okt) {
+                const double x = (nus[i] - c) * rh, x2 = x + x;
+                double b1 = 0.0, b2 = 0.0;
+#pragma unroll
+                for (int k = kFarNodes - 1; k >= 1; --k) {
+                    const double b0 = fma(x2, b1, cf[k] - b2);
+                    b2 = b1, b1 = b0;
+                }
+                val = fma(x, b1, cf[0] - b2);
+            }
+            if (i >= s0 && i < s1) plane[(size_t)d * pld + (i - s0)] = val;
+        }
+    }
 }
 
 // out (+)= sum over the S line subsets, in subset order

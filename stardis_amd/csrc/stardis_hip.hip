@@ -84,6 +84,8 @@ struct sdx_ctx {
     // partial line-opacity planes [n_split + 1][n_depth][nu_count] (last plane: narrow windows)
     void* part_ws = nullptr;
     size_t part_ws_bytes = 0;
+    void* far_ws = nullptr;  // far_range of the line kernels' far field: two ints per global tile
+    size_t far_ws_bytes = 0;
     // cnt_ge[N_nu + 2] (lines per centre index, for the narrow-window kernel)
     void* cnt_ws = nullptr;
     size_t cnt_ws_bytes = 0;
@@ -93,6 +95,7 @@ struct sdx_ctx {
     int64_t prepass_ticket_min_blocks = 16384;  // culled shards: from this many line blocks on the pre-pass draws its work from a counter
     int64_t mixed_precision = 0;       // 1: fp32 rational for far-wing (region I) evaluations of whole-tile windows
     int64_t segmented_raytrace = -1;   // -1: by the size of the GLOBAL grid; 0 never; 1 whenever the kernel supports the shape
+    int64_t far_field = -1;            // -1: by the size of the GLOBAL grid; 0 never; 1 whenever the line kernel runs 256-point tiles
     // timing
     hipEvent_t t0 = nullptr, t1 = nullptr;
     void* cont_ws = nullptr;  // continuum plane [n_depth][nu_count] of the fused step
@@ -382,6 +385,7 @@ void sdx_destroy(sdx_ctx* ctx)
     if (ctx->line_ws) hipFree(ctx->line_ws);
     if (ctx->small_ws) hipFree(ctx->small_ws);
     if (ctx->part_ws) hipFree(ctx->part_ws);
+    if (ctx->far_ws) hipFree(ctx->far_ws);
     if (ctx->cnt_ws) hipFree(ctx->cnt_ws);
     if (ctx->io_dev) hipFree(ctx->io_dev);
     if (ctx->io_pin) hipHostFree(ctx->io_pin);
@@ -427,6 +431,10 @@ int sdx_set_int_option(sdx_ctx* ctx, const char* name, int64_t value)
     }
     if (std::strcmp(name, "segmented_raytrace") == 0) {
         ctx->segmented_raytrace = value < 0 ? -1 : (value ? 1 : 0);
+        return SDX_OK;
+    }
+    if (std::strcmp(name, "far_field") == 0) {
+        ctx->far_field = value < 0 ? -1 : (value ? 1 : 0);
         return SDX_OK;
     }
     return fail(SDX_ERR_ARG, std::string("unknown option ") + name);
@@ -1094,7 +1102,24 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
     // round 4 at S-c3 and on its eight shards with 0 / 14 / 28 such layers: line kernel 2026 / 2048 / 2092 us unsharded, 332 / 344 /
     // 346 us on the slowest shard, no change at S-c2 either: the hit lists fall off by only a factor 4 from the deepest to the
     // shallowest layer, and a launch is bound by its total work, not by its heaviest wave.  Removed.)
-    rc = ensure(ctx, &ctx->part_ws, &ctx->part_ws_bytes, (size_t)2 * n_depth * nu_count * sizeof(double));
+    // FAR FIELD (k_line_far): a third plane.  Like every choice that moves a rounding it is made from the GLOBAL grid — grids of at
+    // least kFarMinPoints frequencies (below that a launch of the line kernel is bound by latency, not by its evaluations) — or set
+    // explicitly (context option "far_field").
+    static const int far_env = knob("SDX_FAR") ? std::atoi(knob("SDX_FAR")) : -1;  // A/B knob: 0 never, 1 whenever possible
+    const int far_mode = ctx->far_field >= 0 ? (int)ctx->far_field : far_env;
+    constexpr int64_t kFarMinPoints = 32768;
+    const bool far = Rm == 4 && far_mode != 0 && (far_mode == 1 || n_nu >= kFarMinPoints);
+    w.far_range = nullptr;
+    if (far) {  // one (ihi, ilo) pair per GLOBAL tile that holds columns of this launch
+        const int64_t t_first = nu_begin / kFarTile, t_last = (nu_begin + nu_count - 1) / kFarTile;
+        rc = ensure(ctx, &ctx->far_ws, &ctx->far_ws_bytes, (size_t)((n_nu + kFarTile - 1) / kFarTile) * 2 * sizeof(int));
+        if (rc) return rc;
+        LaunchScope ls(ctx, "k_far_ranges");
+        hipLaunchKernelGGL(k_far_ranges, dim3((unsigned)((t_last - t_first + kBlock) / kBlock)), dim3(kBlock), 0, ctx->stream, n_nu, nus, t_first,
+                           t_last - t_first + 1, (int*)ctx->far_ws);
+        w.far_range = (const int*)ctx->far_ws;
+    }
+    rc = ensure(ctx, &ctx->part_ws, &ctx->part_ws_bytes, (size_t)(far ? 3 : 2) * n_depth * nu_count * sizeof(double));
     if (rc) return rc;
     double* part = (double*)ctx->part_ws;
     const int64_t pld = nu_count;
@@ -1137,7 +1162,7 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
     static const int narrow_order = knob("SDX_NARROW_ORDER") ? atoi(knob("SDX_NARROW_ORDER")) & 3 : 0;
     REQUIRE(n_wide + n_narrow < ((int64_t)1 << 31), "line opacity: grid too large for one launch");
     static const bool split_launches = knob("SDX_SPLIT_LAUNCHES") != nullptr;  // analysis knob: time the two roles apart
-    const size_t shmem = (size_t)n_split * kWideLdsDoubles * sizeof(double);
+    const size_t shmem = (size_t)n_split * (far && !ctx->mixed_precision && SDX_WIDE_QUEUED ? kWideFarLdsDoubles : kWideLdsDoubles) * sizeof(double);
     const dim3 g((unsigned)(n_wide + n_narrow)), blk((unsigned)(64 * n_split));
     for (int pass = 0; pass < (split_launches ? 2 : 1); ++pass) {
         // (raising the priority of the hot layers' waves with s_setprio was measured in round 4: the instruction has side effects as
@@ -1146,15 +1171,39 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
         LaunchScope ls(ctx, split_launches ? (pass ? "k_line_narrow" : "k_line_wide") : "k_line_all");
 #define SDX_LINE_ARGS (int)n_wide, tiles, n_split, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, part, pld, roles
         if (ctx->mixed_precision && Rm == 8) hipLaunchKernelGGL((k_line_all_mixed<8>), g, blk, shmem, ctx->stream, SDX_LINE_ARGS);
+        else if (ctx->mixed_precision && narrow_sub && far) hipLaunchKernelGGL((k_line_all_mixed<R_MIXED, true, true>), g, blk, shmem, ctx->stream, SDX_LINE_ARGS);
         else if (ctx->mixed_precision && narrow_sub) hipLaunchKernelGGL((k_line_all_mixed<R_MIXED, true>), g, blk, shmem, ctx->stream, SDX_LINE_ARGS);
+        else if (ctx->mixed_precision && far) hipLaunchKernelGGL((k_line_all_mixed<R_MIXED, false, true>), g, blk, shmem, ctx->stream, SDX_LINE_ARGS);
         else if (ctx->mixed_precision) hipLaunchKernelGGL((k_line_all_mixed<R_MIXED>), g, blk, shmem, ctx->stream, SDX_LINE_ARGS);
+        else if (narrow_sub && far) hipLaunchKernelGGL((k_line_all<R, true, true>), g, blk, shmem, ctx->stream, SDX_LINE_ARGS);
         else if (narrow_sub) hipLaunchKernelGGL((k_line_all<R, true>), g, blk, shmem, ctx->stream, SDX_LINE_ARGS);
+        else if (far) hipLaunchKernelGGL((k_line_all<R, false, true>), g, blk, shmem, ctx->stream, SDX_LINE_ARGS);
         else hipLaunchKernelGGL((k_line_all<R>), g, blk, shmem, ctx->stream, SDX_LINE_ARGS);
 #undef SDX_LINE_ARGS
     }
+    if (far) {
+        // units of 4 RF global tiles; RF (1, 2 or 4 node groups per lane) is scheduling only: the widest that still leaves ~4 workgroups per CU
+        const int64_t t_first = nu_begin / (64 * R), t_last = (nu_begin + nu_count - 1) / (64 * R);
+        auto units_of = [&](int rf) { return t_last / (4 * rf) - t_first / (4 * rf) + 1; };
+        static const int far_rf_env = knob("SDX_FAR_RF") ? std::atoi(knob("SDX_FAR_RF")) : 0;  // experiment knob: 1, 2, 4
+        int rf = 4;
+        while (rf > 1 && units_of(rf) * n_depth < (int64_t)4 * ctx->n_cu) rf >>= 1;
+        if (far_rf_env == 1 || far_rf_env == 2 || far_rf_env == 4) rf = far_rf_env;
+        const int64_t units = units_of(rf);
+        REQUIRE(units * n_depth < ((int64_t)1 << 31), "line opacity: grid too large for one launch");
+        const size_t far_shmem = (((size_t)n_split + 2) * rf * 64 + (size_t)n_split * kFarWaveLdsDoubles) * sizeof(double);
+        const dim3 fg((unsigned)(units * n_depth));
+        double* far_plane = part + (size_t)2 * n_depth * pld;
+        LaunchScope ls(ctx, "k_line_far");
+#define SDX_FAR_ARGS (int)units, n_split, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, w, far_plane, pld
+        if (rf == 4) hipLaunchKernelGGL((k_line_far<R, 4>), fg, blk, far_shmem, ctx->stream, SDX_FAR_ARGS);
+        else if (rf == 2) hipLaunchKernelGGL((k_line_far<R, 2>), fg, blk, far_shmem, ctx->stream, SDX_FAR_ARGS);
+        else hipLaunchKernelGGL((k_line_far<R, 1>), fg, blk, far_shmem, ctx->stream, SDX_FAR_ARGS);
+#undef SDX_FAR_ARGS
+    }
     *partial_out = part;
     *pld_out = pld;
-    *n_planes_out = 2;
+    *n_planes_out = far ? 3 : 2;
     if (w_out) *w_out = w;
     return check_launch("line kernels");
 }
@@ -2137,7 +2186,7 @@ int sdx_synthesize_classify_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const d
     if ((rc = check_file_planes(cont, n_nu))) return rc;
     if ((rc = ensure(ctx, &ctx->cont_ws, &ctx->cont_ws_bytes, (size_t)n_depth * nu_count * sizeof(double)))) return rc;
     // (the partial planes of the line kernels: reserved here so that the synthesis that follows moves nothing)
-    if ((rc = ensure(ctx, &ctx->part_ws, &ctx->part_ws_bytes, (size_t)2 * n_depth * nu_count * sizeof(double)))) return rc;
+    if ((rc = ensure(ctx, &ctx->part_ws, &ctx->part_ws_bytes, (size_t)3 * n_depth * nu_count * sizeof(double)))) return rc;
     const ContinuumJob job{cont, nu_begin, nu_count, (double*)ctx->cont_ws};
     const ClassifyPhase first{1, line_begin, line_count, m_max};
     ctx->classified.valid = false;

@@ -40,7 +40,7 @@ def resources():
 
 
 def test_hot_kernels_do_not_spill_vector_registers(resources):
-    hot = [k for k in resources if k.startswith(("k_line_all<", "k_raytrace<1>", "k_raytrace_seg<8", "k_line_prepass<", "k_prepass_continuum<"))]
+    hot = [k for k in resources if k.startswith(("k_line_all<", "k_line_far<", "k_raytrace<1>", "k_raytrace_seg<8", "k_line_prepass<", "k_prepass_continuum<"))]
     assert len(hot) >= 10, sorted(resources)
     for k in hot:
         assert resources[k]["spill"] == 0, (k, resources[k])
@@ -55,9 +55,12 @@ def test_prepass_blocks_fit_two_per_cu(resources):
 
 
 def test_line_kernels_keep_their_occupancy(resources):
-    assert resources["k_line_all<4, false>"]["occ"] >= 7 and resources["k_line_all<4, true>"]["occ"] >= 7
+    assert resources["k_line_all<4, false, false>"]["occ"] >= 7 and resources["k_line_all<4, true, false>"]["occ"] >= 7
+    # (the kernels of the far field queue their hits: twelve more registers, six waves — measured against five and seven)
+    assert resources["k_line_all<4, false, true>"]["occ"] >= 6 and resources["k_line_all<4, true, true>"]["occ"] >= 6
+    assert resources["k_line_far<4, 4>"]["occ"] >= 5 and resources["k_line_far<4, 1>"]["occ"] >= 7
     assert resources["k_raytrace<1>"]["occ"] >= 7 and resources["k_raytrace_seg<8, 7>"]["occ"] >= 6
-    assert resources["k_line_all_mixed<4, false>"]["occ"] >= 6
+    assert resources["k_line_all_mixed<4, false, false>"]["occ"] >= 6
 
 
 def test_analysis_builds_compile():
