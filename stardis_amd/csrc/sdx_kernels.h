@@ -47,9 +47,86 @@ __device__ __forceinline__ void grid_sample_block(const int bid, const int n_blo
 __device__ __forceinline__ void shard_range(int64_t n_nu, const double* __restrict__ nus, int64_t n_lines, const double* __restrict__ line_nus,
                                             int64_t nu_begin, int64_t nu_count, int* __restrict__ sel);
 
-__global__ __launch_bounds__(kBlock) void k_dnu_partial(int64_t n_nu, const double* __restrict__ nus,
-                                                        double* __restrict__ partial, int* __restrict__ zero, int64_t n_zero)
+// ---- far field of the line opacity: the per-tile index ranges (the commentary is at far_eligible, below) ------------------------
+constexpr double kFarRatio = 6.0;
+constexpr int kFarTile = 256;  // the far field lives on the 256-point tiles of the fp64 line kernel (R = 4)
+struct FarReq {
+    int* range;            // [2 T], [2 T + 1] per GLOBAL tile T
+    int64_t first, count;  // the tiles wanted (count = 0: none)
+};
+// centre and half-width of a tile from its end frequencies (exact halvings of one rounded sum / difference each)
+__device__ __forceinline__ void far_tile_geometry(double nu_a, double nu_b, double& c, double& h)
 {
+    c = mul_rn(0.5, add_rn(nu_a, nu_b));
+    h = mul_rn(0.5, sub_rn(nu_a, nu_b));
+}
+// first i in [lo, hi] with nus[i] < v (hi if none) on the descending grid
+__device__ __forceinline__ int64_t first_below(const double* __restrict__ nus, int64_t lo, int64_t hi, double v)
+{
+    while (lo < hi) {
+        const int64_t mid = lo + ((hi - lo) >> 1);
+        if (nus[mid] >= v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+// Sixteen lanes per (tile, bound).  On a smooth grid the bound lies 2.5 tile widths beyond the tile's end, at an offset the tile's own
+// mean spacing predicts to a few points: the lanes probe the sixteen grid points around that guess — ONE round trip behind the two
+// loads of the tile's ends — and the count of frequencies >= the bound follows from their ballot.  Where the crossing is not among
+// them (the spacing jumps), lane 0 searches: a bracket of eight tiles on that side first, then the rest of the grid.
+__device__ __forceinline__ void far_ranges_block(const int bid, const int n_blocks, int64_t n_nu, const double* __restrict__ nus, const FarReq& fr)
+{
+    const int lane = threadIdx.x & 63, sub = lane & 15, grp_shift = lane & 48;
+    const int64_t groups = (int64_t)n_blocks * (blockDim.x >> 4);
+    for (int64_t k0 = (int64_t)bid * (blockDim.x >> 4); k0 < 2 * fr.count; k0 += groups) {  // (uniform trip count per block)
+        const int64_t k = k0 + (threadIdx.x >> 4);
+        const bool live = k < 2 * fr.count;
+        const int64_t T = fr.first + (live ? k >> 1 : 0), i0 = T * kFarTile;
+        const bool upper = (k & 1) == 0;
+        int out = upper ? 0 : 0x7FFFFFFF;
+        bool search = false;
+        double v = 0.0;
+        int64_t guess = 0;
+        if (live && i0 + kFarTile <= n_nu) {
+            double c, h;
+            far_tile_geometry(nus[i0], nus[i0 + kFarTile - 1], c, h);
+            if (h > 0.0) {
+                search = true;
+                v = upper ? add_rn(c, mul_rn(kFarRatio, h)) : sub_rn(c, mul_rn(kFarRatio, h));
+                // (c +- 6 h lies 5 h beyond the tile's end: 5 / 2 * (kFarTile - 1) points at the tile's mean spacing)
+                guess = upper ? i0 - (5 * (kFarTile - 1)) / 2 : i0 + kFarTile - 1 + (5 * (kFarTile - 1)) / 2;
+            }
+        }
+        // the probes: grid points guess - 8 + sub (outside the grid: +inf above, -inf below, so that the ballot stays monotone)
+        const int64_t pi = guess - 8 + sub;
+        const double pv = !search ? 0.0 : (pi < 0 ? INFINITY : (pi >= n_nu ? -INFINITY : nus[pi]));
+        const unsigned long long ge = __ballot(search && pv >= v);
+        const unsigned m16 = (unsigned)(ge >> grp_shift) & 0xFFFFu;  // this group's sixteen answers (bit j: probe j >= v)
+        if (search) {
+            if ((m16 & 1u) && !(m16 & 0x8000u)) {
+                out = (int)(guess - 8 + __popc(m16));  // = #{i : nus[i] >= v}: every point before the window is >= v as well
+            } else if (sub == 0) {
+                if (upper) {
+                    const int64_t b0 = max(i0 - 8 * kFarTile, (int64_t)0);
+                    out = (int)((b0 == 0 || nus[b0 - 1] >= v) ? first_below(nus, b0, i0, v) : first_below(nus, 0, b0 - 1, v));
+                } else {
+                    const int64_t b1 = min(i0 + 9 * kFarTile, n_nu);
+                    out = (int)((b1 == n_nu || nus[b1] < v) ? first_below(nus, i0 + kFarTile, b1, v) : first_below(nus, b1 + 1, n_nu, v));
+                }
+            }
+        }
+        if (live && sub == 0) fr.range[2 * T + (upper ? 0 : 1)] = out;
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_far_ranges(int64_t n_nu, const double* __restrict__ nus, FarReq fr)
+{
+    far_ranges_block(blockIdx.x, gridDim.x, n_nu, nus, fr);
+}
+
+
+__global__ __launch_bounds__(kBlock) void k_dnu_partial(int64_t n_nu, const double* __restrict__ nus,
+                                                        double* __restrict__ partial, int* __restrict__ zero, int64_t n_zero, FarReq far)
+{
+    far_ranges_block(blockIdx.x, gridDim.x, n_nu, nus, far);
     // (culled pre-pass: the per-line maxima the classification pass accumulates into are cleared here, not by a memset node)
     for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < n_zero; k += (int64_t)gridDim.x * kBlock) zero[k] = 0;
     grid_sample_block(blockIdx.x, gridDim.x, n_nu, nus, partial + kGridSampleOffset);
@@ -695,39 +772,14 @@ __global__ __launch_bounds__(kPreBlock) __attribute__((amdgpu_num_sgpr(80), amdg
 // S-c3's tiles: 2.5e-14 relative, rounding included (the direct fp64 sum: 4e-15).  The opacity tolerance is 1e-12, the flux's 1e-10.
 // Which triples are far is a property of the grid and the list (global tiles), not of the shard or the launch geometry; both
 // kernels decide it with THIS function on the same operands, so every triple is evaluated exactly once.
-constexpr double kFarRatio = 6.0;
-constexpr int kFarTile = 256;  // the far field lives on the 256-point tiles of the fp64 line kernel (R = 4)
+constexpr int kFarSplit = 8;  // line subsets (waves per workgroup) of k_line_far: a shard's launch is a few hundred workgroups, its waves' chains are its duration
 constexpr int kFarWaveLdsDoubles = 64 * 6 + 64;  // per wave of k_line_far: 64 staged records, the queue's line indices and tile masks
-// centre and half-width of a tile from its end frequencies (exact halvings of one rounded sum / difference each)
-__device__ __forceinline__ void far_tile_geometry(double nu_a, double nu_b, double& c, double& h)
-{
-    c = mul_rn(0.5, add_rn(nu_a, nu_b));
-    h = mul_rn(0.5, sub_rn(nu_a, nu_b));
-}
 // The distance test in INDEX space, once per tile (one thread each): a line's centre index is cidx = #{i : nus[i] >= nu_l}
 // (closest_index, the reference's own quantity), so with ihi = #{i : nus[i] >= c + 6 h} and ilo = #{i : nus[i] >= c - 6 h}
 //   cidx < ihi  =>  nu_l > nus[ihi - 1] >= c + 6 h        cidx > ilo  =>  nu_l <= nus[ilo] < c - 6 h
 // — rigorous on any descending grid, whatever its spacing does, and the kernels compare integers per candidate instead of
 // carrying its frequency.  Tiles without a far field (cut by the grid's end, or of zero width) get (0, INT_MAX): never far.
-__global__ __launch_bounds__(kBlock) void k_far_ranges(int64_t n_nu, const double* __restrict__ nus, int64_t tile_first, int64_t tile_count,
-                                                        int* __restrict__ far_range)
-{
-    const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (k >= tile_count) return;
-    const int64_t T = tile_first + k, i0 = T * kFarTile;
-    int ihi = 0, ilo = 0x7FFFFFFF;
-    if (i0 + kFarTile <= n_nu) {
-        double c, h;
-        far_tile_geometry(nus[i0], nus[i0 + kFarTile - 1], c, h);
-        if (h > 0.0) {
-            const double reach = mul_rn(kFarRatio, h);
-            ihi = (int)closest_index(nus, n_nu, add_rn(c, reach));
-            ilo = (int)closest_index(nus, n_nu, sub_rn(c, reach));
-        }
-    }
-    far_range[2 * T] = ihi;
-    far_range[2 * T + 1] = ilo;
-}
+// (far_ranges_block, near the top of this file: it rides in the launch that measures the grid's spacing.)
 // The centre index itself is not needed: the core range of a scan word always holds it (prepass_block: clo <= c <= chi, both equal
 // to c where the core is empty), so chi < ihi or clo > ilo decide the same thing from the 16 bytes every candidate test reads anyway
 // — conservatively where a core is wide, which only leaves a few more tiles to the direct sum.
@@ -1449,8 +1501,9 @@ __device__ __forceinline__ void classify_block(const int bid, const int n_blocks
 }
 // this block's share of max(diff(nus)) -> partial[bid]  (blocks [0, n_dnu) of the classification launches)
 __device__ __forceinline__ void dnu_partial_block(const int bid, const int n_blocks, int64_t n_nu, const double* __restrict__ nus,
-                                                  double* __restrict__ partial, double* s_red)
+                                                  double* __restrict__ partial, double* s_red, const FarReq& far)
 {
+    far_ranges_block(bid, n_blocks, n_nu, nus, far);
     grid_sample_block(bid, n_blocks, n_nu, nus, partial + kGridSampleOffset);
     // four independent pairs of loads in flight per thread: the scan is a chain of round trips, not a stream (the grid sits in L2)
     double m0 = -INFINITY, m1 = -INFINITY, m2 = -INFINITY, m3 = -INFINITY;
@@ -1476,12 +1529,12 @@ __global__ __launch_bounds__(kBlock) void k_classify(int n_dnu, int n_depth, int
                                                      const double* __restrict__ doppler, const double* __restrict__ gammas,
                                                      int gamma_cols, const double* __restrict__ alphas, double* __restrict__ m_max,
                                                      const double* __restrict__ nus, const double* __restrict__ line_nus, int64_t nu_begin,
-                                                     int64_t nu_count, int* __restrict__ sel, int64_t cls_begin, int64_t cls_end)
+                                                     int64_t nu_count, int* __restrict__ sel, int64_t cls_begin, int64_t cls_end, FarReq far)
 {
     __shared__ double s_red[kBlock / 64];
     const int b = blockIdx.x;
     if (b < n_dnu) {
-        dnu_partial_block(b, n_dnu, n_nu, nus, dnu_partial, s_red);
+        dnu_partial_block(b, n_dnu, n_nu, nus, dnu_partial, s_red, far);
         return;
     }
     // four threads of the LAST block find the shard's line ranges on the side (four binary searches: chains of dependent loads
@@ -2201,7 +2254,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             const WideRec cur = stage[k];  // (one address for the whole wave: a broadcast read)
             const RegionI k1 = {cur.yk, cur.cv, cur.cd};
             const double c0 = (nu_base_vec - cur.lnu) * cur.inv;
-            if ((mfull >> k) & 1) {  // far from every tile of the unit: no per-lane tests
+            if (((mfull >> k) & 3) == 3 && k + 1 < cnt) {
+                // two test-free hits at once: two independent chains of dependent instructions (a shard's launch has two or three
+                // waves per SIMD: nothing else fills the gaps); the sums keep list order
+                const WideRec nxt = stage[k + 1];
+                const RegionI k2 = {nxt.yk, nxt.cv, nxt.cd};
+                const double c1 = (nu_base_vec - nxt.lnu) * nxt.inv;
+#pragma unroll
+                for (int r = 0; r < RF; ++r) {
+                    acc[r] = region1_add(acc[r], fma(dnu[r], cur.inv, c0), k1);
+                    acc[r] = region1_add(acc[r], fma(dnu[r], nxt.inv, c1), k2);
+                }
+                ++k;
+            } else if ((mfull >> k) & 1) {  // far from every tile of the unit: no per-lane tests
 #pragma unroll
                 for (int r = 0; r < RF; ++r) acc[r] = region1_add(acc[r], fma(dnu[r], cur.inv, c0), k1);
             } else {
@@ -2970,7 +3035,7 @@ __global__ __launch_bounds__(kBlock) void k_classify_continuum(int n_dnu, int n_
                                                                const double* __restrict__ nus, int cont_tiles, int64_t nu_begin, int64_t nu_count,
                                                                ContinuumArgs ca, double* __restrict__ cont_plane, int64_t cont_ld, int stage_table,
                                                                const double* __restrict__ line_nus, int64_t shard_begin, int64_t shard_count,
-                                                               int* __restrict__ sel, int64_t cls_begin, int64_t cls_end)
+                                                               int* __restrict__ sel, int64_t cls_begin, int64_t cls_end, FarReq far)
 {
     // order of the roles in the grid = order of dispatch: the continuum tiles — chains of dependent work (coefficients, a barrier,
     // a table search), eight depths per block so that they are few and long — go first and run behind the stream (round 4, an
@@ -2979,7 +3044,7 @@ __global__ __launch_bounds__(kBlock) void k_classify_continuum(int n_dnu, int n_
     const int b = blockIdx.x;
     if (b < n_dnu) {
         __shared__ double s_red[kBlock / 64];
-        dnu_partial_block(b, n_dnu, n_nu, nus, dnu_partial, s_red);
+        dnu_partial_block(b, n_dnu, n_nu, nus, dnu_partial, s_red, far);
     } else if (b < n_dnu + n_cont) {
         const int c = b - n_dnu;
         continuum_tile_block(c % cont_tiles, c / cont_tiles, (stage_table >> 4) & 15, n_depth, nu_begin, nu_count, nus, ca, cont_plane, cont_ld,

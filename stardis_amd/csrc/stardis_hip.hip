@@ -86,6 +86,8 @@ struct sdx_ctx {
     size_t part_ws_bytes = 0;
     void* far_ws = nullptr;  // far_range of the line kernels' far field: two ints per global tile
     size_t far_ws_bytes = 0;
+    FarReq far_req{nullptr, 0, 0};  // the tiles whose ranges the step's next grid-spacing launch computes on the side (count = 0: none)
+    bool far_req_done = false;       // ... and whether a launch has taken them along
     // cnt_ge[N_nu + 2] (lines per centre index, for the narrow-window kernel)
     void* cnt_ws = nullptr;
     size_t cnt_ws_bytes = 0;
@@ -119,6 +121,7 @@ struct sdx_ctx {
     // continuum plane) and for which problem; the synthesis that follows with options->line_m_max checks and consumes it
     struct {
         bool valid = false;
+        bool far = false;  // ... and the tiles' far ranges (far_ws)
         int n_depth = 0;
         int64_t n_nu = 0, nu_begin = 0, nu_count = 0, n_lines = 0;
         uint64_t generation = 0;
@@ -259,7 +262,8 @@ int launch_dnu(sdx_ctx* ctx, int64_t n_nu, const double* nus, int* n_partial, in
     const int nb = (int)std::min<int64_t>(kDnuPartials, std::max<int64_t>(1, (n_nu + kBlock * 8 - 1) / (kBlock * 8)));
     {
         LaunchScope ls(ctx, "k_dnu_partial");
-        hipLaunchKernelGGL(k_dnu_partial, dim3(nb), dim3(kBlock), 0, ctx->stream, n_nu, nus, (double*)ctx->small_ws, zero, n_zero);
+        hipLaunchKernelGGL(k_dnu_partial, dim3(nb), dim3(kBlock), 0, ctx->stream, n_nu, nus, (double*)ctx->small_ws, zero, n_zero, ctx->far_req);
+        if (ctx->far_req.count) ctx->far_req_done = true;
     }
     *n_partial = nb;
     return check_launch("k_dnu_partial");
@@ -962,15 +966,17 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
                 hipLaunchKernelGGL(k_classify_continuum, dim3((unsigned)n_partial + n_cls_half + (unsigned)cp.cont_tiles * cp.cont_rows), dim3(kBlock), cp.shmem, ctx->stream,
                                    n_partial, (int)n_cls_half, n_depth, n_nu, n_lines, dnu_ws, doppler, gammas, gamma_cols, alphas, m_max, nus,
                                    cp.cont_tiles, job->nu_begin, job->nu_count, cp.ca, job->plane, job->nu_count, cp.stage_table, line_nus, nu_begin, nu_count,
-                                   sel, cls_begin, cls_end);
+                                   sel, cls_begin, cls_end, ctx->far_req);
             } else {
                 hipLaunchKernelGGL(k_classify, dim3((unsigned)n_partial + n_cls), dim3(kBlock), 0, ctx->stream, n_partial, n_depth, n_nu, n_lines, dnu_ws,
-                                   doppler, gammas, gamma_cols, alphas, m_max, nus, line_nus, nu_begin, nu_count, sel, cls_begin, cls_end);
+                                   doppler, gammas, gamma_cols, alphas, m_max, nus, line_nus, nu_begin, nu_count, sel, cls_begin, cls_end, ctx->far_req);
             }
+            if (ctx->far_req.count && n_partial > 0) ctx->far_req_done = true;
         }
         if (ph && ph->phase == 1) {
             auto& c = ctx->classified;
             c.valid = true, c.n_depth = n_depth, c.n_nu = n_nu, c.nu_begin = nu_begin, c.nu_count = nu_count, c.n_lines = n_lines;
+            c.far = ctx->far_req_done;
             c.generation = ctx->ws_generation;
             return check_launch("k_classify");
         }
@@ -1066,6 +1072,30 @@ static int choose_splits(int n_depth, int64_t n_nu_global, int64_t n_lines, int 
     return (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(want, chunks), 8));  // the subsets are the waves of one workgroup
 }
 
+// FAR FIELD (k_line_far): a third plane.  Like every choice that moves a rounding it is made from the GLOBAL grid — grids of at
+// least kFarMinPoints frequencies (below that a launch of the line kernel is bound by latency, not by its evaluations) — or set
+// explicitly (context option "far_field").
+static bool far_field_on(const sdx_ctx* ctx, int64_t n_nu_global)
+{
+    static const int far_env = knob("SDX_FAR") ? std::atoi(knob("SDX_FAR")) : -1;  // A/B knob: 0 never, 1 whenever possible
+    static const int r_mixed_env = knob("SDX_R_MIXED") ? std::atoi(knob("SDX_R_MIXED")) : 4;
+    const int far_mode = ctx->far_field >= 0 ? (int)ctx->far_field : far_env;
+    constexpr int64_t kFarMinPoints = 32768;
+    if (ctx->mixed_precision && r_mixed_env == 8) return false;  // (experiment knob: 512-point tiles)
+    return far_mode != 0 && (far_mode == 1 || n_nu_global >= kFarMinPoints);
+}
+// The (ihi, ilo) pair of every GLOBAL tile that holds columns of the launch: asked of the step's grid-spacing launch (launch_dnu, the
+// classification launch of a culled shard), which computes them on the side.
+static int request_far_ranges(sdx_ctx* ctx, int64_t n_nu, int64_t nu_begin, int64_t nu_count)
+{
+    int rc = ensure(ctx, &ctx->far_ws, &ctx->far_ws_bytes, (size_t)((n_nu + kFarTile - 1) / kFarTile) * 2 * sizeof(int));
+    if (rc) return rc;
+    const int64_t t_first = nu_begin / kFarTile, t_last = (nu_begin + nu_count - 1) / kFarTile;
+    ctx->far_req = FarReq{(int*)ctx->far_ws, t_first, t_last - t_first + 1};
+    ctx->far_req_done = false;
+    return SDX_OK;
+}
+
 // pre-pass + the two gather kernels; leaves *n_planes_out partial planes in *partial_out ([planes][n_depth][*pld_out]):
 // the wide subsets in subset order, then the narrow-window plane.  With `job` the continuum plane of the fused step is
 // computed by the same launch as the pre-pass.
@@ -1076,12 +1106,19 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
 {
     constexpr int R = 4;       // grid points per lane of a wide-role tile (tile = 64 R points)
     constexpr int R_MIXED = 4;  // fp32 far wings (8 — twice the points per fetched record — measured slower: fewer tiles qualify as far wing)
-    LineWork w;
-    int rc = line_prepass(ctx, n_depth, n_nu, nus, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, true, nullptr, nullptr, &w,
-                          count_evals, job, gen, nu_begin, nu_count, ph);
-    if (rc) return rc;
     static const int r_mixed_env = knob("SDX_R_MIXED") ? std::atoi(knob("SDX_R_MIXED")) : R_MIXED;  // experiment knob: 4 or 8
     const int Rm = ctx->mixed_precision ? (r_mixed_env == 8 ? 8 : R_MIXED) : R;
+    const bool far = far_field_on(ctx, n_nu) && nu_count > 0;
+    int rc;
+    const bool classified_far = ph && ph->phase == 2 && ctx->classified.valid && ctx->classified.far;  // (phase 1 computed the ranges)
+    if (far && !classified_far && (rc = request_far_ranges(ctx, n_nu, nu_begin, nu_count))) return rc;
+    LineWork w;
+    rc = line_prepass(ctx, n_depth, n_nu, nus, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, true, nullptr, nullptr, &w,
+                      count_evals, job, gen, nu_begin, nu_count, ph);
+    const FarReq far_req = ctx->far_req;
+    const bool far_req_done = ctx->far_req_done || classified_far;
+    ctx->far_req = FarReq{nullptr, 0, 0};
+    if (rc) return rc;
     const int n_split = choose_splits(n_depth, n_nu, n_lines, Rm, n_lines >= ctx->indexed_min_lines ? 4 : 2);
     // long line lists: the lines with a window wider than kMediumHalfWidth are listed once (they are scanned by every tile);
     // all others are found by centre range.  Short lists are scanned completely.
@@ -1102,21 +1139,12 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
     // round 4 at S-c3 and on its eight shards with 0 / 14 / 28 such layers: line kernel 2026 / 2048 / 2092 us unsharded, 332 / 344 /
     // 346 us on the slowest shard, no change at S-c2 either: the hit lists fall off by only a factor 4 from the deepest to the
     // shallowest layer, and a launch is bound by its total work, not by its heaviest wave.  Removed.)
-    // FAR FIELD (k_line_far): a third plane.  Like every choice that moves a rounding it is made from the GLOBAL grid — grids of at
-    // least kFarMinPoints frequencies (below that a launch of the line kernel is bound by latency, not by its evaluations) — or set
-    // explicitly (context option "far_field").
-    static const int far_env = knob("SDX_FAR") ? std::atoi(knob("SDX_FAR")) : -1;  // A/B knob: 0 never, 1 whenever possible
-    const int far_mode = ctx->far_field >= 0 ? (int)ctx->far_field : far_env;
-    constexpr int64_t kFarMinPoints = 32768;
-    const bool far = Rm == 4 && far_mode != 0 && (far_mode == 1 || n_nu >= kFarMinPoints);
     w.far_range = nullptr;
-    if (far) {  // one (ihi, ilo) pair per GLOBAL tile that holds columns of this launch
-        const int64_t t_first = nu_begin / kFarTile, t_last = (nu_begin + nu_count - 1) / kFarTile;
-        rc = ensure(ctx, &ctx->far_ws, &ctx->far_ws_bytes, (size_t)((n_nu + kFarTile - 1) / kFarTile) * 2 * sizeof(int));
-        if (rc) return rc;
-        LaunchScope ls(ctx, "k_far_ranges");
-        hipLaunchKernelGGL(k_far_ranges, dim3((unsigned)((t_last - t_first + kBlock) / kBlock)), dim3(kBlock), 0, ctx->stream, n_nu, nus, t_first,
-                           t_last - t_first + 1, (int*)ctx->far_ws);
+    if (far) {
+        if (!far_req_done) {  // (no grid-spacing launch in this step: small grids scan the spacing inside the pre-pass blocks)
+            LaunchScope ls(ctx, "k_far_ranges");
+            hipLaunchKernelGGL(k_far_ranges, dim3((unsigned)((2 * far_req.count + kBlock / 16 - 1) / (kBlock / 16))), dim3(kBlock), 0, ctx->stream, n_nu, nus, far_req);
+        }
         w.far_range = (const int*)ctx->far_ws;
     }
     rc = ensure(ctx, &ctx->part_ws, &ctx->part_ws_bytes, (size_t)(far ? 3 : 2) * n_depth * nu_count * sizeof(double));
@@ -1164,6 +1192,32 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
     static const bool split_launches = knob("SDX_SPLIT_LAUNCHES") != nullptr;  // analysis knob: time the two roles apart
     const size_t shmem = (size_t)n_split * (far && !ctx->mixed_precision && SDX_WIDE_QUEUED ? kWideFarLdsDoubles : kWideLdsDoubles) * sizeof(double);
     const dim3 g((unsigned)(n_wide + n_narrow)), blk((unsigned)(64 * n_split));
+    // (k_line_far on a second stream beside k_line_all — a fork and a join per step — was measured in round 5: S-c3 1.857 -> 1.840 ms, its
+    // eighth 0.419 -> 0.420, S-c4m 7.49 -> 7.48: both kernels are bound by their instructions, neither leaves the other idle slots)
+    auto launch_far = [&]() -> int {
+        // units of 4 RF global tiles; RF (1 or 2 node groups per lane) is scheduling only: 2 where that still leaves ~4 workgroups per CU
+        // (4 was measured slower than 2 at every size)
+        const int64_t t_first = nu_begin / (64 * R), t_last = (nu_begin + nu_count - 1) / (64 * R);
+        auto units_of = [&](int rf) { return t_last / (4 * rf) - t_first / (4 * rf) + 1; };
+        static const int far_rf_env = knob("SDX_FAR_RF") ? std::atoi(knob("SDX_FAR_RF")) : 0;  // experiment knob: 1, 2, 4
+        int rf = units_of(2) * n_depth >= (int64_t)4 * ctx->n_cu ? 2 : 1;
+        if (far_rf_env == 1 || far_rf_env == 2 || far_rf_env == 4) rf = far_rf_env;
+        const int64_t units = units_of(rf);
+        REQUIRE(units * n_depth < ((int64_t)1 << 31), "line opacity: grid too large for one launch");
+        // (its own number of line subsets — a constant: it fixes the order of a node's sum)
+        static const int far_split_env = knob("SDX_FAR_SPLIT") ? std::atoi(knob("SDX_FAR_SPLIT")) : 0;  // experiment knob: 1 .. 8
+        const int far_split = far_split_env >= 1 && far_split_env <= 8 ? far_split_env : kFarSplit;
+        const size_t far_shmem = (((size_t)far_split + 2) * rf * 64 + (size_t)far_split * kFarWaveLdsDoubles) * sizeof(double);
+        const dim3 fg((unsigned)(units * n_depth)), fblk((unsigned)(64 * far_split));
+        double* far_plane = part + (size_t)2 * n_depth * pld;
+        LaunchScope ls(ctx, "k_line_far");
+#define SDX_FAR_ARGS (int)units, far_split, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, w, far_plane, pld
+        if (rf == 4) hipLaunchKernelGGL((k_line_far<R, 4>), fg, fblk, far_shmem, ctx->stream, SDX_FAR_ARGS);
+        else if (rf == 2) hipLaunchKernelGGL((k_line_far<R, 2>), fg, fblk, far_shmem, ctx->stream, SDX_FAR_ARGS);
+        else hipLaunchKernelGGL((k_line_far<R, 1>), fg, fblk, far_shmem, ctx->stream, SDX_FAR_ARGS);
+#undef SDX_FAR_ARGS
+        return SDX_OK;
+    };
     for (int pass = 0; pass < (split_launches ? 2 : 1); ++pass) {
         // (raising the priority of the hot layers' waves with s_setprio was measured in round 4: the instruction has side effects as
         // far as the compiler is concerned, the record fetches of the walk stopped being scalar loads and the kernel ran 37 % slower)
@@ -1181,26 +1235,7 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
         else hipLaunchKernelGGL((k_line_all<R>), g, blk, shmem, ctx->stream, SDX_LINE_ARGS);
 #undef SDX_LINE_ARGS
     }
-    if (far) {
-        // units of 4 RF global tiles; RF (1, 2 or 4 node groups per lane) is scheduling only: the widest that still leaves ~4 workgroups per CU
-        const int64_t t_first = nu_begin / (64 * R), t_last = (nu_begin + nu_count - 1) / (64 * R);
-        auto units_of = [&](int rf) { return t_last / (4 * rf) - t_first / (4 * rf) + 1; };
-        static const int far_rf_env = knob("SDX_FAR_RF") ? std::atoi(knob("SDX_FAR_RF")) : 0;  // experiment knob: 1, 2, 4
-        int rf = 4;
-        while (rf > 1 && units_of(rf) * n_depth < (int64_t)4 * ctx->n_cu) rf >>= 1;
-        if (far_rf_env == 1 || far_rf_env == 2 || far_rf_env == 4) rf = far_rf_env;
-        const int64_t units = units_of(rf);
-        REQUIRE(units * n_depth < ((int64_t)1 << 31), "line opacity: grid too large for one launch");
-        const size_t far_shmem = (((size_t)n_split + 2) * rf * 64 + (size_t)n_split * kFarWaveLdsDoubles) * sizeof(double);
-        const dim3 fg((unsigned)(units * n_depth));
-        double* far_plane = part + (size_t)2 * n_depth * pld;
-        LaunchScope ls(ctx, "k_line_far");
-#define SDX_FAR_ARGS (int)units, n_split, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, w, far_plane, pld
-        if (rf == 4) hipLaunchKernelGGL((k_line_far<R, 4>), fg, blk, far_shmem, ctx->stream, SDX_FAR_ARGS);
-        else if (rf == 2) hipLaunchKernelGGL((k_line_far<R, 2>), fg, blk, far_shmem, ctx->stream, SDX_FAR_ARGS);
-        else hipLaunchKernelGGL((k_line_far<R, 1>), fg, blk, far_shmem, ctx->stream, SDX_FAR_ARGS);
-#undef SDX_FAR_ARGS
-    }
+    if (far && (rc = launch_far())) return rc;
     *partial_out = part;
     *pld_out = pld;
     *n_planes_out = far ? 3 : 2;
@@ -2190,8 +2225,11 @@ int sdx_synthesize_classify_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const d
     const ContinuumJob job{cont, nu_begin, nu_count, (double*)ctx->cont_ws};
     const ClassifyPhase first{1, line_begin, line_count, m_max};
     ctx->classified.valid = false;
-    return line_prepass(ctx, n_depth, n_nu, nus, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, true, nullptr, nullptr, nullptr, false, &job,
-                        nullptr, nu_begin, nu_count, &first);
+    if (far_field_on(ctx, n_nu) && (rc = request_far_ranges(ctx, n_nu, nu_begin, nu_count))) return rc;
+    rc = line_prepass(ctx, n_depth, n_nu, nus, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, true, nullptr, nullptr, nullptr, false, &job,
+                      nullptr, nu_begin, nu_count, &first);
+    ctx->far_req = FarReq{nullptr, 0, 0};
+    return rc;
 }
 
 // The fused synthesis for a caller that holds everything in host memory (C, or numpy through ctypes): uploads, runs

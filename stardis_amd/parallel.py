@@ -37,13 +37,19 @@ def padded_count(n_nu, world_size):
     return -(-n_nu // world_size)
 
 
-def window_work(nus, line_nus, doppler_widths, gammas, alphas, core_weight=1.0):
+FAR_FIELD_MIN_POINTS = 32768  # the library's automatic rule for its "far_field" option (include/stardis_hip.h)
+FAR_NEAR_POINTS = 896        # ... with it a window is evaluated point by point only this close to its centre (3.5 tiles of 256)
+
+
+def window_work(nus, line_nus, doppler_widths, gammas, alphas, core_weight=1.0, far_weight=None):
     """Voigt evaluations per grid column, sum over (line, depth) of [lo <= i < hi] with the window rule of
     calc_alan_entries (opacities_solvers/base.py:524-575).  A planning estimate on the host (numpy, O(N_l N_d)): it only
     decides where shard boundaries go, never what is computed.
     core_weight > 1 counts an evaluation in a line core — a narrow window (half-width <= 64 points) or the points of a wide
     window within 15 Doppler widths of the centre, Faddeeva regions II-IV — that many times: those cost 100-250
-    instructions where a far-wing evaluation costs 13."""
+    instructions where a far-wing evaluation costs 13.
+    far_weight (None: no far field): what a window point beyond FAR_NEAR_POINTS of its centre costs when the far field of the
+    line kernels takes it — 16 node evaluations per 256 points, ~1/12 with the interpolation."""
     nus = np.asarray(nus, dtype=np.float64)
     n = nus.size
     if n < 2 or np.asarray(line_nus).size == 0:
@@ -58,6 +64,12 @@ def window_work(nus, line_nus, doppler_widths, gammas, alphas, core_weight=1.0):
     hi = np.clip(centre[:, None] + hw, 0, n)
     # +1 where a window opens, -1 where it closes (np.bincount: the same sums as np.add.at, ~30 times faster on 1.7e7 entries)
     cover = np.bincount(lo.ravel(), minlength=n + 1).astype(np.float64) - np.bincount(hi.ravel(), minlength=n + 1)
+    if far_weight is not None:
+        near = np.minimum(hw, FAR_NEAR_POINTS)
+        nlo = np.clip(centre[:, None] - near, 0, n)
+        nhi = np.clip(centre[:, None] + near, 0, n)
+        cover_near = np.bincount(nlo.ravel(), minlength=n + 1).astype(np.float64) - np.bincount(nhi.ravel(), minlength=n + 1)
+        cover = cover_near + far_weight * (cover - cover_near)
     if core_weight != 1.0:
         y = g / (np.sqrt(np.pi) * np.pi) / dw
         chw = np.minimum(np.where(hw <= 64, hw, np.maximum(15.0 - y, 0.0) * dw / d_nu + 2.0).astype(np.int64), hw)
@@ -82,12 +94,14 @@ def scan_work(nus, line_nus, half_width=4096):
     return (np.searchsorted(centre, i + half_width, side="left") - np.searchsorted(centre, i - half_width, side="right")).astype(np.float64)
 
 
-def column_cost(nus, lines, indexed_min_lines=8192, scan_weight=0.6, fixed=8000.0, core_weight=14.0):
+def column_cost(nus, lines, indexed_min_lines=8192, scan_weight=0.6, fixed=8000.0, core_weight=14.0, far_field=None, far_weight=1.0 / 12):
     """Estimated cost of every grid column in units of one far-wing Voigt evaluation, for balanced_shards: the window
     evaluations (line cores weighted by core_weight), the candidate scan of long lists (scan_weight per line in range) and
     a constant for the continuum and the formal solution — weights measured on MI355X.  A planning estimate on the host: it
-    only decides where shard boundaries go."""
-    cost = window_work(nus, lines["line_nus"], lines["doppler_widths"], lines["gammas"], lines["alphas"], core_weight) + fixed
+    only decides where shard boundaries go.  far_field: whether the library's far field is on (None: its automatic rule)."""
+    if far_field is None: far_field = np.asarray(nus).size >= FAR_FIELD_MIN_POINTS
+    cost = window_work(nus, lines["line_nus"], lines["doppler_widths"], lines["gammas"], lines["alphas"], core_weight,
+                       far_weight if far_field else None) + fixed
     if np.asarray(lines["line_nus"]).size >= indexed_min_lines:
         cost = cost + scan_weight * scan_work(nus, lines["line_nus"])
     return cost
