@@ -45,8 +45,8 @@ FP64_VECTOR_PEAK_TFLOPS = 78.6
 # ceiling the VALU fractions are quoted against.  (Round 3 also quoted a "measured" 439 G/s from a pure-FMA loop; the line
 # kernels beat it — the part clocks higher under their instruction mix — so it was not a ceiling of anything and is gone.)
 FP64_VALU_SPEC = 256 * 4 * 2.4e9 / 4
-KERNELS = ("k_dnu_partial", "k_classify", "k_prepass_continuum", "k_line_prepass", "k_hlist", "k_gather", "k_line_all", "k_line_wide",
-           "k_line_narrow", "k_reduce_partials", "k_total_alphas", "k_raytrace")
+KERNELS = ("k_dnu_partial", "k_classify", "k_prepass_continuum", "k_line_prepass", "k_hlist", "k_gather", "k_far_ranges", "k_line_all", "k_line_wide",
+           "k_line_narrow", "k_line_far", "k_reduce_partials", "k_total_alphas", "k_raytrace")
 
 
 # ------------------------------------------------------------------------------------------------ launch

@@ -26,6 +26,7 @@
  *       SDX_WIDE_BLOCKS   target number of wide-role workgroups -> line subsets per (depth, tile)
  *       SDX_RT_SEG        0 / 1: never / always the segmented formal-solution kernel (the option "segmented_raytrace" wins)
  *       SDX_FAR           0 / 1: never / always the far field of the line kernels (the option "far_field" wins); SDX_FAR_RF 1 / 2 / 4
+ *                         (tiles per unit of k_line_far / 4: scheduling only), SDX_FAR_SPLIT 1 .. 8 (its line subsets: the order of a sum)
  *       SDX_RT_NS         4: segmented kernel with 4 waves x 14 gaps instead of 8 x 7
  *       SDX_RT_P          1, 2, 4: angles per lane of k_raytrace
  *       SDX_R_MIXED       4 / 8: grid points per lane of a mixed-precision tile

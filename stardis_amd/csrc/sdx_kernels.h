@@ -2158,12 +2158,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(R == 4 ? (F
 }
 
 // FAR FIELD of the line opacity (far_eligible above): the third plane of the line kernels.  One workgroup owns (depth d, a unit of
-// 4 RF consecutive global tiles); lane <-> (tile 4 r + lane / 16 of the unit, Chebyshev node lane % 16), r < RF.  Its n_split waves go
-// through the candidate lists exactly as the wide role does (hlist, then the wlist range around the unit; chunk q of 64 candidates
-// belongs to wave q mod n_split): each lane tests ONE candidate against every tile of the unit (tile geometry is wave-uniform) and
-// keeps the mask of the tiles it is far from; the hits are walked in ascending order with scalar record fetches and evaluated at the
-// lanes' nodes with the wide role's own arithmetic (x = fma(dnu, inv, c0), region1_add) — test-free when the candidate is far from
-// every tile of the unit.  The waves' node sums meet in LDS (subset order), wave 0 turns the 16 node values of a tile into the
+// 4 RF consecutive global tiles, RF = 1 or 2); lane <-> (tile 4 r + lane / 16 of the unit, Chebyshev node lane % 16), r < RF.  Its
+// n_split (= kFarSplit) waves go through the candidate lists exactly as the wide role does (hlist, then the wlist range around the
+// unit; chunk q of 64 candidates belongs to wave q mod n_split): each lane tests ONE candidate against the unit (its whole span
+// first, the single tiles where that does not settle it) and keeps the mask of the tiles it is far from; the hits are queued in LDS
+// in list order and evaluated 64 at a time — records fetched by the lanes in one round trip — at the lanes' nodes with the wide
+// role's own arithmetic (x = fma(dnu, inv, c0), region1_add), test-free when the candidate is far from every tile of the unit.  The waves' node sums meet in LDS (subset order), wave 0 turns the 16 node values of a tile into the
 // coefficients of its Chebyshev series (kFarCoef), and every wave evaluates the series of its share of the tiles at their grid
 // points (Clenshaw) and writes the plane — zeros where a tile has no far field.  The sum of a (tile, node) adds its lines in list
 // order within a subset and the subsets in order, whatever RF and whatever the shard: RF is pure scheduling.
@@ -2195,6 +2195,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         ihi[t] = mine ? w.far_range[2 * T] : 0;
         ilo[t] = mine ? w.far_range[2 * T + 1] : 0x7FFFFFFF;
         all_mask |= (ihi[t] != 0 || ilo[t] != 0x7FFFFFFF) ? (1u << t) : 0u;  // (0, INT_MAX): no far field
+    }
+    // ... and what decides most candidates without a look at the single tiles: the span of the tiles that have a far field (they are
+    // consecutive: only the grid's last tile can lack one) and the tightest of their ranges
+    int span_lo = 0x7FFFFFFF, span_hi = 0, min_ihi = 0x7FFFFFFF, max_ilo = 0;
+#pragma unroll
+    for (int t = 0; t < kUnitTiles; ++t) {
+        if ((all_mask >> t) & 1u) {
+            span_lo = min(span_lo, (int)((Tu + t) * kTile));
+            span_hi = max(span_hi, (int)((Tu + t + 1) * kTile));
+            min_ihi = min(min_ihi, ihi[t]);
+            max_ilo = max(max_ilo, ilo[t]);
+        }
     }
     if (all_mask == 0) {  // nothing but a partial last tile: zeros
         for (int t = split; t < kUnitTiles; t += n_split) {
@@ -2320,13 +2332,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             const int line = line_next;
             const WideScan sc = sc_next;
             fetch(q + n_split, line_next, sc_next);
-            unsigned tmask = 0;
+            // Most candidates are far from every tile of the unit (a strong line somewhere else on the grid) or reach none of them: one test
+            // of the whole span each — far_eligible of the span with the tightest range implies it of every tile — and the tile-by-tile
+            // tests only for a chunk that holds a candidate neither settles
+            const bool all_far = far_eligible(sc, span_lo, span_hi, min_ihi, max_ilo);
+            const bool none = (line < 0) | (sc.hi - sc.lo < kTile) | (sc.hi <= span_lo) | (sc.lo >= span_hi);
+            unsigned tmask = all_far && !none ? all_mask : 0u;
+            if (__ballot(!all_far && !none)) {
+                unsigned tm = 0;
 #pragma unroll
-            for (int t = 0; t < kUnitTiles; ++t) {
-                const int i0 = (int)min((Tu + t) * kTile, n_nu);  // (tiles beyond the grid: never far)
-                tmask |= far_eligible(sc, i0, i0 + kTile, ihi[t], ilo[t]) ? (1u << t) : 0u;
+                for (int t = 0; t < kUnitTiles; ++t) {
+                    const int i0 = (int)min((Tu + t) * kTile, n_nu);  // (tiles beyond the grid: never far)
+                    tm |= far_eligible(sc, i0, i0 + kTile, ihi[t], ilo[t]) ? (1u << t) : 0u;
+                }
+                if (!all_far && !none) tmask = tm;
             }
-            if (line < 0) tmask = 0;
             // the hits join the wave's queue (list order); a full queue is evaluated (flush)
             const unsigned long long m = __ballot(tmask != 0);
             const int n = __popcll(m);
