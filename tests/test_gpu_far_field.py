@@ -142,3 +142,20 @@ def test_a_column_of_gammas_and_a_deep_model(far_ctx):
     (line0, _, F0), _ = run(far_ctx, 0, nus, atm, lines, cont, th, w)
     (line1, _, F1), ran = run(far_ctx, 1, nus, atm, lines, cont, th, w)
     assert ran and line1.shape[0] == 150 and rel_err(line1, line0) < FAR_VS_DIRECT and rel_err(F1[1:], F0[1:]) < 1e-11
+
+
+def test_the_stand_alone_line_opacity_entry_point_takes_the_option_too(far_ctx):
+    """sdx_line_opacity_f64 (host buffers; what the mirror's calc_alan_entries calls): three partial planes reduced instead of two,
+    the evaluation count — the reference's window sizes, whoever evaluates them — unchanged"""
+    from stardis_amd import ops
+
+    atm, nus, lines, cont, th, w = workload(4200.0, 4500.0, 1.0e5, 900, seed=12)
+    args = (56, nus, lines["line_nus"], lines["doppler_widths"], lines["gammas"], lines["alphas"])
+    far_ctx.set_option("far_field", 0)
+    a0, n0 = ops.calc_alan_entries(*args, return_evaluations=True, ctx=far_ctx)
+    far_ctx.set_option("far_field", 1)
+    a1, n1 = ops.calc_alan_entries(*args, return_evaluations=True, ctx=far_ctx)
+    assert n0 == n1 and not np.array_equal(a0, a1)
+    assert np.array_equal(a0 == 0, a1 == 0) and rel_err(a1, a0) < FAR_VS_DIRECT
+    ref, evals = oracle.calc_alan_entries(*args, return_evals=True)
+    assert n1 == evals and rel_err(a1, ref) < 1e-12
