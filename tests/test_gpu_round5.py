@@ -18,8 +18,17 @@ def long_list_case(seed=3, n_nu=30000, n_lines=20000):
     return atm, nus, lines, synth.synth_continuum_state(atm), th, w
 
 
+@pytest.fixture(params=[-1, 1], ids=["direct", "far_field"])
+def far(request, ctx):
+    """the 30 000-point grid of these cases is below the far field's automatic threshold: once as it comes, once forced on (the
+    tiles' far ranges are then computed by the classification launch of phase 1 and used by phase 2)"""
+    ctx.set_option("far_field", request.param)
+    yield request.param
+    ctx.set_option("far_field", -1)
+
+
 @pytest.mark.parametrize("world", [3, 8])
-def test_two_collective_mode_reproduces_the_one_call_step(ctx, world):
+def test_two_collective_mode_reproduces_the_one_call_step(ctx, world, far):
     """Each rank classifies 1 / world of the lines, the shares are 'gathered' (here: every share written into one array), the rest
     of the step runs on the gathered array: F_nu, total and line opacity of every shard equal the one-call shard and the unsharded
     run bit for bit — eagerly and as two captured graphs, shares written in place or through a send buffer."""
