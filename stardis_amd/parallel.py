@@ -94,12 +94,15 @@ def scan_work(nus, line_nus, half_width=4096):
     return (np.searchsorted(centre, i + half_width, side="left") - np.searchsorted(centre, i - half_width, side="right")).astype(np.float64)
 
 
-def column_cost(nus, lines, indexed_min_lines=8192, scan_weight=0.6, fixed=8000.0, core_weight=14.0, far_field=None, far_weight=1.0 / 12):
+def column_cost(nus, lines, indexed_min_lines=8192, scan_weight=0.6, fixed=None, core_weight=14.0, far_field=None, far_weight=1.0 / 12):
     """Estimated cost of every grid column in units of one far-wing Voigt evaluation, for balanced_shards: the window
     evaluations (line cores weighted by core_weight), the candidate scan of long lists (scan_weight per line in range) and
     a constant for the continuum and the formal solution — weights measured on MI355X.  A planning estimate on the host: it
     only decides where shard boundaries go.  far_field: whether the library's far field is on (None: its automatic rule)."""
     if far_field is None: far_field = np.asarray(nus).size >= FAR_FIELD_MIN_POINTS
+    # (per column: continuum, formal solution, the far kernel's nodes — 8000 evaluation-equivalents of the direct sum; with the far field the
+    # windows weigh less against them: 16000 measured best over S-c3, S-c4m, S-c3 at R = 5e5 and S-big)
+    if fixed is None: fixed = 16000.0 if far_field else 8000.0
     cost = window_work(nus, lines["line_nus"], lines["doppler_widths"], lines["gammas"], lines["alphas"], core_weight,
                        far_weight if far_field else None) + fixed
     if np.asarray(lines["line_nus"]).size >= indexed_min_lines:
