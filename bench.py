@@ -266,10 +266,33 @@ def secondary_block(tag, device, steps, check):
     ms = (time.perf_counter() - t0) / steps * 1e3
     kern = kernel_times(ctx, syn, 5)
     nd = atm["temperatures"].size
-    line_ms = kern.get("k_line_all", 0.0) + kern.get("k_line_wide", 0.0) + kern.get("k_line_narrow", 0.0)
+    line_ms = kern.get("k_line_all", 0.0) + kern.get("k_line_wide", 0.0) + kern.get("k_line_narrow", 0.0) + kern.get("k_line_far", 0.0)
+    far_field = None
+    if kern.get("k_line_far"):
+        # the far field of the line kernels is on for this grid (include/stardis_hip.h, option "far_field"): the same workload with
+        # every window point evaluated where it lies, and how far the two spectra are apart
+        F_far = syn.F_nu().copy()
+        ctx.set_option("far_field", 0)
+        syn.close()
+        syn.capture()
+        ctx.synchronize()
+        F_direct = syn.F_nu().copy()
+        t_end = time.perf_counter() + 0.3  # settle, as above
+        while time.perf_counter() < t_end:
+            syn.step()
+            ctx.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            syn.step()
+        ctx.synchronize()
+        far_field = {"on": True, "ms_per_step_direct_sum": (time.perf_counter() - t1) / steps * 1e3,
+                     "flux_max_rel_deviation_from_direct_sum": float(np.max(np.abs(F_far[1:] - F_direct[1:]) / np.abs(F_direct[1:]))),
+                     "note": "window points at least three 256-point tiles from their line are summed at 16 Chebyshev nodes per tile and "
+                             "interpolated; `voigt_evaluations` counts the reference's window points either way"}
+        ctx.set_option("far_field", -1)
     out = {
         "workload": synth_desc(tag), "n_nu": int(nus.size), "n_lines": int(syn.n_lines), "steps": steps, "ms_per_step": ms,
-        "spectral_points_per_s": nus.size * nd / (ms * 1e-3), "voigt_evaluations": int(evals),
+        "spectral_points_per_s": nus.size * nd / (ms * 1e-3), "far_field": far_field, "voigt_evaluations": int(evals),
         "voigt_evaluations_per_s_line_kernel": evals / (line_ms * 1e-3) if line_ms else None,
         "avg_kernel_ms": kern, "profiled_pass": PROFILED_PASS.get(id(ctx)), "algorithmic_bytes": int(syn.algorithmic_bytes()),
         "achieved_GBps": syn.algorithmic_bytes() / (ms * 1e-3) / 1e9, "frac_hbm": syn.algorithmic_bytes() / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
