@@ -154,9 +154,11 @@ def kernel_times(ctx, syn, n=10, settle_s=0.3):
         if cnt.value:
             out[name] = ms.value / cnt.value * (cnt.value / n)  # per step (a kernel may run more than once per step)
     variant = kernel_variant(ctx, "k_raytrace")  # (before the records are cleared)
+    line_variant = kernel_variant(ctx, "k_line_all")  # "k_line_all + far role": the far field's workgroups are part of this launch
     ctx.call("sdx_profile_enable", 0)
     ctx.call("sdx_profile_reset")
     PROFILED_PASS[id(ctx)] = {"eager_ms_per_step": eager_ms, "kernel_sum_ms": sum(out.values()), "steps": n, "k_raytrace_is": variant,
+                              "k_line_all_is": line_variant,
                               "how": "eager launches bracketed by HIP events after %.1f s of eager settling; the graph-replayed step of "
                                      "`ms_per_step` runs the same kernels without the event records and host launch gaps" % settle_s}
     return out
@@ -268,7 +270,7 @@ def secondary_block(tag, device, steps, check):
     nd = atm["temperatures"].size
     line_ms = kern.get("k_line_all", 0.0) + kern.get("k_line_wide", 0.0) + kern.get("k_line_narrow", 0.0) + kern.get("k_line_far", 0.0)
     far_field = None
-    if kern.get("k_line_far"):
+    if kern.get("k_line_far") or "far" in (PROFILED_PASS.get(id(ctx)) or {}).get("k_line_all_is", ""):
         # the far field of the line kernels is on for this grid (include/stardis_hip.h, option "far_field"): the same workload with
         # every window point evaluated where it lies, and how far the two spectra are apart
         F_far = syn.F_nu().copy()

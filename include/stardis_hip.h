@@ -26,7 +26,8 @@
  *       SDX_WIDE_BLOCKS   target number of wide-role workgroups -> line subsets per (depth, tile)
  *       SDX_RT_SEG        0 / 1: never / always the segmented formal-solution kernel (the option "segmented_raytrace" wins)
  *       SDX_FAR           0 / 1: never / always the far field of the line kernels (the option "far_field" wins); SDX_FAR_RF 1 / 2 / 4
- *                         (tiles per unit of k_line_far / 4: scheduling only), SDX_FAR_SPLIT 1 .. 8 (its line subsets: the order of a sum)
+ *                         (tiles per unit of the far role / 4: scheduling only); SDX_FAR_LAUNCH: the far field as a launch of its own
+ *                         (k_line_far, 8 line subsets — SDX_FAR_SPLIT 1 .. 8 — instead of the line kernel's: the order of a sum)
  *       SDX_RT_NS         4: segmented kernel with 4 waves x 14 gaps instead of 8 x 7
  *       SDX_RT_P          1, 2, 4: angles per lane of k_raytrace
  *       SDX_R_MIXED       4 / 8: grid points per lane of a mixed-precision tile
@@ -109,7 +110,7 @@ int sdx_synchronize(sdx_ctx* ctx);
  *       256-point tile of the GLOBAL grid, clear of the line's core range (every point of the tile in Faddeeva region I) and with the
  *       line's centre at least three tile widths (6 half-widths, measured in frequency) from the tile's centre, is not evaluated at
  *       the tile's 256 grid points but at its 16 Chebyshev nodes — the same region-I rational, fp64 — and the summed node values are
- *       carried to the grid points by the degree-15 interpolant (k_line_far; a third partial plane).  Nine tenths of the window
+ *       carried to the grid points by the degree-15 interpolant (the far role of the line kernel's launch; a third partial plane).  Nine tenths of the window
  *       evaluations of the 3000 - 10000 A workloads are such triples.  Interpolation error <= 11.9^-16 = 6e-18 of an item's value;
  *       measured against the direct sum: <= 7e-15 relative on the line opacity, 7e-13 on the flux (tolerances 1e-12 / 1e-10).
  *       Which triples are far is a property of the grid and the list, not of the shard: shards stay bit-identical to the unsharded

@@ -289,6 +289,12 @@ class Context:
         check(self.lib.sdx_profile_get(self.handle, kernel.encode(), C.byref(cnt), C.byref(ms)))
         return cnt.value, ms.value
 
+    def profile_variant(self, kernel):
+        """which device kernel / configuration ran under a stage name in the profiled launches ("" when the stage has one form only)"""
+        buf = C.create_string_buffer(96)
+        check(self.lib.sdx_profile_variant(self.handle, kernel.encode(), buf, 96))
+        return buf.value.decode()
+
     @property
     def pinned(self):
         """The context's pool of page-locked host arrays (PinnedPool)."""

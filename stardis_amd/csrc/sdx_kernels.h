@@ -772,7 +772,7 @@ __global__ __launch_bounds__(kPreBlock) __attribute__((amdgpu_num_sgpr(80), amdg
 // S-c3's tiles: 2.5e-14 relative, rounding included (the direct fp64 sum: 4e-15).  The opacity tolerance is 1e-12, the flux's 1e-10.
 // Which triples are far is a property of the grid and the list (global tiles), not of the shard or the launch geometry; both
 // kernels decide it with THIS function on the same operands, so every triple is evaluated exactly once.
-constexpr int kFarSplit = 8;  // line subsets (waves per workgroup) of k_line_far: a shard's launch is a few hundred workgroups, its waves' chains are its duration
+constexpr int kFarSplit = 8;  // line subsets (waves per workgroup) of k_line_far — the far field as a launch of its own (fp32-mixed mode, SDX_FAR_LAUNCH): a shard's launch is a few hundred workgroups, its waves' chains are its duration
 constexpr int kFarWaveLdsDoubles = 64 * 6 + 64;  // per wave of k_line_far: 64 staged records, the queue's line indices and tile masks
 // The distance test in INDEX space, once per tile (one thread each): a line's centre index is cidx = #{i : nus[i] >= nu_l}
 // (closest_index, the reference's own quantity), so with ihi = #{i : nus[i] >= c + 6 h} and ilo = #{i : nus[i] >= c - 6 h}
@@ -817,6 +817,7 @@ __device__ __forceinline__ void wide_reduce_and_store(const int split, const int
         }
         __syncthreads();
         if (split == 0) {
+#pragma unroll 1  // (unrolled eight times the reads of all subsets are hoisted above the sums and spill)
             for (int s = 1; s < n_split; ++s) {
                 const double* other = lds_all + (size_t)s * STRIDE;
 #pragma unroll
@@ -2013,153 +2014,9 @@ __device__ __forceinline__ void line_narrow_subsets32(const int64_t i0, const in
     for (int k = 0; k < F; ++k) acc_out[k] = acc[k];  // (the four subsets of a group meet in the kernel's common reduction)
 }
 
-// Both line kernels in ONE launch of workgroups of S waves (S = number of line subsets): workgroups [0, n_wide) take the
-// wide role — one (depth, tile) each, wave s walks subset s — depth slowest, hottest layers first; the rest take the narrow
-// role, one frequency per wave.  The two roles only share the pre-pass, and each leaves issue slots idle on its own; a
-// cross-stream fork/join would cost two ~12 us inter-queue edges per step, one grid costs nothing.
-// roles: bit 0 wide, bit 1 narrow (both by default; one at a time for split-launch profiling, SDX_SPLIT_LAUNCHES=1).
-// Output planes: [0] the wide windows (all subsets summed), [1] the narrow windows.
-template <int R, bool MIXED, bool SUBSETS, bool FAR = false>
-__device__ __forceinline__ void line_all_body(int n_wide, int tiles, int n_split, int n_depth, int64_t n_nu,
-                                                   const double* __restrict__ nus, int64_t nu_begin, int64_t nu_count,
-                                                   int64_t n_lines, const double* __restrict__ line_nus, LineWork w,
-                                                   double* __restrict__ planes, int64_t pld, int roles)
-{
-    extern __shared__ double s_wide[];  // n_split x kWideLdsDoubles
-    const int b = blockIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform, which the compiler cannot see: chunk and frequency indices stay scalar
-    // SUBSETS (the kernel of dense long lists): both roles end in ONE reduction — every wave of a workgroup brings R partial sums per
-    // lane (a wide wave: R points of its tile; a narrow wave: the R = F frequencies of the workgroup's group), they meet in LDS
-    // and wave 0 adds them in subset order and writes.  One barrier in the kernel: with a second one in the narrow branch the
-    // compiler spilled the WIDE walk's registers, and a kernel that touches scratch at all ran a third slower (round 5).
-    [[maybe_unused]] double part[R];
-    [[maybe_unused]] int out_row = 0, out_col = 0;      // where lane's sums go: row (depth), first column; columns step 64 (wide) or 1 (narrow)
-    [[maybe_unused]] bool out_wide = true, out_valid = true;
-    if (b < n_wide) {
-        if (!(roles & 1)) return;
-        // XCD-aware tile order: workgroup i runs on XCD i % 8, each with its own L2.  Within a depth the workgroups of one XCD
-        // take CONTIGUOUS tiles (position p -> tile prefix(p % 8) + p / 8), so neighbouring tiles, whose line ranges
-        // overlap, hit the same L2 instead of pulling the same records into all eight.
-        const int wg = (roles >> 4) & 15;  // 0: one contiguous eighth of the tiles per XCD; g > 0: groups of g tiles going round the XCDs
-        int tile, d;
-        if (wg == 0) {
-            const int p = b % tiles;
-            d = b / tiles;
-            tile = p >> 3;
-            for (int f = 0; f < (p & 7); ++f) tile += (tiles - f + 7) >> 3;
-        } else {
-            // (the host pads the tiles of a depth to whole rounds of 8 g workgroups: b % 8 is then the XCD within every depth)
-            const int tiles_pad = (tiles + 8 * wg - 1) / (8 * wg) * (8 * wg);
-            const int p = b % tiles_pad, j = p >> 3;
-            d = b / tiles_pad;
-            tile = ((j / wg) * 8 + (p & 7)) * wg + j % wg;
-            if (tile >= tiles) return;
-        }
-        if constexpr (SUBSETS) {
-            line_wide_walk<R, MIXED, true, MIXED, FAR>(tile, wave, n_split, d, n_nu, nus, nu_begin, nu_count, n_lines, w, planes, pld, s_wide, part);
-            out_row = d;
-            out_col = (int)((nu_begin / (64 * R) + (int64_t)tile) * (64 * R)) + (int)(threadIdx.x & 63);
-        } else {
-            line_wide_walk<R, MIXED, false, false, FAR>(tile, wave, n_split, d, n_nu, nus, nu_begin, nu_count, n_lines, w, planes, pld, s_wide);
-        }
-    } else {
-        if (!(roles & 2)) return;
-        // A wave writes one value into each of the N_d rows of the narrow plane: the waves that fill a 64-byte sector of a
-        // row (8 consecutive frequencies) should share an L2, or every XCD writes its own fragment of every sector back on
-        // its own.  Workgroups p, p + 8, ... (one XCD) therefore take GROUPS of kNarrowGroup consecutive workgroups' worth
-        // of frequencies, the groups going round the XCDs.  (Giving each XCD one contiguous eighth of the grid was measured
-        // 45 % slower: the lines per grid point follow the frequency, so one XCD gets several times the work of another.)
-        // (SUBSETS: a workgroup is ONE group of frequencies, not four — sixteen workgroups keep the 64 consecutive frequencies per XCD
-        // whose lines' records then meet in one L2)
-        constexpr int kNarrowGroup = SUBSETS ? 16 : 4;
-        // F consecutive frequencies per wave (roles bits 8-11: 1, 2 or 4 — 8 was measured slower), groups aligned
-        // to the global grid
-        const int F = max(1, (roles >> 8) & 15);
-        // dense long lists (a kernel of their own — SUBSETS — so that neither walk pays for the other's registers: with both narrow
-        // walks in one kernel the WIDE role spilled, and a kernel that touches scratch memory ran a third slower): the workgroup's
-        // four waves share one group of F = 4 frequencies
-        constexpr bool subsets = SUBSETS;
-        const int64_t g0 = nu_begin / F;
-        const int64_t n_grp = (nu_begin + nu_count + F - 1) / F - g0;
-        const int64_t n_narrow = n_grp * ((n_depth + 63) / 64);
-        const int64_t n_nb = subsets ? n_narrow : (n_narrow + n_split - 1) / n_split;
-        const int64_t p = b - n_wide, j = p >> 3;
-        const int order = (roles >> 2) & 3;  // analysis knob (SDX_NARROW_ORDER): 0 grouped (default), 1 plain, 2 one block per XCD
-        int64_t wg = ((j / kNarrowGroup) * 8 + (p & 7)) * kNarrowGroup + j % kNarrowGroup;
-        if (order == 1) wg = p;
-        if (order == 2) wg = (p & 7) * ((n_nb + 7) / 8) + j;
-        if ((order == 2 && j >= (n_nb + 7) / 8) || wg >= n_nb) return;
-        const int64_t c = subsets ? wg : wg * n_split + wave;
-        if (c >= n_narrow) return;  // (subsets: the whole workgroup)
-        const int64_t i0 = (g0 + c % n_grp) * F;
-        const int chunk = (int)(c / n_grp);
-        double* __restrict__ nplane = planes + (size_t)n_depth * pld;
-        if constexpr (SUBSETS) {
-            static_assert(!SUBSETS || R == 4, "the common reduction: R points per wide lane = F frequencies per narrow group");
-            if constexpr (MIXED) line_narrow_subsets32<4>(i0, chunk, wave, n_depth, n_nu, nus, nu_begin, nu_count, w, part);
-            else line_narrow_subsets<4>(i0, chunk, wave, n_depth, n_nu, nus, nu_begin, nu_count, line_nus, w, part);
-            out_wide = false;
-            out_row = chunk * 64 + (int)(threadIdx.x & 63);
-            out_valid = out_row < n_depth;
-            out_col = (int)i0;
-        } else if constexpr (MIXED) {
-            if (F == 4) line_narrow_group32<4>(i0, chunk, n_depth, n_nu, nus, nu_begin, nu_count, w, nplane, pld);
-            else if (F == 2) line_narrow_group32<2>(i0, chunk, n_depth, n_nu, nus, nu_begin, nu_count, w, nplane, pld);
-            else line_narrow_wave32(i0, chunk, n_depth, n_nu, nus, nu_begin, nu_count, w, nplane, pld);
-        } else {
-            if (F == 4) line_narrow_group<4>(i0, chunk, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, nplane, pld);
-            else if (F == 2) line_narrow_group<2>(i0, chunk, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, nplane, pld);
-            else line_narrow_wave(i0, chunk, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, nplane, pld);
-        }
-    }
-    if constexpr (SUBSETS) {
-        constexpr int kLdsStride = (FAR && !MIXED && SDX_WIDE_QUEUED) ? kWideFarLdsDoubles : kWideLdsDoubles;  // (the wide walk's)
-        const int lane = threadIdx.x & 63;
-        if (wave > 0) {
-            double* mine = s_wide + (size_t)wave * kLdsStride;
-#pragma unroll
-            for (int r = 0; r < R; ++r) mine[r * 64 + lane] = part[r];
-        }
-        __syncthreads();
-        if (wave == 0) {
-            for (int s = 1; s < n_split; ++s) {
-                const double* other = s_wide + (size_t)s * kLdsStride;
-#pragma unroll
-                for (int r = 0; r < R; ++r) part[r] = add_rn(part[r], other[r * 64 + lane]);
-            }
-            const int64_t s0 = nu_begin, s1 = nu_begin + nu_count;  // the columns this launch stores
-            double* __restrict__ dst = planes + (out_wide ? (size_t)0 : (size_t)n_depth * pld) + (size_t)out_row * pld;
-            const int stride = out_wide ? 64 : 1;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int64_t col = (int64_t)out_col + (int64_t)r * stride;
-                if (out_valid && col >= s0 && col < s1) dst[col - s0] = part[r];
-            }
-        }
-    }
-}
-
-template <int R, bool SUBSETS = false, bool FAR = false>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FAR ? SDX_FAR_WAVES : 7, 8))) void k_line_all(int n_wide, int tiles, int n_split, int n_depth, int64_t n_nu,
-                                                   const double* __restrict__ nus, int64_t nu_begin, int64_t nu_count,
-                                                   int64_t n_lines, const double* __restrict__ line_nus, LineWork w,
-                                                   double* __restrict__ planes, int64_t pld, int roles)
-{
-    line_all_body<R, false, SUBSETS, FAR>(n_wide, tiles, n_split, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, planes, pld, roles);
-}
-// the mixed-precision variant: 512-point tiles; the register budget is capped at 128 (4 waves per SIMD) — what exceeds it
-// sits in the rarely taken fp64 general path
-template <int R, bool SUBSETS = false, bool FAR = false>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(R == 4 ? (FAR ? 5 : 6) : 4, 8))) void k_line_all_mixed(
-    int n_wide, int tiles, int n_split, int n_depth, int64_t n_nu, const double* __restrict__ nus, int64_t nu_begin, int64_t nu_count,
-    int64_t n_lines, const double* __restrict__ line_nus, LineWork w, double* __restrict__ planes, int64_t pld, int roles)
-{
-    line_all_body<R, true, SUBSETS, FAR>(n_wide, tiles, n_split, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, planes, pld, roles);
-}
-
 // FAR FIELD of the line opacity (far_eligible above): the third plane of the line kernels.  One workgroup owns (depth d, a unit of
 // 4 RF consecutive global tiles, RF = 1 or 2); lane <-> (tile 4 r + lane / 16 of the unit, Chebyshev node lane % 16), r < RF.  Its
-// n_split (= kFarSplit) waves go through the candidate lists exactly as the wide role does (hlist, then the wlist range around the
+// n_split waves (the line kernel's, whose far role this is; kFarSplit in a launch of its own) go through the candidate lists exactly as the wide role does (hlist, then the wlist range around the
 // unit; chunk q of 64 candidates belongs to wave q mod n_split): each lane tests ONE candidate against the unit (its whole span
 // first, the single tiles where that does not settle it) and keeps the mask of the tiles it is far from; the hits are queued in LDS
 // in list order and evaluated 64 at a time — records fetched by the lanes in one round trip — at the lanes' nodes with the wide
@@ -2168,15 +2025,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(R == 4 ? (F
 // points (Clenshaw) and writes the plane — zeros where a tile has no far field.  The sum of a (tile, node) adds its lines in list
 // order within a subset and the subsets in order, whatever RF and whatever the shard: RF is pure scheduling.
 template <int R, int RF>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_line_far(int units, int n_split, int n_depth, int64_t n_nu,
-                                                                                           const double* __restrict__ nus, int64_t nu_begin, int64_t nu_count,
-                                                                                           int64_t n_lines, LineWork w, double* __restrict__ plane, int64_t pld)
+__device__ __forceinline__ void line_far_body(const int block, const int units, const int n_split, int n_depth, int64_t n_nu, const double* __restrict__ nus,
+                                              int64_t nu_begin, int64_t nu_count, int64_t n_lines, LineWork w, double* __restrict__ plane, int64_t pld,
+                                              double* __restrict__ s_far)
 {
+    // s_far: [n_split][64 RF] partial node sums, [64 RF] node values, [64 RF] coefficients, [n_split][kFarWaveLdsDoubles]
     constexpr int kTile = 64 * R, kUnitTiles = 4 * RF;
-    extern __shared__ double s_far[];  // [n_split][64 RF] partial node sums, [64 RF] node values, [64 RF] coefficients, [n_split][kFarWaveLdsDoubles]
     const int lane = threadIdx.x & 63;
     const int split = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int d = blockIdx.x / units, u = blockIdx.x - d * units;
+    const int d = block / units, u = block - d * units;
     const int64_t T_first = nu_begin / kTile, T_last = (nu_begin + nu_count - 1) / kTile;  // the global tiles that hold the shard's columns
     const int64_t Tu = (T_first / kUnitTiles + u) * kUnitTiles;                          // units are aligned to the global tiles too
     const int64_t Ta = max(Tu, T_first), Tb = min(Tu + kUnitTiles - 1, T_last);
@@ -2424,6 +2281,177 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             if (i >= s0 && i < s1) plane[(size_t)d * pld + (i - s0)] = val;
         }
     }
+}
+
+// (the far field as a launch of its own: experiment knob SDX_FAR_LAUNCH; by default its workgroups are the FIRST of the line kernel's grid)
+template <int R, int RF>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_line_far(int units, int n_split, int n_depth, int64_t n_nu,
+                                                                                           const double* __restrict__ nus, int64_t nu_begin, int64_t nu_count,
+                                                                                           int64_t n_lines, LineWork w, double* __restrict__ plane, int64_t pld)
+{
+    extern __shared__ double s_far[];
+    line_far_body<R, RF>(blockIdx.x, units, n_split, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, w, plane, pld, s_far);
+}
+
+// Both line kernels in ONE launch of workgroups of S waves (S = number of line subsets): workgroups [0, n_wide) take the
+// wide role — one (depth, tile) each, wave s walks subset s — depth slowest, hottest layers first; the rest take the narrow
+// role, one frequency per wave.  The two roles only share the pre-pass, and each leaves issue slots idle on its own; a
+// cross-stream fork/join would cost two ~12 us inter-queue edges per step, one grid costs nothing.
+// roles: bit 0 wide, bit 1 narrow (both by default; one at a time for split-launch profiling, SDX_SPLIT_LAUNCHES=1); bits 16-17: the
+// far field's workgroups (line_far_body) come FIRST in the grid, n_depth x far_units of them (fp64 kernels with a far field).
+// Output planes: [0] the wide windows (all subsets summed), [1] the narrow windows.
+template <int R, bool MIXED, bool SUBSETS, bool FAR = false>
+__device__ __forceinline__ void line_all_body(int n_wide, int tiles, int n_split, int n_depth, int64_t n_nu,
+                                                   const double* __restrict__ nus, int64_t nu_begin, int64_t nu_count,
+                                                   int64_t n_lines, const double* __restrict__ line_nus, LineWork w,
+                                                   double* __restrict__ planes, int64_t pld, int roles, int far_units)
+{
+    extern __shared__ double s_wide[];  // n_split x kWideLdsDoubles
+    int b = blockIdx.x;
+    if constexpr (FAR && !MIXED) {  // (the fp32-mixed kernels have no registers for it: the far field keeps its own launch there)
+        // far role (roles bits 16-17: RF, 0 = the far field has a launch of its own): the FIRST workgroups of the grid — their waves are
+        // the longest chains of the launch (a unit walks every huge line of the list) — n_depth x far_units of them
+        const int rf = (roles >> 16) & 3;
+        if (rf) {
+            const int n_far = n_depth * far_units;
+            if (b < n_far) {
+                double* const far_plane = planes + (size_t)2 * n_depth * pld;
+                if (rf == 2) line_far_body<R, 2>(b, far_units, n_split, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, w, far_plane, pld, s_wide);
+                else line_far_body<R, 1>(b, far_units, n_split, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, w, far_plane, pld, s_wide);
+                return;
+            }
+            b -= n_far;
+        }
+    }
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform, which the compiler cannot see: chunk and frequency indices stay scalar
+    // SUBSETS (the kernel of dense long lists): both roles end in ONE reduction — every wave of a workgroup brings R partial sums per
+    // lane (a wide wave: R points of its tile; a narrow wave: the R = F frequencies of the workgroup's group), they meet in LDS
+    // and wave 0 adds them in subset order and writes.  One barrier in the kernel: with a second one in the narrow branch the
+    // compiler spilled the WIDE walk's registers, and a kernel that touches scratch at all ran a third slower (round 5).
+    [[maybe_unused]] double part[R];
+    [[maybe_unused]] int out_row = 0, out_col = 0;      // where lane's sums go: row (depth), first column; columns step 64 (wide) or 1 (narrow)
+    [[maybe_unused]] bool out_wide = true, out_valid = true;
+    if (b < n_wide) {
+        if (!(roles & 1)) return;
+        // XCD-aware tile order: workgroup i runs on XCD i % 8, each with its own L2.  Within a depth the workgroups of one XCD
+        // take CONTIGUOUS tiles (position p -> tile prefix(p % 8) + p / 8), so neighbouring tiles, whose line ranges
+        // overlap, hit the same L2 instead of pulling the same records into all eight.
+        const int wg = (roles >> 4) & 15;  // 0: one contiguous eighth of the tiles per XCD; g > 0: groups of g tiles going round the XCDs
+        int tile, d;
+        if (wg == 0) {
+            const int p = b % tiles;
+            d = b / tiles;
+            tile = p >> 3;
+            for (int f = 0; f < (p & 7); ++f) tile += (tiles - f + 7) >> 3;
+        } else {
+            // (the host pads the tiles of a depth to whole rounds of 8 g workgroups: b % 8 is then the XCD within every depth)
+            const int tiles_pad = (tiles + 8 * wg - 1) / (8 * wg) * (8 * wg);
+            const int p = b % tiles_pad, j = p >> 3;
+            d = b / tiles_pad;
+            tile = ((j / wg) * 8 + (p & 7)) * wg + j % wg;
+            if (tile >= tiles) return;
+        }
+        if constexpr (SUBSETS) {
+            line_wide_walk<R, MIXED, true, MIXED, FAR>(tile, wave, n_split, d, n_nu, nus, nu_begin, nu_count, n_lines, w, planes, pld, s_wide, part);
+            out_row = d;
+            out_col = (int)((nu_begin / (64 * R) + (int64_t)tile) * (64 * R)) + (int)(threadIdx.x & 63);
+        } else {
+            line_wide_walk<R, MIXED, false, false, FAR>(tile, wave, n_split, d, n_nu, nus, nu_begin, nu_count, n_lines, w, planes, pld, s_wide);
+        }
+    } else {
+        if (!(roles & 2)) return;
+        // A wave writes one value into each of the N_d rows of the narrow plane: the waves that fill a 64-byte sector of a
+        // row (8 consecutive frequencies) should share an L2, or every XCD writes its own fragment of every sector back on
+        // its own.  Workgroups p, p + 8, ... (one XCD) therefore take GROUPS of kNarrowGroup consecutive workgroups' worth
+        // of frequencies, the groups going round the XCDs.  (Giving each XCD one contiguous eighth of the grid was measured
+        // 45 % slower: the lines per grid point follow the frequency, so one XCD gets several times the work of another.)
+        // (SUBSETS: a workgroup is ONE group of frequencies, not four — sixteen workgroups keep the 64 consecutive frequencies per XCD
+        // whose lines' records then meet in one L2)
+        constexpr int kNarrowGroup = SUBSETS ? 16 : 4;
+        // F consecutive frequencies per wave (roles bits 8-11: 1, 2 or 4 — 8 was measured slower), groups aligned
+        // to the global grid
+        const int F = max(1, (roles >> 8) & 15);
+        // dense long lists (a kernel of their own — SUBSETS — so that neither walk pays for the other's registers: with both narrow
+        // walks in one kernel the WIDE role spilled, and a kernel that touches scratch memory ran a third slower): the workgroup's
+        // four waves share one group of F = 4 frequencies
+        constexpr bool subsets = SUBSETS;
+        const int64_t g0 = nu_begin / F;
+        const int64_t n_grp = (nu_begin + nu_count + F - 1) / F - g0;
+        const int64_t n_narrow = n_grp * ((n_depth + 63) / 64);
+        const int64_t n_nb = subsets ? n_narrow : (n_narrow + n_split - 1) / n_split;
+        const int64_t p = b - n_wide, j = p >> 3;
+        const int order = (roles >> 2) & 3;  // analysis knob (SDX_NARROW_ORDER): 0 grouped (default), 1 plain, 2 one block per XCD
+        int64_t wg = ((j / kNarrowGroup) * 8 + (p & 7)) * kNarrowGroup + j % kNarrowGroup;
+        if (order == 1) wg = p;
+        if (order == 2) wg = (p & 7) * ((n_nb + 7) / 8) + j;
+        if ((order == 2 && j >= (n_nb + 7) / 8) || wg >= n_nb) return;
+        const int64_t c = subsets ? wg : wg * n_split + wave;
+        if (c >= n_narrow) return;  // (subsets: the whole workgroup)
+        const int64_t i0 = (g0 + c % n_grp) * F;
+        const int chunk = (int)(c / n_grp);
+        double* __restrict__ nplane = planes + (size_t)n_depth * pld;
+        if constexpr (SUBSETS) {
+            static_assert(!SUBSETS || R == 4, "the common reduction: R points per wide lane = F frequencies per narrow group");
+            if constexpr (MIXED) line_narrow_subsets32<4>(i0, chunk, wave, n_depth, n_nu, nus, nu_begin, nu_count, w, part);
+            else line_narrow_subsets<4>(i0, chunk, wave, n_depth, n_nu, nus, nu_begin, nu_count, line_nus, w, part);
+            out_wide = false;
+            out_row = chunk * 64 + (int)(threadIdx.x & 63);
+            out_valid = out_row < n_depth;
+            out_col = (int)i0;
+        } else if constexpr (MIXED) {
+            if (F == 4) line_narrow_group32<4>(i0, chunk, n_depth, n_nu, nus, nu_begin, nu_count, w, nplane, pld);
+            else if (F == 2) line_narrow_group32<2>(i0, chunk, n_depth, n_nu, nus, nu_begin, nu_count, w, nplane, pld);
+            else line_narrow_wave32(i0, chunk, n_depth, n_nu, nus, nu_begin, nu_count, w, nplane, pld);
+        } else {
+            if (F == 4) line_narrow_group<4>(i0, chunk, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, nplane, pld);
+            else if (F == 2) line_narrow_group<2>(i0, chunk, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, nplane, pld);
+            else line_narrow_wave(i0, chunk, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, nplane, pld);
+        }
+    }
+    if constexpr (SUBSETS) {
+        constexpr int kLdsStride = (FAR && !MIXED && SDX_WIDE_QUEUED) ? kWideFarLdsDoubles : kWideLdsDoubles;  // (the wide walk's)
+        const int lane = threadIdx.x & 63;
+        if (wave > 0) {
+            double* mine = s_wide + (size_t)wave * kLdsStride;
+#pragma unroll
+            for (int r = 0; r < R; ++r) mine[r * 64 + lane] = part[r];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll 1
+            for (int s = 1; s < n_split; ++s) {
+                const double* other = s_wide + (size_t)s * kLdsStride;
+#pragma unroll
+                for (int r = 0; r < R; ++r) part[r] = add_rn(part[r], other[r * 64 + lane]);
+            }
+            const int64_t s0 = nu_begin, s1 = nu_begin + nu_count;  // the columns this launch stores
+            double* __restrict__ dst = planes + (out_wide ? (size_t)0 : (size_t)n_depth * pld) + (size_t)out_row * pld;
+            const int stride = out_wide ? 64 : 1;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int64_t col = (int64_t)out_col + (int64_t)r * stride;
+                if (out_valid && col >= s0 && col < s1) dst[col - s0] = part[r];
+            }
+        }
+    }
+}
+
+template <int R, bool SUBSETS = false, bool FAR = false>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FAR ? SDX_FAR_WAVES : 7, 8))) void k_line_all(int n_wide, int tiles, int n_split, int n_depth, int64_t n_nu,
+                                                   const double* __restrict__ nus, int64_t nu_begin, int64_t nu_count,
+                                                   int64_t n_lines, const double* __restrict__ line_nus, LineWork w,
+                                                   double* __restrict__ planes, int64_t pld, int roles, int far_units)
+{
+    line_all_body<R, false, SUBSETS, FAR>(n_wide, tiles, n_split, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, planes, pld, roles, far_units);
+}
+// the mixed-precision variant: 512-point tiles; the register budget is capped at 128 (4 waves per SIMD) — what exceeds it
+// sits in the rarely taken fp64 general path
+template <int R, bool SUBSETS = false, bool FAR = false>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(R == 4 ? (FAR ? 5 : 6) : 4, 8))) void k_line_all_mixed(
+    int n_wide, int tiles, int n_split, int n_depth, int64_t n_nu, const double* __restrict__ nus, int64_t nu_begin, int64_t nu_count,
+    int64_t n_lines, const double* __restrict__ line_nus, LineWork w, double* __restrict__ planes, int64_t pld, int roles, int far_units)
+{
+    line_all_body<R, true, SUBSETS, FAR>(n_wide, tiles, n_split, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, planes, pld, roles, far_units);
 }
 
 // out (+)= sum over the S line subsets, in subset order

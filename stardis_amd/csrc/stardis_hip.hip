@@ -1190,21 +1190,31 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
     static const int narrow_order = knob("SDX_NARROW_ORDER") ? atoi(knob("SDX_NARROW_ORDER")) & 3 : 0;
     REQUIRE(n_wide + n_narrow < ((int64_t)1 << 31), "line opacity: grid too large for one launch");
     static const bool split_launches = knob("SDX_SPLIT_LAUNCHES") != nullptr;  // analysis knob: time the two roles apart
-    const size_t shmem = (size_t)n_split * (far && !ctx->mixed_precision && SDX_WIDE_QUEUED ? kWideFarLdsDoubles : kWideLdsDoubles) * sizeof(double);
-    const dim3 g((unsigned)(n_wide + n_narrow)), blk((unsigned)(64 * n_split));
+    const bool split_launches_early = split_launches;
+    size_t shmem = (size_t)n_split * (far && !ctx->mixed_precision && SDX_WIDE_QUEUED ? kWideFarLdsDoubles : kWideLdsDoubles) * sizeof(double);
+    // FAR FIELD: units of 4 RF global tiles; RF (1 or 2 node groups per lane) is scheduling only: 2 where that still leaves ~4 workgroups
+    // per CU (4 was measured slower than 2 at every size).  Its workgroups are the FIRST of the line kernel's grid (one launch, and a
+    // shard's far waves — the launch's longest chains — run beside the other roles instead of alone on the chip); experiment knob
+    // SDX_FAR_LAUNCH gives them a launch of their own, with kFarSplit waves per workgroup.  Either way the number of line subsets is
+    // a constant of the mode (it fixes the order of a node's sum): n_split merged, kFarSplit alone.
+    static const bool far_own_launch = knob("SDX_FAR_LAUNCH") != nullptr;
+    static const int far_rf_env = knob("SDX_FAR_RF") ? std::atoi(knob("SDX_FAR_RF")) : 0;  // experiment knob: 1, 2
+    const int64_t far_t_first = nu_begin / (64 * R), far_t_last = (nu_begin + nu_count - 1) / (64 * R);
+    auto far_units_of = [&](int f) { return far_t_last / (4 * f) - far_t_first / (4 * f) + 1; };
+    int far_rf = far_units_of(2) * n_depth >= (int64_t)4 * ctx->n_cu ? 2 : 1;
+    if (far_rf_env == 1 || far_rf_env == 2) far_rf = far_rf_env;
+    const int64_t far_units = far ? far_units_of(far_rf) : 0;
+    const bool far_merged = far && !far_own_launch && !split_launches_early && !ctx->mixed_precision;
+    const int64_t n_far = far_merged ? far_units * n_depth : 0;
+    if (far_merged) shmem = std::max(shmem, (((size_t)n_split + 2) * far_rf * 64 + (size_t)n_split * kFarWaveLdsDoubles) * sizeof(double));
+    REQUIRE(n_far + n_wide + n_narrow < ((int64_t)1 << 31), "line opacity: grid too large for one launch");
+    const dim3 g((unsigned)(n_far + n_wide + n_narrow)), blk((unsigned)(64 * n_split));
     // (k_line_far on a second stream beside k_line_all — a fork and a join per step — was measured in round 5: S-c3 1.857 -> 1.840 ms, its
     // eighth 0.419 -> 0.420, S-c4m 7.49 -> 7.48: both kernels are bound by their instructions, neither leaves the other idle slots)
     auto launch_far = [&]() -> int {
-        // units of 4 RF global tiles; RF (1 or 2 node groups per lane) is scheduling only: 2 where that still leaves ~4 workgroups per CU
-        // (4 was measured slower than 2 at every size)
-        const int64_t t_first = nu_begin / (64 * R), t_last = (nu_begin + nu_count - 1) / (64 * R);
-        auto units_of = [&](int rf) { return t_last / (4 * rf) - t_first / (4 * rf) + 1; };
-        static const int far_rf_env = knob("SDX_FAR_RF") ? std::atoi(knob("SDX_FAR_RF")) : 0;  // experiment knob: 1, 2, 4
-        int rf = units_of(2) * n_depth >= (int64_t)4 * ctx->n_cu ? 2 : 1;
-        if (far_rf_env == 1 || far_rf_env == 2 || far_rf_env == 4) rf = far_rf_env;
-        const int64_t units = units_of(rf);
+        const int rf = far_rf;
+        const int64_t units = far_units;
         REQUIRE(units * n_depth < ((int64_t)1 << 31), "line opacity: grid too large for one launch");
-        // (its own number of line subsets — a constant: it fixes the order of a node's sum)
         static const int far_split_env = knob("SDX_FAR_SPLIT") ? std::atoi(knob("SDX_FAR_SPLIT")) : 0;  // experiment knob: 1 .. 8
         const int far_split = far_split_env >= 1 && far_split_env <= 8 ? far_split_env : kFarSplit;
         const size_t far_shmem = (((size_t)far_split + 2) * rf * 64 + (size_t)far_split * kFarWaveLdsDoubles) * sizeof(double);
@@ -1212,8 +1222,7 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
         double* far_plane = part + (size_t)2 * n_depth * pld;
         LaunchScope ls(ctx, "k_line_far");
 #define SDX_FAR_ARGS (int)units, far_split, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, w, far_plane, pld
-        if (rf == 4) hipLaunchKernelGGL((k_line_far<R, 4>), fg, fblk, far_shmem, ctx->stream, SDX_FAR_ARGS);
-        else if (rf == 2) hipLaunchKernelGGL((k_line_far<R, 2>), fg, fblk, far_shmem, ctx->stream, SDX_FAR_ARGS);
+        if (rf == 2) hipLaunchKernelGGL((k_line_far<R, 2>), fg, fblk, far_shmem, ctx->stream, SDX_FAR_ARGS);
         else hipLaunchKernelGGL((k_line_far<R, 1>), fg, fblk, far_shmem, ctx->stream, SDX_FAR_ARGS);
 #undef SDX_FAR_ARGS
         return SDX_OK;
@@ -1221,9 +1230,9 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
     for (int pass = 0; pass < (split_launches ? 2 : 1); ++pass) {
         // (raising the priority of the hot layers' waves with s_setprio was measured in round 4: the instruction has side effects as
         // far as the compiler is concerned, the record fetches of the walk stopped being scalar loads and the kernel ran 37 % slower)
-        const int roles = (split_launches ? (1 << pass) : 3) | (narrow_order << 2) | (wide_group << 4) | (narrow_f << 8) | (narrow_sub << 12);
-        LaunchScope ls(ctx, split_launches ? (pass ? "k_line_narrow" : "k_line_wide") : "k_line_all");
-#define SDX_LINE_ARGS (int)n_wide, tiles, n_split, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, part, pld, roles
+        const int roles = (split_launches ? (1 << pass) : 3) | (narrow_order << 2) | (wide_group << 4) | (narrow_f << 8) | (narrow_sub << 12) | ((far_merged ? far_rf : 0) << 16);
+        LaunchScope ls(ctx, split_launches ? (pass ? "k_line_narrow" : "k_line_wide") : "k_line_all", far_merged ? "k_line_all + far role" : (far ? "k_line_all (far field in k_line_far)" : nullptr));
+#define SDX_LINE_ARGS (int)n_wide, tiles, n_split, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, w, part, pld, roles, (int)far_units
         if (ctx->mixed_precision && Rm == 8) hipLaunchKernelGGL((k_line_all_mixed<8>), g, blk, shmem, ctx->stream, SDX_LINE_ARGS);
         else if (ctx->mixed_precision && narrow_sub && far) hipLaunchKernelGGL((k_line_all_mixed<R_MIXED, true, true>), g, blk, shmem, ctx->stream, SDX_LINE_ARGS);
         else if (ctx->mixed_precision && narrow_sub) hipLaunchKernelGGL((k_line_all_mixed<R_MIXED, true>), g, blk, shmem, ctx->stream, SDX_LINE_ARGS);
@@ -1235,7 +1244,7 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
         else hipLaunchKernelGGL((k_line_all<R>), g, blk, shmem, ctx->stream, SDX_LINE_ARGS);
 #undef SDX_LINE_ARGS
     }
-    if (far && (rc = launch_far())) return rc;
+    if (far && !far_merged && (rc = launch_far())) return rc;
     *partial_out = part;
     *pld_out = pld;
     *n_planes_out = far ? 3 : 2;

@@ -30,7 +30,8 @@ def run(ctx, far, nus, atm, lines, cont, th, w, **kw):
     syn = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], th, w, lines, cont, ctx=ctx, track_evaluations=False, **kw)
     syn.step()
     out = syn.alpha_line().copy(), syn.total_alphas().copy(), syn.F_nu().copy()
-    launched = ctx.profile("k_line_far")[0] > 0
+    # (the far field is a role of the line kernel's launch — or, under an experiment knob, a launch of its own)
+    launched = ctx.profile("k_line_far")[0] > 0 or "far" in ctx.profile_variant("k_line_all")
     ctx.call("sdx_profile_enable", 0)
     syn.close()
     return out, launched

@@ -36,7 +36,7 @@ print("HASHES", " ".join(out))
 
 HOSTILE = dict(SDX_WIDE_BLOCKS="7", SDX_RT_SEG="0", SDX_RT_P="2", SDX_RT_NS="4", SDX_NARROW_F="2", SDX_R_MIXED="8", SDX_NO_CULL="1",
                SDX_NARROW_ORDER="1", SDX_WIDE_GROUP="2", SDX_CONT_DGS="0", SDX_NO_HSCAN="1", SDX_NO_CONT_RIDE="1", SDX_NO_PREPASS_FRONT="1",
-               SDX_PRE_LINES="32", SDX_NO_NARROW_SUBSETS="1", SDX_NARROW_SUBSETS_DENSITY="0", SDX_FAR="1", SDX_FAR_RF="1", SDX_FAR_SPLIT="3")
+               SDX_PRE_LINES="32", SDX_NO_NARROW_SUBSETS="1", SDX_NARROW_SUBSETS_DENSITY="0", SDX_FAR="1", SDX_FAR_RF="1", SDX_FAR_SPLIT="3", SDX_FAR_LAUNCH="1")
 
 
 def _hashes(extra_env):
