@@ -116,7 +116,9 @@ int sdx_synchronize(sdx_ctx* ctx);
  *       Which triples are far is a property of the grid and the list, not of the shard: shards stay bit-identical to the unsharded
  *       run.  -1: grids of at least 32768 frequencies (decided from the GLOBAL grid); 0: never — every window point is evaluated
  *       where it lies, as the reference does; 1: whenever the line kernel runs 256-point tiles (always, unless an experiment knob
- *       says otherwise). */
+ *       says otherwise).  With "mixed_precision" = 1 the far field and what it leaves to the wide windows (a line's near zone, window
+ *       edges) are evaluated in fp64 as in the fp64 mode — the far wings that mode computed in fp32 are the far field's now —; narrow
+ *       windows, delegated cores and the formal solution stay fp32. */
 int sdx_set_int_option(sdx_ctx* ctx, const char* name, int64_t value);
 
 /* device memory for callers that do not bring their own (numpy-only users) */

@@ -772,7 +772,7 @@ __global__ __launch_bounds__(kPreBlock) __attribute__((amdgpu_num_sgpr(80), amdg
 // S-c3's tiles: 2.5e-14 relative, rounding included (the direct fp64 sum: 4e-15).  The opacity tolerance is 1e-12, the flux's 1e-10.
 // Which triples are far is a property of the grid and the list (global tiles), not of the shard or the launch geometry; both
 // kernels decide it with THIS function on the same operands, so every triple is evaluated exactly once.
-constexpr int kFarSplit = 8;  // line subsets (waves per workgroup) of k_line_far — the far field as a launch of its own (fp32-mixed mode, SDX_FAR_LAUNCH): a shard's launch is a few hundred workgroups, its waves' chains are its duration
+constexpr int kFarSplit = 8;  // line subsets (waves per workgroup) of k_line_far — the far field as a launch of its own (experiment knob SDX_FAR_LAUNCH, split-launch profiling): a shard's launch is a few hundred workgroups, its waves' chains are its duration
 constexpr int kFarWaveLdsDoubles = 64 * 6 + 64;  // per wave of k_line_far: 64 staged records, the queue's line indices and tile masks
 // The distance test in INDEX space, once per tile (one thread each): a line's centre index is cidx = #{i : nus[i] >= nu_l}
 // (closest_index, the reference's own quantity), so with ihi = #{i : nus[i] >= c + 6 h} and ilo = #{i : nus[i] >= c - 6 h}
@@ -2308,7 +2308,10 @@ __device__ __forceinline__ void line_all_body(int n_wide, int tiles, int n_split
 {
     extern __shared__ double s_wide[];  // n_split x kWideLdsDoubles
     int b = blockIdx.x;
-    if constexpr (FAR && !MIXED) {  // (the fp32-mixed kernels have no registers for it: the far field keeps its own launch there)
+    // (fp32-mixed kernels with a far field: what is left to the wide role — a line's near zone, window edges, kept cores — is walked in
+    // fp64 by the queued walk like the fp64 kernels'; the narrow role and the formal solution stay the mode's fp32)
+    constexpr bool WM = MIXED && !FAR;  // the wide role's arithmetic
+    if constexpr (FAR) {
         // far role (roles bits 16-17: RF, 0 = the far field has a launch of its own): the FIRST workgroups of the grid — their waves are
         // the longest chains of the launch (a unit walks every huge line of the list) — n_depth x far_units of them
         const int rf = (roles >> 16) & 3;
@@ -2352,11 +2355,11 @@ __device__ __forceinline__ void line_all_body(int n_wide, int tiles, int n_split
             if (tile >= tiles) return;
         }
         if constexpr (SUBSETS) {
-            line_wide_walk<R, MIXED, true, MIXED, FAR>(tile, wave, n_split, d, n_nu, nus, nu_begin, nu_count, n_lines, w, planes, pld, s_wide, part);
+            line_wide_walk<R, WM, true, WM, FAR>(tile, wave, n_split, d, n_nu, nus, nu_begin, nu_count, n_lines, w, planes, pld, s_wide, part);
             out_row = d;
             out_col = (int)((nu_begin / (64 * R) + (int64_t)tile) * (64 * R)) + (int)(threadIdx.x & 63);
         } else {
-            line_wide_walk<R, MIXED, false, false, FAR>(tile, wave, n_split, d, n_nu, nus, nu_begin, nu_count, n_lines, w, planes, pld, s_wide);
+            line_wide_walk<R, WM, false, false, FAR>(tile, wave, n_split, d, n_nu, nus, nu_begin, nu_count, n_lines, w, planes, pld, s_wide);
         }
     } else {
         if (!(roles & 2)) return;
@@ -2409,7 +2412,7 @@ __device__ __forceinline__ void line_all_body(int n_wide, int tiles, int n_split
         }
     }
     if constexpr (SUBSETS) {
-        constexpr int kLdsStride = (FAR && !MIXED && SDX_WIDE_QUEUED) ? kWideFarLdsDoubles : kWideLdsDoubles;  // (the wide walk's)
+        constexpr int kLdsStride = (FAR && SDX_WIDE_QUEUED) ? kWideFarLdsDoubles : kWideLdsDoubles;  // (the wide walk's)
         const int lane = threadIdx.x & 63;
         if (wave > 0) {
             double* mine = s_wide + (size_t)wave * kLdsStride;
@@ -2447,7 +2450,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FAR ? SDX_F
 // the mixed-precision variant: 512-point tiles; the register budget is capped at 128 (4 waves per SIMD) — what exceeds it
 // sits in the rarely taken fp64 general path
 template <int R, bool SUBSETS = false, bool FAR = false>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(R == 4 ? (FAR ? 5 : 6) : 4, 8))) void k_line_all_mixed(
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(R == 4 ? 6 : 4, 8))) void k_line_all_mixed(
     int n_wide, int tiles, int n_split, int n_depth, int64_t n_nu, const double* __restrict__ nus, int64_t nu_begin, int64_t nu_count,
     int64_t n_lines, const double* __restrict__ line_nus, LineWork w, double* __restrict__ planes, int64_t pld, int roles, int far_units)
 {

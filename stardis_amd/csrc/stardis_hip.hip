@@ -1191,7 +1191,7 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
     REQUIRE(n_wide + n_narrow < ((int64_t)1 << 31), "line opacity: grid too large for one launch");
     static const bool split_launches = knob("SDX_SPLIT_LAUNCHES") != nullptr;  // analysis knob: time the two roles apart
     const bool split_launches_early = split_launches;
-    size_t shmem = (size_t)n_split * (far && !ctx->mixed_precision && SDX_WIDE_QUEUED ? kWideFarLdsDoubles : kWideLdsDoubles) * sizeof(double);
+    size_t shmem = (size_t)n_split * (far && SDX_WIDE_QUEUED ? kWideFarLdsDoubles : kWideLdsDoubles) * sizeof(double);
     // FAR FIELD: units of 4 RF global tiles; RF (1 or 2 node groups per lane) is scheduling only: 2 where that still leaves ~4 workgroups
     // per CU (4 was measured slower than 2 at every size).  Its workgroups are the FIRST of the line kernel's grid (one launch, and a
     // shard's far waves — the launch's longest chains — run beside the other roles instead of alone on the chip); experiment knob
@@ -1204,7 +1204,7 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
     int far_rf = far_units_of(2) * n_depth >= (int64_t)4 * ctx->n_cu ? 2 : 1;
     if (far_rf_env == 1 || far_rf_env == 2) far_rf = far_rf_env;
     const int64_t far_units = far ? far_units_of(far_rf) : 0;
-    const bool far_merged = far && !far_own_launch && !split_launches_early && !ctx->mixed_precision;
+    const bool far_merged = far && !far_own_launch && !split_launches_early;
     const int64_t n_far = far_merged ? far_units * n_depth : 0;
     if (far_merged) shmem = std::max(shmem, (((size_t)n_split + 2) * far_rf * 64 + (size_t)n_split * kFarWaveLdsDoubles) * sizeof(double));
     REQUIRE(n_far + n_wide + n_narrow < ((int64_t)1 << 31), "line opacity: grid too large for one launch");
