@@ -2016,14 +2016,15 @@ __device__ __forceinline__ void line_narrow_subsets32(const int64_t i0, const in
 
 // FAR FIELD of the line opacity (far_eligible above): the third plane of the line kernels.  One workgroup owns (depth d, a unit of
 // 4 RF consecutive global tiles, RF = 1 or 2); lane <-> (tile 4 r + lane / 16 of the unit, Chebyshev node lane % 16), r < RF.  Its
-// n_split waves (the line kernel's, whose far role this is; kFarSplit in a launch of its own) go through the candidate lists exactly as the wide role does (hlist, then the wlist range around the
-// unit; chunk q of 64 candidates belongs to wave q mod n_split): each lane tests ONE candidate against the unit (its whole span
-// first, the single tiles where that does not settle it) and keeps the mask of the tiles it is far from; the hits are queued in LDS
-// in list order and evaluated 64 at a time — records fetched by the lanes in one round trip — at the lanes' nodes with the wide
-// role's own arithmetic (x = fma(dnu, inv, c0), region1_add), test-free when the candidate is far from every tile of the unit.  The waves' node sums meet in LDS (subset order), wave 0 turns the 16 node values of a tile into the
-// coefficients of its Chebyshev series (kFarCoef), and every wave evaluates the series of its share of the tiles at their grid
-// points (Clenshaw) and writes the plane — zeros where a tile has no far field.  The sum of a (tile, node) adds its lines in list
-// order within a subset and the subsets in order, whatever RF and whatever the shard: RF is pure scheduling.
+// n_split waves (the line kernel's, whose far role this is; kFarSplit in a launch of its own) go through the candidate lists exactly
+// as the wide role does (hlist, then the wlist range around the unit; chunk q of 64 candidates belongs to wave q mod n_split): each
+// lane tests ONE candidate against the unit (its whole span first, the single tiles where that does not settle it) and keeps the
+// mask of the tiles it is far from; the hits are queued in LDS in list order and evaluated 64 at a time — records fetched by the
+// lanes in one round trip — at the lanes' nodes with the wide role's own arithmetic (x = fma(dnu, inv, c0), region1_add), test-free
+// when the candidate is far from every tile of the unit.  The waves' node sums meet in LDS (subset order), wave 0 turns the 16 node
+// values of a tile into the coefficients of its Chebyshev series (kFarCoef), and every wave evaluates the series of its share of
+// the tiles at their grid points (Clenshaw) and writes the plane — zeros where a tile has no far field.  The sum of a (tile, node)
+// adds its lines in list order within a subset and the subsets in order, whatever RF and whatever the shard: RF is pure scheduling.
 template <int R, int RF>
 __device__ __forceinline__ void line_far_body(const int block, const int units, const int n_split, int n_depth, int64_t n_nu, const double* __restrict__ nus,
                                               int64_t nu_begin, int64_t nu_count, int64_t n_lines, LineWork w, double* __restrict__ plane, int64_t pld,
