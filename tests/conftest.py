@@ -35,6 +35,33 @@ def load_golden(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
 
 
+_SPECIES_Z = {"H": 1, "He": 2}
+_STAGE = {"I": 1, "II": 2, "III": 3}
+
+
+def species_arrays_from_g14(g, keys):
+    """Flat bf / ff arguments for a species list out of the G14 fixture's plasma tables, the way the reference walks them
+    (opacities_solvers/base.py:204-226 and util.py:154-167): species-major, levels in the plasma's index order.
+    -> (offsets, bf_ions, cutoffs, level_density, ff_ions, ff_density)."""
+    H = 6.62607015e-27
+    ions = {tuple(k): g["ion_number_density"][i] for i, k in enumerate(g["ion_index"])}
+    chi = {tuple(k): g["ionization_energy"][i] for i, k in enumerate(g["ionization_index"])}
+    offsets, bf_ions, cutoffs, dens, ff_ions, ff_dens = [0], [], [], [], [], []
+    for key in keys:
+        sym, stage = key.split("_")
+        z = _SPECIES_Z[sym]
+        ion = (int(stage) if stage.isdigit() else _STAGE[stage]) - 1
+        for i, lev in enumerate(g["level_index"]):
+            if lev[0] == z and lev[1] == ion:
+                cutoffs.append((chi[(z, ion + 1)] - g["level_excitation"][i]) / H)
+                dens.append(g["level_density"][i])
+        offsets.append(len(cutoffs))
+        bf_ions.append(ion)
+        ff_ions.append(ion + 1)
+        ff_dens.append(g["n_e"] * ions[(z, ion + 1)])  # util.py:160-165: n_e first, then the ion density
+    return offsets, bf_ions, np.array(cutoffs), np.vstack(dens), ff_ions, np.vstack(ff_dens)
+
+
 @pytest.fixture(scope="session")
 def golden():
     return load_golden

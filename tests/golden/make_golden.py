@@ -914,7 +914,89 @@ def g13_alpha_line_levels(atm, cont):
     )
 
 
-ALL = ("g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13")
+# ----------------------------------------------------------------------------- G14 bf / ff, several species, Z > 1
+def g14_continuum_species(atm, cont):
+    """calc_alpha_bf / calc_alpha_ff (opacities_solvers/base.py:178-317) with more than one species and ion_number > 0:
+    the `(ion_number+1)**4`, `((ion_number+1)*sqrt(nu_R/nu_c))**5` and `ion_number**2` factors, the species loop's summation
+    order, and the level filter on a plasma whose level index interleaves the species."""
+    from stardis_amd import synth
+
+    t = atm["temperatures"]
+    nd = len(t)
+    cols = np.arange(nd)
+    kt = 1.380649e-16 * t
+    ev = 1.602176634e-12
+    n_he1 = cont["n_he1"]
+    n_he2 = n_he1 * 3.0e-3 * (t / 6000.0) ** 6
+    n_he3 = n_he2 * 1.0e-5 * (t / 6000.0) ** 8
+    ind = pd.MultiIndex.from_tuples([(1, 0), (1, 1), (2, 0), (2, 1), (2, 2)], names=["atomic_number", "ion_number"])
+    ion_number_density = pd.DataFrame(np.vstack([cont["n_h1"], cont["n_h2"], n_he1, n_he2, n_he3]), index=ind, columns=cols)
+    # levels: H I (10, hydrogenic), He I (ground + 2 3S + 2 1S), He II (6, hydrogenic Z = 2); index deliberately interleaved
+    he1_exc = np.array([0.0, 19.8196, 20.6158]) * ev
+    he1_g = np.array([1.0, 3.0, 1.0])
+    n = np.arange(1, 7, dtype=np.float64)
+    he2_exc = 54.417763 * ev * (1.0 - 1.0 / n**2)
+    he2_g = 2.0 * n**2
+
+    def boltz(g, exc, total):
+        w = g[:, None] * np.exp(-exc[:, None] / kt[None, :])
+        return w / w.sum(axis=0, keepdims=True) * total[None, :]
+
+    he1_lev, he2_lev = boltz(he1_g, he1_exc, n_he1), boltz(he2_g, he2_exc, n_he2)
+    n_h = cont["level_density"].shape[0]
+    rows = []
+    for k in range(max(n_h, 6)):
+        if k < 6:
+            rows.append(((2, 1, k), he2_exc[k], he2_lev[k]))
+        if k < n_h:
+            rows.append(((1, 0, k), cont["level_excitation"][k], cont["level_density"][k]))
+        if k < 3:
+            rows.append(((2, 0, k), he1_exc[k], he1_lev[k]))
+    lev_index = pd.MultiIndex.from_tuples([r[0] for r in rows], names=["atomic_number", "ion_number", "level_number"])
+    ionization_data = pd.Series(
+        np.array([13.598434, 24.587387, 54.417763]) * ev,
+        index=pd.MultiIndex.from_tuples([(1, 1), (2, 1), (2, 2)], names=["atomic_number", "ion_number"]),
+        name="ionization_energy",
+    )
+    plasma = NS(
+        ion_number_density=ion_number_density,
+        electron_densities=pd.Series(atm["n_e"], index=cols),
+        levels=lev_index,
+        excitation_energy=pd.Series(np.array([r[1] for r in rows]), index=lev_index),
+        level_number_density=pd.DataFrame(np.vstack([r[2] for r in rows]), index=lev_index, columns=cols),
+        ionization_data=ionization_data,
+    )
+    model = fake_model(atm)
+    out = dict(
+        temperatures=t, n_e=atm["n_e"],
+        ion_index=np.array(list(ind), dtype=np.int64), ion_number_density=ion_number_density.values,
+        level_index=np.array(list(lev_index), dtype=np.int64),
+        level_excitation=np.array([r[1] for r in rows]), level_density=np.vstack([r[2] for r in rows]),
+        ionization_index=np.array(list(ionization_data.index), dtype=np.int64), ionization_energy=ionization_data.values,
+    )
+    cases = {
+        "h_he2": ["H_I", "He_II"],
+        "he2_h_he1": ["He_II", "H_I", "He_I"],  # species order = summation order (:204, :235, :237)
+        "he1": ["He_I"],
+        "he2": ["He_2"],  # stage in digits
+    }
+    for tag, nus in {
+        "wide": synth.tracing_grid(1500.0, 24000.0, R=60.0),
+        "uv": synth.tracing_grid(150.0, 4000.0, R=80.0),  # crosses He II n = 1, 2 (228, 911 A), He I ground (504 A), Lyman
+    }.items():
+        out[f"{tag}_nus"] = nus
+        for case, keys in cases.items():
+            species = {k: {} for k in keys}
+            out[f"{tag}_alpha_bf_{case}"] = R.ob.calc_alpha_bf(plasma, model, nus.copy() * u.Hz, species)
+            out[f"{tag}_alpha_ff_{case}"] = R.ob.calc_alpha_ff(plasma, model, nus.copy() * u.Hz, species)
+            print("  g14", tag, case, float(out[f"{tag}_alpha_bf_{case}"].max()), float(out[f"{tag}_alpha_ff_{case}"].max()))
+    out["case_names"] = np.array(list(cases))
+    out["case_species"] = np.array([",".join(v) for v in cases.values()])
+    save("g14_continuum_species", **out)
+
+
+
+ALL = ("g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14")
 
 
 def generate(which):
@@ -950,6 +1032,8 @@ def generate(which):
         g12_sigma_tables(atm)
     if "g13" in which:
         g13_alpha_line_levels(atm, cont)
+    if "g14" in which:
+        g14_continuum_species(atm, cont)
 
 
 def verify(which):

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import oracle
-from conftest import GOLDEN, load_golden, rel_err
+from conftest import GOLDEN, load_golden, rel_err, species_arrays_from_g14
 from stardis_amd import constants as K
 
 
@@ -114,6 +114,21 @@ def test_continuum_golden():
         assert np.array_equal(n2, g[tag + "_nus_after_rayleigh"])  # in-place clipping (base.py:99)
         assert rel_err(oracle.alpha_rayleigh(nus.copy(), g["n_h1"]), g[tag + "_alpha_rayleigh_H_only"]) < 5e-15
         assert np.array_equal(oracle.alpha_electron(len(nus), g["n_e"]), g[tag + "_alpha_electron"])
+
+
+def test_continuum_species_golden():
+    """bf / ff with several species and Z > 1 (reference :202-271, :301-315): G14."""
+    g = load_golden("g14_continuum_species")
+    assert K.H_CGS == 6.62607015e-27
+    for case, species in zip(g["case_names"], g["case_species"]):
+        off, bf_ion, cut, ld, ff_ion, ff_n = species_arrays_from_g14(g, str(species).split(","))
+        for tag in ("wide", "uv"):
+            nus = g[tag + "_nus"]
+            ref_bf, ref_ff = g[f"{tag}_alpha_bf_{case}"], g[f"{tag}_alpha_ff_{case}"]
+            assert ref_bf.max() > 0 and ref_ff.max() > 0
+            # nu**-3, x**5: numpy's pow vs libm, 1 ulp each
+            assert rel_err(oracle.alpha_bf(nus, off, bf_ion, cut, ld), ref_bf) < 1e-15, (case, tag)
+            assert rel_err(oracle.alpha_ff(nus, g["temperatures"], ff_ion, ff_n), ref_ff) < 1e-15, (case, tag)
 
 
 def test_weights_golden():
