@@ -120,6 +120,14 @@ int sdx_synchronize(sdx_ctx* ctx);
  *       edges) are evaluated in fp64 as in the fp64 mode — the far wings that mode computed in fp32 are the far field's now —; narrow
  *       windows, delegated cores and the formal solution stay fp32. */
 int sdx_set_int_option(sdx_ctx* ctx, const char* name, int64_t value);
+/* The far-field rule as the library applies it — for planners that weigh shards (stardis_amd.parallel.column_cost) and must not
+ * carry constants of their own.  sdx_far_field_active: 1 when a synthesis of a GLOBAL grid of n_nu_global points on this context runs
+ * with the far field (the "far_field" option, else the automatic rule: grids of at least *min_points), 0 when not, negative on a null
+ * context.  sdx_far_field_rule: the rule's constants — the automatic threshold, the tile the far field lives on (grid points) and how
+ * close to its centre, in grid points, a window is still evaluated point by point (half a tile + the pole-distance ratio in tile
+ * half-widths).  Replaces nothing in the reference (its sum is always the direct one, opacities_solvers/base.py:577-592). */
+int sdx_far_field_active(const sdx_ctx* ctx, int64_t n_nu_global);
+int sdx_far_field_rule(int64_t* min_points, int* tile_points, int* near_points);
 
 /* device memory for callers that do not bring their own (numpy-only users) */
 /* (freed blocks are kept by the context — up to 4 GiB — and handed out again: all uses are ordered on the context's stream, so the

@@ -118,6 +118,8 @@ PROTOTYPES = {
     "sdx_get_stream": (_vp, [_vp]),
     "sdx_synchronize": (_int, [_vp]),
     "sdx_set_int_option": (_int, [_vp, C.c_char_p, _i64]),
+    "sdx_far_field_active": (_int, [_vp, _i64]),
+    "sdx_far_field_rule": (_int, [C.POINTER(_i64), C.POINTER(_int), C.POINTER(_int)]),
     "sdx_malloc": (_vp, [_vp, C.c_size_t]),
     "sdx_free": (_int, [_vp, _vp]),
     "sdx_memcpy_h2d": (_int, [_vp, _vp, _vp, C.c_size_t]),

@@ -121,7 +121,8 @@ struct sdx_ctx {
     // continuum plane) and for which problem; the synthesis that follows with options->line_m_max checks and consumes it
     struct {
         bool valid = false;
-        bool far = false;  // ... and the tiles' far ranges (far_ws)
+        bool far = false;         // ... the far field was on in phase 1 and
+        bool far_ranges = false;  // ... its launch computed the tiles' far ranges (far_ws)
         int n_depth = 0;
         int64_t n_nu = 0, nu_begin = 0, nu_count = 0, n_lines = 0;
         uint64_t generation = 0;
@@ -259,6 +260,7 @@ int launch_dnu(sdx_ctx* ctx, int64_t n_nu, const double* nus, int* n_partial, in
 {
     int rc = ensure(ctx, &ctx->small_ws, &ctx->small_ws_bytes, kSmallHeader);
     if (rc) return rc;
+    ctx->classified.valid = false;  // (the grid-spacing partials of a two-collective phase 1 are overwritten)
     const int nb = (int)std::min<int64_t>(kDnuPartials, std::max<int64_t>(1, (n_nu + kBlock * 8 - 1) / (kBlock * 8)));
     {
         LaunchScope ls(ctx, "k_dnu_partial");
@@ -442,6 +444,23 @@ int sdx_set_int_option(sdx_ctx* ctx, const char* name, int64_t value)
         return SDX_OK;
     }
     return fail(SDX_ERR_ARG, std::string("unknown option ") + name);
+}
+
+static bool far_field_on(const sdx_ctx* ctx, int64_t n_nu_global);
+int sdx_far_field_active(const sdx_ctx* ctx, int64_t n_nu_global)
+{
+    REQUIRE(ctx, "null context");
+    return far_field_on(ctx, n_nu_global) ? 1 : 0;
+}
+
+int sdx_far_field_rule(int64_t* min_points, int* tile_points, int* near_points)
+{
+    if (min_points) *min_points = 32768;  // kFarMinPoints (static_assert where it is defined)
+    if (tile_points) *tile_points = kFarTile;
+    // a (line, tile) pair is far when the line's centre is >= kFarRatio tile half-widths from the tile's centre: a point closer than
+    // that + half a tile to the centre is always evaluated where it lies
+    if (near_points) *near_points = (int)(kFarRatio * (kFarTile / 2)) + kFarTile / 2;
+    return SDX_OK;
 }
 
 int sdx_synchronize(sdx_ctx* ctx)
@@ -817,6 +836,10 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
     if (nu_count < 0) nu_count = n_nu;
     const LineParams lp = gen ? *gen : LineParams{};
     int n_partial = 0;
+    // every pre-pass rewrites the scratch a two-collective phase 1 leaves for its phase 2 (grid spacing, line ranges, lists): only the
+    // phase 2 that consumes it may find it valid (phase 1 sets the flag again when its launch is enqueued)
+    const bool consumes_classified = ph && ph->phase == 2;
+    if (!consumes_classified) ctx->classified.valid = false;
     int rc = ensure(ctx, &ctx->small_ws, &ctx->small_ws_bytes, kSmallHeader);
     if (rc) return rc;
     const bool scan_in_block = n_nu <= 16384;  // every pre-pass block re-scans a small grid instead of a separate launch
@@ -956,6 +979,9 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
                     "synthesize: options->line_m_max needs sdx_synthesize_classify_dev on this context first, for the same grid, shard and line list");
             REQUIRE(c.generation == ctx->ws_generation, "synthesize: the context's scratch was reallocated between sdx_synthesize_classify_dev and the synthesis");
             REQUIRE(!job || continuum_done, "synthesize: two-collective mode needs the tiled continuum");
+            // consumed: a second phase 2 needs a new phase 1 (the resident inputs may have been updated in place since; a recorded
+            // graph replays both phases without this host check)
+            ctx->classified.valid = false;
         } else {
             REQUIRE(!ph || !job || continuum_done, "synthesize: two-collective mode needs the tiled continuum (at most 4096 bound-free levels)");
             LaunchScope ls(ctx, "k_classify");
@@ -976,7 +1002,8 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
         if (ph && ph->phase == 1) {
             auto& c = ctx->classified;
             c.valid = true, c.n_depth = n_depth, c.n_nu = n_nu, c.nu_begin = nu_begin, c.nu_count = nu_count, c.n_lines = n_lines;
-            c.far = ctx->far_req_done;
+            c.far_ranges = ctx->far_req_done;
+            c.far = far_field_on(ctx, n_nu) && c.far_ranges;
             c.generation = ctx->ws_generation;
             return check_launch("k_classify");
         }
@@ -1075,12 +1102,13 @@ static int choose_splits(int n_depth, int64_t n_nu_global, int64_t n_lines, int 
 // FAR FIELD (k_line_far): a third plane.  Like every choice that moves a rounding it is made from the GLOBAL grid — grids of at
 // least kFarMinPoints frequencies (below that a launch of the line kernel is bound by latency, not by its evaluations) — or set
 // explicitly (context option "far_field").
+constexpr int64_t kFarMinPoints = 32768;
+static_assert(kFarMinPoints == 32768, "sdx_far_field_rule reports this constant");
 static bool far_field_on(const sdx_ctx* ctx, int64_t n_nu_global)
 {
     static const int far_env = knob("SDX_FAR") ? std::atoi(knob("SDX_FAR")) : -1;  // A/B knob: 0 never, 1 whenever possible
     static const int r_mixed_env = knob("SDX_R_MIXED") ? std::atoi(knob("SDX_R_MIXED")) : 4;
     const int far_mode = ctx->far_field >= 0 ? (int)ctx->far_field : far_env;
-    constexpr int64_t kFarMinPoints = 32768;
     if (ctx->mixed_precision && r_mixed_env == 8) return false;  // (experiment knob: 512-point tiles)
     return far_mode != 0 && (far_mode == 1 || n_nu_global >= kFarMinPoints);
 }
@@ -1110,7 +1138,8 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
     const int Rm = ctx->mixed_precision ? (r_mixed_env == 8 ? 8 : R_MIXED) : R;
     const bool far = far_field_on(ctx, n_nu) && nu_count > 0;
     int rc;
-    const bool classified_far = ph && ph->phase == 2 && ctx->classified.valid && ctx->classified.far;  // (phase 1 computed the ranges)
+    // (phase 1 computed the ranges — with the far field on then; if the option was switched on in between, k_far_ranges below does it)
+    const bool classified_far = ph && ph->phase == 2 && ctx->classified.valid && ctx->classified.far && ctx->classified.far_ranges;
     if (far && !classified_far && (rc = request_far_ranges(ctx, n_nu, nu_begin, nu_count))) return rc;
     LineWork w;
     rc = line_prepass(ctx, n_depth, n_nu, nus, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, true, nullptr, nullptr, &w,
@@ -2092,6 +2121,7 @@ static int synthesize_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double
     // two-collective mode: the classification launch ran already (sdx_synthesize_classify_dev), the per-line maxima were gathered
     const ClassifyPhase second{2, 0, 0, opt ? const_cast<double*>(opt->line_m_max) : nullptr};
     REQUIRE(!second.m_max || (n_lines > 0 && !gen), "synthesize: options->line_m_max goes with a dense line list");
+    if (!second.m_max) ctx->classified.valid = false;  // (this step rewrites the continuum plane a phase 1 left behind)
     if (n_lines > 0) {
         LineWork w;
         rc = line_partials(ctx, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, &part, &pld,
@@ -2234,6 +2264,7 @@ int sdx_synthesize_classify_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const d
     const ContinuumJob job{cont, nu_begin, nu_count, (double*)ctx->cont_ws};
     const ClassifyPhase first{1, line_begin, line_count, m_max};
     ctx->classified.valid = false;
+    ctx->far_req_done = false;  // (request_far_ranges resets it only when the far field is on)
     if (far_field_on(ctx, n_nu) && (rc = request_far_ranges(ctx, n_nu, nu_begin, nu_count))) return rc;
     rc = line_prepass(ctx, n_depth, n_nu, nus, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, true, nullptr, nullptr, nullptr, false, &job,
                       nullptr, nu_begin, nu_count, &first);

@@ -23,6 +23,19 @@ def shard_bounds(n_nu, world_size, rank):
     return begin, min(per, n_nu - begin)
 
 
+def _require_f64_buffer(name, buf, n_min):
+    """A DeviceArray or contiguous CUDA tensor of at least n_min float64 values."""
+    ptr_of(buf)  # (type, contiguity)
+    if isinstance(buf, _lib.DeviceArray):
+        dtype_ok, numel = buf.dtype == np.dtype(np.float64), int(np.prod(buf.shape, dtype=np.int64))
+    else:
+        dtype_ok, numel = str(buf.dtype) == "torch.float64", int(buf.numel())
+    if not dtype_ok:
+        raise TypeError(f"{name} must hold float64 values")
+    if numel < n_min:
+        raise ValueError(f"{name} holds {numel} values, {n_min} are needed")
+
+
 class SpectralSynthesizer:
     def __init__(self, nus, temperatures, dist, thetas, theta_weights, lines, continuum=None, ctx=None, shard=None,
                  flux_out=None, track_evaluations=True, keep_line=True, keep_total=True, classify_share=None, m_max=None, m_share_out=None):
@@ -102,6 +115,15 @@ class SpectralSynthesizer:
             raise ValueError("classify_share and m_max go together")
         if m_max is not None and (self.linelist is not None or track_evaluations):
             raise ValueError("the two-collective mode takes dense line lists and no evaluation count")
+        if m_max is not None:
+            # the library writes m_max[first line ...] (or m_share_out[0 ...]) and reads all of m_max: check the buffers here, an
+            # undersized one would be an out-of-bounds device access
+            b, n = (int(v) for v in classify_share)
+            if b < 0 or n < 0 or b + n > self.n_lines:
+                raise ValueError("classify_share lies outside the line list")
+            _require_f64_buffer("m_max", m_max, self.n_lines)
+            if m_share_out is not None:
+                _require_f64_buffer("m_share_out", m_share_out, n)
         c.call("sdx_reserve_line_workspace", self.n_depth, self.n_lines)
 
     # -- set-up ---------------------------------------------------------------------------------
@@ -210,10 +232,11 @@ class SpectralSynthesizer:
         c.call("sdx_raytrace_dev", nd, cnt, self.n_theta, nus_shard, self.d_t.ptr, self.d_ray.ptr, self.d_w.ptr,
                self.d_total.ptr, cnt, self.flux_ptr, cnt, None, 0)
 
-    def capture(self):
+    def capture(self, eager_phase2=True):
         """Record one step into a hipGraph (after one eager step has sized the scratch).  Two-collective mode: two graphs, the
         classification launch and the rest — the caller's all-gather of m_max goes between step_classify() and step(); m_max must
-        hold every rank's share when capture() is called (the eager pass reads it)."""
+        hold every rank's share when capture() is called (the eager pass reads it) unless eager_phase2 is False (a re-capture
+        after the scratch has moved: it is large enough already, and m_max may not have been gathered yet)."""
         c = self.ctx
 
         def record(enqueue):
@@ -227,7 +250,8 @@ class SpectralSynthesizer:
 
         if self.m_max is not None:
             self.enqueue_classify()
-            self.enqueue()
+            if eager_phase2:
+                self.enqueue()
             c.synchronize()
             self.graph_classify = record(self.enqueue_classify)
             self.graph = record(self.enqueue)
@@ -243,8 +267,9 @@ class SpectralSynthesizer:
                 self.ctx.call("sdx_graph_launch", self.graph_classify)
                 return
             except _lib.StaleGraphError:
+                # (m_max holds the previous step's values or nothing yet: no eager phase 2 on it)
                 self.close()
-                self.capture()
+                self.capture(eager_phase2=False)
                 self.ctx.call("sdx_graph_launch", self.graph_classify)
                 return
         self.enqueue_classify()

@@ -37,8 +37,39 @@ def padded_count(n_nu, world_size):
     return -(-n_nu // world_size)
 
 
-FAR_FIELD_MIN_POINTS = 32768  # the library's automatic rule for its "far_field" option (include/stardis_hip.h)
+# The library's far-field rule (include/stardis_hip.h: sdx_far_field_rule) as the planner's DEFAULTS: far_field_rule() asks the
+# library itself whenever it can be loaded, and tests/test_abi_cpu.py pins these numbers to it.
+FAR_FIELD_MIN_POINTS = 32768  # the automatic rule for the "far_field" option
 FAR_NEAR_POINTS = 896        # ... with it a window is evaluated point by point only this close to its centre (3.5 tiles of 256)
+
+
+def far_field_rule():
+    """(min_points, near_points) of the far field as libstardis_hip.so applies it (no GPU needed); the module's defaults if the
+    library is not built."""
+    import ctypes as C
+
+    from . import _lib
+
+    try:
+        lib = _lib.load()
+    except Exception:  # noqa: BLE001  (a planning estimate: the defaults are the library's constants anyway)
+        return FAR_FIELD_MIN_POINTS, FAR_NEAR_POINTS
+    mn, tile, near = C.c_int64(), C.c_int(), C.c_int()
+    _lib.check(lib.sdx_far_field_rule(C.byref(mn), C.byref(tile), C.byref(near)))
+    return int(mn.value), int(near.value)
+
+
+def far_field_active(n_nu, ctx=None):
+    """Whether a synthesis of a global grid of n_nu points runs with the far field: the context's "far_field" option when a
+    context is given (sdx_far_field_active), else the automatic rule."""
+    if ctx is not None:
+        from . import _lib
+
+        rc = ctx.lib.sdx_far_field_active(ctx.handle, int(n_nu))
+        if rc < 0:
+            _lib.check(rc)
+        return bool(rc)
+    return int(n_nu) >= far_field_rule()[0]
 
 
 def window_work(nus, line_nus, doppler_widths, gammas, alphas, core_weight=1.0, far_weight=None):
@@ -65,7 +96,7 @@ def window_work(nus, line_nus, doppler_widths, gammas, alphas, core_weight=1.0, 
     # +1 where a window opens, -1 where it closes (np.bincount: the same sums as np.add.at, ~30 times faster on 1.7e7 entries)
     cover = np.bincount(lo.ravel(), minlength=n + 1).astype(np.float64) - np.bincount(hi.ravel(), minlength=n + 1)
     if far_weight is not None:
-        near = np.minimum(hw, FAR_NEAR_POINTS)
+        near = np.minimum(hw, far_field_rule()[1])
         nlo = np.clip(centre[:, None] - near, 0, n)
         nhi = np.clip(centre[:, None] + near, 0, n)
         cover_near = np.bincount(nlo.ravel(), minlength=n + 1).astype(np.float64) - np.bincount(nhi.ravel(), minlength=n + 1)
@@ -94,12 +125,13 @@ def scan_work(nus, line_nus, half_width=4096):
     return (np.searchsorted(centre, i + half_width, side="left") - np.searchsorted(centre, i - half_width, side="right")).astype(np.float64)
 
 
-def column_cost(nus, lines, indexed_min_lines=8192, scan_weight=0.6, fixed=None, core_weight=14.0, far_field=None, far_weight=1.0 / 12):
+def column_cost(nus, lines, indexed_min_lines=8192, scan_weight=0.6, fixed=None, core_weight=14.0, far_field=None, far_weight=1.0 / 12, ctx=None):
     """Estimated cost of every grid column in units of one far-wing Voigt evaluation, for balanced_shards: the window
     evaluations (line cores weighted by core_weight), the candidate scan of long lists (scan_weight per line in range) and
     a constant for the continuum and the formal solution — weights measured on MI355X.  A planning estimate on the host: it
-    only decides where shard boundaries go.  far_field: whether the library's far field is on (None: its automatic rule)."""
-    if far_field is None: far_field = np.asarray(nus).size >= FAR_FIELD_MIN_POINTS
+    only decides where shard boundaries go.  far_field: whether the library's far field is on (None: ask the library — the
+    "far_field" option of `ctx` when given, else its automatic rule)."""
+    if far_field is None: far_field = far_field_active(np.asarray(nus).size, ctx)
     # (per column: continuum, formal solution, the far kernel's nodes — 8000 evaluation-equivalents of the direct sum; with the far field the
     # windows weigh less against them: 16000 measured best over S-c3, S-c4m, S-c3 at R = 5e5 and S-big)
     if fixed is None: fixed = 16000.0 if far_field else 8000.0

@@ -143,3 +143,17 @@ def test_group_entry_fails_loudly_without_rccl_or_devices():
     if _lib.load().sdx_device_count() == 0:
         proc = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
         assert "HANDLE None CODE -1" in proc.stdout and "not visible" in proc.stdout, proc.stdout + proc.stderr
+
+
+def test_planner_constants_are_the_librarys():
+    """stardis_amd.parallel carries the far-field rule only as defaults: they equal what the library reports, and the planner asks
+    the library (sdx_far_field_rule needs no device)."""
+    from stardis_amd import parallel
+
+    lib = _lib.load()
+    mn, tile, near = ctypes.c_int64(), ctypes.c_int(), ctypes.c_int()
+    assert lib.sdx_far_field_rule(ctypes.byref(mn), ctypes.byref(tile), ctypes.byref(near)) == 0
+    assert (mn.value, near.value) == (parallel.FAR_FIELD_MIN_POINTS, parallel.FAR_NEAR_POINTS) == parallel.far_field_rule()
+    assert tile.value == 256 and near.value == int(3.5 * tile.value)
+    assert parallel.far_field_active(mn.value) and not parallel.far_field_active(mn.value - 1)
+    assert lib.sdx_far_field_active(None, 100000) < 0  # null context

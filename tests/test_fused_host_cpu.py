@@ -151,3 +151,33 @@ def test_sorted_line_tables_follow_pandas_in_grid_order():
     assert fused._sorted_line_tables(lines, alpha, masses, False) is None  # pandas' NaN handling: general path
     with pytest.raises(KeyError):
         fused._mass_of(masses, np.array([1, 6]))
+
+
+def test_witnesses_are_per_call_and_per_thread():
+    """The once-per-call witness table of try_fused is thread-local: a call on another thread neither sees nor clears it."""
+    import threading
+
+    from stardis_amd.radiation_field import fused_cache as FC
+
+    a = np.arange(8.0)
+    seen_in_thread, errors = [], []
+
+    def other():
+        try:
+            assert getattr(FC._CALL, "seen", None) is None  # nothing leaks across threads
+            with FC.one_call():
+                FC._witness_once(a)
+                seen_in_thread.append(len(FC._CALL.seen))
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    with FC.one_call():
+        w = FC._witness_once(a)
+        t = threading.Thread(target=other)
+        t.start(), t.join()
+        assert not errors and seen_in_thread == [1]
+        assert FC._CALL.seen and FC._witness_once(a) is w  # still this call's table, untouched by the other thread's exit
+        a[0] = 5.0
+        assert FC._witness_once(a) is w  # within ONE call an object is read once
+    assert getattr(FC._CALL, "seen", None) is None
+    assert FC._witness_once(a) != w  # outside a call: always the current content

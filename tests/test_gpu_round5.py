@@ -101,3 +101,71 @@ def test_two_collective_mode_refuses_what_it_does_not_cover(ctx):
         SpectralSynthesizer(*args, ctx=ctx, shard=(b, c), classify_share=(0, n_l))  # share without the array
     for s in (syn, other, unsharded, few):
         s.close()
+
+
+def test_phase_two_needs_its_own_phase_one(ctx):
+    """What phase 1 leaves in the context's scratch (grid spacing, line ranges, continuum plane, far ranges) belongs to ONE phase 2:
+    a second phase 2 without a new phase 1, or a phase 2 after any other step on the context has rewritten the scratch, is refused
+    (SDX_ERR_ARG) instead of reading another problem's data."""
+    atm, nus, lines, cont, th, w = long_list_case(n_nu=20000, n_lines=9000)
+    args = (nus, atm["temperatures"], atm["dist"], th, w, lines, cont)
+    n_l = lines["line_nus"].size
+    m = ctx.zeros((n_l,))
+    b, c = shard_bounds(nus.size, 4, 1)
+    a = SpectralSynthesizer(*args, ctx=ctx, shard=(b, c), track_evaluations=False, classify_share=(0, n_l), m_max=m)
+    a.enqueue_classify()
+    a.enqueue()
+    F = a.F_nu()
+    with pytest.raises(ValueError, match="sdx_synthesize_classify_dev"):
+        a.enqueue()  # consumed
+    # classify(A), a one-call step of another problem B on the same context, phase 2 (A)
+    other_lines = synth.synth_lines(nus, atm, 9000, seed=11, mix=(0.85, 0.12, 0.03))
+    bb = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], th, w, other_lines, cont, ctx=ctx, shard=shard_bounds(nus.size, 4, 3), track_evaluations=False)
+    a.enqueue_classify()
+    bb.enqueue()
+    with pytest.raises(ValueError, match="sdx_synthesize_classify_dev"):
+        a.enqueue()
+    # ... and a separate line-opacity call
+    a.enqueue_classify()
+    bb.enqueue_unfused()
+    with pytest.raises(ValueError, match="sdx_synthesize_classify_dev"):
+        a.enqueue()
+    a.enqueue_classify()
+    a.enqueue()
+    assert np.array_equal(a.F_nu(), F)
+    # buffers are checked where they are handed over
+    with pytest.raises(ValueError, match="m_max holds"):
+        SpectralSynthesizer(*args, ctx=ctx, shard=(b, c), track_evaluations=False, classify_share=(0, n_l), m_max=ctx.zeros((n_l - 1,)))
+    with pytest.raises(ValueError, match="m_share_out holds"):
+        SpectralSynthesizer(*args, ctx=ctx, shard=(b, c), track_evaluations=False, classify_share=(0, n_l), m_max=m, m_share_out=ctx.zeros((10,)))
+    with pytest.raises(TypeError, match="float64"):
+        SpectralSynthesizer(*args, ctx=ctx, shard=(b, c), track_evaluations=False, classify_share=(0, n_l), m_max=ctx.zeros((n_l,), np.float32))
+    for s in (a, bb):
+        s.close()
+
+
+def test_far_field_option_may_change_between_the_phases(ctx):
+    """Phase 1 with the far field off, phase 2 with it on (and the reverse): phase 2 computes the tiles' far ranges itself when
+    phase 1 has not, and ignores them when the far field is off — the bits of the one-call step in that mode."""
+    atm, nus, lines, cont, th, w = long_list_case(n_nu=20000, n_lines=9000)
+    args = (nus, atm["temperatures"], atm["dist"], th, w, lines, cont)
+    n_l = lines["line_nus"].size
+    b, c = shard_bounds(nus.size, 4, 2)
+    want = {}
+    for mode in (0, 1):
+        ctx.set_option("far_field", mode)
+        one = SpectralSynthesizer(*args, ctx=ctx, shard=(b, c), track_evaluations=False)
+        one.step()
+        want[mode] = one.F_nu()
+        one.close()
+    try:
+        for first, second in ((1, 0), (0, 1), (1, 0)):  # (the third pair: far_req_done left set by an earlier far-field phase 1)
+            syn = SpectralSynthesizer(*args, ctx=ctx, shard=(b, c), track_evaluations=False, classify_share=(0, n_l), m_max=ctx.zeros((n_l,)))
+            ctx.set_option("far_field", first)
+            syn.enqueue_classify()
+            ctx.set_option("far_field", second)
+            syn.enqueue()
+            assert np.array_equal(syn.F_nu(), want[second]), (first, second)
+            syn.close()
+    finally:
+        ctx.set_option("far_field", -1)
