@@ -296,6 +296,7 @@ def secondary_block(tag, device, steps, check):
         "workload": synth_desc(tag), "n_nu": int(nus.size), "n_lines": int(syn.n_lines), "steps": steps, "ms_per_step": ms,
         "spectral_points_per_s": nus.size * nd / (ms * 1e-3), "far_field": far_field, "voigt_evaluations": int(evals),
         "voigt_evaluations_per_s_line_kernel": evals / (line_ms * 1e-3) if line_ms else None,
+        "voigt_evaluations_performed": performed_evaluations(w, bool(far_field)),
         "avg_kernel_ms": kern, "profiled_pass": PROFILED_PASS.get(id(ctx)), "algorithmic_bytes": int(syn.algorithmic_bytes()),
         "achieved_GBps": syn.algorithmic_bytes() / (ms * 1e-3) / 1e9, "frac_hbm": syn.algorithmic_bytes() / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
         "setup_s": setup_s,
@@ -601,6 +602,21 @@ class Runner:
     def close(self):
         for syn, _, _ in self.lanes:
             syn.close()
+
+
+def performed_evaluations(w, far_field_on):
+    """{nominal, performed, note}: the reference's window points (what `voigt_evaluations` counts: sum of hi - lo) next to what the
+    line kernels evaluate — with the far field on, a (line, depth, tile) triple far from its line costs 16 Chebyshev nodes instead of
+    256 points (stardis_amd.parallel.window_evaluations_performed, a host estimate; dense line tables only)."""
+    from stardis_amd import parallel
+
+    ln = w["lines"]
+    if not isinstance(ln, dict):
+        return None
+    performed, nominal = parallel.window_evaluations_performed(w["nus"], ln["line_nus"], ln["doppler_widths"], ln["gammas"], ln["alphas"], far_field_on)
+    return {"nominal_window_points": int(nominal), "performed": int(performed), "far_field": bool(far_field_on),
+            "note": "performed = direct window points + 16 nodes per far (line, depth, tile) triple; a host estimate in index space"
+                    if far_field_on else "no far field on this grid: every window point is evaluated where it lies"}
 
 
 def timed(runner, steps, warmup, world, local, settle_s=0.5, cold=True):
@@ -926,6 +942,7 @@ def main():
         copy_gbps = measured_copy_bandwidth(local) if world == 1 else None
         dom_traffic = profiled_traffic(args.workload, dom) if world == 1 else None
         line_ms = kern.get("k_line_all", 0.0) + kern.get("k_line_wide", 0.0) + kern.get("k_line_narrow", 0.0)
+        far_on = "far" in (PROFILED_PASS.get(id(ctx)) or {}).get("k_line_all_is", "") or bool(kern.get("k_line_far"))
         scaling_text = {"weak": "weak (fixed points per GPU: N x the resolving power on the same window)",
                         "strong": "strong (BASELINE's fixed grid split N ways in shards of equal estimated work)"}[args.scaling]
         out = {
@@ -937,6 +954,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "ms_per_step_cold": (tm["cold"] / args.steps * 1e3) if tm["cold"] is not None else None,
+            "value_cold": (pts_total * args.steps / tm["cold"]) if tm["cold"] else None,
             "untimed_settle_steps_after_warmup": settle,
             "timed_region": ("the K steps follow the W warm-up steps directly" if settle == 0 else
                              f"K steps after W warm-up steps + {settle} untimed settling steps (~0.5 s: clocks; runs of >= 200 steps skip it); "
@@ -960,6 +978,12 @@ def main():
                 "voigt_evaluations_global": int(evals) if evals is not None else None,
                 "parallelism": f"nu-shard x{world}" + (", 1 all-gather of F_nu[-1] per step" + (" overlapped with the next step" if runner.overlap else "") if world > 1 else ""),
                 "hip_graph": not args.no_graph,
+                # how `value` was timed (the driver keeps `config`): `value` / `ms_per_step` are the K steps after the W warm-up steps and,
+                # for runs of fewer than 200 steps, this many further untimed steps (~0.5 s: the clocks ramp); *_cold are the same K steps
+                # timed right after the W warm-up steps — the figure that honours the command line to the letter
+                "untimed_settle_steps_after_warmup": settle,
+                "ms_per_step_cold": (tm["cold"] / args.steps * 1e3) if tm["cold"] is not None else None,
+                "value_cold": (pts_total * args.steps / tm["cold"]) if tm["cold"] else None,
                 "line_inputs": args.inputs,
                 "outputs": "F_nu and total_alphas (N_d, N_nu); the optional alpha_line plane is not written",
             },
@@ -985,6 +1009,9 @@ def main():
                 "note": "path is fp64-VALU bound (Faddeeva evaluations), not HBM bound: see DESIGN.md and roofline_fp64_valu; peak = the data sheet's 8 TB/s, "
                         "peak_measured_copy = a device-to-device copy timed in this run (read + write)",
                 "voigt_evaluations_per_s": (evals / world) / (line_ms * 1e-3) if (line_ms and evals is not None) else None,
+                "voigt_evaluations_per_s_is": "the reference's window points (sum of hi - lo) per second of the line kernel: nominal where the far "
+                                              "field is on (see voigt_evaluations_performed)",
+                "voigt_evaluations_performed": performed_evaluations(w, far_on) if world == 1 else None,
             },
         }
         if world > 1:

@@ -12,7 +12,7 @@ while [ $# -gt 0 ]; do if [ "$1" = "--" ]; then shift; EXTRA=("$@"); break; fi; 
 mkdir -p $O
 N=40; case $T in S-c2) N=200;; S-c4m|S-big) N=20;; esac
 SQ="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY"
-SUF=""; for a in "${EXTRA[@]}"; do [ "$a" = "--mixed" ] && SUF="mixed"; done
+SUF=""; for a in "${EXTRA[@]}"; do [ "$a" = "--mixed" ] && SUF="mixed"; [ "$a" = "--linelist" ] && SUF="-linelist"; done
 for P in "${PASSES[@]}"; do
   case $P in
     stats) timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}${SUF}_stats -- python3 scripts/profile_step.py $T $N --graph "${EXTRA[@]}" > $O/${T}${SUF}_stats.log 2>&1;;

@@ -38,6 +38,19 @@ __device__ __forceinline__ double doppler_width(double nu, double t, double mass
     return mul_rn(nu / kC, sqrt(add_rn(mul_rn(mul_rn(2.0, kKB), t) / mass, mul_rn(xi, xi))));
 }
 
+// (vbar / 1e6) ** (1 - alpha) of the ABO van der Waals width (broadening.py:939-948), vbar = sqrt((8 k T / pi) (1/mu)): the power as
+// exp((1 - alpha) (0.5 (log(8 k T / pi) + log(1 / mu)) - log 1e6)) — the two logarithms depend on the depth alone and on the line
+// alone, so an item costs one inline exponential where the reference's form costs a square root, a division and a pow.  Against
+// that form: the logarithms are ~27 and ~55 in magnitude, their half-sum is within 1e-14 of the exact exponent, the result within
+// ~1e-14 relative (tests: <= 1e-13 on gamma against the reference's arrays).  The dense kernel (vald_vdw) and the generating
+// pre-pass (gen_gamma) share this function: they agree bit for bit.
+constexpr double kLn1e6 = 0x1.ba18a998fffa0p+3;  // log(1e6), correctly rounded
+__device__ __forceinline__ double exp_inline(double x);
+__device__ __forceinline__ double abo_speed_power(double log_vb, double log_inv_mu, double one_minus_alpha)
+{
+    return exp_inline(mul_rn(one_minus_alpha, sub_rn(mul_rn(0.5, add_rn(log_vb, log_inv_mu)), kLn1e6)));
+}
+
 // broadening.py:880-1006
 __device__ __forceinline__ double vald_stark(double ne, double stark, double t)
 {
@@ -58,9 +71,8 @@ __device__ inline double vald_vdw(double vdw, double t, double mass, double e_up
         const double sigma = mul_rn(mul_rn(vi, kBohr), kBohr);
         const double alpha = sub_rn(vdw, vi);
         const double inv_mu = add_rn(1.0 / mul_rn(1.008, kAmu), 1.0 / mass);
-        const double vbar = sqrt(mul_rn(mul_rn(mul_rn(8.0, kKB), t) / kPi, inv_mu));
         g = mul_rn(mul_rn(mul_rn(mul_rn(mul_rn(2.0, pow(4.0 / kPi, alpha / 2)), tgamma(sub_rn(4.0, alpha) / 2)), 1e6), sigma),
-                   pow(vbar / 1e6, sub_rn(1.0, alpha)));
+                   abo_speed_power(log(mul_rn(mul_rn(8.0, kKB), t) / kPi), log(inv_mu), sub_rn(1.0, alpha)));
     }
     return mul_rn(g, nh);
 }
@@ -117,7 +129,7 @@ struct GenDepth {
     double t16;      // (T / 1e4) ** (1/6) [VALD] or T ** (1/6) * ... see gen_item
     double t38;      // (T / 1e4) ** 0.38                      VALD van der Waals, log form
     double vw;       // 17 (8 k T / (pi m_p)) ** 0.3           Unsoeld van der Waals
-    double vb;       // 8 k T / pi                             ABO van der Waals (mean speed)
+    double lvb;      // log(8 k T / pi)                        ABO van der Waals (abo_speed_power)
     double qd;       // 1e19 k_B n_e                           quadratic Stark
 };
 struct GenLine {
@@ -129,7 +141,10 @@ struct GenLine {
     double p10w;       // 10 ** waals (log form)
     double ab;         // 2 (4/pi)**(alpha/2) Gamma((4-alpha)/2) 1e6 sigma   (ABO)
     double oma;        // 1 - alpha                                           (ABO)
-    double inv_mu;     // 1/(1.008 amu) + 1/m                                 (ABO)
+    double lmu;        // log(1/(1.008 amu) + 1/m)                            (ABO)
+    // the line's own scalars, read once per line instead of once per item (a pre-pass block keeps its lines' GenLine in LDS)
+    double nu, e_low_ev, g_lo, strength, mass, inv_mass, a_ul, stark, waals;
+    int pop_row, is_h;  // is_h: atomic number 1 (the line takes the linear Stark term)
 };
 
 __device__ inline GenDepth gen_depth(const LineParams& p, int d)
@@ -146,7 +161,7 @@ __device__ inline GenDepth gen_depth(const LineParams& p, int d)
     if (p.flags & 1) D.ne23 = pow(D.ne, 2.0 / 3.0);
     if (p.flags & 4) {
         D.vw = mul_rn(17.0, pow(mul_rn(mul_rn(8.0, kKB), t) / mul_rn(kPi, kMp), 0.3));
-        D.vb = mul_rn(mul_rn(8.0, kKB), t) / kPi;
+        if (p.gamma_mode == 1) D.lvb = log(mul_rn(mul_rn(8.0, kKB), t) / kPi);
     }
     if (p.gamma_mode == 0) {
         if (p.flags & 2) {
@@ -164,7 +179,22 @@ __device__ inline GenLine gen_line(const LineParams& p, double line_nu, int64_t 
 {
     GenLine L{};
     L.nu_over_c = line_nu / kC;
+    L.nu = line_nu;
+    if (p.strength) {  // (alpha from per-line scalars: gen_alpha)
+        L.e_low_ev = p.e_low_ev[l];
+        L.g_lo = p.g_lo ? p.g_lo[l] : 1.0;
+        L.strength = p.strength[l];
+        L.pop_row = p.pop_row[l];
+    }
+    L.mass = p.mass[l];
+    L.inv_mass = 1.0 / L.mass;
+    if (p.gamma_mode <= 2 && p.a_ul) L.a_ul = p.a_ul[l];
     if (p.gamma_mode > 1) return L;
+    L.is_h = (p.flags & 1) && p.z[l] == 1;
+    if (p.gamma_mode == 1) {
+        if (p.flags & 2) L.stark = p.stark[l];
+        if (p.flags & 4) L.waals = p.waals[l];
+    }
     const int ion = p.ion[l];
     const double e_ion = p.e_ion[l], e_up = p.e_up[l], e_lo = p.e_lo[l];
     const bool vald = p.gamma_mode == 1;
@@ -203,7 +233,7 @@ __device__ inline GenLine gen_line(const LineParams& p, double line_nu, int64_t 
                 const double vi = trunc(vdw);
                 const double sigma = mul_rn(mul_rn(vi, kBohr), kBohr);
                 const double alpha = sub_rn(vdw, vi);
-                L.inv_mu = add_rn(1.0 / mul_rn(1.008, kAmu), 1.0 / p.mass[l]);
+                L.lmu = log(add_rn(1.0 / mul_rn(1.008, kAmu), 1.0 / p.mass[l]));
                 L.ab = mul_rn(mul_rn(mul_rn(mul_rn(2.0, pow(4.0 / kPi, alpha / 2)), tgamma(sub_rn(4.0, alpha) / 2)), 1e6), sigma);
                 L.oma = sub_rn(1.0, alpha);
             }
@@ -212,51 +242,71 @@ __device__ inline GenLine gen_line(const LineParams& p, double line_nu, int64_t 
     return L;
 }
 
-// out-of-line library calls for the pre-pass: inlined, pow / exp push the generating pre-pass past 64 VGPRs, and beyond
-// that only ONE 1024-thread block fits a CU
-__device__ __attribute__((noinline)) double pow_call(double a, double b) { return pow(a, b); }
-__device__ __attribute__((noinline)) double exp_call(double a) { return exp(a); }
-
-__device__ inline double gen_alpha(const LineParams& p, const GenDepth& D, double line_nu, int64_t l, int d, int n_depth)
+// exp(x) for the arguments an item meets (-E / kT, -h nu / kT, the ABO exponent: |x| < 700): the device library's sequence written out
+// (exp_neg: the same constants and FMAs, hence the same bits) with its coefficients in scalar registers — ~25 instructions and no call
+// (rounds 4 - 5 called the library's exp out of line: inlined, it pushed the pre-pass past its 64 VGPRs).  Round 6: the two calls per item were a fifth of the
+// generating pre-pass's 1020 instructions per (line, depth).
+__device__ __forceinline__ double exp_inline(double x)
 {
-    const double expo = exp_call(mul_rn(mul_rn(-p.e_low_ev[l], D.inv_kt), kEvJ));             // base.py:247-251
-    double n_lower = mul_rn(expo, p.pop[(size_t)p.pop_row[l] * n_depth + d]);                  // :254-266
-    if (p.g_lo) n_lower = mul_rn(n_lower, p.g_lo[l]);
-    const double corr = sub_rn(1.0, exp_call(mul_rn((-kHsi) / kKBsi, mul_rn(line_nu, D.inv_t))));  // :276-286
-    return mul_rn(mul_rn(mul_rn(p.alpha_coefficient, n_lower), p.strength[l]), corr);          // :288-296
+    // (the library's own range handling around the same core: 0 below the smallest subnormal, inf above the largest double; NaN passes)
+    const double r = exp_neg(-x);
+    return x < -745.2 ? 0.0 : (x > 709.8 ? INFINITY : r);
+}
+// a / b, correctly rounded, from the correctly rounded reciprocal rb = 1 / b (Markstein: q = a rb is within an ulp, the residual
+// a - q b is exact in one FMA, one correction step rounds correctly): three instructions where the division sequence takes ~25.
+// Non-finite or overflowing quotients take the division itself.
+__device__ __forceinline__ double div_by(double a, double b, double rb)
+{
+    const double q = mul_rn(a, rb);
+    const double e = fma(-q, b, a);
+    const double r = fma(e, rb, q);
+    return (fabs(q) < 1e300 && fabs(q) > 1e-290) ? r : a / b;
 }
 
-__device__ inline double gen_doppler(const LineParams& p, const GenLine& L, const GenDepth& D, int64_t l)
+__device__ inline double gen_alpha(const LineParams& p, const GenLine& L, const GenDepth& D, int d, int n_depth)
 {
-    return mul_rn(L.nu_over_c, sqrt(add_rn(D.two_kt / p.mass[l], mul_rn(p.xi, p.xi))));  // broadening.py:32-66
+    const double expo = exp_inline(mul_rn(mul_rn(-L.e_low_ev, D.inv_kt), kEvJ));               // base.py:247-251
+    double n_lower = mul_rn(expo, p.pop[(size_t)L.pop_row * n_depth + d]);                     // :254-266
+    if (p.g_lo) n_lower = mul_rn(n_lower, L.g_lo);
+    const double corr = sub_rn(1.0, exp_inline(mul_rn((-kHsi) / kKBsi, mul_rn(L.nu, D.inv_t))));  // :276-286
+    return mul_rn(mul_rn(mul_rn(p.alpha_coefficient, n_lower), L.strength), corr);             // :288-296
 }
 
-__device__ inline double gen_gamma(const LineParams& p, const GenLine& L, const GenDepth& D, int64_t l)
+__device__ inline double gen_doppler(const LineParams& p, const GenLine& L, const GenDepth& D)
 {
-    if (p.gamma_mode == 2) return p.a_ul[l];  // broadening.py:799-801
+    // (2 k T / m by div_by's three instructions without its fall-back: T and m are ordinary positive magnitudes — a zero mass or
+    // temperature never reaches the generating pre-pass, the host refuses it)
+    const double q = mul_rn(D.two_kt, L.inv_mass);
+    const double two_kt_over_m = fma(fma(-q, L.mass, D.two_kt), L.inv_mass, q);
+    return mul_rn(L.nu_over_c, sqrt(add_rn(two_kt_over_m, mul_rn(p.xi, p.xi))));  // broadening.py:32-66
+}
+
+__device__ inline double gen_gamma(const LineParams& p, const GenLine& L, const GenDepth& D)
+{
+    if (p.gamma_mode == 2) return L.a_ul;  // broadening.py:799-801
     if (p.gamma_mode == 3) return 0.0;
-    const bool lin = (p.flags & 1) && p.z[l] == 1;
+    const bool lin = (p.flags & 1) && L.is_h;
     const double g_lin = lin ? mul_rn(L.lin, D.ne23) : 0.0;  // :193-229
     if (p.gamma_mode == 0) {                                   // :550-656
         const double g_q = (p.flags & 2) ? mul_rn(mul_rn(D.qd, L.c4p), D.t16) : 0.0;   // :281-343
         const double g_w = (p.flags & 4) ? mul_rn(mul_rn(D.vw, L.c6p), D.nh) : 0.0;    // :420-473
-        const double g_r = (p.flags & 8) ? p.a_ul[l] : 0.0;
+        const double g_r = (p.flags & 8) ? L.a_ul : 0.0;
         return add_rn(add_rn(add_rn(g_lin, g_q), g_w), g_r);
     }
     double g = 0.0;  // :1009-1085
-    if (p.flags & 8) g = add_rn(g, p.a_ul[l]);
+    if (p.flags & 8) g = add_rn(g, L.a_ul);
     if (lin) g = add_rn(g, g_lin);
     if (p.flags & 2) {  // :880-910
         const double gs = mul_rn(mul_rn(D.ne, L.p10s), D.t16);
-        g = add_rn(g, (mul_rn(D.ne, p.stark[l]) >= 0) ? 0.0 : gs);
+        g = add_rn(g, (mul_rn(D.ne, L.stark) >= 0) ? 0.0 : gs);
     }
     if (p.flags & 4) {  // :913-1006
-        const double vdw = p.waals[l];
+        const double vdw = L.waals;
         double gw = 0.0;
         if (vdw < 0) gw = mul_rn(L.p10w, D.t38);
         else if (vdw == 0.0) gw = 0.0;
         else if (vdw < 20) gw = mul_rn(mul_rn(mul_rn(D.vw, L.c6p), 1.0), vdw);
-        else gw = mul_rn(L.ab, pow_call(sqrt(mul_rn(D.vb, L.inv_mu)) / 1e6, L.oma));
+        else gw = mul_rn(L.ab, abo_speed_power(D.lvb, L.lmu, L.oma));
         g = add_rn(g, mul_rn(gw, D.nh));
     }
     return g / 2;

@@ -191,6 +191,12 @@ __device__ __forceinline__ double block_dnu_scan(const double* __restrict__ nus,
 
 // index of the first grid frequency strictly below line_nu in the DESCENDING grid
 //   = N_nu - searchsorted(nus[::-1], line_nu)   (base.py:556-558)
+__device__ __forceinline__ double recip_guarded(double d)
+{
+    // Newton-refined hardware reciprocal for ordinary magnitudes, IEEE division otherwise (0, inf, NaN, subnormal)
+    return (d > 1e-290 && d < 1e290) ? recip(d) : 1.0 / d;
+}
+constexpr double kInvSqrtPiPi = 0x1.6fcb5f827b97fp-3;  // 1 / (sqrt(pi) pi), correctly rounded
 __device__ __forceinline__ int64_t closest_index(const double* __restrict__ nus, int64_t n_nu, double line_nu)
 {
     int64_t lo = 0, hi = n_nu;  // first i with nus[i] < line_nu
@@ -202,10 +208,11 @@ __device__ __forceinline__ int64_t closest_index(const double* __restrict__ nus,
 }
 
 // window rule base.py:561-575, bit-for-bit (each operation rounds once, same order)
-__device__ __forceinline__ int64_t window_rule(int64_t c, int64_t n_nu, double d_nu, double gamma, double dw, double alpha,
+// (the quotient by d_nu — one divisor for every item — through div_by: the correctly rounded quotient from 1 / d_nu, computed once)
+__device__ __forceinline__ int64_t window_rule(int64_t c, int64_t n_nu, double d_nu, double r_dnu, double gamma, double dw, double alpha,
                                                int& lo, int& hi)
 {
-    const double pixels = mul_rn(mul_rn(add_rn(gamma, dw), alpha) / d_nu, 20.0);
+    const double pixels = mul_rn(div_by(mul_rn(add_rn(gamma, dw), alpha), d_nu, r_dnu), 20.0);
     const double forced = pixels > 10.0 ? pixels : 10.0;  // max(10, x); NaN keeps 10
     const int64_t hw = forced >= (double)n_nu ? n_nu : (int64_t)forced;  // int() truncates; saturating is equivalent
     const int64_t l = c - hw, h = c + hw;
@@ -447,7 +454,7 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
     // The block's dense inputs are requested now (kPreItems per thread): their latency hides behind the centre search below —
     // whose one global load they precede in the queue — instead of following it; requested before the barrier above they only
     // held eighteen registers through the sample's hand-over.
-    double r_dw[kPreItems], r_a[kPreItems], r_g[kPreItems];
+    [[maybe_unused]] double r_dw[kPreItems], r_a[kPreItems], r_g[kPreItems];
     if constexpr (!GEN) {
 #pragma unroll
         for (int it = 0; it < kPreItems; ++it) {
@@ -491,14 +498,18 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
     SDX_PRE_STAMP(2);  // this wave's centres are found
     // d_nu (:524-526): from the partial maxima of k_dnu_partial, or — small grids — scanned here directly
     // (its barriers also publish the centres and the cleared maxima)
-    const double d_nu = block_max_to_dnu(dnu_local, s_red);
+    // (block-uniform: both live in scalar registers — three items per thread leave the 64-VGPR budget no room for them)
+    const double d_nu_v = block_max_to_dnu(dnu_local, s_red);
+    const double d_nu = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(d_nu_v)), __builtin_amdgcn_readfirstlane(__double2loint(d_nu_v)));
+    const double r_dnu_v = 1.0 / d_nu_v;
+    const double r_dnu = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(r_dnu_v)), __builtin_amdgcn_readfirstlane(__double2loint(r_dnu_v)));
     SDX_PRE_STAMP(3);  // grid spacing known
 
+    [[maybe_unused]] __shared__ GenDepth s_gd[GEN ? kPreDepths : 1];
+    [[maybe_unused]] __shared__ GenLine s_gl[GEN ? kPreLines : 1];
     if constexpr (GEN) {
         // line parameters from per-line scalars and per-depth state (f1): nothing dense to read.  The per-depth and the
         // per-line factors (every pow / tgamma / n_eff) are evaluated once per block column / row and shared through LDS.
-        __shared__ GenDepth s_gd[kPreDepths];
-        __shared__ GenLine s_gl[kPreLines];
         if (tid < nd) s_gd[tid] = gen_depth(lp, d0 + tid);
         else if (tid >= 64 && tid < 64 + nl) s_gl[tid - 64] = gen_line(lp, line_nus[SDX_LINE_OF(tid - 64)], SDX_LINE_OF(tid - 64));
         __syncthreads();
@@ -508,12 +519,11 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
             r_dw[it] = r_a[it] = r_g[it] = 0.0;
             if (k < nl * nd) {
                 const int ll = small_div(k, nd_magic), dd = k - ll * nd;
-                const int64_t l = SDX_LINE_OF(ll);
                 const GenDepth& D = s_gd[dd];  // fields are read from LDS where they are used: copies would cost ~40 VGPRs
                 const GenLine& L = s_gl[ll];
-                r_dw[it] = gen_doppler(lp, L, D, l);
-                r_a[it] = gen_alpha(lp, D, line_nus[l], l, d0 + dd, n_depth);
-                r_g[it] = gen_gamma(lp, L, D, l);
+                r_dw[it] = gen_doppler(lp, L, D);
+                r_a[it] = gen_alpha(lp, L, D, d0 + dd, n_depth);
+                r_g[it] = gen_gamma(lp, L, D);
             }
         }
     }
@@ -535,11 +545,14 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
         const double dw = r_dw[it], g = r_g[it], a = r_a[it];
         const int64_t c = s_c[ll];
         int lo, hi;
-        const int64_t hw = window_rule(c, n_nu, d_nu, g, dw, a, lo, hi);
+        const int64_t hw = window_rule(c, n_nu, d_nu, r_dnu, g, dw, a, lo, hi);
         const bool narrow = hw <= kNarrowHalfWidth;
-        const double inv = 1.0 / dw;
-        const double yy = (g / mul_rn(kSqrtPi, kPi)) / dw;  // voigt.py:148
-        const double amp = a / mul_rn(kSqrtPi, dw);         // voigt.py:149 x base.py:627
+        // 1 / dw once (the refined hardware reciprocal: the correctly rounded value but for ~1 in 1e8 arguments), y and the amplitude
+        // as products with it — within 2 ulp of the reference's quotients (voigt.py:148-149), which the kernels multiply into x = dnu (1 / dw)
+        // and the profile anyway; three divisions (~25 instructions each) fewer per item (round 6)
+        const double inv = recip_guarded(dw);
+        const double yy = mul_rn(mul_rn(g, kInvSqrtPiPi), inv);  // voigt.py:148
+        const double amp = mul_rn(mul_rn(a, kInvSqrtPi), inv);   // voigt.py:149 x base.py:627
         int core_hw = 0;
         bool delegated = false;
         if (w.wscan) {
@@ -549,7 +562,7 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
                 // core: grid points with |x| + y <= 15 lie within (15 - y) doppler widths of the line, i.e. within
                 // floor(that / d_nu) + 1 points of the centre (d_nu is the SMALLEST spacing of the grid, :524-526).  A margin
                 // (15.001, + 2 points) covers the rounding of x = delta_nu * (1 / dw); a superset costs nothing but speed.
-                const double reach = mul_rn(15.001 - yy, dw) / d_nu;
+                const double reach = mul_rn(mul_rn(15.001 - yy, dw), r_dnu);
                 const int64_t chw = yy < 15.001 ? (reach >= (double)n_nu ? n_nu : (int64_t)reach + 2) : 0;
                 keep_chw[it] = (int)min(chw, (int64_t)2147483647);
                 sc.lo = lo;
@@ -2590,9 +2603,9 @@ __global__ __launch_bounds__(kBlock) void k_line_params(int64_t n_lines, int n_d
     const double lnu = line_nus[l];
     const GenDepth D = gen_depth(lp, d);
     const GenLine L = gen_line(lp, lnu, l);
-    if (alphas) alphas[k] = gen_alpha(lp, D, lnu, l, d, n_depth);
-    if (doppler) doppler[k] = gen_doppler(lp, L, D, l);
-    if (gammas && (gamma_cols > 1 || d == 0)) gammas[l * gamma_cols + (gamma_cols > 1 ? d : 0)] = gen_gamma(lp, L, D, l);
+    if (alphas) alphas[k] = gen_alpha(lp, L, D, d, n_depth);
+    if (doppler) doppler[k] = gen_doppler(lp, L, D);
+    if (gammas && (gamma_cols > 1 || d == 0)) gammas[l * gamma_cols + (gamma_cols > 1 ? d : 0)] = gen_gamma(lp, L, D);
 }
 
 // plasma/base.py:130-175 AlphaLine: alpha = ((ALPHA_COEFFICIENT * n_lower) * stimulated_emission_factor) * f_lu, n_lower
@@ -3224,11 +3237,6 @@ __global__ __launch_bounds__(kBlock) void k_raytrace_basic(int n_depth, int64_t 
 //            per step for the sum.  tau = 0 gives the same inf/NaN pattern as the reference's unguarded divisions.
 //   flux     I_theta * w_theta goes to LDS; every kBatch gaps the wave sums each (gap, frequency) over theta in
 //            ascending order (the reference's order, :324-338) and writes F_nu.
-__device__ __forceinline__ double recip_guarded(double d)
-{
-    // Newton-refined hardware reciprocal for ordinary magnitudes, IEEE division otherwise (0, inf, NaN, subnormal)
-    return (d > 1e-290 && d < 1e290) ? recip(d) : 1.0 / d;
-}
 
 // Optional fusion of Opacities.calc_total_alphas into the raytrace's column staging: total = continuum + line,
 // line = sum of the partial planes in subset order (the same additions k_total_alphas performs).

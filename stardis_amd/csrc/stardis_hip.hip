@@ -1221,8 +1221,7 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
     static const bool split_launches = knob("SDX_SPLIT_LAUNCHES") != nullptr;  // analysis knob: time the two roles apart
     const bool split_launches_early = split_launches;
     size_t shmem = (size_t)n_split * (far && SDX_WIDE_QUEUED ? kWideFarLdsDoubles : kWideLdsDoubles) * sizeof(double);
-    // FAR FIELD: units of 4 RF global tiles; RF (1 or 2 node groups per lane) is scheduling only: 2 where that still leaves ~4 workgroups
-    // per CU (4 was measured slower than 2 at every size).  Its workgroups are the FIRST of the line kernel's grid (one launch, and a
+    // FAR FIELD: units of 4 RF global tiles; RF (1 or 2 node groups per lane) is scheduling only (4 was measured slower than 2 at every size).  Its workgroups are the FIRST of the line kernel's grid (one launch, and a
     // shard's far waves — the launch's longest chains — run beside the other roles instead of alone on the chip); experiment knob
     // SDX_FAR_LAUNCH gives them a launch of their own, with kFarSplit waves per workgroup.  Either way the number of line subsets is
     // a constant of the mode (it fixes the order of a node's sum): n_split merged, kFarSplit alone.
@@ -1230,7 +1229,9 @@ static int line_partials(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* 
     static const int far_rf_env = knob("SDX_FAR_RF") ? std::atoi(knob("SDX_FAR_RF")) : 0;  // experiment knob: 1, 2
     const int64_t far_t_first = nu_begin / (64 * R), far_t_last = (nu_begin + nu_count - 1) / (64 * R);
     auto far_units_of = [&](int f) { return far_t_last / (4 * f) - far_t_first / (4 * f) + 1; };
-    int far_rf = far_units_of(2) * n_depth >= (int64_t)4 * ctx->n_cu ? 2 : 1;
+    // (round 6: units of 8 tiles at every size — on the eighths of S-c3 / S-c4m, where the rule above chose 4, the line launch ran 2 - 5 %
+    // faster with 8: half as many waves walk the huge lines' scan words)
+    int far_rf = 2;
     if (far_rf_env == 1 || far_rf_env == 2) far_rf = far_rf_env;
     const int64_t far_units = far ? far_units_of(far_rf) : 0;
     const bool far_merged = far && !far_own_launch && !split_launches_early;

@@ -43,7 +43,12 @@ def test_hot_kernels_do_not_spill_vector_registers(resources):
     hot = [k for k in resources if k.startswith(("k_line_all<", "k_line_far<", "k_raytrace<1>", "k_raytrace_seg<8", "k_line_prepass<", "k_prepass_continuum<"))]
     assert len(hot) >= 10, sorted(resources)
     for k in hot:
-        assert resources[k]["spill"] == 0, (k, resources[k])
+        # the GENERATING pre-pass variants (<true, ...>: line parameters from per-line scalars, f1) evaluate every pow, log and tgamma of the
+        # block's depth points and lines once per block (gen_depth / gen_line, two waves) and park up to 21 registers around that section;
+        # measured in round 6 at 1e6 lines: 1.59 ms with these spills against 1.84 for the spill-free round-5 kernel (two library exp
+        # calls per item) — and 2.44 ms with the section moved out of line to get rid of them (its calls copy LineParams to scratch)
+        cold_calls = k.startswith(("k_line_prepass<true", "k_prepass_continuum<true"))
+        assert resources[k]["spill"] <= (24 if cold_calls else 0), (k, resources[k])
 
 
 def test_prepass_blocks_fit_two_per_cu(resources):
