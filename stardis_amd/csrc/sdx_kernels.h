@@ -197,6 +197,14 @@ __device__ __forceinline__ double recip_guarded(double d)
     return (d > 1e-290 && d < 1e290) ? recip(d) : 1.0 / d;
 }
 constexpr double kInvSqrtPiPi = 0x1.6fcb5f827b97fp-3;  // 1 / (sqrt(pi) pi), correctly rounded
+// 1 / dw, y and the amplitude of a (line, depth) item from its doppler width, gamma and alpha (voigt.py:148-149, base.py:627) — what the
+// pre-pass stores in a narrow record, and what the narrow role forms itself when it reads the raw inputs (LineWork::narrow_raw)
+__device__ __forceinline__ void narrow_params(double dw, double g, double a, double& inv, double& y, double& amp)
+{
+    inv = recip_guarded(dw);
+    y = mul_rn(mul_rn(g, kInvSqrtPiPi), inv);
+    amp = mul_rn(mul_rn(a, kInvSqrtPi), inv);
+}
 __device__ __forceinline__ int64_t closest_index(const double* __restrict__ nus, int64_t n_nu, double line_nu)
 {
     int64_t lo = 0, hi = n_nu;  // first i with nus[i] < line_nu
@@ -284,6 +292,11 @@ struct LineWork {
     double* n_inv;   // 1 / doppler
     double* n_y;
     double* n_amp;
+    // narrow_raw != 0 (long dense lists, fp64; round 6): NO narrow records — n_inv / n_y / n_amp point at the CALLER'S doppler widths,
+    // gammas and alphas (the same line-major layout; narrow_raw = the gammas' columns, 1 or N_d) and the narrow role forms 1 / dw, y and
+    // the amplitude itself for the items it evaluates (narrow_params: the pre-pass's own three operations, hence the same bits): the
+    // pre-pass writes one byte per narrow item instead of 25 — 1.35 of its 1.67 GB at 1e6 lines
+    int narrow_raw;
     // mixed-precision mode: the narrow role evaluates in fp32 — the same three arrays as floats, and the line frequencies
     // as hi + lo float pairs [N_l]
     float* n_inv32;
@@ -550,9 +563,8 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
         // 1 / dw once (the refined hardware reciprocal: the correctly rounded value but for ~1 in 1e8 arguments), y and the amplitude
         // as products with it — within 2 ulp of the reference's quotients (voigt.py:148-149), which the kernels multiply into x = dnu (1 / dw)
         // and the profile anyway; three divisions (~25 instructions each) fewer per item (round 6)
-        const double inv = recip_guarded(dw);
-        const double yy = mul_rn(mul_rn(g, kInvSqrtPiPi), inv);  // voigt.py:148
-        const double amp = mul_rn(mul_rn(a, kInvSqrtPi), inv);   // voigt.py:149 x base.py:627
+        double inv, yy, amp;
+        narrow_params(dw, g, a, inv, yy, amp);
         int core_hw = 0;
         bool delegated = false;
         if (w.wscan) {
@@ -605,7 +617,7 @@ __device__ __forceinline__ void prepass_block(const int bx, const int by, const 
         if (w.nhw) {
             // the narrow role's window: a narrow item's own half-width, the delegated core's, or nothing
             w.nhw[o] = (unsigned char)(narrow ? (int)hw : (delegated ? core_hw : 0));
-            if (narrow || delegated) {
+            if ((narrow || delegated) && !w.narrow_raw) {
                 if (w.n_inv32) {
                     w.n_inv32[o] = (float)inv;
                     w.n_y32[o] = (float)yy;
@@ -1576,6 +1588,7 @@ __device__ __forceinline__ void line_narrow_wave(const int64_t i, const int dept
     const bool valid = d < n_depth;
     const int dc = valid ? d : n_depth - 1;
     const unsigned dcu = (unsigned)dc;
+    const bool one_gamma = w.narrow_raw == 1;  // (raw inputs with gammas (N_l, 1): the line's one value for every depth)
     const int ii = (int)i;
     // lines with centre c in [i - H + 1, i + H]
     const int64_t pa = max(i - kNarrowReach + 1, (int64_t)0);
@@ -1616,7 +1629,7 @@ __device__ __forceinline__ void line_narrow_wave(const int64_t i, const int dept
             const int l = base + bit;
             const size_t ob = (size_t)l * n_depth;
             cl = __builtin_amdgcn_readlane(c, bit);
-            h = (w.nhw + ob)[dcu], y = (w.n_y + ob)[dcu], amp = (w.n_amp + ob)[dcu], inv = (w.n_inv + ob)[dcu], lnu = line_nus[l];
+            h = (w.nhw + ob)[dcu], y = (w.n_y + (one_gamma ? (size_t)l : ob))[one_gamma ? 0u : dcu], amp = (w.n_amp + ob)[dcu], inv = (w.n_inv + ob)[dcu], lnu = line_nus[l];
         }
         while (m) {
             m &= m - 1;
@@ -1627,12 +1640,13 @@ __device__ __forceinline__ void line_narrow_wave(const int64_t i, const int dept
                 const int l = base + bit;
                 const size_t ob = (size_t)l * n_depth;
                 cl_n = __builtin_amdgcn_readlane(c, bit);
-                h_n = (w.nhw + ob)[dcu], y_n = (w.n_y + ob)[dcu], amp_n = (w.n_amp + ob)[dcu], inv_n = (w.n_inv + ob)[dcu], lnu_n = line_nus[l];
+                h_n = (w.nhw + ob)[dcu], y_n = (w.n_y + (one_gamma ? (size_t)l : ob))[one_gamma ? 0u : dcu], amp_n = (w.n_amp + ob)[dcu], inv_n = (w.n_inv + ob)[dcu], lnu_n = line_nus[l];
             }
 #ifdef SDX_WALK_STATS
             if (__ballot(valid && ii >= cl - h && ii < cl + h)) ++st_eval;
 #endif
             if (valid && ii >= cl - h && ii < cl + h) {  // (h = 0: empty)
+                if (w.narrow_raw) narrow_params(inv, y, amp, inv, y, amp);  // (inv, y, amp hold dw, gamma, alpha)
                 const RegionI k1 = region1_setup(y, amp);
                 acc = voigt_add(acc, nu_i - lnu, inv, y, amp, k1);
             }
@@ -1667,6 +1681,7 @@ __device__ __forceinline__ void line_narrow_group(const int64_t i0, const int de
     const bool valid = d < n_depth;
     const int dc = valid ? d : n_depth - 1;
     const unsigned dcu = (unsigned)dc;
+    const bool one_gamma = w.narrow_raw == 1;  // (raw inputs with gammas (N_l, 1): the line's one value for every depth)
     const int ia = (int)i0;
     // lines with centre c in [i0 - H + 1, i0 + F - 1 + H]
     const int64_t pa = max(i0 - kNarrowReach + 1, (int64_t)0);
@@ -1698,7 +1713,7 @@ __device__ __forceinline__ void line_narrow_group(const int64_t i0, const int de
             const int l = base + bit;
             const size_t ob = (size_t)l * n_depth;
             cl = __builtin_amdgcn_readlane(c, bit);
-            h = (w.nhw + ob)[dcu], y = (w.n_y + ob)[dcu], amp = (w.n_amp + ob)[dcu], inv = (w.n_inv + ob)[dcu], lnu = line_nus[l];
+            h = (w.nhw + ob)[dcu], y = (w.n_y + (one_gamma ? (size_t)l : ob))[one_gamma ? 0u : dcu], amp = (w.n_amp + ob)[dcu], inv = (w.n_inv + ob)[dcu], lnu = line_nus[l];
         }
         while (m) {
             m &= m - 1;
@@ -1709,10 +1724,11 @@ __device__ __forceinline__ void line_narrow_group(const int64_t i0, const int de
                 const int l = base + bit;
                 const size_t ob = (size_t)l * n_depth;
                 cl_n = __builtin_amdgcn_readlane(c, bit);
-                h_n = (w.nhw + ob)[dcu], y_n = (w.n_y + ob)[dcu], amp_n = (w.n_amp + ob)[dcu], inv_n = (w.n_inv + ob)[dcu], lnu_n = line_nus[l];
+                h_n = (w.nhw + ob)[dcu], y_n = (w.n_y + (one_gamma ? (size_t)l : ob))[one_gamma ? 0u : dcu], amp_n = (w.n_amp + ob)[dcu], inv_n = (w.n_inv + ob)[dcu], lnu_n = line_nus[l];
             }
             const int lo = cl - h, hi = cl + h;  // (h = 0: empty; the clamp to the grid is implied by ia + k being a grid index)
             if (valid && ia + (F - 1) >= lo && ia < hi) {
+                if (w.narrow_raw) narrow_params(inv, y, amp, inv, y, amp);  // (inv, y, amp hold dw, gamma, alpha)
                 const RegionI k1 = region1_setup(y, amp);
 #pragma unroll
                 for (int k = 0; k < F; ++k)
@@ -1745,6 +1761,7 @@ __device__ __forceinline__ void line_narrow_subsets(const int64_t i0, const int 
     const bool valid = d < n_depth;
     const int dc = valid ? d : n_depth - 1;
     const unsigned dcu = (unsigned)dc;
+    const bool one_gamma = w.narrow_raw == 1;  // (raw inputs with gammas (N_l, 1): the line's one value for every depth)
     const int ia = (int)i0;
     // lines with centre c in [i0 - H + 1, i0 + F - 1 + H]
     const int64_t pa = max(i0 - kNarrowReach + 1, (int64_t)0);
@@ -1779,7 +1796,7 @@ __device__ __forceinline__ void line_narrow_subsets(const int64_t i0, const int 
             const int l = base + ((bit >> 4) << 6) + (subset << 4) + (bit & 15);
             const size_t ob = (size_t)l * n_depth;
             cl = __builtin_amdgcn_readlane(c, bit);
-            h = (w.nhw + ob)[dcu], y = (w.n_y + ob)[dcu], amp = (w.n_amp + ob)[dcu], inv = (w.n_inv + ob)[dcu], lnu = line_nus[l];
+            h = (w.nhw + ob)[dcu], y = (w.n_y + (one_gamma ? (size_t)l : ob))[one_gamma ? 0u : dcu], amp = (w.n_amp + ob)[dcu], inv = (w.n_inv + ob)[dcu], lnu = line_nus[l];
         }
         while (m) {
             m &= m - 1;
@@ -1790,10 +1807,11 @@ __device__ __forceinline__ void line_narrow_subsets(const int64_t i0, const int 
                 const int l = base + ((bit >> 4) << 6) + (subset << 4) + (bit & 15);
                 const size_t ob = (size_t)l * n_depth;
                 cl_n = __builtin_amdgcn_readlane(c, bit);
-                h_n = (w.nhw + ob)[dcu], y_n = (w.n_y + ob)[dcu], amp_n = (w.n_amp + ob)[dcu], inv_n = (w.n_inv + ob)[dcu], lnu_n = line_nus[l];
+                h_n = (w.nhw + ob)[dcu], y_n = (w.n_y + (one_gamma ? (size_t)l : ob))[one_gamma ? 0u : dcu], amp_n = (w.n_amp + ob)[dcu], inv_n = (w.n_inv + ob)[dcu], lnu_n = line_nus[l];
             }
             const int lo = cl - h, hi = cl + h;  // (h = 0: empty; the clamp to the grid is implied by ia + k being a grid index)
             if (valid && ia + (F - 1) >= lo && ia < hi) {
+                if (w.narrow_raw) narrow_params(inv, y, amp, inv, y, amp);  // (inv, y, amp hold dw, gamma, alpha)
                 const RegionI k1 = region1_setup(y, amp);
 #pragma unroll
                 for (int k = 0; k < F; ++k)

@@ -877,6 +877,20 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
     w.gather = 0;
     w.ticket = nullptr;
     w.front = 0;
+    // VERY dense long fp64 lists (>= 4 lines per grid point: the rule of the narrow role's subsets): no narrow records — the narrow role
+    // reads the caller's three tables itself (LineWork::narrow_raw).  Pure scheduling (the same three operations form 1 / dw, y and the
+    // amplitude either way).  Measured in round 6 (profiles/r06_raw.txt): 1e6 lines on 120 398 points — pre-pass 904 -> 721 us (it is bound
+    // by its 3 GB of traffic, 1.35 GB of them these records), line kernel 5.93 -> 6.07 ms (ten more instructions per evaluated line), step
+    // 7.27 -> 7.24 ms and 1.35 GB less scratch; 1.5e5 lines: pre-pass 165 -> 149 us, line kernel 1.218 -> 1.241 ms, the step 7 us SLOWER —
+    // hence the density in the rule.
+    static const int narrow_records_env = knob("SDX_NARROW_RECORDS") ? std::atoi(knob("SDX_NARROW_RECORDS")) : -1;  // A/B knob: 1 records at every size, 0 never (long lists)
+    const bool very_dense = 2 * n_lines >= 8 * n_nu;
+    if (fill_work && !gen && !ctx->mixed_precision && n_lines >= ctx->indexed_min_lines && (narrow_records_env == 0 || (very_dense && narrow_records_env != 1))) {
+        w.narrow_raw = gamma_cols > 1 ? n_depth : 1;
+        w.n_inv = const_cast<double*>(doppler);
+        w.n_y = const_cast<double*>(gammas);
+        w.n_amp = const_cast<double*>(alphas);
+    }
     // long lists find their wide lines through hlist / wlist: the scan words of a line without a wide window anywhere are never
     // read (needs the line's widest window inside one block: one depth block per line)
     w.skip_unlisted_scan = (fill_work && n_lines >= ctx->indexed_min_lines && n_depth <= kPreDepths) ? 1 : 0;
