@@ -118,7 +118,13 @@ int sdx_synchronize(sdx_ctx* ctx);
  *       where it lies, as the reference does; 1: whenever the line kernel runs 256-point tiles (always, unless an experiment knob
  *       says otherwise).  With "mixed_precision" = 1 the far field and what it leaves to the wide windows (a line's near zone, window
  *       edges) are evaluated in fp64 as in the fp64 mode — the far wings that mode computed in fp32 are the far field's now —; narrow
- *       windows, delegated cores and the formal solution stay fp32. */
+ *       windows, delegated cores and the formal solution stay fp32. 
+ *   "narrow_records" (default -1): where the narrow role of the line kernel (windows of at most 64 points, delegated line cores) finds 1 / dw, y
+ *       and the amplitude of a (line, depth) item.  1: in records the pre-pass writes (24 bytes per narrow item); 0: it forms them itself from
+ *       the caller's doppler widths, gammas and alphas — the same three operations, so the results are bit-identical — and the pre-pass
+ *       writes one byte per item (long dense fp64 lists only: lists of at least "indexed_min_lines" lines, no line-list scalars, no
+ *       "mixed_precision"); -1: 0 for lists of at least four lines per grid point (1e6 lines: 1.35 GB less traffic and scratch per
+ *       synthesis, the step 0.5 % faster), 1 otherwise (1.5e5 lines: the step is 0.4 % slower without the records). */
 int sdx_set_int_option(sdx_ctx* ctx, const char* name, int64_t value);
 /* The far-field rule as the library applies it — for planners that weigh shards (stardis_amd.parallel.column_cost) and must not
  * carry constants of their own.  sdx_far_field_active: 1 when a synthesis of a GLOBAL grid of n_nu_global points on this context runs

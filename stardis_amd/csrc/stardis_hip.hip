@@ -98,6 +98,7 @@ struct sdx_ctx {
     int64_t mixed_precision = 0;       // 1: fp32 rational for far-wing (region I) evaluations of whole-tile windows
     int64_t segmented_raytrace = -1;   // -1: by the size of the GLOBAL grid; 0 never; 1 whenever the kernel supports the shape
     int64_t far_field = -1;            // -1: by the size of the GLOBAL grid; 0 never; 1 whenever the line kernel runs 256-point tiles
+    int64_t narrow_records = -1;       // -1: by the density of the list; 1: the pre-pass writes narrow records; 0: the narrow role reads the caller's tables (long dense fp64 lists)
     // timing
     hipEvent_t t0 = nullptr, t1 = nullptr;
     void* cont_ws = nullptr;  // continuum plane [n_depth][nu_count] of the fused step
@@ -441,6 +442,10 @@ int sdx_set_int_option(sdx_ctx* ctx, const char* name, int64_t value)
     }
     if (std::strcmp(name, "far_field") == 0) {
         ctx->far_field = value < 0 ? -1 : (value ? 1 : 0);
+        return SDX_OK;
+    }
+    if (std::strcmp(name, "narrow_records") == 0) {
+        ctx->narrow_records = value < 0 ? -1 : (value ? 1 : 0);
         return SDX_OK;
     }
     return fail(SDX_ERR_ARG, std::string("unknown option ") + name);
@@ -883,9 +888,10 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
     // by its 3 GB of traffic, 1.35 GB of them these records), line kernel 5.93 -> 6.07 ms (ten more instructions per evaluated line), step
     // 7.27 -> 7.24 ms and 1.35 GB less scratch; 1.5e5 lines: pre-pass 165 -> 149 us, line kernel 1.218 -> 1.241 ms, the step 7 us SLOWER —
     // hence the density in the rule.
-    static const int narrow_records_env = knob("SDX_NARROW_RECORDS") ? std::atoi(knob("SDX_NARROW_RECORDS")) : -1;  // A/B knob: 1 records at every size, 0 never (long lists)
+    static const int narrow_records_env = knob("SDX_NARROW_RECORDS") ? std::atoi(knob("SDX_NARROW_RECORDS")) : -1;  // A/B knob; the option "narrow_records" wins
+    const int narrow_records = ctx->narrow_records >= 0 ? (int)ctx->narrow_records : narrow_records_env;
     const bool very_dense = 2 * n_lines >= 8 * n_nu;
-    if (fill_work && !gen && !ctx->mixed_precision && n_lines >= ctx->indexed_min_lines && (narrow_records_env == 0 || (very_dense && narrow_records_env != 1))) {
+    if (fill_work && !gen && !ctx->mixed_precision && n_lines >= ctx->indexed_min_lines && (narrow_records == 0 || (very_dense && narrow_records != 1))) {
         w.narrow_raw = gamma_cols > 1 ? n_depth : 1;
         w.n_inv = const_cast<double*>(doppler);
         w.n_y = const_cast<double*>(gammas);

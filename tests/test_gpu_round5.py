@@ -169,3 +169,31 @@ def test_far_field_option_may_change_between_the_phases(ctx):
             syn.close()
     finally:
         ctx.set_option("far_field", -1)
+
+
+@pytest.mark.parametrize("gamma_per_depth", [True, False])
+def test_narrow_role_from_the_callers_tables_gives_the_same_bits(ctx, gamma_per_depth):
+    """Option "narrow_records": the narrow role takes 1 / dw, y and the amplitude from records the pre-pass writes (1) or forms them
+    itself from the caller's doppler widths, gammas and alphas (0) — the same three operations, so line opacity, total and flux are
+    bit-identical: whole grid, a frequency shard, gammas (N_l, N_d) and (N_l, 1), the far field forced on."""
+    atm, nus, lines, cont, th, w = long_list_case(seed=5)
+    if not gamma_per_depth:
+        lines = dict(lines, gammas=np.ascontiguousarray(lines["gammas"][:, :1]))
+    args = (nus, atm["temperatures"], atm["dist"], th, w, lines, cont)
+    out = {}
+    try:
+        for mode in (1, 0, -1):
+            ctx.set_option("narrow_records", mode)
+            for far in (-1, 1):
+                ctx.set_option("far_field", far)
+                for shard in (None, shard_bounds(nus.size, 4, 1)):
+                    syn = SpectralSynthesizer(*args, ctx=ctx, shard=shard, track_evaluations=False)
+                    syn.step()
+                    out[(mode, far, shard)] = (syn.F_nu(), syn.total_alphas(), syn.alpha_line())
+                    syn.close()
+    finally:
+        ctx.set_option("narrow_records", -1)
+        ctx.set_option("far_field", -1)
+    for (mode, far, shard), got in out.items():
+        for a, b in zip(got, out[(1, far, shard)]):
+            assert np.array_equal(a, b), (mode, far, shard)
