@@ -1,7 +1,7 @@
 """GPU experiment: strong scaling of one workload by frequency sharding, emulated on one GPU — each rank's step is timed
 alone (ranks are independent: no data-path exchange; the flux gather overlaps the next step), the projected speed-up is
 t(1) / max_r t_r(P).  Steps are replayed as hipGraphs, like bench.py; the slowest rank's per-kernel times are printed.
-python scripts/strong_scaling_probe.py [TAG] [WORLD ...] [--balanced] [--all-ranks] [--verbose] [--two-collectives]
+python scripts/strong_scaling_probe.py [TAG] [WORLD ...] [--balanced] [--all-ranks] [--verbose] [--two-collectives] [--in-flight=2]
 --two-collectives: every rank classifies 1 / WORLD of the line list and reads the other shares from a buffer filled beforehand (what
 the all-gather of m_max would deliver; its cost is NOT in the time printed — profiles/README.md models it)."""
 import ctypes as C, os, sys, time
@@ -12,6 +12,7 @@ from stardis_amd.engine import SpectralSynthesizer, shard_bounds
 tag = sys.argv[1] if len(sys.argv) > 1 else "S-c3"
 balanced = "--balanced" in sys.argv
 worlds = [int(a) for a in sys.argv[2:] if a.isdigit()] or [1, 2, 4, 8]
+in_flight = 2 if "--in-flight=2" in sys.argv else 1
 w = synth.make_workload(tag)
 atm, nus, ln = w["atm"], w["nus"], w["lines"]
 # per-column cost: window evaluations + the column's share of the formal solution and continuum (~8000 evaluation-equivalents)
@@ -31,27 +32,48 @@ def rank_time(world, rank, reps=20):
     syn = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], w["thetas"], w["weights"], w["lines"], w["cont"], shard=shard,
                               track_evaluations=False, keep_line=False, **extra)
     ctx = syn.ctx
+    # --in-flight=2: a second synthesis of the same shard on a context (stream, scratch) of its own, the two stepped alternately — what a
+    # rank does with a queue of independent syntheses (a grid of models): the stream-bound and launch-bound parts of one step run beside
+    # the arithmetic of the other.  The time printed is then per step of the PAIR's throughput.
+    twin = None
+    if in_flight == 2 and not two:
+        ctx_b = _lib.Context(ctx.device if hasattr(ctx, "device") else 0)
+        twin = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], w["thetas"], w["weights"], w["lines"], w["cont"], shard=shard,
+                                   track_evaluations=False, keep_line=False, ctx=ctx_b)
+        twin.capture()
     if two:  # every share once (the other ranks' part of the gathered array), then this rank's own from now on
         syn.enqueue_classify(); ctx.synchronize()
         syn.classify_share = (min(rank * per, n_l), max(0, min(per, n_l - rank * per)))
     syn.capture()
 
+    flip = [0]
+
     def one():
+        if twin is not None:
+            flip[0] ^= 1
+            (twin if flip[0] else syn).step()
+            return
         if two: syn.step_classify()
         syn.step()
 
+    def sync():
+        syn.synchronize()
+        if twin is not None: twin.synchronize()
+
     # steady state, like bench.py's timed loop: ~0.2 s of untimed replays (clocks settle), then the best of five blocks of replays
-    one(); syn.synchronize()
+    one(); sync()
     t_end = time.perf_counter() + 0.2
     while time.perf_counter() < t_end:
         for _ in range(reps): one()
-        syn.synchronize()
+        sync()
     t = 1e9
     for _ in range(5):
         t0 = time.perf_counter()
         for _ in range(reps): one()
-        syn.synchronize()
+        sync()
         t = min(t, (time.perf_counter() - t0) / reps)
+    if twin is not None:
+        twin.close(); twin.ctx.close()
     ctx.call("sdx_profile_enable", 1); ctx.call("sdx_profile_reset")
     for _ in range(3):
         if two: syn.enqueue_classify()
