@@ -521,8 +521,10 @@ def profiled_valu(workload, kern):
 class Runner:
     """One rank's synthesizer(s) + flux gather for a workload: step(), drain()."""
 
-    def __init__(self, w, world, rank, local, ctx, scaling, use_graph, overlap, two_collectives=False):
+    def __init__(self, w, world, rank, local, ctx, scaling, use_graph, overlap, two_collectives=False, in_flight=1):
         import torch
+
+        from stardis_amd import _lib
 
         from stardis_amd import parallel
         from stardis_amd.engine import SpectralSynthesizer, shard_bounds
@@ -540,8 +542,18 @@ class Runner:
         self.classes = None
         if two_collectives and world > 1 and scaling == "strong" and isinstance(w["lines"], dict):
             self.classes = parallel.ClassificationGatherer(int(np.asarray(w["lines"]["line_nus"]).size), world, rank, dev)
+        # --in-flight 2: the second lane is a synthesis on a context (HIP stream, scratch) of its own, stepped alternately with the first:
+        # two independent syntheses of a queue (a grid of models) in flight per GPU — the stream-bound and launch-bound stretches of one
+        # step run beside the arithmetic of the other.  Each lane's gather is ordered behind ITS stream.
+        self.in_flight = 2 if (in_flight == 2 and self.classes is None) else 1
         self.lanes = []
-        for k in range(2 if self.overlap else 1):
+        self.streams = [torch.cuda.current_stream()]
+        self.contexts = [ctx]
+        for k in range(2 if (self.overlap or self.in_flight == 2) else 1):
+            if k > 0 and self.in_flight == 2:
+                self.streams.append(torch.cuda.Stream(device=local))
+                self.contexts.append(_lib.Context(local, stream=self.streams[-1].cuda_stream))
+                ctx = self.contexts[-1]
             flux = torch.zeros((self.nd, self.count), dtype=torch.float64, device=dev)
             extra = {}
             if self.classes is not None:
@@ -556,13 +568,14 @@ class Runner:
             self.classes.gather()
             self.evals = None  # (the counting pre-pass is the unculled one: not part of this mode)
         self.syn.step()
-        ctx.synchronize()
+        self.contexts[0].synchronize()
         if self.classes is None:
             self.evals = self.syn.evaluations()
             self.syn.count_evaluations = False  # known now; the counter costs a memset + a copy per step
         if use_graph:
-            for lane in self.lanes:
-                lane[0].capture()
+            for k, lane in enumerate(self.lanes):
+                with torch.cuda.stream(self.streams[k % len(self.streams)]):
+                    lane[0].capture()
         self.counter = 0
         self.last = None
 
@@ -573,9 +586,18 @@ class Runner:
         syn.step()
 
     def step(self):
-        syn, flux, gather = self.lanes[self.counter % len(self.lanes)]
+        import torch
+
+        k = self.counter % len(self.lanes)
+        syn, flux, gather = self.lanes[k]
         self.counter += 1
         self.last = gather
+        if self.in_flight == 2:
+            with torch.cuda.stream(self.streams[k]):  # (the collective is enqueued behind the current torch stream: this lane's)
+                gather.finish()
+                self._run(syn)
+                gather.start(flux[-1])
+            return None
         if self.overlap:
             gather.finish()  # the gather that last read this lane's flux buffer
             self._run(syn)
@@ -585,7 +607,13 @@ class Runner:
         return gather(flux[-1])
 
     def drain(self):
-        if self.overlap:
+        import torch
+
+        if self.in_flight == 2:
+            for k, (_, _, gather) in enumerate(self.lanes):
+                with torch.cuda.stream(self.streams[k]):
+                    gather.finish()
+        elif self.overlap:
             for _, _, gather in self.lanes:
                 gather.finish()
 
@@ -684,36 +712,44 @@ def timed(runner, steps, warmup, world, local, settle_s=0.5, cold=True):
     return dict(elapsed=elapsed, local=t_local, cold=t_cold, settle=extra + 1)
 
 
-def n1_same_workload(w, local, steps, use_graph):
+def n1_same_workload(w, local, steps, use_graph, in_flight=1):
     """The whole grid of `w` on ONE GPU (this rank's), graph-replayed like the timed loop: the denominator of the strong-scaling
-    speed-up, measured in the same process and run."""
+    speed-up, measured in the same process and run — with as many syntheses in flight as the timed loop keeps."""
     import torch
 
     from stardis_amd import _lib
     from stardis_amd.engine import SpectralSynthesizer
 
     atm, nus = w["atm"], w["nus"]
-    ctx = _lib.Context(local)
-    syn = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], w["thetas"], w["weights"], w["lines"], w["cont"], ctx=ctx,
-                              track_evaluations=False, keep_line=False)
+    ctxs = [_lib.Context(local) for _ in range(in_flight)]
+    syns = [SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], w["thetas"], w["weights"], w["lines"], w["cont"], ctx=c,
+                                track_evaluations=False, keep_line=False) for c in ctxs]
     if use_graph:
-        syn.capture()
+        for syn in syns:
+            syn.capture()
+
+    def sync():
+        for c in ctxs:
+            c.synchronize()
+
     t_end = time.perf_counter() + 0.3
     n = 0
     while n < 3 or time.perf_counter() < t_end:
-        syn.step()
-        ctx.synchronize()
+        syns[n % in_flight].step()
+        sync()
         n += 1
     t0 = time.perf_counter()
-    for _ in range(steps):
-        syn.step()
-    ctx.synchronize()
+    for k in range(steps):
+        syns[k % in_flight].step()
+    sync()
     ms = (time.perf_counter() - t0) / steps * 1e3
-    spectrum_hash = sha16(syn.F_nu()[-1])
-    syn.close()
-    ctx.close()
+    spectrum_hash = sha16(syns[0].F_nu()[-1])
+    for syn, c in zip(syns, ctxs):
+        syn.close()
+        c.close()
     torch.cuda.synchronize()
     return {"ms_per_step": ms, "value": nus.size * atm["temperatures"].size / (ms * 1e-3), "steps": steps, "spectrum_sha256_16": spectrum_hash,
+            "in_flight": in_flight,
             "how": "the unsharded grid on rank 0's GPU, same process, after the timed region (other ranks wait at a barrier)"}
 
 
@@ -840,6 +876,9 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default=None,
                     help="what `value` measures at N > 1. strong (default): the workload's grid split across the GPUs in shards of equal "
                          "estimated work (stardis_amd.parallel.balanced_shards); weak: fixed grid points per GPU (N x the resolving power)")
+    ap.add_argument("--in-flight", type=int, choices=(1, 2), default=1,
+                    help="2: every rank keeps two syntheses in flight (two contexts, stepped alternately) — throughput of a queue of independent "
+                         "syntheses instead of one step after the other; `value` then counts both (default 1: serial steps)")
     ap.add_argument("--two-collectives", action="store_true",
                     help="N > 1, strong scaling: every rank classifies 1 / N of the line list and the per-line maxima are all-gathered "
                          "(a second collective of 8 N_l bytes per step) instead of every rank streaming the whole list")
@@ -881,7 +920,7 @@ def main():
     # N > 1: two flux buffers alternate so that the all-gather of step k (RCCL, its own stream) overlaps the kernels
     # of step k+1; a buffer is reused only after its gather has been waited for.  SDX_BENCH_SYNC_GATHER=1: blocking gather.
     overlap = os.environ.get("SDX_BENCH_SYNC_GATHER") != "1"
-    runner = Runner(w, world, rank, local, ctx, args.scaling, not args.no_graph, overlap, args.two_collectives)
+    runner = Runner(w, world, rank, local, ctx, args.scaling, not args.no_graph, overlap, args.two_collectives, args.in_flight)
     # a run of >= 200 timed steps is long enough for the clocks to have settled within its first few percent: the W warm-up steps
     # the driver asked for are then ALL that precedes the timed region; shorter runs get ~0.5 s of untimed settling (disclosed)
     tm = timed(runner, args.steps, args.warmup, world, local, settle_s=0.0 if args.steps >= 200 else 0.5, cold=args.steps < 200)
@@ -900,7 +939,7 @@ def main():
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
         if rank == 0 and args.scaling == "strong":
-            n1 = n1_same_workload(w, local, max(5, min(args.steps, 40)), not args.no_graph)
+            n1 = n1_same_workload(w, local, max(5, min(args.steps, 40)), not args.no_graph, runner.in_flight)
         torch.cuda.synchronize()
         dist.barrier()
 
@@ -978,6 +1017,7 @@ def main():
                 "voigt_evaluations_global": int(evals) if evals is not None else None,
                 "parallelism": f"nu-shard x{world}" + (", 1 all-gather of F_nu[-1] per step" + (" overlapped with the next step" if runner.overlap else "") if world > 1 else ""),
                 "hip_graph": not args.no_graph,
+                "syntheses_in_flight_per_gpu": runner.in_flight,
                 # how `value` was timed (the driver keeps `config`): `value` / `ms_per_step` are the K steps after the W warm-up steps and,
                 # for runs of fewer than 200 steps, this many further untimed steps (~0.5 s: the clocks ramp); *_cold are the same K steps
                 # timed right after the W warm-up steps — the figure that honours the command line to the letter
