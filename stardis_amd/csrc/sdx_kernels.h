@@ -2056,7 +2056,11 @@ __device__ __forceinline__ void line_narrow_subsets32(const int64_t i0, const in
 // values of a tile into the coefficients of its Chebyshev series (kFarCoef), and every wave evaluates the series of its share of
 // the tiles at their grid points (Clenshaw) and writes the plane — zeros where a tile has no far field.  The sum of a (tile, node)
 // adds its lines in list order within a subset and the subsets in order, whatever RF and whatever the shard: RF is pure scheduling.
-template <int R, int RF>
+// F32 (the fp32-mixed tolerance mode, units of 8 tiles): the node sums in PACKED fp32 — a lane's two nodes are one float pair, a hit is
+// region1_f32x2 on the pre-pass's 32-byte fp32 record (nine instructions where the fp64 form takes twenty-three for the pair) — and the
+// Chebyshev transform and the Clenshaw recurrence in fp64 as before.  Per term ~1e-6 relative (the node's distance from the line is
+// known to 3e-7: offsets from an fp32 base frequency, exact difference of two fp32 frequencies), well inside the mode's 1e-4.
+template <int R, int RF, bool F32 = false>
 __device__ __forceinline__ void line_far_body(const int block, const int units, const int n_split, int n_depth, int64_t n_nu, const double* __restrict__ nus,
                                               int64_t nu_begin, int64_t nu_count, int64_t n_lines, LineWork w, double* __restrict__ plane, int64_t pld,
                                               double* __restrict__ s_far)
@@ -2132,7 +2136,18 @@ __device__ __forceinline__ void line_far_body(const int block, const int units, 
     const WideScan* __restrict__ scan_row = w.wscan + row;
     const WideScan* __restrict__ hscan_row = w.hscan + row;
     const WideRec* __restrict__ rec_row = w.wrec + row;
+    [[maybe_unused]] const WideRec32* __restrict__ rec32_row = F32 ? w.wrec32 + row : nullptr;
     const int n_h = w.hlist ? __builtin_amdgcn_readfirstlane(*w.hcount) : 0;
+    // F32: the lane's two nodes as fp32 offsets from the base frequency ROUNDED to fp32 (what the fp32 records' hi parts are differences to)
+    static_assert(!F32 || RF == 2, "the packed fp32 far role pairs a lane's two nodes");
+    [[maybe_unused]] float base_h = (float)nu_base;
+    [[maybe_unused]] float2v dq32 = {0.f, 0.f}, acc32 = {0.f, 0.f};
+    if constexpr (F32) {
+        asm("" : "+v"(base_h));
+        const double shift = nu_base - (double)base_h;
+        dq32.x = (float)(dnu[0] + shift);
+        dq32.y = (float)(dnu[RF - 1] + shift);
+    }
 
     // Scan and evaluation are decoupled: a wave that fetched the record of every hit when it met it spent its time waiting for one
     // dependent load after the other (~500 hits, a microsecond each).  The hits of the chunks are QUEUED in LDS instead — line index
@@ -2140,6 +2155,7 @@ __device__ __forceinline__ void line_far_body(const int block, const int units, 
     // in ONE round trip, into LDS, and the wave goes through them with broadcast reads.
     double* const wave_lds = s_far + (size_t)(n_split + 2) * RF * 64 + (size_t)split * kFarWaveLdsDoubles;
     WideRec* const stage = reinterpret_cast<WideRec*>(wave_lds);  // 64 x 48 B
+    [[maybe_unused]] WideRec32* const stage32 = reinterpret_cast<WideRec32*>(wave_lds);  // (F32: 64 x 32 B in the same space)
     int* const q_line = reinterpret_cast<int*>(wave_lds + 64 * 6);
     int* const q_mask = q_line + 64;
     int count = 0;
@@ -2148,9 +2164,29 @@ __device__ __forceinline__ void line_far_body(const int block, const int units, 
         wave_sync();
         const bool mine = lane < cnt;
         const unsigned qm = mine ? (unsigned)q_mask[lane] : 0u;
-        if (mine) stage[lane] = rec_row[q_line[lane]];
+        if constexpr (F32) {
+            if (mine) stage32[lane] = rec32_row[q_line[lane]];
+        } else {
+            if (mine) stage[lane] = rec_row[q_line[lane]];
+        }
         const unsigned long long mfull = __ballot(mine && qm == all_mask);
         wave_sync();
+        if constexpr (F32) {
+            for (int k = 0; k < cnt; ++k) {
+                const WideRec32 cur = stage32[k];  // (one address for the whole wave: a broadcast read)
+                const float c0 = region1_c0(base_h, cur);
+                if ((mfull >> k) & 1) {  // far from every tile of the unit: no per-lane tests
+                    acc32 = region1_f32x2(acc32, dq32, c0, cur);
+                } else {
+                    const unsigned tm = (unsigned)__builtin_amdgcn_readlane((int)qm, k);
+                    const float2v v = region1_f32x2(float2v{0.f, 0.f}, dq32, c0, cur);
+                    acc32.x += ((tm >> tg) & 1u) ? v.x : 0.f;
+                    acc32.y += ((tm >> (4 + tg)) & 1u) ? v.y : 0.f;
+                }
+            }
+            wave_sync();
+            return;
+        }
         for (int k = 0; k < cnt; ++k) {
             const WideRec cur = stage[k];  // (one address for the whole wave: a broadcast read)
             const RegionI k1 = {cur.yk, cur.cv, cur.cd};
@@ -2253,6 +2289,7 @@ __device__ __forceinline__ void line_far_body(const int block, const int units, 
         }
     }
     flush(count);
+    if constexpr (F32) acc[0] = (double)acc32.x, acc[RF - 1] = (double)acc32.y;
 
     // the subsets' node sums, in subset order
     double* red = s_far;
@@ -2351,7 +2388,8 @@ __device__ __forceinline__ void line_all_body(int n_wide, int tiles, int n_split
             const int n_far = n_depth * far_units;
             if (b < n_far) {
                 double* const far_plane = planes + (size_t)2 * n_depth * pld;
-                if (rf == 2) line_far_body<R, 2>(b, far_units, n_split, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, w, far_plane, pld, s_wide);
+                // (fp32-mixed mode: the node sums in packed fp32 — units of 8 tiles, the default; the experiment knob's units of 4 stay fp64)
+                if (rf == 2) line_far_body<R, 2, MIXED>(b, far_units, n_split, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, w, far_plane, pld, s_wide);
                 else line_far_body<R, 1>(b, far_units, n_split, n_depth, n_nu, nus, nu_begin, nu_count, n_lines, w, far_plane, pld, s_wide);
                 return;
             }
