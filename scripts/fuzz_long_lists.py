@@ -1,5 +1,6 @@
 """GPU experiment: the seeded random long-list configurations of tests/test_gpu_long_random.py beyond the four the suite runs.
-python scripts/fuzz_long_lists.py FIRST LAST [--mixed] [--ticket]   (--ticket: the counter-driven pre-pass of very long lists forced on these)"""
+python scripts/fuzz_long_lists.py FIRST LAST [--mixed] [--ticket] [--raw]   (--ticket: the counter-driven pre-pass of very long lists forced on
+these; --raw: option narrow_records = 0, the narrow role reads the caller's tables whatever the density of the list)"""
 import os, sys, traceback
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root)
@@ -10,6 +11,8 @@ from stardis_amd._lib import default_context
 ctx = default_context()
 if "--ticket" in sys.argv:
     ctx.set_option("prepass_ticket_min_blocks", 0)
+if "--raw" in sys.argv:
+    ctx.set_option("narrow_records", 0)
 bad = 0
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 for seed in range(int(args[0]), int(args[1])):
