@@ -2179,9 +2179,11 @@ __device__ __forceinline__ void line_far_body(const int block, const int units, 
                     acc32 = region1_f32x2(acc32, dq32, c0, cur);
                 } else {
                     const unsigned tm = (unsigned)__builtin_amdgcn_readlane((int)qm, k);
-                    const float2v v = region1_f32x2(float2v{0.f, 0.f}, dq32, c0, cur);
-                    acc32.x += ((tm >> tg) & 1u) ? v.x : 0.f;
-                    acc32.y += ((tm >> (4 + tg)) & 1u) ? v.y : 0.f;
+                    // (the accumulating FMA of the test-free form, kept or dropped per node: a tile's sum must not depend on whether its
+                    // unit's other tiles — which a shard may not own — let the hit take the test-free path)
+                    const float2v v = region1_f32x2(acc32, dq32, c0, cur);
+                    acc32.x = ((tm >> tg) & 1u) ? v.x : acc32.x;
+                    acc32.y = ((tm >> (4 + tg)) & 1u) ? v.y : acc32.y;
                 }
             }
             wave_sync();
