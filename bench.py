@@ -540,12 +540,14 @@ class Runner:
         # the optional SECOND collective (--two-collectives): each rank classifies 1 / N of the line list, the shares of the per-line
         # maxima are all-gathered, the rest of the step runs on the gathered array (stardis_amd.parallel.ClassificationGatherer)
         self.classes = None
-        if two_collectives and world > 1 and scaling == "strong" and isinstance(w["lines"], dict):
+        two = two_collectives and world > 1 and scaling == "strong" and isinstance(w["lines"], dict)
+        if two:
             self.classes = parallel.ClassificationGatherer(int(np.asarray(w["lines"]["line_nus"]).size), world, rank, dev)
         # --in-flight 2: the second lane is a synthesis on a context (HIP stream, scratch) of its own, stepped alternately with the first:
         # two independent syntheses of a queue (a grid of models) in flight per GPU — the stream-bound and launch-bound stretches of one
         # step run beside the arithmetic of the other.  Each lane's gather is ordered behind ITS stream.
-        self.in_flight = 2 if (in_flight == 2 and self.classes is None) else 1
+        self.in_flight = 2 if in_flight == 2 else 1
+        self.lane_classes = []  # (two collectives: every lane gathers into buffers of its own)
         self.lanes = []
         self.streams = [torch.cuda.current_stream()]
         self.contexts = [ctx]
@@ -557,15 +559,20 @@ class Runner:
             flux = torch.zeros((self.nd, self.count), dtype=torch.float64, device=dev)
             extra = {}
             if self.classes is not None:
-                extra = dict(classify_share=self.classes.share, m_max=self.classes.full, m_share_out=self.classes.send)
+                cls = self.classes if k == 0 else parallel.ClassificationGatherer(self.classes.n_lines, world, rank, dev)
+                self.lane_classes.append(cls)
+                extra = dict(classify_share=cls.share, m_max=cls.full, m_share_out=cls.send)
             syn = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], w["thetas"], w["weights"], w["lines"], w["cont"], ctx=ctx,
                                       shard=(self.begin, self.count), flux_out=flux, track_evaluations=(k == 0 and self.classes is None),
                                       keep_line=False, **extra)
             self.lanes.append([syn, flux, parallel.FluxGatherer(nus.size, world, flux.device, shards=self.shards)])
         self.syn, self.flux = self.lanes[0][0], self.lanes[0][1]
         if self.classes is not None:
-            self.syn.enqueue_classify()
-            self.classes.gather()
+            for k, (lane, cls) in enumerate(zip(self.lanes, self.lane_classes)):  # (every lane's gathered array must be valid before its graphs are captured)
+                with torch.cuda.stream(self.streams[k % len(self.streams)]):
+                    lane[0].enqueue_classify()
+                    cls.gather()
+            torch.cuda.synchronize()
             self.evals = None  # (the counting pre-pass is the unculled one: not part of this mode)
         self.syn.step()
         self.contexts[0].synchronize()
@@ -579,10 +586,10 @@ class Runner:
         self.counter = 0
         self.last = None
 
-    def _run(self, syn):
+    def _run(self, syn, k=0):
         if self.classes is not None:
             syn.step_classify()
-            self.classes.gather()
+            self.lane_classes[k].gather()
         syn.step()
 
     def step(self):
@@ -595,15 +602,15 @@ class Runner:
         if self.in_flight == 2:
             with torch.cuda.stream(self.streams[k]):  # (the collective is enqueued behind the current torch stream: this lane's)
                 gather.finish()
-                self._run(syn)
+                self._run(syn, k)
                 gather.start(flux[-1])
             return None
         if self.overlap:
             gather.finish()  # the gather that last read this lane's flux buffer
-            self._run(syn)
+            self._run(syn, k)
             gather.start(flux[-1])
             return None
-        self._run(syn)
+        self._run(syn, k)
         return gather(flux[-1])
 
     def drain(self):

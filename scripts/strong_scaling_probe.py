@@ -36,10 +36,14 @@ def rank_time(world, rank, reps=20):
     # rank does with a queue of independent syntheses (a grid of models): the stream-bound and launch-bound parts of one step run beside
     # the arithmetic of the other.  The time printed is then per step of the PAIR's throughput.
     twin = None
-    if in_flight == 2 and not two:
+    if in_flight == 2:
         ctx_b = _lib.Context(ctx.device if hasattr(ctx, "device") else 0)
+        extra_b = dict(classify_share=(0, n_l), m_max=ctx_b.empty((n_l,))) if two else {}
         twin = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], w["thetas"], w["weights"], w["lines"], w["cont"], shard=shard,
-                                   track_evaluations=False, keep_line=False, ctx=ctx_b)
+                                   track_evaluations=False, keep_line=False, ctx=ctx_b, **extra_b)
+        if two:
+            twin.enqueue_classify(); ctx_b.synchronize()
+            twin.classify_share = (min(rank * per, n_l), max(0, min(per, n_l - rank * per)))
         twin.capture()
     if two:  # every share once (the other ranks' part of the gathered array), then this rank's own from now on
         syn.enqueue_classify(); ctx.synchronize()
@@ -51,7 +55,9 @@ def rank_time(world, rank, reps=20):
     def one():
         if twin is not None:
             flip[0] ^= 1
-            (twin if flip[0] else syn).step()
+            which = twin if flip[0] else syn
+            if two: which.step_classify()
+            which.step()
             return
         if two: syn.step_classify()
         syn.step()

@@ -76,17 +76,17 @@ def test_bench_self_launches_two_ranks():
     assert out["ms_per_step_cold"] > 0
 
 
-@pytest.mark.parametrize("mode", ["one collective", "two collectives", "two in flight"])
+@pytest.mark.parametrize("mode", ["one collective", "two collectives", "two in flight", "two collectives, two in flight"])
 def test_bench_eight_ranks_on_one_device_rehearse_the_scale_run(mode):
     """The closest thing to the driver's 8-GPU SCALE run a one-GPU box allows: `bench.py --gpus 8` (all ranks on device 0, gloo) —
     eight per-rank entries, shards that tile the 120 398-point grid of configs[2], and the gathered spectrum bit-equal to the
     one-GPU run of the same workload in the same process; with --two-collectives every rank classifies an eighth of the list; with
     --in-flight 2 every rank alternates two syntheses on two contexts (each gather ordered behind its own stream)."""
-    two_collectives = mode == "two collectives"
+    two_collectives = "two collectives" in mode
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(SDX_BENCH_BACKEND="gloo", SDX_BENCH_SINGLE_DEVICE="1")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
-    extra = {"one collective": [], "two collectives": ["--two-collectives"], "two in flight": ["--in-flight", "2"]}[mode]
+    extra = (["--two-collectives"] if two_collectives else []) + (["--in-flight", "2"] if "two in flight" in mode else [])
     proc = subprocess.run(cmd + extra, env=env, capture_output=True, text=True, timeout=1800)
     assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-3000:]
     out = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1])
@@ -102,7 +102,7 @@ def test_bench_eight_ranks_on_one_device_rehearse_the_scale_run(mode):
         assert out["collective"]["second_collective"]["bytes_per_rank"] == 8 * -(-150000 // 8)
     assert out["gathered_spectrum_equals_n1_bit_for_bit"] is True
     assert out["n1_same_workload"]["ms_per_step"] > 0 and out["speedup_vs_n1"] > 0
-    assert out["config"]["syntheses_in_flight_per_gpu"] == out["n1_same_workload"]["in_flight"] == (2 if mode == "two in flight" else 1)
+    assert out["config"]["syntheses_in_flight_per_gpu"] == out["n1_same_workload"]["in_flight"] == (2 if "two in flight" in mode else 1)
 
 
 def test_shards_of_the_million_line_workload_reproduce_the_unsharded_bits():
