@@ -637,6 +637,9 @@ class Runner:
     def close(self):
         for syn, _, _ in self.lanes:
             syn.close()
+        for extra in self.contexts[1:]:  # (the second lane's own context of --in-flight 2; the first is the caller's)
+            extra.close()
+        self.contexts = self.contexts[:1]
 
 
 def performed_evaluations(w, far_field_on):
