@@ -541,7 +541,11 @@ int sdx_synthesize_opt_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double
  *   3. sdx_synthesize_opt_dev(..., options->line_m_max = m_max)   the rest of the step — same context, same grid, shard, lists.
  * Results are bit-identical to the one-call step (the classes of the lines follow from the same numbers).  Only for culled
  * shards: dense lists of >= `indexed_min_lines` lines, grids of more than 16384 points, nu_count < n_nu, no evaluation count;
- * anything else is SDX_ERR_ARG (-1), as is step 3 without step 1. */
+ * anything else is SDX_ERR_ARG (-1), as is step 3 without step 1.  What step 1 leaves in the scratch belongs to ONE step 3: it is
+ * consumed by it, and invalidated by any other call on the context that prepares lines or a continuum plane in between (a second
+ * step 3, a synthesis of another problem, sdx_line_opacity_dev ...: SDX_ERR_ARG instead of another problem's data).  A recorded
+ * hipGraph replays steps 1 and 3 without these host-side checks: replay them in pairs.  The "far_field" option may differ between
+ * the steps (step 3 computes the tiles' far ranges itself when step 1 has not). */
 int sdx_synthesize_classify_dev(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t nu_begin, int64_t nu_count,
                                 int64_t n_lines, const double* line_nus, const double* doppler_widths, const double* gammas,
                                 int gamma_cols, const double* alphas, const sdx_continuum* cont, int64_t line_begin,
