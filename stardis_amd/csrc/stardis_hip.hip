@@ -884,8 +884,8 @@ static int line_prepass(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* n
     w.front = 0;
     // VERY dense long fp64 lists (>= 4 lines per grid point: the rule of the narrow role's subsets): no narrow records — the narrow role
     // reads the caller's three tables itself (LineWork::narrow_raw).  Pure scheduling (the same three operations form 1 / dw, y and the
-    // amplitude either way).  Measured in round 6 (profiles/r06_raw.txt): 1e6 lines on 120 398 points — pre-pass 904 -> 721 us (it is bound
-    // by its 3 GB of traffic, 1.35 GB of them these records), line kernel 5.93 -> 6.07 ms (ten more instructions per evaluated line), step
+    // amplitude either way).  Measured in round 6 (profiles/r06_raw.txt): 1e6 lines on 120 398 points — pre-pass 904 -> 721 us (a stream:
+    // 2.13 GB of traffic counted, 1.31 GB of it these records), line kernel 5.93 -> 6.07 ms (ten more instructions per evaluated line), step
     // 7.27 -> 7.24 ms and 1.35 GB less scratch; 1.5e5 lines: pre-pass 165 -> 149 us, line kernel 1.218 -> 1.241 ms, the step 7 us SLOWER —
     // hence the density in the rule.
     static const int narrow_records_env = knob("SDX_NARROW_RECORDS") ? std::atoi(knob("SDX_NARROW_RECORDS")) : -1;  // A/B knob; the option "narrow_records" wins
