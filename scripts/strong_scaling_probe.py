@@ -1,7 +1,7 @@
 """GPU experiment: strong scaling of one workload by frequency sharding, emulated on one GPU — each rank's step is timed
 alone (ranks are independent: no data-path exchange; the flux gather overlaps the next step), the projected speed-up is
 t(1) / max_r t_r(P).  Steps are replayed as hipGraphs, like bench.py; the slowest rank's per-kernel times are printed.
-python scripts/strong_scaling_probe.py [TAG] [WORLD ...] [--balanced] [--all-ranks] [--verbose] [--two-collectives] [--in-flight=2]
+python scripts/strong_scaling_probe.py [TAG] [WORLD ...] [--balanced] [--all-ranks] [--verbose] [--two-collectives] [--in-flight=K]
 --two-collectives: every rank classifies 1 / WORLD of the line list and reads the other shares from a buffer filled beforehand (what
 the all-gather of m_max would deliver; its cost is NOT in the time printed — profiles/README.md models it)."""
 import ctypes as C, os, sys, time
@@ -12,7 +12,7 @@ from stardis_amd.engine import SpectralSynthesizer, shard_bounds
 tag = sys.argv[1] if len(sys.argv) > 1 else "S-c3"
 balanced = "--balanced" in sys.argv
 worlds = [int(a) for a in sys.argv[2:] if a.isdigit()] or [1, 2, 4, 8]
-in_flight = 2 if "--in-flight=2" in sys.argv else 1
+in_flight = next((int(a.split("=")[1]) for a in sys.argv if a.startswith("--in-flight=")), 1)
 w = synth.make_workload(tag)
 atm, nus, ln = w["atm"], w["nus"], w["lines"]
 # per-column cost: window evaluations + the column's share of the formal solution and continuum (~8000 evaluation-equivalents)
@@ -36,7 +36,8 @@ def rank_time(world, rank, reps=20):
     # rank does with a queue of independent syntheses (a grid of models): the stream-bound and launch-bound parts of one step run beside
     # the arithmetic of the other.  The time printed is then per step of the PAIR's throughput.
     twin = None
-    if in_flight == 2:
+    twins = []
+    for _ in range(in_flight - 1):
         ctx_b = _lib.Context(ctx.device if hasattr(ctx, "device") else 0)
         extra_b = dict(classify_share=(0, n_l), m_max=ctx_b.empty((n_l,))) if two else {}
         twin = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], w["thetas"], w["weights"], w["lines"], w["cont"], shard=shard,
@@ -45,6 +46,7 @@ def rank_time(world, rank, reps=20):
             twin.enqueue_classify(); ctx_b.synchronize()
             twin.classify_share = (min(rank * per, n_l), max(0, min(per, n_l - rank * per)))
         twin.capture()
+        twins.append(twin)
     if two:  # every share once (the other ranks' part of the gathered array), then this rank's own from now on
         syn.enqueue_classify(); ctx.synchronize()
         syn.classify_share = (min(rank * per, n_l), max(0, min(per, n_l - rank * per)))
@@ -54,8 +56,8 @@ def rank_time(world, rank, reps=20):
 
     def one():
         if twin is not None:
-            flip[0] ^= 1
-            which = twin if flip[0] else syn
+            flip[0] = (flip[0] + 1) % in_flight
+            which = twins[flip[0] - 1] if flip[0] else syn
             if two: which.step_classify()
             which.step()
             return
@@ -64,7 +66,7 @@ def rank_time(world, rank, reps=20):
 
     def sync():
         syn.synchronize()
-        if twin is not None: twin.synchronize()
+        for t_ in twins: t_.synchronize()
 
     # steady state, like bench.py's timed loop: ~0.2 s of untimed replays (clocks settle), then the best of five blocks of replays
     one(); sync()
@@ -78,8 +80,8 @@ def rank_time(world, rank, reps=20):
         for _ in range(reps): one()
         sync()
         t = min(t, (time.perf_counter() - t0) / reps)
-    if twin is not None:
-        twin.close(); twin.ctx.close()
+    for t_ in twins:
+        t_.close(); t_.ctx.close()
     ctx.call("sdx_profile_enable", 1); ctx.call("sdx_profile_reset")
     for _ in range(3):
         if two: syn.enqueue_classify()
