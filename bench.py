@@ -518,10 +518,13 @@ def profiled_valu(workload, kern):
 
 
 # ------------------------------------------------------------------------------------------------ timed region
+GRAPH_STEPS = 10  # at most this many steps per hipGraph launch of the one-GPU timed loop (--graph-steps)
+
+
 class Runner:
     """One rank's synthesizer(s) + flux gather for a workload: step(), drain()."""
 
-    def __init__(self, w, world, rank, local, ctx, scaling, use_graph, overlap, two_collectives=False, in_flight=1):
+    def __init__(self, w, world, rank, local, ctx, scaling, use_graph, overlap, two_collectives=False, in_flight=1, graph_steps=10, steps=0):
         import torch
 
         from stardis_amd import _lib
@@ -579,10 +582,24 @@ class Runner:
         if self.classes is None:
             self.evals = self.syn.evaluations()
             self.syn.count_evaluations = False  # known now; the counter costs a memset + a copy per step
+        # one GPU, one synthesis after the other: the timed steps are enqueued as hipGraph replays of up to --graph-steps (10) steps each (+ single-step
+        # replays for a remainder, at drain()) — successive graph launches are ~8.5 us apart on this runtime whatever they hold, a tenth of
+        # the S-c2 step; every step of a batch is the whole step (pre-pass, line kernel, formal solution) on the resident inputs
+        # (the largest batch <= --graph-steps that divides the K timed steps: the timed region is then batch launches only — a launch of a
+        # DIFFERENT graph than the stream's last one costs ~60-100 us on this runtime, so batches and single steps must not alternate)
+        self.batch = 1
+        # Runs of fewer than 100 timed steps keep one launch per step: a batch graph's own launch latency (the GPU is idle at the start
+        # of the timed region) outweighs the gaps it saves over a handful of launches (measured at 20 steps: 95-111 us against 93-94).
+        if use_graph and world == 1 and self.in_flight == 1 and self.classes is None and steps >= 100:
+            self.batch = max([d for d in range(1, max(1, int(graph_steps)) + 1) if steps % d == 0])
+        self.pending = 0
         if use_graph:
             for k, lane in enumerate(self.lanes):
                 with torch.cuda.stream(self.streams[k % len(self.streams)]):
-                    lane[0].capture()
+                    lane[0].capture(batch=self.batch if k == 0 else 1)
+            if self.batch > 1:  # (a graph's first launch uploads it: part of the set-up, like the eager step above)
+                self.syn.step_batch()
+                self.contexts[0].synchronize()
         self.counter = 0
         self.last = None
 
@@ -595,6 +612,12 @@ class Runner:
     def step(self):
         import torch
 
+        if self.batch > 1:  # (one GPU: a full batch goes out as one graph launch; drain() sends what is left, step by step)
+            self.pending += 1
+            if self.pending == self.batch:
+                self.syn.step_batch()
+                self.pending = 0
+            return None
         k = self.counter % len(self.lanes)
         syn, flux, gather = self.lanes[k]
         self.counter += 1
@@ -616,6 +639,9 @@ class Runner:
     def drain(self):
         import torch
 
+        while self.pending:
+            self.syn.step()
+            self.pending -= 1
         if self.in_flight == 2:
             for k, (_, _, gather) in enumerate(self.lanes):
                 with torch.cuda.stream(self.streams[k]):
@@ -714,6 +740,8 @@ def timed(runner, steps, warmup, world, local, settle_s=0.5, cold=True):
     torch.cuda.synchronize()
     one = max(time.perf_counter() - t0, 1e-6)
     extra = int(rank_max(int(min(10000, settle_s / one)), torch.int64))
+    b = int(getattr(runner, "batch", 1))
+    extra = -(-extra // b) * b  # (whole batches: the launches that precede the timed region are of the graph it replays)
     for _ in range(extra):
         runner.step()
     runner.drain()
@@ -886,6 +914,9 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default=None,
                     help="what `value` measures at N > 1. strong (default): the workload's grid split across the GPUs in shards of equal "
                          "estimated work (stardis_amd.parallel.balanced_shards); weak: fixed grid points per GPU (N x the resolving power)")
+    ap.add_argument("--graph-steps", type=int, default=GRAPH_STEPS,
+                    help="one GPU: at most this many steps per hipGraph launch of the timed loop (default 10; the largest divisor of --steps is taken; "
+                         "1: one launch per step, as rounds 1-5 timed it)")
     ap.add_argument("--in-flight", type=int, choices=(1, 2), default=1,
                     help="2: every rank keeps two syntheses in flight (two contexts, stepped alternately) — throughput of a queue of independent "
                          "syntheses instead of one step after the other; `value` then counts both (default 1: serial steps)")
@@ -930,7 +961,7 @@ def main():
     # N > 1: two flux buffers alternate so that the all-gather of step k (RCCL, its own stream) overlaps the kernels
     # of step k+1; a buffer is reused only after its gather has been waited for.  SDX_BENCH_SYNC_GATHER=1: blocking gather.
     overlap = os.environ.get("SDX_BENCH_SYNC_GATHER") != "1"
-    runner = Runner(w, world, rank, local, ctx, args.scaling, not args.no_graph, overlap, args.two_collectives, args.in_flight)
+    runner = Runner(w, world, rank, local, ctx, args.scaling, not args.no_graph, overlap, args.two_collectives, args.in_flight, args.graph_steps, args.steps)
     # a run of >= 200 timed steps is long enough for the clocks to have settled within its first few percent: the W warm-up steps
     # the driver asked for are then ALL that precedes the timed region; shorter runs get ~0.5 s of untimed settling (disclosed)
     tm = timed(runner, args.steps, args.warmup, world, local, settle_s=0.0 if args.steps >= 200 else 0.5, cold=args.steps < 200)
@@ -1027,6 +1058,7 @@ def main():
                 "voigt_evaluations_global": int(evals) if evals is not None else None,
                 "parallelism": f"nu-shard x{world}" + (", 1 all-gather of F_nu[-1] per step" + (" overlapped with the next step" if runner.overlap else "") if world > 1 else ""),
                 "hip_graph": not args.no_graph,
+                "graph_steps_per_launch": runner.batch,
                 "syntheses_in_flight_per_gpu": runner.in_flight,
                 # how `value` was timed (the driver keeps `config`): `value` / `ms_per_step` are the K steps after the W warm-up steps and,
                 # for runs of fewer than 200 steps, this many further untimed steps (~0.5 s: the clocks ramp); *_cold are the same K steps

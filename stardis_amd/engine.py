@@ -110,6 +110,7 @@ class SpectralSynthesizer:
         self.count_evaluations = track_evaluations  # sum(hi - lo) per step costs a memset + copy: switch off when timing
         self.graph = None
         self.graph_classify = None
+        self.graph_batch, self.batch = None, 1
         self.classify_share, self.m_max, self.m_share_out = classify_share, m_max, m_share_out
         if (classify_share is None) != (m_max is None):
             raise ValueError("classify_share and m_max go together")
@@ -232,8 +233,10 @@ class SpectralSynthesizer:
         c.call("sdx_raytrace_dev", nd, cnt, self.n_theta, nus_shard, self.d_t.ptr, self.d_ray.ptr, self.d_w.ptr,
                self.d_total.ptr, cnt, self.flux_ptr, cnt, None, 0)
 
-    def capture(self, eager_phase2=True):
-        """Record one step into a hipGraph (after one eager step has sized the scratch).  Two-collective mode: two graphs, the
+    def capture(self, eager_phase2=True, batch=1):
+        """Record one step into a hipGraph (after one eager step has sized the scratch).  batch > 1: ALSO a graph of `batch` consecutive
+        steps (step_batch()): successive graph launches are ~8.5 us apart on this runtime whatever they hold — a tenth of a 92 us step —
+        so a caller with a queue of syntheses replays several steps per launch.  Two-collective mode: two graphs, the
         classification launch and the rest — the caller's all-gather of m_max goes between step_classify() and step(); m_max must
         hold every rank's share when capture() is called (the eager pass reads it) unless eager_phase2 is False (a re-capture
         after the scratch has moved: it is large enough already, and m_max may not have been gathered yet)."""
@@ -259,6 +262,11 @@ class SpectralSynthesizer:
         self.enqueue()
         c.synchronize()
         self.graph = record(self.enqueue)
+        if batch > 1:
+            def many():
+                for _ in range(batch):
+                    self.enqueue()
+            self.graph_batch, self.batch = record(many), int(batch)
         return self
 
     def step_classify(self):
@@ -286,6 +294,20 @@ class SpectralSynthesizer:
                 self.ctx.call("sdx_graph_launch", self.graph)
         else:
             self.enqueue()
+
+    def step_batch(self):
+        """`self.batch` consecutive steps as ONE graph launch (capture(batch=n)); -> the number of steps enqueued."""
+        if self.graph_batch is None:
+            self.step()
+            return 1
+        try:
+            self.ctx.call("sdx_graph_launch", self.graph_batch)
+        except _lib.StaleGraphError:
+            n = self.batch
+            self.close()
+            self.capture(batch=n)
+            self.ctx.call("sdx_graph_launch", self.graph_batch)
+        return self.batch
 
     def synchronize(self):
         self.ctx.synchronize()
@@ -325,6 +347,9 @@ class SpectralSynthesizer:
         if self.graph_classify is not None:
             self.ctx.call("sdx_graph_destroy", self.graph_classify)
             self.graph_classify = None
+        if self.graph_batch is not None:
+            self.ctx.call("sdx_graph_destroy", self.graph_batch)
+            self.graph_batch, self.batch = None, 1
 
 
 class SynthesisPool:
