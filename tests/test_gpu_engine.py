@@ -479,3 +479,25 @@ def test_an_empty_line_list_counts_zero_evaluations(ctx):
     assert int(d_ev.numpy()[0]) == 0 and (syn.F_nu()[-1] > 0).all()
     syn.close()
 
+
+
+def test_several_steps_per_graph_launch(ctx):
+    """capture(batch=n): a second hipGraph that holds n consecutive steps; step_batch() enqueues it (-> n).  Every step of a batch is
+    the whole step on the resident inputs — an input updated on the device between two launches is seen by the next one — and the
+    results are the single-step graph's bits."""
+    atm, nus, lines, cont, th, w = small_workload()
+    syn = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], th, w, lines, cont, ctx=ctx, track_evaluations=False)
+    syn.capture(batch=4)
+    syn.step()
+    one = (syn.F_nu().copy(), syn.total_alphas().copy())
+    syn.d_F.zero()
+    assert syn.step_batch() == 4
+    assert np.array_equal(syn.F_nu(), one[0]) and np.array_equal(syn.total_alphas(), one[1])
+    # the batch reads the inputs at every step: halve the line strengths in place, replay
+    syn.d_a.set(0.5 * lines["alphas"])
+    assert syn.step_batch() == 4
+    half = syn.F_nu().copy()
+    syn.step()
+    assert np.array_equal(syn.F_nu(), half) and not np.array_equal(half, one[0])
+    syn.close()
+    assert syn.graph_batch is None and syn.step_batch() == 1  # (no graph: one eager step)
