@@ -16,7 +16,7 @@ in_flight = next((int(a.split("=")[1]) for a in sys.argv if a.startswith("--in-f
 w = synth.make_workload(tag)
 atm, nus, ln = w["atm"], w["nus"], w["lines"]
 # per-column cost: window evaluations + the column's share of the formal solution and continuum (~8000 evaluation-equivalents)
-work = parallel.column_cost(nus, ln, **{k: float(os.environ[e]) for k, e in (("scan_weight", "SDX_SCAN_WEIGHT"), ("core_weight", "SDX_CORE_WEIGHT"), ("fixed", "SDX_FIXED"), ("far_weight", "SDX_FAR_WEIGHT")) if e in os.environ}) if balanced else None
+work = parallel.column_cost(nus, ln, **{k: float(os.environ[e]) for k, e in (("scan_weight", "SDX_SCAN_WEIGHT"), ("core_weight", "SDX_CORE_WEIGHT"), ("fixed", "SDX_FIXED"), ("far_weight", "SDX_FAR_WEIGHT"), ("huge_weight", "SDX_HUGE_WEIGHT")) if e in os.environ}) if balanced else None
 KERNELS = ("k_dnu_partial", "k_classify", "k_prepass_continuum", "k_line_prepass", "k_hlist", "k_gather", "k_far_ranges", "k_line_all", "k_line_wide", "k_line_narrow", "k_line_far", "k_raytrace")
 
 

@@ -72,7 +72,7 @@ def far_field_active(n_nu, ctx=None):
     return int(n_nu) >= far_field_rule()[0]
 
 
-def window_work(nus, line_nus, doppler_widths, gammas, alphas, core_weight=1.0, far_weight=None):
+def window_work(nus, line_nus, doppler_widths, gammas, alphas, core_weight=1.0, far_weight=None, count_huge=None):
     """Voigt evaluations per grid column, sum over (line, depth) of [lo <= i < hi] with the window rule of
     calc_alan_entries (opacities_solvers/base.py:524-575).  A planning estimate on the host (numpy, O(N_l N_d)): it only
     decides where shard boundaries go, never what is computed.
@@ -80,7 +80,9 @@ def window_work(nus, line_nus, doppler_widths, gammas, alphas, core_weight=1.0, 
     window within 15 Doppler widths of the centre, Faddeeva regions II-IV — that many times: those cost 100-250
     instructions where a far-wing evaluation costs 13.
     far_weight (None: no far field): what a window point beyond FAR_NEAR_POINTS of its centre costs when the far field of the
-    line kernels takes it — 16 node evaluations per 256 points, ~1/12 with the interpolation."""
+    line kernels takes it — 16 node evaluations per 256 points, ~1/12 with the interpolation.
+    count_huge: a list that receives the number of lines whose widest window exceeds 4096 points (the kernels' huge-line list, which
+    every tile of every depth scans whatever its position)."""
     nus = np.asarray(nus, dtype=np.float64)
     n = nus.size
     if n < 2 or np.asarray(line_nus).size == 0:
@@ -91,6 +93,8 @@ def window_work(nus, line_nus, doppler_widths, gammas, alphas, core_weight=1.0, 
     dw = np.asarray(doppler_widths, dtype=np.float64)
     pixels = (g + dw) * np.asarray(alphas, dtype=np.float64) / d_nu * 20.0
     hw = np.minimum(np.where(pixels > 10.0, pixels, 10.0), float(n)).astype(np.int64)
+    if count_huge is not None:
+        count_huge.append(int(np.count_nonzero(hw.max(axis=1) > 4096)))
     lo = np.clip(centre[:, None] - hw, 0, n)
     hi = np.clip(centre[:, None] + hw, 0, n)
     # +1 where a window opens, -1 where it closes (np.bincount: the same sums as np.add.at, ~30 times faster on 1.7e7 entries)
@@ -125,7 +129,8 @@ def scan_work(nus, line_nus, half_width=4096):
     return (np.searchsorted(centre, i + half_width, side="left") - np.searchsorted(centre, i - half_width, side="right")).astype(np.float64)
 
 
-def column_cost(nus, lines, indexed_min_lines=8192, scan_weight=0.6, fixed=None, core_weight=14.0, far_field=None, far_weight=1.0 / 12, ctx=None):
+def column_cost(nus, lines, indexed_min_lines=8192, scan_weight=0.6, fixed=None, core_weight=14.0, far_field=None, far_weight=1.0 / 12, ctx=None,
+                huge_weight=2.3, huge_free=15000):
     """Estimated cost of every grid column in units of one far-wing Voigt evaluation, for balanced_shards: the window
     evaluations (line cores weighted by core_weight), the candidate scan of long lists (scan_weight per line in range) and
     a constant for the continuum and the formal solution — weights measured on MI355X.  A planning estimate on the host: it
@@ -135,8 +140,15 @@ def column_cost(nus, lines, indexed_min_lines=8192, scan_weight=0.6, fixed=None,
     # (per column: continuum, formal solution, the far kernel's nodes — 8000 evaluation-equivalents of the direct sum; with the far field the
     # windows weigh less against them: 16000 measured best over S-c3, S-c4m, S-c3 at R = 5e5 and S-big)
     if fixed is None: fixed = 16000.0 if far_field else 8000.0
+    huge = []
     cost = window_work(nus, lines["line_nus"], lines["doppler_widths"], lines["gammas"], lines["alphas"], core_weight,
-                       far_weight if far_field else None) + fixed
+                       far_weight if far_field else None, count_huge=huge) + fixed
+    # every (tile, depth) of the wide and far roles scans the WHOLE huge-line list: a per-column cost that does not depend on the column.
+    # Up to ~15 000 huge lines it hides behind the roles' other work (S-c3: 2 246, S-c3 at R = 5e5: 5 141, S-c4m: 13 939 — a linear
+    # term made all three 1 - 3 % worse); at R = 1e6 with 1e6 lines (42 503) the line kernel spends 18 ns per column on it whatever the
+    # column holds, and shards balanced without this term ran 5.3 - 8.0 ms (now 6.3 - 6.6).  A fit on that one workload (round 6).
+    if far_field and np.asarray(lines["line_nus"]).size >= indexed_min_lines:
+        cost = cost + huge_weight * max(0, huge[0] - huge_free)
     if np.asarray(lines["line_nus"]).size >= indexed_min_lines:
         cost = cost + scan_weight * scan_work(nus, lines["line_nus"])
     return cost
