@@ -143,10 +143,12 @@ def column_cost(nus, lines, indexed_min_lines=8192, scan_weight=0.6, fixed=None,
     huge = []
     cost = window_work(nus, lines["line_nus"], lines["doppler_widths"], lines["gammas"], lines["alphas"], core_weight,
                        far_weight if far_field else None, count_huge=huge) + fixed
-    # every (tile, depth) of the wide and far roles scans the WHOLE huge-line list: a per-column cost that does not depend on the column.
-    # Up to ~15 000 huge lines it hides behind the roles' other work (S-c3: 2 246, S-c3 at R = 5e5: 5 141, S-c4m: 13 939 — a linear
-    # term made all three 1 - 3 % worse); at R = 1e6 with 1e6 lines (42 503) the line kernel spends 18 ns per column on it whatever the
-    # column holds, and shards balanced without this term ran 5.3 - 8.0 ms (now 6.3 - 6.6).  A fit on that one workload (round 6).
+    # a per-column cost of the line kernel that does not depend on what the column holds and grows with the number of HUGE lines (widest
+    # window > 4096 points): at R = 1e6 with 1e6 lines (42 503 huge) the kernel costs 46.6 ns per column at the blue end and 26.4 at the red
+    # end where the variable terms above say 3.5 : 1 — 18 ns per column are constant — and shards balanced without this term ran 5.3 - 8.0 ms
+    # (now 6.3 - 6.6).  Up to ~15 000 huge lines nothing of it shows (S-c3: 2 246, S-c3 at R = 5e5: 5 141, S-c4m: 13 939 — a linear term made
+    # all three 1 - 3 % worse).  Not the scan of the huge list (chunk summaries that skip most of it changed no kernel time: EXPERIMENTS).
+    # A fit on that one workload (round 6).
     if far_field and np.asarray(lines["line_nus"]).size >= indexed_min_lines:
         cost = cost + huge_weight * max(0, huge[0] - huge_free)
     if np.asarray(lines["line_nus"]).size >= indexed_min_lines:
