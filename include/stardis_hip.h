@@ -105,7 +105,7 @@ int sdx_synchronize(sdx_ctx* ctx);
  *       a fixed constant (grids under 3 x 4 x 256 k_raytrace waves take the segmented kernel) — never from the shard's own
  *       width or the device's CU count, so that a frequency shard and the unsharded grid run the same arithmetic and stay
  *       bit-identical; 0: never the segmented kernel; 1: whenever it supports the shape.  The fp32-mixed twins (*_f32mix) that
- *       SURVEY §8b proposed are this library's "mixed_precision" option instead: one set of entry points, two modes.
+ *       SURVEY §8b proposed exist for the host-buffer entry points (below) and are this library's "mixed_precision" option for the rest.
  *   "far_field" (default -1): the far field of the line opacity.  A (line, depth) item whose window (base.py:561-575) contains a whole
  *       256-point tile of the GLOBAL grid, clear of the line's core range (every point of the tile in Faddeeva region I) and with the
  *       line's centre at least three tile widths (6 half-widths, measured in frequency) from the tile's centre, is not evaluated at
@@ -408,6 +408,25 @@ int sdx_synthesize_f64(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nu
                        const sdx_continuum* cont, int n_theta, const double* temperature, const double* ray_dist,
                        const double* theta_weights, double* alpha_line_out, double* total_alphas, double* F_nu,
                        int64_t* n_evaluations);
+
+/* ---- fp32-mixed twins of the host-buffer entry points (`*_f32mix`) ---------------------------
+ * The same signatures and semantics as sdx_line_opacity_f64 / sdx_raytrace_f64 / sdx_synthesize_f64 with the context's
+ * "mixed_precision" option on for the duration of the call (and restored afterwards, whatever it was): the tolerance path of BASELINE
+ * configs[4] — far wings, window edges and narrow windows in packed fp32, the formal solution of plane-parallel grids in fp32; the
+ * pre-pass, the continuum and kept line cores in fp64; stated tolerance 1e-4 on the flux against the fp64 path (measured 1e-6).  The
+ * device-pointer entry points (*_dev) take the option instead: sdx_set_int_option(ctx, "mixed_precision", 1).  The reference has no
+ * counterpart (its arithmetic is fp64 throughout, opacities_solvers/base.py:487-627, radiation_field_solvers/base.py:85-346). */
+int sdx_line_opacity_f32mix(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t n_lines,
+                            const double* line_nus, const double* doppler_widths, const double* gammas, int gamma_cols,
+                            const double* alphas, double* out, int64_t* n_evaluations);
+int sdx_raytrace_f32mix(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, const double* nus,
+                        const double* temperature, const double* ray_dist, const double* theta_weights,
+                        const double* total_alphas, double* F_nu, double* I_nus);
+int sdx_synthesize_f32mix(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t n_lines, const double* line_nus,
+                          const double* doppler_widths, const double* gammas, int gamma_cols, const double* alphas,
+                          const sdx_continuum* cont, int n_theta, const double* temperature, const double* ray_dist,
+                          const double* theta_weights, double* alpha_line_out, double* total_alphas, double* F_nu,
+                          int64_t* n_evaluations);
 
 /* ---- one process, several GPUs ---------------------------------------------------
  * The frequency axis shards with no data-path exchange: every output column depends only on its own frequency

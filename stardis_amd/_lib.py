@@ -142,6 +142,10 @@ PROTOTYPES = {
     "sdx_profile_get": (_int, [_vp, C.c_char_p, C.POINTER(_i64), c_dp]),
     "sdx_line_opacity_dev": (_int, [_vp, _int, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _int, _vp, _vp, _i64, _int, _vp]),
     "sdx_line_opacity_f64": (_int, [_vp, _int, _i64, _vp, _i64, _vp, _vp, _vp, _int, _vp, _vp, C.POINTER(_i64)]),
+    "sdx_line_opacity_f32mix": (_int, [_vp, _int, _i64, _vp, _i64, _vp, _vp, _vp, _int, _vp, _vp, C.POINTER(_i64)]),
+    "sdx_raytrace_f32mix": (_int, [_vp, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sdx_synthesize_f32mix": (_int, [_vp, _int, _i64, _vp, _i64, _vp, _vp, _vp, _int, _vp, C.POINTER(Continuum), _int, _vp, _vp, _vp, _vp, _vp,
+                                     _vp, _vp]),
     "sdx_line_windows_dev": (_int, [_vp, _int, _i64, _vp, _i64, _vp, _vp, _vp, _int, _vp, _vp, _vp]),
     "sdx_faddeeva_dev": (_int, [_vp, _i64, _vp, _vp]),
     "sdx_voigt_profile_dev": (_int, [_vp, _i64, _vp, _vp, _vp, _vp]),

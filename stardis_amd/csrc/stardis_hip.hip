@@ -2497,6 +2497,48 @@ int sdx_continuum_f64(sdx_ctx* ctx, int n_depth, int64_t n_nu, double* nus, cons
     return io.finish();
 }
 
+// ---- fp32-mixed twins of the host-buffer entry points (include/stardis_hip.h): the option on for the call, restored afterwards
+namespace {
+struct MixedScope {
+    sdx_ctx* ctx;
+    int64_t saved;
+    explicit MixedScope(sdx_ctx* c) : ctx(c), saved(c ? c->mixed_precision : 0)
+    {
+        if (ctx) ctx->mixed_precision = 1;
+    }
+    ~MixedScope()
+    {
+        if (ctx) ctx->mixed_precision = saved;
+    }
+};
+}  // namespace
+
+int sdx_line_opacity_f32mix(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t n_lines, const double* line_nus,
+                            const double* doppler, const double* gammas, int gamma_cols, const double* alphas, double* out, int64_t* n_evaluations)
+{
+    REQUIRE(ctx, "null context");
+    MixedScope on(ctx);
+    return sdx_line_opacity_f64(ctx, n_depth, n_nu, nus, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, out, n_evaluations);
+}
+
+int sdx_raytrace_f32mix(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, const double* nus, const double* temps, const double* ray_dist,
+                        const double* wts, const double* alphas, double* F, double* I_nus)
+{
+    REQUIRE(ctx, "null context");
+    MixedScope on(ctx);
+    return sdx_raytrace_f64(ctx, n_depth, n_nu, n_theta, nus, temps, ray_dist, wts, alphas, F, I_nus);
+}
+
+int sdx_synthesize_f32mix(sdx_ctx* ctx, int n_depth, int64_t n_nu, const double* nus, int64_t n_lines, const double* line_nus, const double* doppler,
+                          const double* gammas, int gamma_cols, const double* alphas, const sdx_continuum* cont, int n_theta, const double* temps,
+                          const double* ray_dist, const double* wts, double* alpha_line_out, double* total_alphas, double* F_nu, int64_t* n_evaluations)
+{
+    REQUIRE(ctx, "null context");
+    MixedScope on(ctx);
+    return sdx_synthesize_f64(ctx, n_depth, n_nu, nus, n_lines, line_nus, doppler, gammas, gamma_cols, alphas, cont, n_theta, temps, ray_dist, wts,
+                              alpha_line_out, total_alphas, F_nu, n_evaluations);
+}
+
 }  // extern "C"
 
 // ================================================================================================ one process, several GPUs

@@ -501,3 +501,53 @@ def test_several_steps_per_graph_launch(ctx):
     assert np.array_equal(syn.F_nu(), half) and not np.array_equal(half, one[0])
     syn.close()
     assert syn.graph_batch is None and syn.step_batch() == 1  # (no graph: one eager step)
+
+
+def test_f32mix_twins_of_the_host_entry_points(ctx):
+    """sdx_line_opacity_f32mix / sdx_raytrace_f32mix / sdx_synthesize_f32mix: the fp64 host entry points with the
+    "mixed_precision" option on for the call — the bits of the option path, the option restored afterwards, within the stated 1e-4 of fp64."""
+    import ctypes as C
+
+    from stardis_amd import _lib
+
+    atm, nus, lines, cont, th, w = small_workload(n_lines=400, step=0.005, seed=23, n_theta=6)
+    nd, n_nu, n_l = atm["temperatures"].size, nus.size, lines["line_nus"].size
+    keep = []
+
+    def host(a, dt=np.float64):
+        a = np.ascontiguousarray(a, dtype=dt)
+        keep.append(a)
+        return a.ctypes.data
+
+    g = np.ascontiguousarray(lines["gammas"]).reshape(n_l, -1)
+    ray = np.asarray(atm["dist"]).reshape(-1, 1) / np.cos(th)
+    c = _lib.Continuum()
+    c.electron_density = host(cont["n_e"])
+    line_args = (ctx.handle, nd, n_nu, host(nus), n_l, host(lines["line_nus"]), host(lines["doppler_widths"]), host(g), g.shape[1], host(lines["alphas"]))
+
+    def run(fn_line, fn_ray, fn_syn):
+        line, F1, total, F2 = (np.empty((nd, n_nu)) for _ in range(4))
+        _lib.check(fn_line(*line_args, line.ctypes.data, None))
+        plane = line + 1e-9
+        _lib.check(fn_ray(ctx.handle, nd, n_nu, th.size, host(nus), host(atm["temperatures"]), host(ray), host(w), host(plane), F1.ctypes.data, None))
+        _lib.check(fn_syn(*line_args, C.byref(c), th.size, host(atm["temperatures"]), host(ray), host(w), None, total.ctypes.data, F2.ctypes.data, None))
+        return line, F1, total, F2
+
+    lib = ctx.lib
+    ref = run(lib.sdx_line_opacity_f64, lib.sdx_raytrace_f64, lib.sdx_synthesize_f64)
+    twin = run(lib.sdx_line_opacity_f32mix, lib.sdx_raytrace_f32mix, lib.sdx_synthesize_f32mix)
+    again = run(lib.sdx_line_opacity_f64, lib.sdx_raytrace_f64, lib.sdx_synthesize_f64)  # the option was restored: fp64 again
+    ctx.set_option("mixed_precision", 1)
+    try:
+        option = run(lib.sdx_line_opacity_f64, lib.sdx_raytrace_f64, lib.sdx_synthesize_f64)
+        inside = run(lib.sdx_line_opacity_f32mix, lib.sdx_raytrace_f32mix, lib.sdx_synthesize_f32mix)  # (on before, on after)
+        still_on = run(lib.sdx_line_opacity_f64, lib.sdx_raytrace_f64, lib.sdx_synthesize_f64)
+    finally:
+        ctx.set_option("mixed_precision", 0)
+    for a, b, o, i, s_, r in zip(twin, again, option, inside, still_on, ref):
+        assert np.array_equal(b, r)                                  # restored to fp64
+        assert np.array_equal(a, o) and np.array_equal(i, o) and np.array_equal(s_, o)  # the twin = the option path, which stays on
+    assert not np.array_equal(twin[3], ref[3])
+    assert rel_err(twin[3][1:], ref[3][1:]) < 1e-4 and rel_err(twin[1][1:], ref[1][1:]) < 1e-4  # stated tolerance on the flux
+    with pytest.raises(ValueError):
+        _lib.check(lib.sdx_synthesize_f32mix(None, *line_args[1:], C.byref(c), th.size, host(atm["temperatures"]), host(ray), host(w), None, None, None, None))
