@@ -526,7 +526,7 @@ def test_f32mix_twins_of_the_host_entry_points(ctx):
     line_args = (ctx.handle, nd, n_nu, host(nus), n_l, host(lines["line_nus"]), host(lines["doppler_widths"]), host(g), g.shape[1], host(lines["alphas"]))
 
     def run(fn_line, fn_ray, fn_syn):
-        line, F1, total, F2 = (np.empty((nd, n_nu)) for _ in range(4))
+        line, F1, total, F2 = (np.zeros((nd, n_nu)) for _ in range(4))  # (F_nu is accumulated into: zeros, like RadiationField.__init__)
         _lib.check(fn_line(*line_args, line.ctypes.data, None))
         plane = line + 1e-9
         _lib.check(fn_ray(ctx.handle, nd, n_nu, th.size, host(nus), host(atm["temperatures"]), host(ray), host(w), host(plane), F1.ctypes.data, None))
