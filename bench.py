@@ -159,8 +159,8 @@ def kernel_times(ctx, syn, n=10, settle_s=0.3):
     ctx.call("sdx_profile_reset")
     PROFILED_PASS[id(ctx)] = {"eager_ms_per_step": eager_ms, "kernel_sum_ms": sum(out.values()), "steps": n, "k_raytrace_is": variant,
                               "k_line_all_is": line_variant,
-                              "how": "eager launches bracketed by HIP events after %.1f s of eager settling; the graph-replayed step of "
-                                     "`ms_per_step` runs the same kernels without the event records and host launch gaps" % settle_s}
+                              "how": "eager launches bracketed by HIP events after %.1f s of eager settling; the timed step of "
+                                     "`ms_per_step` runs the same kernels without the event records" % settle_s}
     return out
 
 
@@ -602,17 +602,49 @@ class Runner:
                 self.contexts[0].synchronize()
         self.counter = 0
         self.last = None
+        self.replay = use_graph  # (False with a captured graph: plain launches; calibrate() may switch)
+
+    def calibrate(self, steps):
+        """One GPU, neither --graph nor --no-graph given: time `steps` untimed steps as plain launches and as graph replays and keep the
+        faster for the timed region (both run the same three kernels; which wins depends on the host's enqueue rate against the
+        runtime's 8.5-9 us between graph launches).  -> {mode, plain_ms_per_step, graph_ms_per_step}"""
+        import torch
+
+        out = {}
+        for mode in (False, True):
+            self.replay = mode
+            for _ in range(max(8, steps // 4)):
+                self.step()
+            self.drain()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.step()
+            self.drain()
+            torch.cuda.synchronize()
+            out["graph_ms_per_step" if mode else "plain_ms_per_step"] = (time.perf_counter() - t0) / steps * 1e3
+        self.replay = out["graph_ms_per_step"] < out["plain_ms_per_step"]
+        out["mode"] = "hipGraph replay" if self.replay else "plain launches"
+        # (the launches that precede the timed region are of the kind it uses)
+        for _ in range(max(8, steps // 4)):
+            self.step()
+        self.drain()
+        torch.cuda.synchronize()
+        return out
 
     def _run(self, syn, k=0):
         if self.classes is not None:
             syn.step_classify()
             self.lane_classes[k].gather()
-        syn.step()
+        if self.replay or syn.graph is None:
+            syn.step()
+        else:
+            syn.enqueue()
 
     def step(self):
         import torch
 
-        if self.batch > 1:  # (one GPU: a full batch goes out as one graph launch; drain() sends what is left, step by step)
+        if self.batch > 1 and self.replay:  # (one GPU: a full batch goes out as one graph launch; drain() sends what is left, step by step)
             self.pending += 1
             if self.pending == self.batch:
                 self.syn.step_batch()
@@ -640,7 +672,7 @@ class Runner:
         import torch
 
         while self.pending:
-            self.syn.step()
+            self._run(self.syn)
             self.pending -= 1
         if self.in_flight == 2:
             for k, (_, _, gather) in enumerate(self.lanes):
@@ -728,7 +760,7 @@ def timed(runner, steps, warmup, world, local, settle_s=0.5, cold=True):
     fence()
     if settle_s <= 0:  # a long run: the W warm-up steps are all that precedes the timed region
         elapsed, t_local = run(steps)
-        return dict(elapsed=elapsed, local=t_local, cold=elapsed, settle=0)
+        return dict(elapsed=elapsed, local=t_local, cold=elapsed, settle=0, launch=None)
     # the K steps right after the W requested warm-up steps: clocks still ramping (reported as ms_per_step_cold)
     t_cold = run(steps)[0] if cold else None
     # clocks and caches settle over the first tenths of a second of work: a short --steps run would otherwise time the ramp
@@ -746,8 +778,14 @@ def timed(runner, steps, warmup, world, local, settle_s=0.5, cold=True):
         runner.step()
     runner.drain()
     fence()
+    launch = None
+    if getattr(runner, "auto_mode", False):
+        n_cal = max(steps, 100)
+        launch = runner.calibrate(n_cal)
+        extra += 2 * n_cal + 3 * max(8, n_cal // 4)  # (the calibration's steps are untimed steps before the timed region too)
+        fence()
     elapsed, t_local = run(steps)
-    return dict(elapsed=elapsed, local=t_local, cold=t_cold, settle=extra + 1)
+    return dict(elapsed=elapsed, local=t_local, cold=t_cold, settle=extra + 1, launch=launch)
 
 
 def n1_same_workload(w, local, steps, use_graph, in_flight=1):
@@ -923,7 +961,11 @@ def main():
     ap.add_argument("--two-collectives", action="store_true",
                     help="N > 1, strong scaling: every rank classifies 1 / N of the line list and the per-line maxima are all-gathered "
                          "(a second collective of 8 N_l bytes per step) instead of every rank streaming the whole list")
-    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="plain launches (the default on ONE GPU since round 6, see --graph)")
+    ap.add_argument("--graph", action="store_true",
+                    help="one GPU: replay the step as a hipGraph (the default on several GPUs).  Round 6 measured successive graph launches "
+                         "8.5-9 us apart on this runtime while plain launches of the same three kernels follow each other closely and cost the "
+                         "host 10 us per step: S-c2 86-88 us per step with plain launches, 91-93 as graph replays")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip every leg that runs the CPU oracle (baseline and parity checks)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the S-c3 / S-c4m / S-c5 / drop-in blocks")
     args = ap.parse_args()
@@ -961,7 +1003,14 @@ def main():
     # N > 1: two flux buffers alternate so that the all-gather of step k (RCCL, its own stream) overlaps the kernels
     # of step k+1; a buffer is reused only after its gather has been waited for.  SDX_BENCH_SYNC_GATHER=1: blocking gather.
     overlap = os.environ.get("SDX_BENCH_SYNC_GATHER") != "1"
-    runner = Runner(w, world, rank, local, ctx, args.scaling, not args.no_graph, overlap, args.two_collectives, args.in_flight, args.graph_steps, args.steps)
+    # several GPUs: hipGraph replays.  One GPU: --graph / --no-graph as asked; by default the graph is captured, the run starts with plain
+    # launches and the settling phase times both kinds of launch and keeps the faster (Runner.calibrate)
+    auto_mode = world == 1 and not args.graph and not args.no_graph and args.in_flight == 1
+    use_graph = (args.graph or world > 1 or auto_mode) and not args.no_graph
+    runner = Runner(w, world, rank, local, ctx, args.scaling, use_graph, overlap, args.two_collectives, args.in_flight, args.graph_steps, args.steps)
+    if auto_mode and args.steps < 200:
+        runner.replay = False   # (the cold figure — K steps right after the W warm-up steps — is taken with plain launches)
+        runner.auto_mode = True  # ... and the settling phase that short runs have anyway decides (timed(): calibrate)
     # a run of >= 200 timed steps is long enough for the clocks to have settled within its first few percent: the W warm-up steps
     # the driver asked for are then ALL that precedes the timed region; shorter runs get ~0.5 s of untimed settling (disclosed)
     tm = timed(runner, args.steps, args.warmup, world, local, settle_s=0.0 if args.steps >= 200 else 0.5, cold=args.steps < 200)
@@ -980,7 +1029,7 @@ def main():
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
         if rank == 0 and args.scaling == "strong":
-            n1 = n1_same_workload(w, local, max(5, min(args.steps, 40)), not args.no_graph, runner.in_flight)
+            n1 = n1_same_workload(w, local, max(5, min(args.steps, 40)), use_graph, runner.in_flight)
         torch.cuda.synchronize()
         dist.barrier()
 
@@ -993,7 +1042,7 @@ def main():
         ctx_b = _lib.Context(local)
         syn_b = SpectralSynthesizer(nus, atm["temperatures"], atm["dist"], w["thetas"], w["weights"], w["lines"], w["cont"],
                                     ctx=ctx_b, track_evaluations=False, keep_line=False)
-        if not args.no_graph:
+        if use_graph:
             syn_b.capture()
         for _ in range(max(2, args.warmup // 2)):
             syn.step()
@@ -1057,7 +1106,9 @@ def main():
                 "n_theta": int(len(w["thetas"])),
                 "voigt_evaluations_global": int(evals) if evals is not None else None,
                 "parallelism": f"nu-shard x{world}" + (", 1 all-gather of F_nu[-1] per step" + (" overlapped with the next step" if runner.overlap else "") if world > 1 else ""),
-                "hip_graph": not args.no_graph,
+                "hip_graph": bool(runner.replay),
+                "launch_mode": (tm.get("launch") or {"mode": "hipGraph replay" if runner.replay else "plain launches",
+                                                    "chosen": "by flag" if (args.graph or args.no_graph) else "default (several GPUs, runs of >= 200 steps, --in-flight 2)"}),
                 "graph_steps_per_launch": runner.batch,
                 "syntheses_in_flight_per_gpu": runner.in_flight,
                 # how `value` was timed (the driver keeps `config`): `value` / `ms_per_step` are the K steps after the W warm-up steps and,
