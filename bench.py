@@ -955,12 +955,15 @@ def main():
     ap.add_argument("--graph-steps", type=int, default=GRAPH_STEPS,
                     help="one GPU: at most this many steps per hipGraph launch of the timed loop (default 10; the largest divisor of --steps is taken; "
                          "1: one launch per step, as rounds 1-5 timed it)")
-    ap.add_argument("--in-flight", type=int, choices=(1, 2), default=1,
+    ap.add_argument("--in-flight", type=int, choices=(1, 2), default=None,
                     help="2: every rank keeps two syntheses in flight (two contexts, stepped alternately) — throughput of a queue of independent "
-                         "syntheses instead of one step after the other; `value` then counts both (default 1: serial steps)")
+                         "syntheses instead of one step after the other; `value` then counts both, and on several GPUs one synthesis's collectives "
+                         "run under the other's kernels.  Default: 2 for strong scaling on several GPUs, 1 otherwise (serial steps)")
     ap.add_argument("--two-collectives", action="store_true",
-                    help="N > 1, strong scaling: every rank classifies 1 / N of the line list and the per-line maxima are all-gathered "
-                         "(a second collective of 8 N_l bytes per step) instead of every rank streaming the whole list")
+                    help="N > 1, strong scaling (the default there): every rank classifies 1 / N of the line list and the per-line maxima are "
+                         "all-gathered (a second collective of 8 N_l bytes per step) instead of every rank streaming the whole list")
+    ap.add_argument("--one-collective", action="store_true",
+                    help="N > 1, strong scaling: every rank classifies the whole line list itself; the flux gather is the only collective")
     ap.add_argument("--no-graph", action="store_true", help="plain launches (the default on ONE GPU since round 6, see --graph)")
     ap.add_argument("--graph", action="store_true",
                     help="one GPU: replay the step as a hipGraph (the default on several GPUs).  Round 6 measured successive graph launches "
@@ -973,6 +976,11 @@ def main():
         args.workload = "S-c2" if args.gpus == 1 else "S-c3"
     if args.scaling is None:
         args.scaling = "weak" if args.gpus == 1 else "strong"
+
+    strong_many = args.gpus > 1 and args.scaling == "strong"
+    if args.in_flight is None:
+        args.in_flight = 2 if strong_many else 1
+    args.two_collectives = (args.two_collectives or strong_many) and not args.one_collective
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args, sys.argv[1:]))

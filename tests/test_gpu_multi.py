@@ -80,13 +80,16 @@ def test_bench_self_launches_two_ranks():
 def test_bench_eight_ranks_on_one_device_rehearse_the_scale_run(mode):
     """The closest thing to the driver's 8-GPU SCALE run a one-GPU box allows: `bench.py --gpus 8` (all ranks on device 0, gloo) —
     eight per-rank entries, shards that tile the 120 398-point grid of configs[2], and the gathered spectrum bit-equal to the
-    one-GPU run of the same workload in the same process; with --two-collectives every rank classifies an eighth of the list; with
-    --in-flight 2 every rank alternates two syntheses on two contexts (each gather ordered behind its own stream)."""
+    one-GPU run of the same workload in the same process; with two collectives (the default; --one-collective turns it off) every rank
+    classifies an eighth of the list; with two syntheses in flight (the default; --in-flight 1) every rank alternates two syntheses on two
+    contexts (each gather ordered behind its own stream)."""
     two_collectives = "two collectives" in mode
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(SDX_BENCH_BACKEND="gloo", SDX_BENCH_SINGLE_DEVICE="1")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
-    extra = (["--two-collectives"] if two_collectives else []) + (["--in-flight", "2"] if "two in flight" in mode else [])
+    # (the defaults of a strong-scaling run on several GPUs are "two collectives, two in flight": that mode passes no flag at all)
+    default = mode == "two collectives, two in flight"
+    extra = [] if default else ((["--two-collectives"] if two_collectives else ["--one-collective"]) + ["--in-flight", "2" if "two in flight" in mode else "1"])
     proc = subprocess.run(cmd + extra, env=env, capture_output=True, text=True, timeout=1800)
     assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-3000:]
     out = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1])
