@@ -1016,9 +1016,11 @@ def main():
     auto_mode = world == 1 and not args.graph and not args.no_graph and args.in_flight == 1
     use_graph = (args.graph or world > 1 or auto_mode) and not args.no_graph
     runner = Runner(w, world, rank, local, ctx, args.scaling, use_graph, overlap, args.two_collectives, args.in_flight, args.graph_steps, args.steps)
-    if auto_mode and args.steps < 200:
+    if auto_mode:
         runner.replay = False   # (the cold figure — K steps right after the W warm-up steps — is taken with plain launches)
-        runner.auto_mode = True  # ... and the settling phase that short runs have anyway decides (timed(): calibrate)
+        # ... and the settling phase that short runs have anyway decides (timed(): calibrate); a run of >= 200 steps has no settling
+        # phase and stays with plain launches, the faster kind in every comparison of round 6 (86 - 88 us against 89 - 91 in batched replays)
+        runner.auto_mode = args.steps < 200
     # a run of >= 200 timed steps is long enough for the clocks to have settled within its first few percent: the W warm-up steps
     # the driver asked for are then ALL that precedes the timed region; shorter runs get ~0.5 s of untimed settling (disclosed)
     tm = timed(runner, args.steps, args.warmup, world, local, settle_s=0.0 if args.steps >= 200 else 0.5, cold=args.steps < 200)
@@ -1116,8 +1118,8 @@ def main():
                 "parallelism": f"nu-shard x{world}" + (", 1 all-gather of F_nu[-1] per step" + (" overlapped with the next step" if runner.overlap else "") if world > 1 else ""),
                 "hip_graph": bool(runner.replay),
                 "launch_mode": (tm.get("launch") or {"mode": "hipGraph replay" if runner.replay else "plain launches",
-                                                    "chosen": "by flag" if (args.graph or args.no_graph) else "default (several GPUs, runs of >= 200 steps, --in-flight 2)"}),
-                "graph_steps_per_launch": runner.batch,
+                                                    "chosen": "by flag" if (args.graph or args.no_graph) else ("default of one-GPU runs of >= 200 steps" if world == 1 and not runner.replay else "default (several GPUs, --in-flight 2)")}),
+                "graph_steps_per_launch": runner.batch if runner.replay else 1,
                 "syntheses_in_flight_per_gpu": runner.in_flight,
                 # how `value` was timed (the driver keeps `config`): `value` / `ms_per_step` are the K steps after the W warm-up steps and,
                 # for runs of fewer than 200 steps, this many further untimed steps (~0.5 s: the clocks ramp); *_cold are the same K steps
