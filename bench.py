@@ -819,13 +819,14 @@ def n1_same_workload(w, local, steps, use_graph, in_flight=1):
         syns[k % in_flight].step()
     sync()
     ms = (time.perf_counter() - t0) / steps * 1e3
-    spectrum_hash = sha16(syns[0].F_nu()[-1])
+    last = np.array(syns[0].F_nu()[-1], dtype=np.float64)
+    spectrum_hash = sha16(last)
     for syn, c in zip(syns, ctxs):
         syn.close()
         c.close()
     torch.cuda.synchronize()
     return {"ms_per_step": ms, "value": nus.size * atm["temperatures"].size / (ms * 1e-3), "steps": steps, "spectrum_sha256_16": spectrum_hash,
-            "in_flight": in_flight,
+            "in_flight": in_flight, "_spectrum": last,
             "how": "the unsharded grid on rank 0's GPU, same process, after the timed region (other ranks wait at a barrier)"}
 
 
@@ -1163,6 +1164,11 @@ def main():
                 out["gathered_spectrum_sha256_16"] = sha16(spectrum)
                 if n1 is not None:
                     out["gathered_spectrum_equals_n1_bit_for_bit"] = bool(n1.get("spectrum_sha256_16") == sha16(spectrum))
+                    ref = n1.pop("_spectrum", None)
+                    if ref is not None and ref.shape == np.shape(spectrum):  # (0.0 where the bits agree; the north star asks for 1e-10)
+                        out["max_rel_dev_vs_n1"] = float(np.max(np.abs(np.asarray(spectrum, dtype=np.float64) - ref) / np.maximum(np.abs(ref), 1e-300)))
+            if n1 is not None:
+                n1.pop("_spectrum", None)
             out["per_rank"] = per_rank
             out["config"]["shards"] = [[int(b), int(c)] for b, c in (runner.shards or [])] or "equal blocks of ceil(N_nu / N)"
             if n1 is not None:
