@@ -3516,16 +3516,18 @@ __global__ __launch_bounds__(kRtBlock) void k_raytrace(int n_depth, int64_t n_nu
 
 // The formal solution of the fp32-mixed TOLERANCE path (mixed_precision = 1; plane-parallel, one angle per lane, flux only): the
 // layout of k_raytrace<1> — lane <-> (frequency, angle), columns staged per wave — with the recurrence in fp32 (rt_coef32:
-// hardware exp2 / rcp, ~27 instructions per step at twice the fp64 issue rate against ~54).  sqrt(alpha), the source function
-// and the ray lengths are staged as floats (the totals are formed in fp64 and rounded once); F_nu is written as doubles.
+// hardware exp2 / rcp, ~27 instructions per step at twice the fp64 issue rate against ~54).  sqrt(alpha), the source function, its
+// differences between adjacent points (formed as differences: planck32_pair) and the ray lengths are staged as floats (the totals
+// are formed in fp64 and rounded once); F_nu is written as doubles.
 // Against the fp64 kernels: < 1e-5 of the flux on the full-size workloads (tests/test_gpu_configs.py, stated tolerance 1e-4).
+constexpr int kRt32Batch = 8;  // gaps per flux reduction of k_raytrace_f32 (6 measured: no gain from the eighth block a CU's LDS then holds)
 __global__ __launch_bounds__(kRtBlock) void k_raytrace_f32(int n_depth, int64_t n_nu, int n_theta, int theta_stride, int G,
                                                            const double* __restrict__ nus, const double* __restrict__ temps,
                                                            const double* __restrict__ ray_dist, const double* __restrict__ wts,
                                                            const double* __restrict__ alphas, int64_t ald, double* __restrict__ F,
                                                            int64_t fld, int gpw, FusedTotal ft)
 {
-    constexpr int kBatch = 8;
+    constexpr int kBatch = kRt32Batch;
     extern __shared__ double smem[];
     float* fmem = (float*)smem;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -3537,16 +3539,29 @@ __global__ __launch_bounds__(kRtBlock) void k_raytrace_f32(int n_depth, int64_t 
     const int64_t ic = i < n_nu ? i : n_nu - 1;
     const int n_gap = n_depth - 1, col = n_depth;
     float* sRD = fmem;                                   // ray_dist [n_gap][n_theta], shared by the block
-    float* wbase = sRD + n_gap * n_theta + (size_t)wave * (2 * gpw * col + kBatch * gpw * G);
-    float* sS = wbase;                                   // source function [gpw][col]
-    float* sA = sS + gpw * col;                          // sqrt(alpha)
-    float* sX = sA + gpw * col;                          // flux terms [kBatch][gpw][G]
+    float* sK = sRD + n_gap * n_theta;                   // 1 / (k T_d) [col], shared by the block
+    float* sR = sK + col;                                // (T_d - T_{d+1}) / T_{d+1} [col]: the difference formed in fp64
+    // per wave: what a step of the recurrence needs of its NEXT point as ONE 16-byte LDS read — sP[k] = (sqrt(alpha_{k+1}), S_{k+1},
+    // S_k - S_{k+1}, -) for k < n_gap, the difference formed as a difference (planck32_pair), not from the two rounded values; the
+    // first point's (sqrt(alpha_0), S_0) in the spare slot k = n_gap
+    const int shared_floats = (n_gap * n_theta + 2 * col + 3) & ~3;
+    float* wbase = fmem + shared_floats + (size_t)wave * (4 * gpw * col + kBatch * gpw * G);
+    float4* sP = (float4*)wbase;                         // [gpw][col]
+    float* sX = wbase + 4 * gpw * col;                   // flux terms [kBatch][gpw][G]
     const double nu = nus[ic];
     for (int k = threadIdx.x; k < n_gap * n_theta; k += kRtBlock) {
         const int gp = k / n_theta, t = k - gp * n_theta;
         sRD[k] = (float)ray_dist[(size_t)gp * theta_stride + t];
     }
+    for (int k = threadIdx.x; k < n_depth; k += kRtBlock) {
+        const double t = temps[k], tn = temps[min(k + 1, n_depth - 1)];
+        sK[k] = __builtin_amdgcn_rcpf((float)mul_rn(kKB, t));
+        sR[k] = (float)sub_rn(t, tn) * __builtin_amdgcn_rcpf((float)tn);
+    }
+    __syncthreads();
     if (active) {
+        const float hn = (float)mul_rn(kH, nu);
+        const float pre = (float)(mul_rn(mul_rn(2.0, kH), mul_rn(mul_rn(nu, nu), nu)) * (1.0 / (kC * kC)));
         for (int d = g; d < n_depth; d += G) {
             double a;
             if (ft.cont) {
@@ -3562,8 +3577,18 @@ __global__ __launch_bounds__(kRtBlock) void k_raytrace_f32(int n_depth, int64_t 
             } else {
                 a = alphas[(size_t)d * ald + ic];
             }
-            sA[grp * col + d] = __builtin_sqrtf((float)a);
-            sS[grp * col + d] = ft.source ? (float)ft.source[(size_t)d * ft.sld + ic] : planck32(nu, temps[d]);
+            const float sa = __builtin_sqrtf((float)a);
+            const int dn = min(d + 1, n_depth - 1);
+            float sv, dv;
+            if (ft.source) {
+                const double s0 = ft.source[(size_t)d * ft.sld + ic];
+                sv = (float)s0, dv = (float)sub_rn(s0, ft.source[(size_t)dn * ft.sld + ic]);
+            } else {
+                planck32_pair(hn, pre, sK[d], sK[dn], sR[d], sv, dv);
+            }
+            float* const mine = (float*)(sP + grp * col + (d > 0 ? d - 1 : n_gap));
+            mine[0] = sa, mine[1] = sv;
+            ((float*)(sP + grp * col + d))[2] = dv;  // (slot n_gap: the last point's 0, never read)
         }
     }
     __syncthreads();
@@ -3572,9 +3597,10 @@ __global__ __launch_bounds__(kRtBlock) void k_raytrace_f32(int n_depth, int64_t 
     const float wt = g < n_theta ? (float)wts[th] : 0.f;
     if (valid && g == 0) F[i] = 0.0;
     float inten = 0.f;
-    float a1 = sA[gi + 1];
-    float t0 = (sA[gi] * a1) * sRD[th];
-    float s1 = sS[gi + 1], d10 = sS[gi] - s1;
+    const float4 p0 = sP[gi];
+    float a1 = p0.x;
+    float t0 = (sP[gi + n_gap].x * a1) * sRD[th];
+    float s1 = p0.y, d10 = p0.z;
     const float inv_gpw = 1.0f / (float)gpw;
     for (int gap0 = 0; gap0 < n_gap; gap0 += kBatch) {
         const int nb = min(kBatch, n_gap - gap0);
@@ -3582,9 +3608,10 @@ __global__ __launch_bounds__(kRtBlock) void k_raytrace_f32(int n_depth, int64_t 
             const int gap = gap0 + b;
             const bool last = gap == n_gap - 1;
             const int nx = last ? gap : gap + 1;
-            const float s2 = sS[gi + nx + 1], a2 = sA[gi + nx + 1];
+            const float4 p = sP[gi + nx];
+            const float s2 = p.y, a2 = p.x;
             const float t1 = (a1 * a2) * sRD[nx * n_theta + th];
-            const float d21 = s2 - s1;
+            const float d21 = last ? 0.f : -p.z;
             float c, e;
             rt_coef32(t0, t1, d10, d21, s1, last, c, e);
             inten = fmaf(c, inten, e);

@@ -2011,7 +2011,8 @@ static int raytrace_impl(sdx_ctx* ctx, int n_depth, int64_t n_nu, int n_theta, c
         // the tolerance path (mixed_precision = 1): plane-parallel, all angles in one launch, flux only -> the fp32 recurrence
         if (ctx->mixed_precision && P == 1 && !inward && !acc && !inus && F && n_theta <= 64) {
             const int g32 = 64 / G;
-            const size_t shmem32 = ((size_t)(n_depth - 1) * nth + (size_t)(kRtBlock / 64) * (2 * (size_t)g32 * n_depth + 8 * (size_t)g32 * G)) * sizeof(float);
+            const size_t shmem32 = ((((size_t)(n_depth - 1) * nth + 2 * (size_t)n_depth + 3) & ~(size_t)3) +
+                                    (size_t)(kRtBlock / 64) * (4 * (size_t)g32 * n_depth + kRt32Batch * (size_t)g32 * G)) * sizeof(float);
             if (shmem32 <= 64 * 1024) {
                 {
                     LaunchScope ls(ctx, "k_raytrace", "k_raytrace_f32");

@@ -327,6 +327,39 @@ def test_deep_models_and_many_angles(ctx, n_depth, n_theta):
             assert (lo[l, d], hi[l, d]) == oracle.window(nus, lines["line_nus"][l], lines["gammas"][l, d], lines["doppler_widths"][l, d], lines["alphas"][l, d])
 
 
+def test_fp32_formal_solution_on_a_nearly_isothermal_gap_ahead_of_a_thin_one(ctx):
+    """The second-order terms of the recurrence (radiation_field_solvers/base.py:208-249) multiply the source DIFFERENCES by up to
+    1 / tau of a thin gap.  Formed from two rounded fp32 source values, a difference of 0.1 % of the source carries 3e-4 of itself
+    (scripts/fuzz_raytrace.py, seed 849: 2.9e-4 of the flux); the fp32 kernel stages the differences themselves (planck32_pair:
+    S_d E expm1(x' - x) / (E' - 1) with T - T' from the fp64 temperatures) and stays two orders below its stated 1e-4."""
+    from stardis_amd import ops
+
+    n_depth, n_theta = 40, 20
+    rng = np.random.default_rng(849)
+    temps = np.sort(rng.uniform(9000.0, 9700.0, n_depth))[::-1].copy()
+    temps[16], temps[17] = 9590.1, 9586.7                     # 0.035 % apart: dS / S = 1.4e-3
+    dist = rng.uniform(2e5, 4e7, n_depth - 1)
+    nus = np.linspace(9.0e14, 6.0e14, 96)
+    alphas = 10.0 ** rng.uniform(-9.0, -7.0, (n_depth, nus.size))
+    alphas[15] = 1.4e-3                                       # an opaque point, then two thin gaps: tau ~ 0.4 ahead of tau ~ 1e-6
+    alphas[16], alphas[17] = 4e-13, 1.5e-14
+    th, w = synth.thetas_and_weights(n_theta)
+    rd = dist.reshape(-1, 1) / np.cos(th)
+    F64, _ = ops.raytrace_arrays(nus, temps, rd, w, alphas, ctx=ctx)
+    try:
+        ctx.set_option("mixed_precision", 1)
+        ctx.set_option("segmented_raytrace", 0)  # (a grid this small would take the segmented fp64 kernel whatever the mode)
+        F32, _ = ops.raytrace_arrays(nus, temps, rd, w, alphas, ctx=ctx)
+    finally:
+        ctx.set_option("mixed_precision", 0)
+        ctx.set_option("segmented_raytrace", -1)
+    assert np.isfinite(F64).all() and not np.array_equal(F32, F64)
+    assert F64[17].max() > 20 * F64[15].max()                 # the amplified second-order term dominates the flux there
+    dev = np.max(np.abs(F32 - F64) / np.abs(F64).max(axis=0, keepdims=True))
+    print("fp32 formal solution, amplified source difference: max dev", dev)
+    assert dev < 2e-5
+
+
 def test_mixed_precision_mode_is_a_tolerance_path(ctx):
     """BASELINE config 5's tolerance path: far-wing evaluations and window edges in packed fp32, narrow windows through the
     fp32 Faddeeva routine (all four regions), cores kept by wide windows, continuum and formal solution in fp64.  The mode's
