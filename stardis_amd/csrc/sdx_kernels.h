@@ -3353,9 +3353,8 @@ __global__ __launch_bounds__(kRtBlock) void k_raytrace(int n_depth, int64_t n_nu
     const int n_gap = n_depth - 1;
     const int col = n_depth;  // LDS row stride per group
     double* wbase = smem + (size_t)wave * (2 * gpw * col + kBatch * gpw * TH);
-    double* sS = wbase;                       // source function  [gpw][col]
-    double* sA = sS + gpw * col;              // sqrt(alpha)      [gpw][col]
-    double* sX = sA + gpw * col;              // flux terms       [kBatch][gpw][TH]
+    double2* sP = (double2*)wbase;            // (source function, sqrt(alpha)) [gpw][col]: a point's pair is ONE 16-byte LDS read
+    double* sX = wbase + 2 * gpw * col;       // flux terms       [kBatch][gpw][TH]
     const double nu = nus[ic];
 
     // (Staging the columns a batch of G depth points AHEAD of the recurrence — the loads of batch b + 1 requested when batch b is
@@ -3379,8 +3378,7 @@ __global__ __launch_bounds__(kRtBlock) void k_raytrace(int n_depth, int64_t n_nu
             } else {
                 a = alphas[(size_t)d * ald + ic];
             }
-            sA[grp * col + d] = sqrt(a);
-            sS[grp * col + d] = ft.source ? ft.source[(size_t)d * ft.sld + ic] : planck_staged(nu, temps[d]);
+            sP[grp * col + d] = double2{ft.source ? ft.source[(size_t)d * ft.sld + ic] : planck_staged(nu, temps[d]), sqrt(a)};
         }
     }
     wave_sync();  // (nothing is shared between the waves of a block any more: the ray table is read from L1)
@@ -3403,8 +3401,9 @@ __global__ __launch_bounds__(kRtBlock) void k_raytrace(int n_depth, int64_t n_nu
         for (int gap = n_gap - 1; gap >= 0; --gap) {
             const int gm = gap > 0 ? gap - 1 : n_gap - 1;
             const int dm = gap > 0 ? gap - 1 : n_depth - 1;
-            const double s0 = sS[gi + gap + 1], s1 = sS[gi + gap], s2 = sS[gi + dm];
-            const double mg = sA[gi + gap] * sA[gi + gap + 1], mm = sA[gi + gm] * sA[gi + gm + 1];
+            const double2 q0 = sP[gi + gap + 1], q1 = sP[gi + gap], q2 = sP[gi + dm];
+            const double s0 = q0.x, s1 = q1.x, s2 = q2.x;
+            const double mg = q1.y * q0.y, mm = sP[gi + gm].y * sP[gi + gm + 1].y;
 #pragma unroll
             for (int k = 0; k < P; ++k) {
                 const double tg = mul_rn(mg, ray_dist[(size_t)gap * theta_stride + th[k]]), tm = mul_rn(mm, ray_dist[(size_t)gm * theta_stride + th[k]]);
@@ -3437,9 +3436,10 @@ __global__ __launch_bounds__(kRtBlock) void k_raytrace(int n_depth, int64_t n_nu
     // per gap, requested a gap ahead; staged in LDS it cost every block 9 KB, and with them two of seven workgroups per CU)
     double tau0[P], rd_next[P];
     const double* rdp[P];
-    double a1 = sA[gi + 1];
+    const double2 p0 = sP[gi], p1 = sP[gi + 1];
+    double a1 = p1.y;
     {
-        const double mean0 = sA[gi] * a1;
+        const double mean0 = p0.y * a1;
 #pragma unroll
         for (int k = 0; k < P; ++k) {
             rdp[k] = ray_dist + th[k];
@@ -3448,7 +3448,7 @@ __global__ __launch_bounds__(kRtBlock) void k_raytrace(int n_depth, int64_t n_nu
             rd_next[k] = *rdp[k];  // gap 1
         }
     }
-    double s1 = sS[gi + 1], d10 = sS[gi] - s1;
+    double s1 = p1.x, d10 = p0.x - s1;
     const float inv_gpw = 1.0f / (float)gpw;
 
     for (int gap0 = 0; gap0 < n_gap; gap0 += kBatch) {
@@ -3456,7 +3456,8 @@ __global__ __launch_bounds__(kRtBlock) void k_raytrace(int n_depth, int64_t n_nu
         for (int b = 0; b < nb; ++b) {
             const int gap = gap0 + b;
             if (gap < n_gap - 1) {  // :208-249
-                const double s2 = sS[gi + gap + 2], a2 = sA[gi + gap + 2];
+                const double2 p2 = sP[gi + gap + 2];
+                const double s2 = p2.x, a2 = p2.y;
                 const double mean1 = a1 * a2, d21 = s2 - s1;
 #pragma unroll
                 for (int k = 0; k < P; ++k) {
@@ -3682,8 +3683,9 @@ __global__ __launch_bounds__(64 * NS) __attribute__((amdgpu_waves_per_eu(NS >= 8
     const int rstride = n_gap | 1;             // odd row stride: the angles of a wave read distinct banks
     double* sAB = smem;                        // [NS][64][2] segment maps
     double* sRT = sAB + NS * 128;              // ray_dist TRANSPOSED [n_theta][rstride]: a lane's gaps are consecutive (immediate offsets)
-    double* sS = sRT + n_theta * rstride;      // source function [gpw][col]
-    double* sA = sS + gpw * col;               // sqrt(alpha): the geometric-mean opacity of a gap (:121) is the product of its two ends'
+    // (source function, sqrt(alpha)) [gpw][col], a point's pair ONE 16-byte LDS read; the geometric-mean opacity of a gap (:121) is
+    // the product of its two ends' square roots
+    double2* sP = (double2*)(sRT + ((n_theta * rstride + 1) & ~1));
     double* sFx = sRT;                         // after the barrier of step 2: flux terms [NS][LMAX][gpw][G]
 
     // staging without a division per item: lane <-> (one of 64 / n_theta gaps, angle) once; then a wave takes one frequency's
@@ -3701,7 +3703,7 @@ __global__ __launch_bounds__(64 * NS) __attribute__((amdgpu_waves_per_eu(NS >= 8
         const int64_t ic = vq ? iq : n_nu - 1;
         if (source) {
             const double nu = nus[ic];
-            for (int d = lane; d < n_depth; d += 64) sS[gq * col + d] = ft.source ? ft.source[(size_t)d * ft.sld + ic] : planck_staged(nu, temps[d]);
+            for (int d = lane; d < n_depth; d += 64) sP[gq * col + d].x = ft.source ? ft.source[(size_t)d * ft.sld + ic] : planck_staged(nu, temps[d]);
             continue;
         }
         for (int d = lane; d < n_depth; d += 64) {
@@ -3719,7 +3721,7 @@ __global__ __launch_bounds__(64 * NS) __attribute__((amdgpu_waves_per_eu(NS >= 8
             } else {
                 a = alphas[(size_t)d * ald + ic];
             }
-            sA[gq * col + d] = sqrt(a);
+            sP[gq * col + d].y = sqrt(a);
         }
     }
     __syncthreads();
@@ -3742,18 +3744,19 @@ __global__ __launch_bounds__(64 * NS) __attribute__((amdgpu_waves_per_eu(NS >= 8
     unsigned long long redo = 0;
     const int gc = count > 0 ? g_lo : 0;
     {
-        const double* pS = sS + gi + gc - j0;
-        const double* pA = sA + gi + gc - j0;
+        const double2* pP = sP + gi + gc - j0;
         const double* pR = sRT + th * rstride + gc - j0;
-        double a1 = pA[j0 + 1], s1 = pS[j0 + 1];
-        double d10 = pS[j0] - s1;
-        double t0 = mul_rn(pA[j0] * a1, pR[j0]);
+        const double2 q0 = pP[j0], q1 = pP[j0 + 1];
+        double a1 = q1.y, s1 = q1.x;
+        double d10 = q0.x - s1;
+        double t0 = mul_rn(q0.y * a1, pR[j0]);
 #pragma unroll
         for (int j = 0; j < LMAX; ++j) {
             c[j] = 1.0, e[j] = 0.0;
             if (j >= j0) {
                 if (j < LMAX - 1 || seg < NS - 1) {  // :208-249
-                    const double s2 = pS[j + 2], a2 = pA[j + 2];
+                    const double2 q2 = pP[j + 2];
+                    const double s2 = q2.x, a2 = q2.y;
                     const double t1 = mul_rn(a1 * a2, pR[j + 1]);
                     const double d21 = s2 - s1;
                     redo |= rt_coef_fast<false>(t0, t1, d10, d21, s1, c[j], e[j]);
@@ -3770,12 +3773,12 @@ __global__ __launch_bounds__(64 * NS) __attribute__((amdgpu_waves_per_eu(NS >= 8
         A = 1.0, B = 0.0;
         for (int j = j0; j < LMAX; ++j) {
             const int gap = gc + j - j0;
-            const double s0 = sS[gi + gap], s1 = sS[gi + gap + 1];
-            const double t0 = mul_rn(sA[gi + gap] * sA[gi + gap + 1], sRT[th * rstride + gap]);
+            const double s0 = sP[gi + gap].x, s1 = sP[gi + gap + 1].x;
+            const double t0 = mul_rn(sP[gi + gap].y * sP[gi + gap + 1].y, sRT[th * rstride + gap]);
             double cj, ej;
             if (gap < n_gap - 1) {
-                const double t1 = mul_rn(sA[gi + gap + 1] * sA[gi + gap + 2], sRT[th * rstride + gap + 1]);
-                rt_coef_reference<false>(t0, t1, s0 - s1, sS[gi + gap + 2] - s1, s1, cj, ej);
+                const double t1 = mul_rn(sP[gi + gap + 1].y * sP[gi + gap + 2].y, sRT[th * rstride + gap + 1]);
+                rt_coef_reference<false>(t0, t1, s0 - s1, sP[gi + gap + 2].x - s1, s1, cj, ej);
             } else {
                 rt_coef_reference<true>(t0, 0.0, s0 - s1, 0.0, s1, cj, ej);
             }

@@ -795,9 +795,9 @@ static const int kSegMax = kSegWaves == 4 ? 14 : 7;
 static size_t seg_lds_doubles(int n_depth, int nth)
 {
     const int gpw = 64 / nth;
-    // segment maps, then the larger of the staging arrays (transposed ray table with an odd row stride, source and sqrt(alpha)
-    // columns) and the flux terms that reuse their space
-    return (size_t)kSegWaves * 128 + std::max((size_t)nth * ((n_depth - 1) | 1) + (size_t)2 * gpw * n_depth, (size_t)kSegWaves * kSegMax * gpw * nth);
+    // segment maps, then the larger of the staging arrays (transposed ray table with an odd row stride, then — 16-byte aligned — the
+    // (source, sqrt(alpha)) pairs) and the flux terms that reuse their space
+    return (size_t)kSegWaves * 128 + std::max((((size_t)nth * ((n_depth - 1) | 1) + 1) & ~(size_t)1) + (size_t)2 * gpw * n_depth, (size_t)kSegWaves * kSegMax * gpw * nth);
 }
 // Which kernel runs must not depend on how the grid is sharded or on the device (the two differ by the rounding of the affine
 // composition, a few ulp: a shard below the threshold next to an unsharded run above it would break the bit-identity of
